@@ -1,0 +1,78 @@
+"""Oracle pins for the policy / GAE / PPO restatement."""
+import torch
+import torch.nn as nn
+
+from embodied_clip_amd import synthetic as syn
+from oracle import policy as opol
+from oracle import ppo as oppo
+
+
+def test_policy_param_checksum():
+    assert opol.param_count(syn.policy_state_dict(0)) == 3_480_775
+
+
+def test_gru_matches_torch_nn_gru_without_resets():
+    sd = syn.policy_state_dict(1, in_channels=64, spatial=2, hidden=32)
+    T, N, I, H = 5, 3, 32 * 4, 32
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(T, N, I, generator=g); h0 = torch.randn(1, N, H, generator=g)
+    gru = nn.GRU(I, H, 1)
+    gru.load_state_dict({k.split("rnn.")[1]: v for k, v in sd.items() if "rnn." in k})
+    ref, hT = gru(x, h0)
+    out, h = opol.rnn_state_encoder(x, h0, torch.ones(T, N, 1), sd)
+    assert torch.allclose(out, ref, atol=1e-5) and torch.allclose(h, hT, atol=1e-5)
+
+
+def test_gru_mask_resets_hidden():
+    sd = syn.policy_state_dict(1, in_channels=64, spatial=2, hidden=32)
+    T, N, I, H = 4, 2, 128, 32
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(T, N, I, generator=g); h0 = torch.randn(1, N, H, generator=g)
+    m = torch.ones(T, N, 1); m[2, 1, 0] = 0
+    out, _ = opol.rnn_state_encoder(x, h0, m, sd)
+    # sampler 1 from t=2 on must equal a fresh run from zero hidden state
+    out2, _ = opol.rnn_state_encoder(x[2:, 1:2], torch.zeros(1, 1, H), torch.ones(2, 1, 1), sd)
+    assert torch.allclose(out[2:, 1:2], out2, atol=1e-6)
+
+
+def test_goal_encoder_flatten_is_channel_major():
+    sd = syn.policy_state_dict(2, in_channels=16, spatial=3, hidden=8)
+    feat = torch.randn(2, 16, 3, 3, generator=torch.Generator().manual_seed(0))
+    goal = torch.tensor([3, 7])
+    y = opol.goal_encoder(feat, goal, sd)
+    assert y.shape == (2, 32 * 9)
+
+
+def test_gae_closed_form_single_step():
+    r = torch.tensor([[[1.0]]]); v = torch.tensor([[[0.5]], [[2.0]]]); m = torch.ones(2, 1, 1)
+    R = oppo.compute_returns(r, v, m, 0.99, 0.95)
+    assert torch.allclose(R[0], torch.tensor([[1.0 + 0.99 * 2.0]]))
+    m[1] = 0
+    R = oppo.compute_returns(r, v, m, 0.99, 0.95)
+    assert torch.allclose(R[0], torch.tensor([[1.0]]))
+
+
+def test_adam_matches_torch_optim():
+    g = torch.Generator().manual_seed(0)
+    p0 = torch.randn(50, generator=g)
+    p_ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([p_ref], lr=3e-4)
+    p = p0.clone(); m = [torch.zeros(50)]; v = [torch.zeros(50)]
+    for step in range(1, 4):
+        gr = torch.randn(50, generator=g)
+        p_ref.grad = gr.clone(); opt.step()
+        oppo.adam_step([p], [gr.clone()], m, v, step)
+    assert torch.allclose(p, p_ref.detach(), atol=1e-7)
+
+
+def test_ppo_loss_at_ratio_one():
+    T, N, A = 3, 2, 6
+    g = torch.Generator().manual_seed(0)
+    logits = torch.randn(T, N, A, generator=g); actions = torch.randint(0, A, (T, N), generator=g)
+    old_lp = opol.categorical_log_prob(logits, actions).unsqueeze(-1)
+    values = torch.randn(T, N, 1, generator=g); returns = torch.randn(T, N, 1, generator=g)
+    adv = torch.randn(T, N, 1, generator=g)
+    total, info = oppo.ppo_loss(logits, values, actions, old_lp, values.clone(), returns, adv)
+    assert abs(info["action"] - float(-adv.mean())) < 1e-6
+    assert abs(info["value"] - float(0.5 * ((values - returns) ** 2).mean())) < 1e-6
+    assert abs(info["ratio_mean"] - 1.0) < 1e-6

