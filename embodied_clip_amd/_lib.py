@@ -1,0 +1,77 @@
+"""ctypes binding of the C-ABI in include/ec_amd.h.
+
+The product path has NO CPU fallback: if the HIP library is missing this
+module raises, loudly.  (The CPU oracle under oracle/ is test infrastructure
+and is never imported from here.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libec_amd.so")
+
+c_void_p, c_int, c_size_t, c_float = C.c_void_p, C.c_int, C.c_size_t, C.c_float
+
+# name -> (restype, argtypes); must list every symbol include/ec_amd.h declares
+# (tests/test_cabi_symbols.py parses the header and checks both directions).
+SIGNATURES = {
+    "ec_version": (c_int, []),
+    "ec_strerror": (C.c_char_p, [c_int]),
+    "ec_conv_bf16": (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p]),
+    "ec_gemm_bf16": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
+    "ec_stem_conv1": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
+    "ec_avgpool2_bf16": (c_int, [c_void_p] * 2 + [c_int] * 4 + [c_void_p]),
+    "ec_nhwc_bf16_to_nchw_f32": (c_int, [c_void_p] * 2 + [c_int] * 3 + [c_void_p]),
+    "ec_spatial_mean_bf16": (c_int, [c_void_p] * 2 + [c_int] * 3 + [c_void_p]),
+    "ec_rn50_create": (c_int, [C.POINTER(c_void_p), c_int, C.POINTER(c_int), c_int, c_void_p, c_void_p, c_size_t,
+                               c_void_p, c_size_t]),
+    "ec_rn50_destroy": (None, [c_void_p]),
+    "ec_rn50_workspace_bytes": (c_size_t, [c_void_p, c_int]),
+    "ec_rn50_out_channels": (c_int, [c_void_p]),
+    "ec_rn50_out_spatial": (c_int, [c_void_p]),
+    "ec_rn50_forward": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p, c_int, c_void_p]),
+    "ec_rn50_num_ops": (c_int, [c_void_p]),
+}
+
+_lib = None
+
+
+class EcError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load libec_amd.so (built by ``__graft_entry__.build()`` / ``make``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"embodied_clip_amd: HIP library not found at {LIB_PATH}. Build it with `make` or "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc, gfx950). "
+            "There is deliberately no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError here == header/library drift: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().ec_strerror(rc).decode()
+        raise EcError(f"{what or 'ec_amd call'} failed: {msg} (code {rc})")
+
+
+def ptr(t) -> int:
+    """Device pointer of a torch tensor (or None -> NULL)."""
+    return 0 if t is None else t.data_ptr()
+
+
+def stream_ptr() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream

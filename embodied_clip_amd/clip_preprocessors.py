@@ -1,0 +1,117 @@
+"""Drop-in ``ClipResNetPreprocessor`` / ``ClipViTPreprocessor``.
+
+Same constructor keywords, attributes and ``process`` / ``to`` behaviour as
+[U] ``allenact_plugins/clip_plugin/clip_preprocessors.py`` (the plugin the
+reference installs: readme_files/baselines_robothor_objectnav.md:25, used by
+the experiment config named at :51), so RoboTHOR/Habitat experiment configs
+keep working unchanged; the arithmetic behind ``process`` is the hand-written
+gfx950 HIP path (include/ec_amd.h) instead of ``clip.load(...).visual``
+(reference call site: primitive_probing/generate_data/thor_image_features.py:57-67).
+
+Weights: ``clip`` / network access are unavailable in the build image, so the
+visual tower's ``state_dict`` (OpenAI key layout) is supplied via
+``state_dict=`` / ``weights_path=`` / ``$EC_CLIP_WEIGHTS_DIR/<type>.pt``; if the
+``clip`` package is importable it is used exactly as the reference does.
+"""
+from __future__ import annotations
+
+import os
+from typing import Any, Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import spaces
+
+
+def _load_visual_state_dict(clip_model_type: str, state_dict, weights_path):
+    if state_dict is not None:
+        return state_dict
+    cand = weights_path
+    if cand is None and os.environ.get("EC_CLIP_WEIGHTS_DIR"):
+        cand = os.path.join(os.environ["EC_CLIP_WEIGHTS_DIR"], clip_model_type.replace("/", "-") + ".pt")
+    if cand is not None and os.path.exists(cand):
+        obj = torch.load(cand, map_location="cpu")
+        sd = obj.state_dict() if hasattr(obj, "state_dict") else obj
+        if any(k.startswith("visual.") for k in sd):
+            sd = {k[len("visual."):]: v for k, v in sd.items() if k.startswith("visual.")}
+        return sd
+    try:  # exactly what the reference does (thor_image_features.py:57,59)
+        import clip  # type: ignore
+        model, _ = clip.load(clip_model_type, device="cpu")
+        return model.visual.float().state_dict()
+    except ImportError as e:
+        raise RuntimeError(
+            f"No CLIP weights for {clip_model_type!r}: pass state_dict=/weights_path=, set EC_CLIP_WEIGHTS_DIR, "
+            "or install openai/CLIP") from e
+
+
+class _PreprocessorBase:
+    """Duck-types ``allenact.base_abstractions.preprocessor.Preprocessor``."""
+
+    CLIP_RGB_MEANS = (0.48145466, 0.4578275, 0.40821073)
+    CLIP_RGB_STDS = (0.26862954, 0.26130258, 0.27577711)
+
+    def __init__(self, input_uuids: List[str], output_uuid: str, observation_space):
+        self.input_uuids = input_uuids
+        self.uuid = output_uuid
+        self.observation_space = observation_space
+
+    def to(self, device: torch.device):
+        self.device = torch.device(device)
+        self._model = None   # rebuilt lazily on the new device
+        return self
+
+
+class ClipResNetPreprocessor(_PreprocessorBase):
+    """[U] ``ClipResNetPreprocessor(rgb_input_uuid, clip_model_type, pool, device, device_ids, output_uuid)``.
+
+    ``process(obs)``: ``obs[rgb]`` fp32 NHWC [N,224,224,3] (already normalised
+    with CLIP_RGB_MEANS/STDS by the sensor) -> fp32 NCHW [N,2048,7,7]
+    (``pool=False``) or [N,2048] (``pool=True``), on ``device``.
+    """
+
+    def __init__(self, rgb_input_uuid: str, clip_model_type: str, pool: bool,
+                 device: Optional[torch.device] = None, device_ids: Optional[List[torch.device]] = None,
+                 output_uuid: str = "rgb_clip_resnet", state_dict=None, weights_path: Optional[str] = None,
+                 chunk: int = 0, **kwargs: Any):
+        assert clip_model_type in ("RN50", "RN50x16")
+        if clip_model_type == "RN50":
+            output_shape = (2048, 7, 7)
+        else:
+            raise NotImplementedError("RN50x16 (width 96) is not supported by the gfx950 kernels yet")
+        if pool:
+            output_shape = output_shape[:1]
+        self.clip_model_type = clip_model_type
+        self.pool = pool
+        self.device = torch.device("cuda") if device is None else torch.device(device)
+        self.device_ids = device_ids or []
+        self._state_dict = state_dict
+        self._weights_path = weights_path
+        self._chunk = chunk
+        self._model = None
+        low, high = -np.inf, np.inf
+        super().__init__([rgb_input_uuid], output_uuid,
+                         spaces.Box(low=low, high=high, shape=output_shape, dtype=np.float32))
+
+    @property
+    def resnet(self):
+        if self._model is None:   # lazy, like the reference plugin
+            from .encoder import RN50Trunk
+            sd = _load_visual_state_dict(self.clip_model_type, self._state_dict, self._weights_path)
+            self._model = RN50Trunk(sd, device=self.device, chunk=self._chunk)
+        return self._model
+
+    def process(self, obs: Dict[str, Any], *args: Any, **kwargs: Any) -> torch.Tensor:
+        x = obs[self.input_uuids[0]]
+        if x.shape[-1] == 1:      # depth input: repeated to 3 channels, as upstream does
+            x = x.expand(*x.shape[:-1], 3)
+        x = x.to(self.device, dtype=torch.float32).contiguous()
+        trunk = self.resnet
+        feat = trunk.forward(x)
+        return trunk.spatial_mean(feat) if self.pool else trunk.to_nchw_f32(feat)
+
+    def process_bf16_nhwc(self, rgb: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """MI355X-native fast path: device fp32 NHWC frame -> bf16 NHWC [N,7,7,2048] written
+        straight into ``out`` (a slice of the rollout feature buffer)."""
+        return self.resnet.forward(rgb, out)

@@ -1,0 +1,50 @@
+// Shared device helpers for the gfx950 (CDNA4, wave64) kernels of the
+// embodied-clip hot path.  HIP only -- no CUDA compatibility layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ec_amd.h"
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef short s16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+#define EC_WAVE 64
+
+__device__ __forceinline__ uint16_t ec_f2bf(float f) {
+    // round-to-nearest-even fp32 -> bf16 (finite inputs)
+    uint32_t u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float ec_bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ uint32_t ec_pack2(float lo, float hi) {
+    return (uint32_t)ec_f2bf(lo) | ((uint32_t)ec_f2bf(hi) << 16);
+}
+__device__ __forceinline__ float ec_lo(uint32_t p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float ec_hi(uint32_t p) { return __uint_as_float(p & 0xffff0000u); }
+
+// Bijective XCD-aware remap of a linear block id (cdna guide T1): the
+// dispatcher places block b on XCD b % 8; give each XCD a contiguous chunk of
+// the logical tile space so neighbouring tiles share an L2.
+__device__ __forceinline__ unsigned ec_xcd_remap(unsigned bid, unsigned nwg) {
+    const unsigned nx = 8;
+    if (nwg < nx * 2) return bid;
+    unsigned xcd = bid % nx, q = nwg / nx, r = nwg % nx;
+    unsigned base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + bid / nx;
+}
+
+static inline int ec_ilog2(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+
+#define EC_CHECK_LAUNCH()                                   \
+    do {                                                    \
+        hipError_t e__ = hipGetLastError();                 \
+        if (e__ != hipSuccess) return EC_ERR_LAUNCH;        \
+    } while (0)

@@ -1,0 +1,166 @@
+// CLIP ModifiedResNet trunk executor (stem + layer1..4, attnpool detached).
+//
+// Replaces `clip_features = clip_model(clip_input)` with
+// `clip_model.attnpool = nn.Identity()`
+// (primitive_probing/generate_data/thor_image_features.py:59-67,109) ==
+// [U] allenact_plugins/clip_plugin ClipResNetEmbedder.forward.
+//
+// The op list is derived from the architecture ([U] openai/CLIP clip/model.py
+// ModifiedResNet.__init__/_make_layer, Bottleneck): it is a straight line of
+// fused conv launches over five ping-pong NHWC bf16 buffers in the caller's
+// workspace.  CLIP's anti-aliased stride (3x3 conv at full resolution, then
+// AvgPool2d(2)) is fused into the 3x3 conv's epilogue; the residual add + ReLU
+// is fused into conv3's epilogue.
+#include <new>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+enum OpKind { OP_STEM1, OP_CONV, OP_POOL };
+
+struct Op {
+    OpKind kind;
+    int src, dst, res;       // buffer ids; -1 = none; src -2 = rgb input; dst -3 = final output
+    int H, W, Cin, Cout, ks, pool, act;
+    size_t w_off, b_off;     // element offsets into w_bf16 / bias
+};
+
+}  // namespace
+
+struct ec_rn50 {
+    int width, res, out_c, out_sp;
+    std::vector<Op> ops;
+    size_t max_elems_per_frame;   // largest activation (bf16 elements) per frame
+    const float* stem_w;
+    const uint16_t* w;
+    const float* bias;
+    size_t n_w, n_b;
+};
+
+namespace {
+constexpr int NBUF = 5;
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+}  // namespace
+
+extern "C" int ec_rn50_create(ec_rn50_t** out, int width, const int* layers4, int input_resolution,
+                              const float* stem_w_f32, const void* w_bf16, size_t n_w, const float* bias,
+                              size_t n_bias) {
+    if (!out || !layers4 || !stem_w_f32 || !w_bf16 || !bias) return EC_ERR_ARG;
+    if (width % 32 != 0 || (width & (width - 1)) != 0 || input_resolution % 32 != 0) return EC_ERR_SHAPE;
+    ec_rn50* h = new (std::nothrow) ec_rn50();
+    if (!h) return EC_ERR_ALLOC;
+    h->width = width; h->res = input_resolution;
+    h->stem_w = stem_w_f32; h->w = (const uint16_t*)w_bf16; h->bias = bias;
+    size_t wo = 0, bo = 0, mx = 0;
+    auto track = [&](int H, int W, int C) { mx = std::max(mx, (size_t)H * W * C); };
+    auto conv = [&](int src, int dst, int res, int H, int W, int Cin, int Cout, int ks, int pool, int act) {
+        Op o{OP_CONV, src, dst, res, H, W, Cin, Cout, ks, pool, act, wo, bo};
+        wo += (size_t)Cout * ks * ks * Cin;
+        bo += Cout;
+        h->ops.push_back(o);
+        track(pool ? H / 2 : H, pool ? W / 2 : W, Cout);
+    };
+    int R = input_resolution / 2;
+    // buffers: 0 = X (block input / output), 1,2 = temporaries, 3 = identity path, 4 = Y
+    {   // stem
+        Op o{OP_STEM1, -2, 1, -1, input_resolution, input_resolution, 3, width / 2, 3, 0, EC_ACT_RELU, 0, bo};
+        bo += width / 2;
+        h->ops.push_back(o);
+        track(R, R, width / 2);
+        conv(1, 2, -1, R, R, width / 2, width / 2, 3, 0, EC_ACT_RELU);
+        conv(2, 0, -1, R, R, width / 2, width, 3, 1, EC_ACT_RELU);   // + fused AvgPool2d(2)
+        R /= 2;
+    }
+    int inplanes = width, x = 0;
+    for (int li = 0; li < 4; ++li) {
+        const int planes = width << li;
+        for (int b = 0; b < layers4[li]; ++b) {
+            const int stride = (b == 0 && li > 0) ? 2 : 1;
+            const bool ds = stride > 1 || inplanes != planes * 4;
+            const int y = (x == 0) ? 4 : 0;
+            const int Ro = R / stride;
+            conv(x, 1, -1, R, R, inplanes, planes, 1, 0, EC_ACT_RELU);
+            conv(1, 2, -1, R, R, planes, planes, 3, stride > 1 ? 1 : 0, EC_ACT_RELU);
+            int idt = x;
+            // weights are laid out conv1, conv2, conv3, downsample; the downsample conv
+            // has to run BEFORE conv3 (conv3 consumes its output as the residual), so
+            // reserve conv3's weight slot first.
+            const size_t w_c3 = wo, b_c3 = bo;
+            wo += (size_t)planes * 4 * planes; bo += planes * 4;
+            if (ds) {
+                int dsrc = x;
+                if (stride > 1) {
+                    Op o{OP_POOL, x, 1, -1, R, R, inplanes, inplanes, 0, 0, 0, 0, 0};
+                    h->ops.push_back(o);
+                    track(Ro, Ro, inplanes);
+                    dsrc = 1;
+                }
+                conv(dsrc, 3, -1, Ro, Ro, inplanes, planes * 4, 1, 0, EC_ACT_NONE);
+                idt = 3;
+            }
+            {
+                Op o{OP_CONV, 2, y, idt, Ro, Ro, planes, planes * 4, 1, 0, EC_ACT_RELU, w_c3, b_c3};
+                h->ops.push_back(o);
+                track(Ro, Ro, planes * 4);
+            }
+            x = y;
+            inplanes = planes * 4;
+            R = Ro;
+        }
+    }
+    h->ops.back().dst = -3;
+    h->out_c = inplanes; h->out_sp = R;
+    h->max_elems_per_frame = mx;
+    h->n_w = wo; h->n_b = bo;
+    if (n_w != wo || n_bias != bo) { delete h; return EC_ERR_SHAPE; }
+    *out = h;
+    return EC_OK;
+}
+
+extern "C" void ec_rn50_destroy(ec_rn50_t* h) { delete h; }
+extern "C" int ec_rn50_out_channels(const ec_rn50_t* h) { return h ? h->out_c : 0; }
+extern "C" int ec_rn50_out_spatial(const ec_rn50_t* h) { return h ? h->out_sp : 0; }
+extern "C" int ec_rn50_num_ops(const ec_rn50_t* h) { return h ? (int)h->ops.size() : 0; }
+
+extern "C" size_t ec_rn50_workspace_bytes(const ec_rn50_t* h, int batch) {
+    if (!h || batch <= 0) return 0;
+    return NBUF * align_up(h->max_elems_per_frame * 2 * (size_t)batch, 256);
+}
+
+extern "C" int ec_rn50_forward(const ec_rn50_t* h, const float* rgb, int batch, void* workspace, size_t ws_bytes,
+                               void* feat, int chunk, ec_stream_t stream) {
+    if (!h || !rgb || !workspace || !feat) return EC_ERR_ARG;
+    if (batch <= 0) return EC_ERR_SHAPE;
+    if (chunk <= 0 || chunk > batch) chunk = batch;
+    if (ws_bytes < ec_rn50_workspace_bytes(h, chunk)) return EC_ERR_WORKSPACE;
+    const size_t bufsz = align_up(h->max_elems_per_frame * 2 * (size_t)chunk, 256);
+    unsigned char* base = (unsigned char*)workspace;
+    const size_t rgb_stride = (size_t)h->res * h->res * 3;
+    const size_t out_stride = (size_t)h->out_sp * h->out_sp * h->out_c;
+    for (int b0 = 0; b0 < batch; b0 += chunk) {
+        const int nb = std::min(chunk, batch - b0);
+        auto buf = [&](int id) -> void* {
+            if (id == -3) return (uint16_t*)feat + (size_t)b0 * out_stride;
+            return base + (size_t)id * bufsz;
+        };
+        for (const Op& o : h->ops) {
+            int rc;
+            switch (o.kind) {
+                case OP_STEM1:
+                    rc = ec_stem_conv1(rgb + (size_t)b0 * rgb_stride, h->stem_w, h->bias + o.b_off, buf(o.dst), nb, o.H,
+                                       o.W, o.Cout, stream);
+                    break;
+                case OP_POOL:
+                    rc = ec_avgpool2_bf16(buf(o.src), buf(o.dst), nb, o.H, o.W, o.Cin, stream);
+                    break;
+                default:
+                    rc = ec_conv_bf16(buf(o.src), h->w + o.w_off, h->bias + o.b_off, o.res >= 0 ? buf(o.res) : nullptr,
+                                      buf(o.dst), nb, o.H, o.W, o.Cin, o.Cout, o.ks, o.pool, o.act, stream);
+            }
+            if (rc != EC_OK) return rc;
+        }
+    }
+    return EC_OK;
+}

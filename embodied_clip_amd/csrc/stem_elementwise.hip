@@ -1,0 +1,186 @@
+// Stem conv1 (fp32 NHWC frame -> bf16 NHWC) and small bandwidth-bound helpers.
+//
+// Replaces: the first conv-bn-relu of [U] openai/CLIP ModifiedResNet.forward
+// (called at primitive_probing/generate_data/thor_image_features.py:109) plus
+// the `permute(0,3,1,2)` + dtype cast of [U] ClipResNetPreprocessor.process --
+// the kernel reads the sensor's NHWC fp32 frame directly, so neither the
+// permute nor a cast pass over the image ever touches HBM.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// stem conv1: 3x3, stride 2, pad 1, Cin = 3 -> COUT, folded BN + ReLU.
+// K = 27 is too thin for MFMA and the op is bandwidth-bound (602 KB in,
+// 803 KB out per 224^2 frame, 10.8 MMAC), so it is an fp32 VALU kernel:
+// a workgroup stages the (2*16+1)^2 x 3 fp32 input patch of a 16x16 output
+// tile in LDS with coalesced row loads, each lane then owns one output pixel
+// and all COUT channels; weights are wave-uniform (scalar loads).
+// ---------------------------------------------------------------------------
+constexpr int ST = 16;                 // output tile edge
+constexpr int SP = 2 * ST + 1;         // input patch edge (33)
+constexpr int SROW = SP * 3;           // floats per patch row (99)
+
+template <int COUT>
+__global__ __launch_bounds__(256) void stem_conv1_kernel(const float* __restrict__ rgb, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, uint16_t* __restrict__ out,
+                                                         int H, int W, int Ho, int Wo, int tiles_x, int tiles_y) {
+    __shared__ float patch[SP * SROW + 1];
+    int bid = blockIdx.x;
+    const int tx = bid % tiles_x; bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int b = bid / tiles_y;
+    const int oy0 = ty * ST, ox0 = tx * ST;
+    const int iy0 = 2 * oy0 - 1, ix0 = 2 * ox0 - 1;
+    const float* img = rgb + (long)b * H * W * 3;
+    for (int e = threadIdx.x; e < SP * SROW; e += 256) {
+        const int r = e / SROW, c = e - r * SROW;
+        const int iy = iy0 + r;
+        const int ixc = ix0 * 3 + c;   // float index within the image row
+        float v = 0.f;
+        if (iy >= 0 && iy < H && ixc >= 0 && ixc < W * 3) v = img[(long)iy * W * 3 + ixc];
+        patch[e] = v;
+    }
+    __syncthreads();
+    const int ly = threadIdx.x / ST, lx = threadIdx.x % ST;
+    const int oy = oy0 + ly, ox = ox0 + lx;
+    float acc[COUT];
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) acc[c] = bias[c];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci) {
+                const float v = patch[(2 * ly + ky) * SROW + (2 * lx + kx) * 3 + ci];
+                const float* wr = w + ((ky * 3 + kx) * 3 + ci) * COUT;
+#pragma unroll
+                for (int c = 0; c < COUT; ++c) acc[c] = fmaf(v, wr[c], acc[c]);
+            }
+    if (oy < Ho && ox < Wo) {
+        uint4* dst = reinterpret_cast<uint4*>(out + ((long)(b * Ho + oy) * Wo + ox) * COUT);
+#pragma unroll
+        for (int c = 0; c < COUT; c += 8) {
+            uint4 v;
+            v.x = ec_pack2(fmaxf(acc[c + 0], 0.f), fmaxf(acc[c + 1], 0.f));
+            v.y = ec_pack2(fmaxf(acc[c + 2], 0.f), fmaxf(acc[c + 3], 0.f));
+            v.z = ec_pack2(fmaxf(acc[c + 4], 0.f), fmaxf(acc[c + 5], 0.f));
+            v.w = ec_pack2(fmaxf(acc[c + 6], 0.f), fmaxf(acc[c + 7], 0.f));
+            dst[c / 8] = v;
+        }
+    }
+}
+
+// AvgPool2d(2) on bf16 NHWC, 8 channels (16 B) per lane.
+__global__ __launch_bounds__(256) void avgpool2_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out,
+                                                      int H, int W, int C8, long total) {
+    const int Ho = H >> 1, Wo = W >> 1;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        long t = i;
+        const int c = (int)(t % C8); t /= C8;
+        const int xo = (int)(t % Wo); t /= Wo;
+        const int yo = (int)(t % Ho);
+        const long b = t / Ho;
+        const uint4* p = reinterpret_cast<const uint4*>(in) + ((b * H + 2 * yo) * W + 2 * xo) * C8 + c;
+        const uint4 a = p[0], bq = p[C8], cq = p[(long)W * C8], d = p[(long)W * C8 + C8];
+        uint4 o;
+        o.x = ec_pack2(0.25f * (ec_lo(a.x) + ec_lo(bq.x) + ec_lo(cq.x) + ec_lo(d.x)),
+                       0.25f * (ec_hi(a.x) + ec_hi(bq.x) + ec_hi(cq.x) + ec_hi(d.x)));
+        o.y = ec_pack2(0.25f * (ec_lo(a.y) + ec_lo(bq.y) + ec_lo(cq.y) + ec_lo(d.y)),
+                       0.25f * (ec_hi(a.y) + ec_hi(bq.y) + ec_hi(cq.y) + ec_hi(d.y)));
+        o.z = ec_pack2(0.25f * (ec_lo(a.z) + ec_lo(bq.z) + ec_lo(cq.z) + ec_lo(d.z)),
+                       0.25f * (ec_hi(a.z) + ec_hi(bq.z) + ec_hi(cq.z) + ec_hi(d.z)));
+        o.w = ec_pack2(0.25f * (ec_lo(a.w) + ec_lo(bq.w) + ec_lo(cq.w) + ec_lo(d.w)),
+                       0.25f * (ec_hi(a.w) + ec_hi(bq.w) + ec_hi(cq.w) + ec_hi(d.w)));
+        reinterpret_cast<uint4*>(out)[i] = o;
+    }
+}
+
+// bf16 [B, HW, C] -> fp32 [B, C, HW]; one workgroup per (frame, 64-channel slab):
+// coalesced bf16 reads along C, LDS transpose, the slab's [64][HW] floats are
+// one contiguous run of the NCHW output.
+constexpr int TC = 64;
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const uint16_t* __restrict__ in, float* __restrict__ out,
+                                                          int HW, int C) {
+    extern __shared__ float tile[];   // [HW][TC+1]
+    const int slabs = C / TC;
+    const int b = blockIdx.x / slabs, c0 = (blockIdx.x % slabs) * TC;
+    const uint16_t* src = in + (long)b * HW * C + c0;
+    for (int e = threadIdx.x; e < HW * TC; e += 256) {
+        const int hw = e / TC, c = e % TC;
+        tile[hw * (TC + 1) + c] = ec_bf2f(src[(long)hw * C + c]);
+    }
+    __syncthreads();
+    float* dst = out + ((long)b * C + c0) * HW;
+    for (int e = threadIdx.x; e < HW * TC; e += 256) {
+        const int c = e / HW, hw = e % HW;
+        dst[e] = tile[hw * (TC + 1) + c];
+    }
+}
+
+// mean over HW of bf16 [B, HW, C] -> fp32 [B, C]
+__global__ __launch_bounds__(256) void spatial_mean_kernel(const uint16_t* __restrict__ in, float* __restrict__ out,
+                                                          int HW, int C, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const long b = i / C;
+    const int c = (int)(i % C);
+    const uint16_t* p = in + b * HW * C + c;
+    float s = 0.f;
+    for (int hw = 0; hw < HW; ++hw) s += ec_bf2f(p[(long)hw * C]);
+    out[i] = s / (float)HW;
+}
+
+}  // namespace
+
+extern "C" int ec_stem_conv1(const float* rgb, const float* w, const float* bias, void* out, int B, int H, int W,
+                             int Cout, ec_stream_t stream) {
+    if (!rgb || !w || !bias || !out) return EC_ERR_ARG;
+    if (B <= 0 || H < 2 || W < 2) return EC_ERR_SHAPE;
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const int tx = (Wo + ST - 1) / ST, ty = (Ho + ST - 1) / ST;
+    dim3 grid((unsigned)(B * tx * ty));
+    hipStream_t s = (hipStream_t)stream;
+    if (Cout == 32)
+        hipLaunchKernelGGL(stem_conv1_kernel<32>, grid, dim3(256), 0, s, rgb, w, bias, (uint16_t*)out, H, W, Ho, Wo, tx, ty);
+    else if (Cout == 48)
+        hipLaunchKernelGGL(stem_conv1_kernel<48>, grid, dim3(256), 0, s, rgb, w, bias, (uint16_t*)out, H, W, Ho, Wo, tx, ty);
+    else
+        return EC_ERR_SHAPE;
+    EC_CHECK_LAUNCH();
+    return EC_OK;
+}
+
+extern "C" int ec_avgpool2_bf16(const void* in, void* out, int B, int H, int W, int C, ec_stream_t stream) {
+    if (!in || !out) return EC_ERR_ARG;
+    if (B <= 0 || (H & 1) || (W & 1) || C % 8 != 0) return EC_ERR_SHAPE;
+    const long total = (long)B * (H / 2) * (W / 2) * (C / 8);
+    long blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(avgpool2_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t*)in, (uint16_t*)out, H, W, C / 8, total);
+    EC_CHECK_LAUNCH();
+    return EC_OK;
+}
+
+extern "C" int ec_nhwc_bf16_to_nchw_f32(const void* in, float* out, int B, int HW, int C, ec_stream_t stream) {
+    if (!in || !out) return EC_ERR_ARG;
+    if (B <= 0 || HW <= 0 || C % TC != 0) return EC_ERR_SHAPE;
+    const size_t lds = (size_t)HW * (TC + 1) * sizeof(float);
+    if (lds > 64 * 1024) return EC_ERR_SHAPE;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)(B * (C / TC))), dim3(256), lds, (hipStream_t)stream,
+                       (const uint16_t*)in, out, HW, C);
+    EC_CHECK_LAUNCH();
+    return EC_OK;
+}
+
+extern "C" int ec_spatial_mean_bf16(const void* in, float* out, int B, int HW, int C, ec_stream_t stream) {
+    if (!in || !out) return EC_ERR_ARG;
+    if (B <= 0 || HW <= 0 || C <= 0) return EC_ERR_SHAPE;
+    const long total = (long)B * C;
+    hipLaunchKernelGGL(spatial_mean_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t*)in, out, HW, C, total);
+    EC_CHECK_LAUNCH();
+    return EC_OK;
+}

@@ -1,0 +1,161 @@
+"""GPU parity: HIP encoder kernels (through the C-ABI) vs the CPU oracle.
+
+Tolerances (floating point, bf16 storage + fp32 MFMA accumulate):
+  * vs the oracle's bf16-emulation mode (same rounding points): rel-L2 <= 4e-3
+    -- the tight check that catches indexing / layout bugs;
+  * vs the pure fp32 oracle: rel-L2 <= 2e-2 and cosine >= 0.999.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from embodied_clip_amd import synthetic as syn
+from oracle import clip_resnet as ocr
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return ((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-12)).item()
+
+
+def _bf(x):
+    return x.to(torch.bfloat16)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def _conv_case(dev, B, H, W, Cin, Cout, ks, pool, res, act, seed):
+    from embodied_clip_amd import encoder as enc
+    g = torch.Generator().manual_seed(seed)
+    x = _bf(torch.randn(B, H, W, Cin, generator=g))
+    w = _bf(torch.randn(Cout, ks, ks, Cin, generator=g) * (ks * ks * Cin) ** -0.5)
+    b = torch.randn(Cout, generator=g) * 0.1
+    r = _bf(torch.randn(B, H, W, Cout, generator=g)) if res else None
+    # oracle (fp32 math on the bf16-rounded operands; asymmetric random data => transposes are caught)
+    y = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), b, padding=ks // 2)
+    if r is not None:
+        y = y + r.float().permute(0, 3, 1, 2)
+    if act == 1:
+        y = F.relu(y)
+    elif act == 2:
+        y = y * torch.sigmoid(1.702 * y)
+    if pool:
+        y = F.avg_pool2d(y, 2)
+    y = y.permute(0, 2, 3, 1)
+    out = enc.conv_bf16(x.to(dev), w.reshape(Cout, -1).to(dev), b.to(dev), None if r is None else r.to(dev),
+                        ksize=ks, pool=pool, act=act)
+    torch.cuda.synchronize()
+    return out.cpu().float(), y
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,ks,pool,res,act", [
+    (2, 8, 8, 64, 128, 1, False, False, 1),      # 1x1, 128x128 tile
+    (1, 7, 7, 512, 2048, 1, False, True, 1),     # layer4 conv3 + residual, M=49 tail
+    (2, 12, 12, 32, 32, 3, False, False, 1),     # stem conv2: Cin=32 (tap split inside a K tile), BN=32 tile
+    (2, 12, 12, 32, 64, 3, True, False, 1),      # stem conv3 + fused avgpool, BN=64 tile
+    (3, 14, 14, 128, 128, 3, True, False, 1),    # bottleneck conv2 + fused avgpool
+    (2, 14, 14, 256, 256, 3, False, False, 1),   # 3x3 K=2304
+    (5, 7, 7, 64, 256, 1, False, True, 0),       # residual, no activation
+    (1, 10, 6, 128, 384, 1, False, False, 2),    # QuickGELU epilogue, non-square
+    (2, 6, 10, 16, 96, 3, False, False, 1),      # Cin=16, Cout=96 (32-wide tile)
+])
+def test_conv_bf16_matches_oracle(dev, B, H, W, Cin, Cout, ks, pool, res, act):
+    got, ref = _conv_case(dev, B, H, W, Cin, Cout, ks, pool, res, act, seed=B * 1000 + Cin + Cout + ks)
+    assert got.shape == ref.shape
+    # fp32-accumulated result rounded once to bf16: half-ulp 2^-9 relative on each element
+    assert _rel(got, ref) < 4e-3, _rel(got, ref)
+    assert (got - ref).abs().max() <= 2e-2 * ref.abs().max() + 1e-3
+
+
+def test_gemm_bf16_tail_shapes(dev):
+    from embodied_clip_amd import encoder as enc
+    g = torch.Generator().manual_seed(7)
+    for (M, N, K) in [(50, 768, 768), (100, 2304, 768), (37, 64, 200), (300, 32, 3072)]:
+        a = _bf(torch.randn(M, K, generator=g)); w = _bf(torch.randn(N, K, generator=g) * K ** -0.5)
+        b = torch.randn(N, generator=g) * 0.1
+        ref = a.float() @ w.float().t() + b
+        got = enc.gemm_bf16(a.to(dev), w.to(dev), b.to(dev)).cpu().float()
+        assert _rel(got, ref) < 4e-3, (M, N, K, _rel(got, ref))
+
+
+def test_stem_pool_layout_kernels(dev):
+    from embodied_clip_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(3)
+    # stem conv1 vs F.conv2d
+    x = torch.randn(2, 40, 40, 3, generator=g)
+    w = torch.randn(32, 3, 3, 3, generator=g) * 0.2
+    b = torch.randn(32, generator=g) * 0.1
+    ref = F.relu(F.conv2d(x.permute(0, 3, 1, 2), w, b, stride=2, padding=1)).permute(0, 2, 3, 1)
+    wk = w.permute(2, 3, 1, 0).reshape(27, 32).contiguous().to(dev)
+    out = torch.empty(2, 20, 20, 32, dtype=torch.bfloat16, device=dev)
+    xd, bd = x.to(dev), b.to(dev)    # keep device buffers alive: data_ptr() of a temporary dangles
+    _lib.check(lib.ec_stem_conv1(xd.data_ptr(), wk.data_ptr(), bd.data_ptr(), out.data_ptr(), 2, 40, 40, 32, 0))
+    torch.cuda.synchronize()
+    assert _rel(out.cpu(), ref) < 4e-3
+    # avgpool2
+    a = _bf(torch.randn(3, 6, 10, 16, generator=g))
+    o = torch.empty(3, 3, 5, 16, dtype=torch.bfloat16, device=dev)
+    ad = a.to(dev)
+    _lib.check(lib.ec_avgpool2_bf16(ad.data_ptr(), o.data_ptr(), 3, 6, 10, 16, 0))
+    refp = F.avg_pool2d(a.float().permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+    assert _rel(o.cpu(), refp) < 4e-3
+    # nhwc bf16 -> nchw f32 is exact
+    f = _bf(torch.randn(3, 49, 128, generator=g))
+    o2 = torch.empty(3, 128, 49, dtype=torch.float32, device=dev)
+    fd = f.to(dev)
+    _lib.check(lib.ec_nhwc_bf16_to_nchw_f32(fd.data_ptr(), o2.data_ptr(), 3, 49, 128, 0))
+    assert torch.equal(o2.cpu(), f.float().permute(0, 2, 1).contiguous())
+    o3 = torch.empty(3, 128, dtype=torch.float32, device=dev)
+    _lib.check(lib.ec_spatial_mean_bf16(fd.data_ptr(), o3.data_ptr(), 3, 49, 128, 0))
+    assert torch.allclose(o3.cpu(), f.float().mean(1), atol=1e-5)
+
+
+@pytest.mark.parametrize("width,layers,res", [(64, (1, 1, 1, 1), 64), (64, (3, 4, 6, 3), 224)])
+def test_rn50_trunk_matches_oracle(dev, width, layers, res):
+    from embodied_clip_amd.encoder import RN50Trunk
+    sd = syn.rn50_visual_state_dict(11, width=width, layers=layers, output_dim=64, heads=4, input_resolution=res)
+    trunk = RN50Trunk(sd, device=dev, input_resolution=res)
+    B = 3
+    rgb = syn.synthetic_rgb(1000, B, res)
+    feat = trunk.forward(rgb.to(dev))
+    got = trunk.to_nchw_f32(feat).cpu()
+    x = rgb.permute(0, 3, 1, 2)
+    ref_emul = ocr.rn50_trunk(x, sd, emulate_bf16=True)
+    ref_fp32 = ocr.rn50_trunk(x, sd)
+    assert got.shape == ref_fp32.shape
+    assert _rel(got, ref_emul) < 4e-3 * (1 + sum(layers)) ** 0.5, _rel(got, ref_emul)
+    assert _rel(got, ref_fp32) < 2e-2, _rel(got, ref_fp32)
+    cos = F.cosine_similarity(got.flatten(1), ref_fp32.flatten(1)).min().item()
+    assert cos > 0.999, cos
+    # sub-batch chunking is a pure scheduling choice: identical bits
+    trunk.chunk = 2
+    feat2 = trunk.forward(rgb.to(dev))
+    assert torch.equal(feat2.cpu(), feat.cpu())
+    # pool=True head
+    pooled = trunk.spatial_mean(feat).cpu()
+    assert torch.allclose(pooled, got.mean((2, 3)), atol=1e-3 * got.abs().max().item())
+
+
+def test_preprocessor_api_surface(dev):
+    from embodied_clip_amd.clip_preprocessors import ClipResNetPreprocessor
+    sd = syn.rn50_visual_state_dict(0)
+    pre = ClipResNetPreprocessor(rgb_input_uuid="rgb_lowres", clip_model_type="RN50", pool=False,
+                                 output_uuid="rgb_clip_resnet", state_dict=sd, device=dev)
+    assert pre.input_uuids == ["rgb_lowres"] and pre.uuid == "rgb_clip_resnet"
+    assert pre.observation_space.shape == (2048, 7, 7)
+    rgb = syn.synthetic_rgb(5, 2)            # CPU fp32 NHWC, as the sensor hands it over
+    out = pre.to(dev).process({"rgb_lowres": rgb})
+    assert out.shape == (2, 2048, 7, 7) and out.dtype == torch.float32 and out.is_cuda
+    ref = ocr.clip_resnet_preprocessor(rgb, sd)
+    assert _rel(out.cpu(), ref) < 2e-2
+    pre_p = ClipResNetPreprocessor("rgb_lowres", "RN50", pool=True, state_dict=sd, device=dev)
+    assert pre_p.observation_space.shape == (2048,)
+    outp = pre_p.process({"rgb_lowres": rgb})
+    assert outp.shape == (2, 2048)
+    assert _rel(outp.cpu(), ocr.clip_resnet_preprocessor(rgb, sd, pool=True)) < 2e-2
