@@ -33,7 +33,29 @@ SIGNATURES = {
     "ec_rn50_out_spatial": (c_int, [c_void_p]),
     "ec_rn50_forward": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p, c_int, c_void_p]),
     "ec_rn50_num_ops": (c_int, [c_void_p]),
+    "ec_gemm_f32": (c_int, [c_void_p] * 3 + [c_int] * 3 + [C.c_long] * 4 + [c_int, c_int] + [c_void_p] * 3 + [c_int]
+                    + [c_void_p] * 2 + [c_int, c_void_p]),
+    "ec_policy_create": (c_int, [C.POINTER(c_void_p), c_void_p]),
+    "ec_policy_destroy": (None, [c_void_p]),
+    "ec_policy_num_param_tensors": (c_int, [c_void_p]),
+    "ec_policy_flat_size": (c_size_t, [c_void_p]),
+    "ec_policy_param_offset": (c_int, [c_void_p, c_int, C.POINTER(c_size_t), C.POINTER(c_size_t)]),
+    "ec_policy_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int, c_int]),
+    "ec_policy_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                  c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    "ec_policy_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_size_t,
+                                   c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ec_gae": (c_int, [c_void_p] * 7 + [c_int, c_int, c_float, c_float, c_float, c_void_p]),
+    "ec_ppo_loss": (c_int, [c_void_p] * 8 + [C.c_long, c_int, c_float, c_float, c_float, c_float, c_void_p]),
+    "ec_sample_actions": (c_int, [c_void_p] * 4 + [c_int, c_int, C.c_uint64, C.c_uint64, c_void_p]),
+    "ec_clip_adam_step": (c_int, [c_void_p] * 5 + [C.c_long, c_float, c_float, c_float, c_float, c_float, c_int,
+                                  c_void_p]),
 }
+
+
+class PolicyCfg(C.Structure):
+    _fields_ = [(n, c_int) for n in ("in_channels", "spatial", "hidden", "goal_dims", "num_goals", "num_actions",
+                                     "compress_hid", "compress_out", "comb_hid", "comb_out")]
 
 _lib = None
 

@@ -1,0 +1,390 @@
+// GRU actor-critic policy: forward and hand-written backward.
+//
+// Replaces ``ActorCriticModel.forward`` as ``ResnetTensorObjectNavActorCritic``
+// and the autograd graph torch builds behind ``total_loss.backward()``
+// ([U] allenai/allenact ~v0.5.0: projects/objectnav_baselines/models/
+// object_nav_models.py ResnetTensorGoalEncoder; allenact/embodiedai/models/
+// basic_models.py RNNStateEncoder, LinearActorHead, LinearCriticHead;
+// launched by the reference at readme_files/baselines_robothor_objectnav.md:48-51;
+// SURVEY.md §8a a11-a14).
+//
+// Data layout (all fp32 except the frozen features):
+//   feat  [T*N, S, C]      NHWC rows of the rollout feature buffer (bf16 or fp32)
+//   params one flat fp32 buffer in AllenAct parameter order (ec_policy_param_offset)
+//   grads  one flat fp32 buffer, same offsets (one all-reduce bucket)
+// The goal embedding is folded into a [num_goals, 128] row-group bias table
+// E1 = embed_class @ W3[:, 32:]^T + b3, so the 64-channel concat is never built.
+#include <new>
+
+#include "common.h"
+
+extern "C" int ec_gemm_f32(const void* A, const void* B, float* Cp, int M, int N, int K, long sam, long sak, long sbk,
+                           long sbn, int ldc, int flags, const float* bias, const float* gbias, const int* gidx,
+                           int group, const float* dmask, const float* rowscale, int splitk, ec_stream_t stream);
+
+namespace {
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+
+__global__ void goal_to_i32_kernel(const long long* g, int* o, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) o[i] = (int)g[i];
+}
+
+// x[b, c*S + p] = x4[(b*S + p)*Cc + c]   (channel-major flatten of the combiner output)
+__global__ void to_cmajor_kernel(const float* __restrict__ x4, float* __restrict__ x, int S, int Cc, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int per = S * Cc;
+    const long b = i / per;
+    const int r = (int)(i - b * per);
+    const int c = r / S, p = r - c * S;
+    x[i] = x4[(b * S + p) * Cc + c];
+}
+__global__ void from_cmajor_kernel(const float* __restrict__ dx, float* __restrict__ dx4, int S, int Cc, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int per = S * Cc;
+    const long b = i / per;
+    const int r = (int)(i - b * per);
+    const int p = r / Cc, c = r - p * Cc;
+    dx4[i] = dx[b * per + c * S + p];
+}
+
+// torch.nn.GRU cell with the RNNStateEncoder episode mask:
+//   hp = m*h_prev;  r = s(gi_r + m*gh_r + b_hr);  z = s(gi_z + m*gh_z + b_hz)
+//   hn = m*gh_n + b_hn;  n = tanh(gi_n + r*hn);  h = (1-z)*n + z*hp
+// (gh = h_prev W_hh^T without bias; the mask commutes with the row-wise GEMM).
+__global__ void gru_gates_fwd_kernel(const float* __restrict__ gi, const float* __restrict__ gh,
+                                     const float* __restrict__ bhh, const float* __restrict__ hprev,
+                                     const float* __restrict__ mask, float* __restrict__ hout,
+                                     float* __restrict__ gates, float* __restrict__ hn_s, float* __restrict__ hp_s,
+                                     int N, int H) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * H) return;
+    const int n = i / H, j = i - n * H;
+    const float m = mask[n];
+    const float* gir = gi + (long)n * 3 * H;
+    const float* ghr = gh + (long)n * 3 * H;
+    const float hp = m * hprev[i];
+    const float r = sigmoidf_(gir[j] + m * ghr[j] + bhh[j]);
+    const float z = sigmoidf_(gir[H + j] + m * ghr[H + j] + bhh[H + j]);
+    const float hn = m * ghr[2 * H + j] + bhh[2 * H + j];
+    const float nn = tanhf(gir[2 * H + j] + r * hn);
+    hout[i] = (1.f - z) * nn + z * hp;
+    if (gates) {
+        float* g = gates + (long)n * 3 * H;
+        g[j] = r; g[H + j] = z; g[2 * H + j] = nn;
+        hn_s[i] = hn;
+        hp_s[i] = hp;
+    }
+}
+
+// reverse step: dh = dhs + dh_carry;  outputs dgi (wrt gi), dghb (wrt m*gh + b_hh),
+// dh_carry <- m * dh * z   (the GEMM m*(dghb W_hh) is accumulated on top afterwards)
+__global__ void gru_gates_bwd_kernel(const float* __restrict__ dhs, float* __restrict__ dh_carry,
+                                     const float* __restrict__ gates, const float* __restrict__ hn_s,
+                                     const float* __restrict__ hp_s, const float* __restrict__ mask,
+                                     float* __restrict__ dgi, float* __restrict__ dghb, int N, int H) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * H) return;
+    const int n = i / H, j = i - n * H;
+    const float* g = gates + (long)n * 3 * H;
+    const float r = g[j], z = g[H + j], nn = g[2 * H + j];
+    const float hn = hn_s[i], hp = hp_s[i];
+    const float dh = dhs[i] + dh_carry[i];
+    const float dn_pre = dh * (1.f - z) * (1.f - nn * nn);
+    const float dz_pre = dh * (hp - nn) * z * (1.f - z);
+    const float dr_pre = dn_pre * hn * r * (1.f - r);
+    float* a = dgi + (long)n * 3 * H;
+    float* b = dghb + (long)n * 3 * H;
+    a[j] = dr_pre; a[H + j] = dz_pre; a[2 * H + j] = dn_pre;
+    b[j] = dr_pre; b[H + j] = dz_pre; b[2 * H + j] = dn_pre * r;
+    dh_carry[i] = mask[n] * dh * z;
+}
+
+// out[n] += sum_m Y[m*ld + n]
+__global__ void colsum_kernel(const float* __restrict__ Y, float* __restrict__ out, long M, int N, int ld,
+                              int rows_per_block) {
+    const int n = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int sub = threadIdx.x >> 6;   // 4 row lanes
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    const long r1 = min(M, r0 + rows_per_block);
+    float s = 0.f;
+    if (n < N)
+        for (long r = r0 + sub; r < r1; r += 4) s += Y[r * ld + n];
+    __shared__ float red[4][64];
+    red[sub][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (sub == 0 && n < N) atomicAdd(out + n, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// dE1[goal[b], n] += sum_p dm1[(b*S + p)*N + n]
+__global__ void group_sum_scatter_kernel(const float* __restrict__ dm1, const int* __restrict__ goal,
+                                         float* __restrict__ dE1, int S, int N, long B) {
+    const long b = blockIdx.x;
+    if (b >= B) return;
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        const float* p = dm1 + b * S * N + n;
+        float s = 0.f;
+        for (int q = 0; q < S; ++q) s += p[(long)q * N];
+        atomicAdd(dE1 + (long)goal[b] * N + n, s);
+    }
+}
+
+inline size_t al(size_t v) { return (v + 255) / 256 * 256; }
+
+enum { P_EMB, P_W1, P_B1, P_W2, P_B2, P_W3, P_B3, P_W4, P_B4, P_WIH, P_WHH, P_BIH, P_BHH, P_WA, P_BA, P_WC, P_BC, P_COUNT };
+
+}  // namespace
+
+struct ec_policy {
+    ec_policy_cfg c;
+    size_t off[P_COUNT], num[P_COUNT], total;
+};
+
+namespace {
+
+struct Ws {   // float offsets into the workspace
+    size_t E1, c1, c2, m1, x4, x, gi, gh, gates, hn, hp, hs, goal32;
+    size_t dhs, dhc, dgi, dghb, dx, dx4, dm1, dc2, dc1, dE1, end;
+};
+
+Ws layout(const ec_policy* h, int T, int N, bool bwd) {
+    const ec_policy_cfg& c = h->c;
+    const size_t B = (size_t)T * N, S = (size_t)c.spatial * c.spatial, M49 = B * S, H = c.hidden;
+    const size_t flat = (size_t)c.comb_out * S;
+    Ws w; size_t o = 0;
+    auto take = [&](size_t n) { size_t r = o; o += al(n * 4) / 4; return r; };
+    w.E1 = take((size_t)c.num_goals * c.comb_hid);
+    w.c1 = take(M49 * c.compress_hid);
+    w.c2 = take(M49 * c.compress_out);
+    w.m1 = take(M49 * c.comb_hid);
+    w.x4 = take(M49 * c.comb_out);
+    w.x = take(B * flat);
+    w.gi = take(B * 3 * H);
+    w.gh = take((size_t)N * 3 * H);
+    w.gates = take(B * 3 * H);
+    w.hn = take(B * H);
+    w.hp = take(B * H);
+    w.hs = take(B * H);
+    w.goal32 = take(B);
+    w.dhs = w.dhc = w.dgi = w.dghb = w.dx = w.dx4 = w.dm1 = w.dc2 = w.dc1 = w.dE1 = o;
+    if (bwd) {
+        w.dhs = take(B * H);
+        w.dhc = take((size_t)N * H);
+        w.dgi = take(B * 3 * H);
+        w.dghb = take(B * 3 * H);
+        w.dx = take(B * flat);
+        w.dx4 = take(M49 * c.comb_out);
+        w.dm1 = take(M49 * c.comb_hid);
+        w.dc2 = take(M49 * c.compress_out);
+        w.dc1 = take(M49 * c.compress_hid);
+        w.dE1 = take((size_t)c.num_goals * c.comb_hid);
+    }
+    w.end = o;
+    return w;
+}
+
+int pick_splitk(long M, long N, long K) {
+    const long tiles = ((M + 127) / 128) * ((N + 127) / 128);
+    long s = 1024 / (tiles > 0 ? tiles : 1);
+    const long nk = (K + 31) / 32;
+    if (s > nk / 4) s = nk / 4;
+    if (s < 1) s = 1;
+    if (s > 256) s = 256;
+    return (int)s;
+}
+
+#define RC(x) do { int rc__ = (x); if (rc__ != EC_OK) return rc__; } while (0)
+
+}  // namespace
+
+extern "C" int ec_policy_create(ec_policy_t** out, const ec_policy_cfg* cfg) {
+    if (!out || !cfg) return EC_ERR_ARG;
+    const ec_policy_cfg& c = *cfg;
+    if (c.in_channels <= 0 || c.spatial <= 0 || c.hidden <= 0 || c.goal_dims <= 0 || c.num_goals <= 0 ||
+        c.num_actions <= 0 || c.compress_hid <= 0 || c.compress_out <= 0 || c.comb_hid <= 0 || c.comb_out <= 0)
+        return EC_ERR_SHAPE;
+    if ((c.in_channels & 3) || (c.hidden & 3) || (c.compress_hid & 3) || (c.compress_out & 3) || (c.comb_hid & 3) ||
+        (c.comb_out & 3) || (c.goal_dims & 3))
+        return EC_ERR_SHAPE;
+    ec_policy* h = new (std::nothrow) ec_policy();
+    if (!h) return EC_ERR_ALLOC;
+    h->c = c;
+    const size_t S = (size_t)c.spatial * c.spatial, flat = c.comb_out * S, H = c.hidden;
+    const size_t n[P_COUNT] = {(size_t)c.num_goals * c.goal_dims,
+                               (size_t)c.compress_hid * c.in_channels, (size_t)c.compress_hid,
+                               (size_t)c.compress_out * c.compress_hid, (size_t)c.compress_out,
+                               (size_t)c.comb_hid * (c.compress_out + c.goal_dims), (size_t)c.comb_hid,
+                               (size_t)c.comb_out * c.comb_hid, (size_t)c.comb_out,
+                               3 * H * flat, 3 * H * H, 3 * H, 3 * H,
+                               (size_t)c.num_actions * H, (size_t)c.num_actions, H, 1};
+    size_t o = 0;
+    for (int i = 0; i < P_COUNT; ++i) { h->off[i] = o; h->num[i] = n[i]; o += (n[i] + 3) / 4 * 4; }   // 16-B aligned
+    h->total = o;
+    *out = h;
+    return EC_OK;
+}
+extern "C" void ec_policy_destroy(ec_policy_t* h) { delete h; }
+extern "C" int ec_policy_num_param_tensors(const ec_policy_t*) { return P_COUNT; }
+extern "C" size_t ec_policy_flat_size(const ec_policy_t* h) { return h ? h->total : 0; }
+extern "C" int ec_policy_param_offset(const ec_policy_t* h, int idx, size_t* off, size_t* numel) {
+    if (!h || idx < 0 || idx >= P_COUNT || !off || !numel) return EC_ERR_ARG;
+    *off = h->off[idx]; *numel = h->num[idx];
+    return EC_OK;
+}
+extern "C" size_t ec_policy_workspace_bytes(const ec_policy_t* h, int T, int N, int for_backward) {
+    if (!h || T <= 0 || N <= 0) return 0;
+    return layout(h, T, N, for_backward != 0).end * 4;
+}
+
+extern "C" int ec_policy_forward(const ec_policy_t* h, const float* params, const void* feat, int feat_bf16,
+                                 const int64_t* goal, const float* h0, const float* masks, int T, int N,
+                                 void* workspace, size_t ws_bytes, float* hv, float* h_final, ec_stream_t stream) {
+    if (!h || !params || !feat || !goal || !h0 || !masks || !workspace || !hv) return EC_ERR_ARG;
+    if (T <= 0 || N <= 0) return EC_ERR_SHAPE;
+    const ec_policy_cfg& c = h->c;
+    const Ws w = layout(h, T, N, false);
+    if (ws_bytes < w.end * 4) return EC_ERR_WORKSPACE;
+    float* ws = (float*)workspace;
+    hipStream_t s = (hipStream_t)stream;
+    const int B = T * N, S = c.spatial * c.spatial, H = c.hidden, A1 = c.num_actions + 1;
+    const int M49 = B * S, C = c.in_channels, cat = c.compress_out + c.goal_dims, flat = c.comb_out * S;
+    const float* P = params;
+    auto W = [&](int i) { return P + h->off[i]; };
+    int* goal32 = (int*)(ws + w.goal32);
+    hipLaunchKernelGGL(goal_to_i32_kernel, dim3((B + 255) / 256), dim3(256), 0, s, (const long long*)goal, goal32, B);
+    // E1 = embed_class @ W3[:, co:]^T + b3
+    RC(ec_gemm_f32(W(P_EMB), W(P_W3) + c.compress_out, ws + w.E1, c.num_goals, c.comb_hid, c.goal_dims, c.goal_dims, 1,
+                   1, cat, c.comb_hid, 0, W(P_B3), nullptr, nullptr, 0, nullptr, nullptr, 1, stream));
+    // resnet_compressor
+    RC(ec_gemm_f32(feat, W(P_W1), ws + w.c1, M49, c.compress_hid, C, C, 1, 1, C, c.compress_hid,
+                   EC_GEMM_RELU | (feat_bf16 ? EC_GEMM_A_BF16 : 0), W(P_B1), nullptr, nullptr, 0, nullptr, nullptr, 1,
+                   stream));
+    RC(ec_gemm_f32(ws + w.c1, W(P_W2), ws + w.c2, M49, c.compress_out, c.compress_hid, c.compress_hid, 1, 1,
+                   c.compress_hid, c.compress_out, EC_GEMM_RELU, W(P_B2), nullptr, nullptr, 0, nullptr, nullptr, 1,
+                   stream));
+    // target_obs_combiner (goal half folded into the row-group bias E1[goal])
+    RC(ec_gemm_f32(ws + w.c2, W(P_W3), ws + w.m1, M49, c.comb_hid, c.compress_out, c.compress_out, 1, 1, cat,
+                   c.comb_hid, EC_GEMM_RELU, nullptr, ws + w.E1, goal32, S, nullptr, nullptr, 1, stream));
+    RC(ec_gemm_f32(ws + w.m1, W(P_W4), ws + w.x4, M49, c.comb_out, c.comb_hid, c.comb_hid, 1, 1, c.comb_hid,
+                   c.comb_out, 0, W(P_B4), nullptr, nullptr, 0, nullptr, nullptr, 1, stream));
+    {
+        const long total = (long)B * flat;
+        hipLaunchKernelGGL(to_cmajor_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ws + w.x4, ws + w.x,
+                           S, c.comb_out, total);
+    }
+    // GRU: input projection for all T at once, then the sequential recurrence
+    RC(ec_gemm_f32(ws + w.x, W(P_WIH), ws + w.gi, B, 3 * H, flat, flat, 1, 1, flat, 3 * H, 0, W(P_BIH), nullptr,
+                   nullptr, 0, nullptr, nullptr, 1, stream));
+    for (int t = 0; t < T; ++t) {
+        const float* hprev = (t == 0) ? h0 : ws + w.hs + (size_t)(t - 1) * N * H;
+        RC(ec_gemm_f32(hprev, W(P_WHH), ws + w.gh, N, 3 * H, H, H, 1, 1, H, 3 * H, 0, nullptr, nullptr, nullptr, 0,
+                       nullptr, nullptr, 1, stream));
+        const size_t o3 = (size_t)t * N * 3 * H, o1 = (size_t)t * N * H;
+        hipLaunchKernelGGL(gru_gates_fwd_kernel, dim3((N * H + 255) / 256), dim3(256), 0, s, ws + w.gi + o3, ws + w.gh,
+                           W(P_BHH), hprev, masks + (size_t)t * N, ws + w.hs + o1, ws + w.gates + o3, ws + w.hn + o1,
+                           ws + w.hp + o1, N, H);
+    }
+    // heads: hv[:, :A] = actor logits, hv[:, A] = critic value
+    RC(ec_gemm_f32(ws + w.hs, W(P_WA), hv, B, c.num_actions, H, H, 1, 1, H, A1, 0, W(P_BA), nullptr, nullptr, 0,
+                   nullptr, nullptr, 1, stream));
+    RC(ec_gemm_f32(ws + w.hs, W(P_WC), hv + c.num_actions, B, 1, H, H, 1, 1, H, A1, 0, W(P_BC), nullptr, nullptr, 0,
+                   nullptr, nullptr, 1, stream));
+    if (h_final)
+        (void)hipMemcpyAsync(h_final, ws + w.hs + (size_t)(T - 1) * N * H, (size_t)N * H * 4, hipMemcpyDeviceToDevice, s);
+    EC_CHECK_LAUNCH();
+    return EC_OK;
+}
+
+extern "C" int ec_policy_backward(const ec_policy_t* h, const float* params, const void* feat, int feat_bf16,
+                                  const float* masks, int T, int N, void* workspace, size_t ws_bytes, const float* dhv,
+                                  const float* dh_final, float* grads, ec_stream_t stream) {
+    if (!h || !params || !feat || !masks || !workspace || !dhv || !grads) return EC_ERR_ARG;
+    if (T <= 0 || N <= 0) return EC_ERR_SHAPE;
+    const ec_policy_cfg& c = h->c;
+    const Ws w = layout(h, T, N, true);
+    if (ws_bytes < w.end * 4) return EC_ERR_WORKSPACE;
+    float* ws = (float*)workspace;
+    hipStream_t s = (hipStream_t)stream;
+    const int B = T * N, S = c.spatial * c.spatial, H = c.hidden, A = c.num_actions, A1 = A + 1;
+    const int M49 = B * S, C = c.in_channels, cat = c.compress_out + c.goal_dims, flat = c.comb_out * S;
+    auto W = [&](int i) { return params + h->off[i]; };
+    auto G = [&](int i) { return grads + h->off[i]; };
+    const int* goal32 = (const int*)(ws + w.goal32);
+    auto colsum = [&](const float* Y, float* out, long M, int Ncol, int ld) {
+        const int rpb = 2048;
+        dim3 grid((unsigned)((Ncol + 63) / 64), (unsigned)((M + rpb - 1) / rpb));
+        hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, s, Y, out, M, Ncol, ld, rpb);
+    };
+    // ---- heads ----
+    RC(ec_gemm_f32(dhv, W(P_WA), ws + w.dhs, B, H, A, A1, 1, H, 1, H, 0, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
+                   1, stream));
+    RC(ec_gemm_f32(dhv + A, W(P_WC), ws + w.dhs, B, H, 1, A1, 1, H, 1, H, EC_GEMM_ACCUMULATE, nullptr, nullptr, nullptr,
+                   0, nullptr, nullptr, 1, stream));
+    RC(ec_gemm_f32(dhv, ws + w.hs, G(P_WA), A, H, B, 1, A1, H, 1, H, EC_GEMM_ACCUMULATE, nullptr, nullptr, nullptr, 0,
+                   nullptr, nullptr, pick_splitk(A, H, B), stream));
+    RC(ec_gemm_f32(dhv + A, ws + w.hs, G(P_WC), 1, H, B, 1, A1, H, 1, H, EC_GEMM_ACCUMULATE, nullptr, nullptr, nullptr,
+                   0, nullptr, nullptr, pick_splitk(1, H, B), stream));
+    colsum(dhv, G(P_BA), B, A, A1);
+    colsum(dhv + A, G(P_BC), B, 1, A1);
+    // ---- GRU, reverse time ----
+    if (dh_final) (void)hipMemcpyAsync(ws + w.dhc, dh_final, (size_t)N * H * 4, hipMemcpyDeviceToDevice, s);
+    else (void)hipMemsetAsync(ws + w.dhc, 0, (size_t)N * H * 4, s);
+    for (int t = T - 1; t >= 0; --t) {
+        const size_t o3 = (size_t)t * N * 3 * H, o1 = (size_t)t * N * H;
+        hipLaunchKernelGGL(gru_gates_bwd_kernel, dim3((N * H + 255) / 256), dim3(256), 0, s, ws + w.dhs + o1, ws + w.dhc,
+                           ws + w.gates + o3, ws + w.hn + o1, ws + w.hp + o1, masks + (size_t)t * N, ws + w.dgi + o3,
+                           ws + w.dghb + o3, N, H);
+        // dh_carry += m * (dghb @ W_hh)
+        RC(ec_gemm_f32(ws + w.dghb + o3, W(P_WHH), ws + w.dhc, N, H, 3 * H, 3 * H, 1, H, 1, H, EC_GEMM_ACCUMULATE, nullptr,
+                       nullptr, nullptr, 0, nullptr, masks + (size_t)t * N, 1, stream));
+    }
+    // weight grads of the recurrence / input projection (TN over all T*N rows)
+    auto tn = [&](const float* dY, int ldy, const void* X, int ldx, int x_bf16, float* dW, int Mo, int No, long K,
+                  int ldc) {
+        const int sk = pick_splitk(Mo, No, K);   // grads += ... (atomics when split, += otherwise)
+        return ec_gemm_f32(dY, X, dW, Mo, No, (int)K, 1, ldy, ldx, 1, ldc,
+                           EC_GEMM_ACCUMULATE | (x_bf16 ? EC_GEMM_B_BF16 : 0), nullptr, nullptr, nullptr, 0, nullptr,
+                           nullptr, sk, stream);
+    };
+    RC(tn(ws + w.dghb, 3 * H, ws + w.hp, H, 0, G(P_WHH), 3 * H, H, B, H));
+    colsum(ws + w.dghb, G(P_BHH), B, 3 * H, 3 * H);
+    RC(tn(ws + w.dgi, 3 * H, ws + w.x, flat, 0, G(P_WIH), 3 * H, flat, B, flat));
+    colsum(ws + w.dgi, G(P_BIH), B, 3 * H, 3 * H);
+    // dx = dgi @ W_ih
+    RC(ec_gemm_f32(ws + w.dgi, W(P_WIH), ws + w.dx, B, flat, 3 * H, 3 * H, 1, flat, 1, flat, 0, nullptr, nullptr, nullptr,
+                   0, nullptr, nullptr, 1, stream));
+    {
+        const long total = (long)B * flat;
+        hipLaunchKernelGGL(from_cmajor_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ws + w.dx,
+                           ws + w.dx4, S, c.comb_out, total);
+    }
+    // ---- target_obs_combiner ----
+    RC(tn(ws + w.dx4, c.comb_out, ws + w.m1, c.comb_hid, 0, G(P_W4), c.comb_out, c.comb_hid, M49, c.comb_hid));
+    colsum(ws + w.dx4, G(P_B4), M49, c.comb_out, c.comb_out);
+    RC(ec_gemm_f32(ws + w.dx4, W(P_W4), ws + w.dm1, M49, c.comb_hid, c.comb_out, c.comb_out, 1, c.comb_hid, 1, c.comb_hid,
+                   0, nullptr, nullptr, nullptr, 0, ws + w.m1, nullptr, 1, stream));
+    RC(tn(ws + w.dm1, c.comb_hid, ws + w.c2, c.compress_out, 0, G(P_W3), c.comb_hid, c.compress_out, M49, cat));
+    (void)hipMemsetAsync(ws + w.dE1, 0, (size_t)c.num_goals * c.comb_hid * 4, s);
+    hipLaunchKernelGGL(group_sum_scatter_kernel, dim3((unsigned)B), dim3(128), 0, s, ws + w.dm1, goal32, ws + w.dE1, S,
+                       c.comb_hid, (long)B);
+    colsum(ws + w.dE1, G(P_B3), c.num_goals, c.comb_hid, c.comb_hid);
+    RC(tn(ws + w.dE1, c.comb_hid, W(P_EMB), c.goal_dims, 0, G(P_W3) + c.compress_out, c.comb_hid, c.goal_dims,
+          c.num_goals, cat));
+    RC(ec_gemm_f32(ws + w.dE1, W(P_W3) + c.compress_out, G(P_EMB), c.num_goals, c.goal_dims, c.comb_hid, c.comb_hid, 1,
+                   cat, 1, c.goal_dims, EC_GEMM_ACCUMULATE, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 1, stream));
+    // ---- resnet_compressor ----
+    RC(ec_gemm_f32(ws + w.dm1, W(P_W3), ws + w.dc2, M49, c.compress_out, c.comb_hid, c.comb_hid, 1, cat, 1,
+                   c.compress_out, 0, nullptr, nullptr, nullptr, 0, ws + w.c2, nullptr, 1, stream));
+    RC(tn(ws + w.dc2, c.compress_out, ws + w.c1, c.compress_hid, 0, G(P_W2), c.compress_out, c.compress_hid, M49,
+          c.compress_hid));
+    colsum(ws + w.dc2, G(P_B2), M49, c.compress_out, c.compress_out);
+    RC(ec_gemm_f32(ws + w.dc2, W(P_W2), ws + w.dc1, M49, c.compress_hid, c.compress_out, c.compress_out, 1,
+                   c.compress_hid, 1, c.compress_hid, 0, nullptr, nullptr, nullptr, 0, ws + w.c1, nullptr, 1, stream));
+    RC(tn(ws + w.dc1, c.compress_hid, feat, C, feat_bf16, G(P_W1), c.compress_hid, C, M49, C));
+    colsum(ws + w.dc1, G(P_B1), M49, c.compress_hid, c.compress_hid);
+    EC_CHECK_LAUNCH();
+    return EC_OK;
+}

@@ -1,0 +1,260 @@
+// GAE returns, advantage normalisation, PPO loss (forward + analytic backward),
+// categorical sampling, global-norm clip + Adam on the flat parameter bucket.
+//
+// Replaces ([U] allenai/allenact ~v0.5.0):
+//   RolloutStorage.compute_returns(use_gae=True)      (onpolicy_sync/storage.py)
+//   PPO.loss_per_step / PPO.loss                       (onpolicy_sync/losses/ppo.py)
+//   CategoricalDistr.sample / log_prob / entropy       (base_abstractions/distributions.py)
+//   clip_grad_norm_(max_grad_norm) + Adam.step()       (onpolicy_sync/engine.py backprop_step)
+// All fp32; reductions accumulate in fp64 so the result does not depend on
+// the launch geometry beyond fp32 rounding of the inputs.
+#include <math.h>
+
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+// block (256 threads) reduction of up to NV doubles, then one atomicAdd per value
+template <int NV>
+__device__ __forceinline__ void block_atomic_sum(double (&v)[NV], double* out) {
+    __shared__ double red[4][NV];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const double s = wave_sum(v[i]);
+        if (lane == 0) red[wave][i] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) atomicAdd(out + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// One lane per sampler: reverse scan over T.
+//   delta = r[t] + g*V[t+1]*m[t+1] - V[t];  gae = delta + g*tau*m[t+1]*gae;  R[t] = gae + V[t]
+// adv[t] = R[t] - V[t]; also accumulates sum(adv), sum(adv^2) for the normalisation.
+__global__ void gae_kernel(const float* __restrict__ rew, const float* __restrict__ val, const float* __restrict__ msk,
+                           float* __restrict__ ret, float* __restrict__ adv, double* __restrict__ stats, int T, int N,
+                           float gamma, float tau) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    double acc[2] = {0.0, 0.0};
+    if (n < N) {
+        float gae = 0.f;
+        ret[(long)T * N + n] = val[(long)T * N + n];
+        for (int t = T - 1; t >= 0; --t) {
+            const float m1 = msk[(long)(t + 1) * N + n];
+            const float v = val[(long)t * N + n];
+            const float delta = rew[(long)t * N + n] + gamma * val[(long)(t + 1) * N + n] * m1 - v;
+            gae = delta + gamma * tau * m1 * gae;
+            ret[(long)t * N + n] = gae + v;
+            adv[(long)t * N + n] = gae;
+            acc[0] += (double)gae;
+            acc[1] += (double)gae * (double)gae;
+        }
+    }
+    block_atomic_sum<2>(acc, stats);
+}
+
+// norm_adv = (adv - mean) / (std_unbiased + eps)
+__global__ void adv_norm_kernel(const float* __restrict__ adv, const double* __restrict__ stats, float* __restrict__ out,
+                                long n, float eps) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double mean = stats[0] / (double)n;
+    double var = (stats[1] - (double)n * mean * mean) / (double)(n > 1 ? n - 1 : 1);
+    if (var < 0) var = 0;
+    out[i] = (float)(((double)adv[i] - mean) / (sqrt(var) + (double)eps));
+}
+
+// PPO loss, forward + backward in one pass over the [B] steps.
+// hv[b, 0:A] = logits, hv[b, A] = value.  sums[0..3] += {action, value, entropy(-H), ratio}
+// dhv = d(total)/d(hv) * grad_scale with total = mean(La) + vc*mean(Lv) + ec*mean(Le).
+template <int MAXA>
+__global__ void ppo_loss_kernel(const float* __restrict__ hv, const long long* __restrict__ actions,
+                                const float* __restrict__ old_logp, const float* __restrict__ old_val,
+                                const float* __restrict__ returns, const float* __restrict__ nadv,
+                                float* __restrict__ dhv, double* __restrict__ sums, long B, int A, float clip,
+                                float vcoef, float ecoef, float grad_scale) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    double acc[4] = {0, 0, 0, 0};
+    if (i < B) {
+        const float* row = hv + i * (A + 1);
+        float lg[MAXA];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < MAXA; ++k) {
+            lg[k] = (k < A) ? row[k] : -INFINITY;
+            mx = fmaxf(mx, lg[k]);
+        }
+        float se = 0.f;
+#pragma unroll
+        for (int k = 0; k < MAXA; ++k) se += (k < A) ? expf(lg[k] - mx) : 0.f;
+        const float lse = mx + logf(se);
+        const int a = (int)actions[i];
+        float ent = 0.f, lp_a = 0.f;
+        float pr[MAXA], lpk[MAXA];
+#pragma unroll
+        for (int k = 0; k < MAXA; ++k) {
+            lpk[k] = (k < A) ? lg[k] - lse : 0.f;
+            pr[k] = (k < A) ? expf(lpk[k]) : 0.f;
+            ent -= pr[k] * lpk[k];
+            if (k == a) lp_a = lpk[k];
+        }
+        const float adv = nadv[i];
+        const float ratio = expf(lp_a - old_logp[i]);
+        const float surr1 = ratio * adv;
+        const float rc = fminf(fmaxf(ratio, 1.f - clip), 1.f + clip);
+        const float surr2 = rc * adv;
+        const bool use2 = surr2 < surr1;
+        const float la = -(use2 ? surr2 : surr1);
+        // d(-min)/d(ratio): surr1 branch -> -adv; surr2 branch -> -adv inside the clamp range, 0 outside
+        const bool in_rng = (ratio >= 1.f - clip) && (ratio <= 1.f + clip);
+        const float dla_dratio = use2 ? (in_rng ? -adv : 0.f) : -adv;
+        const float dla_dlp = dla_dratio * ratio;
+        const float v = row[A], vo = old_val[i], R = returns[i];
+        const float dv = v - vo;
+        const float vcl = vo + fminf(fmaxf(dv, -clip), clip);
+        const float l1 = (v - R) * (v - R), l2 = (vcl - R) * (vcl - R);
+        const float lv = 0.5f * fmaxf(l1, l2);
+        const bool v_in = (dv >= -clip) && (dv <= clip);
+        const float g1 = (v - R), g2 = v_in ? (vcl - R) : 0.f;
+        const float dlv_dv = (l1 > l2) ? g1 : ((l2 > l1) ? g2 : 0.5f * (g1 + g2));   // torch.max splits ties evenly
+        const float invB = grad_scale / (float)B;
+        float* drow = dhv + i * (A + 1);
+#pragma unroll
+        for (int k = 0; k < MAXA; ++k)
+            if (k < A) {
+                const float dlp = ((k == a) ? 1.f : 0.f) - pr[k];
+                const float dent = pr[k] * (lpk[k] + ent);          // d(-H)/dlogit_k
+                drow[k] = invB * (dla_dlp * dlp + ecoef * dent);
+            }
+        drow[A] = invB * vcoef * dlv_dv;
+        acc[0] = la; acc[1] = lv; acc[2] = -ent; acc[3] = ratio;
+    }
+    block_atomic_sum<4>(acc, sums);
+}
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// CategoricalDistr.sample() + log_prob(): inverse-CDF on a counter-based uniform.
+template <int MAXA>
+__global__ void sample_kernel(const float* __restrict__ hv, long long* __restrict__ actions, float* __restrict__ logp,
+                              float* __restrict__ values, int N, int A, uint64_t seed, uint64_t step) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const float* row = hv + (long)n * (A + 1);
+    float mx = -INFINITY;
+    for (int k = 0; k < A; ++k) mx = fmaxf(mx, row[k]);
+    float se = 0.f;
+    for (int k = 0; k < A; ++k) se += expf(row[k] - mx);
+    const float lse = mx + logf(se);
+    const uint64_t h = mix64(mix64(seed) ^ (step * 0x100000001B3ull + (uint64_t)n));
+    const float u = (float)((h >> 40) * (1.0 / 16777216.0));   // [0,1) with 24 bits
+    float cdf = 0.f;
+    int a = A - 1;
+    for (int k = 0; k < A; ++k) {
+        cdf += expf(row[k] - lse);
+        if (u < cdf) { a = k; break; }
+    }
+    actions[n] = a;
+    logp[n] = row[a] - lse;
+    if (values) values[n] = row[A];
+}
+
+__global__ void sumsq_kernel(const float* __restrict__ g, double* __restrict__ out, long n) {
+    double acc[1] = {0.0};
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) acc[0] += (double)g[i] * (double)g[i];
+    block_atomic_sum<1>(acc, out);
+}
+
+// clip_grad_norm_ (coef = min(1, max_norm/(norm+1e-6))) fused into torch.optim.Adam's update
+__global__ void clip_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                 float* __restrict__ v, const double* __restrict__ sumsq, long n, float max_norm,
+                                 float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float coef = 1.f;
+    if (max_norm > 0.f) {
+        const float norm = (float)sqrt(sumsq[0]);
+        coef = fminf(max_norm / (norm + 1e-6f), 1.f);
+    }
+    const float gi = g[i] * coef;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] -= (lr / bc1) * (mi / denom);
+}
+
+}  // namespace
+
+extern "C" int ec_gae(const float* rewards, const float* values, const float* masks, float* returns, float* adv,
+                      float* norm_adv, double* stats2, int T, int N, float gamma, float tau, float eps,
+                      ec_stream_t stream) {
+    if (!rewards || !values || !masks || !returns || !adv || !stats2) return EC_ERR_ARG;
+    if (T <= 0 || N <= 0) return EC_ERR_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    (void)hipMemsetAsync(stats2, 0, 2 * sizeof(double), s);
+    hipLaunchKernelGGL(gae_kernel, dim3((N + 255) / 256), dim3(256), 0, s, rewards, values, masks, returns, adv, stats2, T,
+                       N, gamma, tau);
+    if (norm_adv) {
+        const long n = (long)T * N;
+        hipLaunchKernelGGL(adv_norm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, adv, stats2, norm_adv, n,
+                           eps);
+    }
+    EC_CHECK_LAUNCH();
+    return EC_OK;
+}
+
+extern "C" int ec_ppo_loss(const float* hv, const int64_t* actions, const float* old_logp, const float* old_values,
+                           const float* returns, const float* norm_adv, float* dhv, double* sums4, long B, int A,
+                           float clip, float vcoef, float ecoef, float grad_scale, ec_stream_t stream) {
+    if (!hv || !actions || !old_logp || !old_values || !returns || !norm_adv || !dhv || !sums4) return EC_ERR_ARG;
+    if (B <= 0 || A <= 0 || A > 16) return EC_ERR_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    (void)hipMemsetAsync(sums4, 0, 4 * sizeof(double), s);
+    dim3 grid((unsigned)((B + 255) / 256));
+    if (A <= 8)
+        hipLaunchKernelGGL(ppo_loss_kernel<8>, grid, dim3(256), 0, s, hv, (const long long*)actions, old_logp, old_values,
+                           returns, norm_adv, dhv, sums4, B, A, clip, vcoef, ecoef, grad_scale);
+    else
+        hipLaunchKernelGGL(ppo_loss_kernel<16>, grid, dim3(256), 0, s, hv, (const long long*)actions, old_logp, old_values,
+                           returns, norm_adv, dhv, sums4, B, A, clip, vcoef, ecoef, grad_scale);
+    EC_CHECK_LAUNCH();
+    return EC_OK;
+}
+
+extern "C" int ec_sample_actions(const float* hv, int64_t* actions, float* logp, float* values, int N, int A,
+                                 uint64_t seed, uint64_t step, ec_stream_t stream) {
+    if (!hv || !actions || !logp) return EC_ERR_ARG;
+    if (N <= 0 || A <= 0) return EC_ERR_SHAPE;
+    hipLaunchKernelGGL(sample_kernel<16>, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, hv,
+                       (long long*)actions, logp, values, N, A, seed, step);
+    EC_CHECK_LAUNCH();
+    return EC_OK;
+}
+
+extern "C" int ec_clip_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, double* sumsq1,
+                                 long n, float max_grad_norm, float lr, float beta1, float beta2, float eps, int step,
+                                 ec_stream_t stream) {
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !sumsq1) return EC_ERR_ARG;
+    if (n <= 0 || step <= 0) return EC_ERR_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    (void)hipMemsetAsync(sumsq1, 0, sizeof(double), s);
+    long blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, s, grads, sumsq1, n);
+    const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+    const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    hipLaunchKernelGGL(clip_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, params, grads, exp_avg, exp_avg_sq,
+                       sumsq1, n, max_grad_norm, lr, beta1, beta2, eps, bc1, bc2s);
+    EC_CHECK_LAUNCH();
+    return EC_OK;
+}

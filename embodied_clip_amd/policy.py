@@ -1,0 +1,311 @@
+"""Drop-in ``ResnetTensorObjectNavActorCritic`` (an AllenAct ``ActorCriticModel``)
+whose forward AND backward are the hand-written gfx950 kernels behind
+``ec_policy_forward`` / ``ec_policy_backward`` (include/ec_amd.h).
+
+Mirrors [U] allenai/allenact ~v0.5.0
+``projects/objectnav_baselines/models/object_nav_models.py`` (the model the
+reference's RoboTHOR config instantiates:
+readme_files/baselines_robothor_objectnav.md:51) -- same constructor keywords,
+``forward(observations, memory, prev_actions, masks)`` contract, recurrent
+memory specification and parameter names, so checkpoints,
+optimisers and the engine's per-parameter all-reduce keep working.
+
+MI355X-first differences, invisible through the API:
+  * all 17 parameters are views into ONE flat fp32 buffer (and their grads into
+    one flat grad buffer): a single RCCL all-reduce bucket and one fused
+    clip+Adam launch instead of 17 of each;
+  * the forward is autograd-visible through a ``torch.autograd.Function`` whose
+    backward is the HIP backward (no torch autograd graph inside the policy).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import OrderedDict
+from typing import Any, Dict, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib, spaces
+from .synthetic import POLICY_PARAM_ORDER, policy_param_shapes
+
+
+# ---- AllenAct duck types ---------------------------------------------------------------------
+
+class Memory(dict):
+    """Minimal ``allenact.base_abstractions.misc.Memory``: key -> (tensor, sampler_dim)."""
+
+    def check_append(self, key: str, tensor: torch.Tensor, sampler_dim: int) -> "Memory":
+        self[key] = (tensor, sampler_dim)
+        return self
+
+    def tensor(self, key: str) -> torch.Tensor:
+        return self[key][0]
+
+    def sampler_dim(self, key: str) -> int:
+        return self[key][1]
+
+    def set_tensor(self, key: str, tensor: torch.Tensor) -> "Memory":
+        self[key] = (tensor, self[key][1] if key in self else 1)
+        return self
+
+
+class CategoricalDistr:
+    """``allenact.base_abstractions.distributions.CategoricalDistr`` over logits [..., A]."""
+
+    def __init__(self, logits: torch.Tensor):
+        self.logits = logits
+
+    @property
+    def log_probs_tensor(self):
+        return torch.log_softmax(self.logits, dim=-1)
+
+    @property
+    def probs_tensor(self):
+        return torch.softmax(self.logits, dim=-1)
+
+    def log_prob(self, actions: torch.Tensor) -> torch.Tensor:
+        return self.log_probs_tensor.gather(-1, actions.unsqueeze(-1)).squeeze(-1)
+
+    def entropy(self) -> torch.Tensor:
+        lp = self.log_probs_tensor
+        return -(lp.exp() * lp).sum(-1)
+
+    def mode(self) -> torch.Tensor:
+        return self.logits.argmax(dim=-1)
+
+    def sample(self, sample_shape=torch.Size()) -> torch.Tensor:
+        p = self.probs_tensor
+        return torch.multinomial(p.reshape(-1, p.shape[-1]), 1).reshape(p.shape[:-1])
+
+
+class ActorCriticOutput:
+    def __init__(self, distributions, values, extras):
+        self.distributions, self.values, self.extras = distributions, values, extras
+
+    def __iter__(self):   # allow tuple-unpacking like the upstream NamedTuple
+        return iter((self.distributions, self.values, self.extras))
+
+
+# ---- handle ----------------------------------------------------------------------------------
+
+class PolicyHandle:
+    """``ec_policy_t`` plus the flat-buffer layout."""
+
+    def __init__(self, **cfg: int):
+        self.lib = _lib.load()
+        self.cfg = dict(in_channels=2048, spatial=7, hidden=512, goal_dims=32, num_goals=12, num_actions=6,
+                        compress_hid=128, compress_out=32, comb_hid=128, comb_out=32)
+        self.cfg.update(cfg)
+        c = _lib.PolicyCfg(**self.cfg)
+        h = C.c_void_p()
+        _lib.check(self.lib.ec_policy_create(C.byref(h), C.byref(c)), "ec_policy_create")
+        self.h = h
+        self.flat_size = self.lib.ec_policy_flat_size(h)
+        self.shapes = policy_param_shapes(**self.cfg)
+        self.offsets: "OrderedDict[str, Tuple[int, int]]" = OrderedDict()
+        assert self.lib.ec_policy_num_param_tensors(h) == len(POLICY_PARAM_ORDER)
+        for i, name in enumerate(POLICY_PARAM_ORDER):
+            off, num = C.c_size_t(), C.c_size_t()
+            _lib.check(self.lib.ec_policy_param_offset(h, i, C.byref(off), C.byref(num)))
+            n = 1
+            for d in self.shapes[name]:
+                n *= d
+            assert n == num.value, (name, n, num.value)
+            self.offsets[name] = (off.value, num.value)
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.ec_policy_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    @property
+    def A(self):
+        return self.cfg["num_actions"]
+
+    @property
+    def H(self):
+        return self.cfg["hidden"]
+
+    def workspace_bytes(self, T: int, N: int, backward: bool) -> int:
+        return self.lib.ec_policy_workspace_bytes(self.h, T, N, int(backward))
+
+    def flatten(self, sd: Dict[str, torch.Tensor], device) -> torch.Tensor:
+        flat = torch.zeros(self.flat_size, dtype=torch.float32, device=device)
+        for name, (off, num) in self.offsets.items():
+            flat[off:off + num].copy_(sd[name].reshape(-1).to(device=device, dtype=torch.float32))
+        return flat
+
+    def views(self, flat: torch.Tensor) -> "OrderedDict[str, torch.Tensor]":
+        return OrderedDict((n, flat[o:o + k].view(self.shapes[n])) for n, (o, k) in self.offsets.items())
+
+    def forward(self, flat_params, feat, goal, h0, masks, T, N, ws, hv=None, h_final=None):
+        """feat: bf16 or fp32 NHWC rows [T*N, S*S, C]; returns (hv [T*N, A+1], h_final [N,H])."""
+        assert feat.is_contiguous() and feat.dtype in (torch.bfloat16, torch.float32)
+        dev = flat_params.device
+        if hv is None:
+            hv = torch.empty((T * N, self.A + 1), dtype=torch.float32, device=dev)
+        if h_final is None:
+            h_final = torch.empty((N, self.H), dtype=torch.float32, device=dev)
+        _lib.check(self.lib.ec_policy_forward(
+            self.h, flat_params.data_ptr(), feat.data_ptr(), int(feat.dtype == torch.bfloat16), goal.data_ptr(),
+            h0.data_ptr(), masks.data_ptr(), T, N, ws.data_ptr(), ws.numel() * ws.element_size(), hv.data_ptr(),
+            h_final.data_ptr(), _lib.stream_ptr()), "ec_policy_forward")
+        return hv, h_final
+
+    def backward(self, flat_params, feat, masks, T, N, ws, dhv, dh_final, flat_grads):
+        _lib.check(self.lib.ec_policy_backward(
+            self.h, flat_params.data_ptr(), feat.data_ptr(), int(feat.dtype == torch.bfloat16), masks.data_ptr(), T, N,
+            ws.data_ptr(), ws.numel() * ws.element_size(), dhv.data_ptr(), _lib.ptr(dh_final), flat_grads.data_ptr(),
+            _lib.stream_ptr()), "ec_policy_backward")
+        return flat_grads
+
+
+class _PolicyFn(torch.autograd.Function):
+    """Autograd bridge: HIP forward, HIP backward."""
+
+    @staticmethod
+    def forward(ctx, handle: PolicyHandle, flat, feat, goal, h0, masks, T, N, *params):
+        need_grad = any(ctx.needs_input_grad)   # (grad mode is always off inside Function.forward)
+        nbytes = handle.workspace_bytes(T, N, need_grad)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=flat.device)
+        hv, h_final = handle.forward(flat, feat, goal, h0, masks, T, N, ws)
+        if need_grad:
+            ctx.handle, ctx.T, ctx.N = handle, T, N
+            ctx.save_for_backward(flat, feat, masks, ws)
+        return hv, h_final
+
+    @staticmethod
+    def backward(ctx, dhv, dh_final):
+        flat, feat, masks, ws = ctx.saved_tensors
+        h: PolicyHandle = ctx.handle
+        g = torch.zeros_like(flat)
+        dhv = dhv.contiguous() if dhv is not None else torch.zeros((ctx.T * ctx.N, h.A + 1), device=flat.device)
+        dhf = dh_final.contiguous() if dh_final is not None else None
+        h.backward(flat, feat, masks, ctx.T, ctx.N, ws, dhv, dhf, g)
+        grads = tuple(g[o:o + k].view(h.shapes[n]) for n, (o, k) in h.offsets.items())
+        return (None, None, None, None, None, None, None, None) + grads
+
+
+class _Holder(nn.Module):
+    """Creates parameter sub-module paths like ``goal_visual_encoder.resnet_compressor.0.weight``."""
+
+
+def _set_nested(root: nn.Module, dotted: str, p: nn.Parameter):
+    parts = dotted.split(".")
+    m = root
+    for part in parts[:-1]:
+        if not hasattr(m, part):
+            m.add_module(part, _Holder())
+        m = getattr(m, part)
+    m.register_parameter(parts[-1], p)
+
+
+class ResnetTensorObjectNavActorCritic(nn.Module):
+    """[U] ``ResnetTensorObjectNavActorCritic(action_space, observation_space, goal_sensor_uuid,
+    rgb_resnet_preprocessor_uuid, depth_resnet_preprocessor_uuid=None, hidden_size=512, goal_dims=32,
+    resnet_compressor_hidden_out_dims=(128, 32), combiner_hidden_out_dims=(128, 32))``."""
+
+    def __init__(self, action_space, observation_space, goal_sensor_uuid: str,
+                 rgb_resnet_preprocessor_uuid: Optional[str], depth_resnet_preprocessor_uuid: Optional[str] = None,
+                 hidden_size: int = 512, goal_dims: int = 32, resnet_compressor_hidden_out_dims=(128, 32),
+                 combiner_hidden_out_dims=(128, 32), state_dict: Optional[Dict[str, torch.Tensor]] = None,
+                 device="cuda"):
+        super().__init__()
+        if depth_resnet_preprocessor_uuid is not None:
+            raise NotImplementedError("RGB-only (the CLIP configs of the reference are RGB-only)")
+        self.action_space = action_space
+        self.observation_space = observation_space
+        self.goal_uuid = goal_sensor_uuid
+        self.resnet_uuid = rgb_resnet_preprocessor_uuid
+        self._hidden_size = hidden_size
+        rs = observation_space.spaces[self.resnet_uuid].shape        # (C, S, S)
+        num_goals = getattr(observation_space.spaces[self.goal_uuid], "n", 12)
+        self.handle = PolicyHandle(in_channels=rs[0], spatial=rs[1], hidden=hidden_size, goal_dims=goal_dims,
+                                   num_goals=num_goals, num_actions=action_space.n,
+                                   compress_hid=resnet_compressor_hidden_out_dims[0],
+                                   compress_out=resnet_compressor_hidden_out_dims[1],
+                                   comb_hid=combiner_hidden_out_dims[0], comb_out=combiner_hidden_out_dims[1])
+        dev = torch.device(device)
+        if state_dict is None:
+            from .synthetic import policy_state_dict
+            state_dict = policy_state_dict(0, **self.handle.cfg)
+        self._flat = self.handle.flatten(state_dict, dev)
+        self._flat_grad = torch.zeros_like(self._flat)
+        for name, v in self.handle.views(self._flat).items():
+            _set_nested(self, name, nn.Parameter(v))
+        self._bind_grads()
+
+    # -- flat bucket maintenance -----------------------------------------------------------------
+    def _named(self):
+        d = dict(self.named_parameters())
+        return [(n, d[n]) for n in POLICY_PARAM_ORDER]
+
+    def _bind_grads(self):
+        for (n, p), (_, g) in zip(self._named(), self.handle.views(self._flat_grad).items()):
+            p.grad = g
+
+    def ensure_flat(self):
+        """Re-establish 'parameters are views of one flat buffer' after .to()/.cuda()/load."""
+        ok = all(p.data_ptr() == self._flat.data_ptr() + 4 * off and p.device == self._flat.device
+                 for (n, p), (off, _) in zip(self._named(), self.handle.offsets.values()))
+        if ok:
+            return
+        dev = self._named()[0][1].device
+        self._flat = self.handle.flatten({n: p.data for n, p in self._named()}, dev)
+        self._flat_grad = torch.zeros_like(self._flat)
+        for (n, p), v in zip(self._named(), self.handle.views(self._flat).values()):
+            p.data = v
+        self._bind_grads()
+
+    @property
+    def flat_params(self) -> torch.Tensor:
+        self.ensure_flat()
+        return self._flat
+
+    @property
+    def flat_grads(self) -> torch.Tensor:
+        self.ensure_flat()
+        return self._flat_grad
+
+    # -- ActorCriticModel surface ----------------------------------------------------------------
+    @property
+    def recurrent_hidden_state_size(self) -> int:
+        return self._hidden_size
+
+    @property
+    def num_recurrent_layers(self) -> int:
+        return 1
+
+    def _recurrent_memory_specification(self):
+        return dict(rnn=((("layer", self.num_recurrent_layers), ("sampler", None),
+                          ("hidden", self.recurrent_hidden_state_size)), torch.float32))
+
+    def forward(self, observations: Dict[str, torch.Tensor], memory: Memory, prev_actions: torch.Tensor,
+                masks: torch.Tensor):
+        """observations[resnet_uuid]: [T,N,C,S,S] fp32 (or bf16/fp32 channels-last [T,N,S,S,C] from
+        ``ClipResNetPreprocessor.process_bf16_nhwc``); observations[goal_uuid]: [T,N] int;
+        memory 'rnn': [1,N,H]; masks: [T,N,1].  -> (ActorCriticOutput, Memory)."""
+        self.ensure_flat()
+        feat = observations[self.resnet_uuid]
+        goal = observations[self.goal_uuid]
+        T, N = masks.shape[:2]
+        c = self.handle.cfg
+        if feat.shape[-1] == c["in_channels"] and feat.shape[-2] == c["spatial"]:
+            rows = feat.reshape(T * N, c["spatial"] ** 2, c["in_channels"]).contiguous()
+        else:   # the reference's NCHW layout -> NHWC rows (lossless re-layout)
+            rows = feat.reshape(T * N, c["in_channels"], -1).transpose(1, 2).contiguous()
+        if rows.dtype not in (torch.bfloat16, torch.float32):
+            rows = rows.float()
+        goal = goal.reshape(T * N).to(torch.int64).contiguous()
+        h0 = memory.tensor("rnn").reshape(N, self._hidden_size).to(torch.float32).contiguous()
+        m = masks.reshape(T * N).to(torch.float32).contiguous()
+        params = [p for _, p in self._named()]
+        hv, h_final = _PolicyFn.apply(self.handle, self._flat, rows, goal, h0, m, T, N, *params)
+        A = self.handle.A
+        hv = hv.view(T, N, A + 1)
+        out = ActorCriticOutput(distributions=CategoricalDistr(hv[..., :A]), values=hv[..., A:], extras={})
+        return out, memory.set_tensor("rnn", h_final.view(1, N, self._hidden_size))

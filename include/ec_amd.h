@@ -116,6 +116,92 @@ int ec_rn50_forward(const ec_rn50_t* h, const float* rgb_nhwc, int batch, void* 
  * kept; instead run only the first `n_ops` ops and return the op's output dims. */
 int ec_rn50_num_ops(const ec_rn50_t* h);
 
+
+/* ------------------------------------------------------------------------
+ * General fp32 GEMM on the exact-fp32 MFMA:  C (+)= epi(A B),
+ * A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn]  (NT / NN / TN by strides).
+ * Replaces the cuBLAS calls behind nn.Conv2d(1x1) / nn.Linear / nn.GRU and their
+ * autograd backward in the policy ([U] allenact ResnetTensorGoalEncoder,
+ * RNNStateEncoder, LinearActorHead/CriticHead).
+ * Epilogue order: + bias[n] + gbias[gidx[m/group]][n] -> relu -> * rowscale[m]
+ * -> * (dmask[m,n] > 0) -> store / += / atomicAdd (splitk > 1; C pre-initialised).
+ * ---------------------------------------------------------------------- */
+enum {
+    EC_GEMM_A_BF16 = 1,      /* A stored as bf16 (the frozen CLIP features) */
+    EC_GEMM_B_BF16 = 2,
+    EC_GEMM_RELU = 4,
+    EC_GEMM_ACCUMULATE = 8   /* C += ... */
+};
+int ec_gemm_f32(const void* A, const void* B, float* C, int M, int N, int K, long sam, long sak, long sbk, long sbn,
+                int ldc, int flags, const float* bias, const float* gbias, const int* gidx, int group,
+                const float* dmask, const float* rowscale, int splitk, ec_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * GRU actor-critic policy == ActorCriticModel.forward as
+ * ResnetTensorObjectNavActorCritic ([U] allenact; launched by
+ * readme_files/baselines_robothor_objectnav.md:48-51) and its backward.
+ * params/grads: ONE flat fp32 buffer each, tensors in AllenAct order
+ * (embed_class, compressor.0.{w,b}, compressor.2.{w,b}, combiner.0.{w,b},
+ * combiner.2.{w,b}, rnn.weight_ih_l0, weight_hh_l0, bias_ih_l0, bias_hh_l0,
+ * actor.linear.{w,b}, critic.fc.{w,b}) at ec_policy_param_offset() (16-B aligned).
+ * ---------------------------------------------------------------------- */
+typedef struct {
+    int in_channels;   /* 2048 */
+    int spatial;       /* 7    */
+    int hidden;        /* 512  */
+    int goal_dims;     /* 32   */
+    int num_goals;     /* 12   */
+    int num_actions;   /* 6    */
+    int compress_hid;  /* 128  */
+    int compress_out;  /* 32   */
+    int comb_hid;      /* 128  */
+    int comb_out;      /* 32   */
+} ec_policy_cfg;
+typedef struct ec_policy ec_policy_t;
+
+int ec_policy_create(ec_policy_t** out, const ec_policy_cfg* cfg);
+void ec_policy_destroy(ec_policy_t* h);
+int ec_policy_num_param_tensors(const ec_policy_t* h);
+size_t ec_policy_flat_size(const ec_policy_t* h);                      /* floats, incl. alignment padding */
+int ec_policy_param_offset(const ec_policy_t* h, int idx, size_t* off, size_t* numel);
+size_t ec_policy_workspace_bytes(const ec_policy_t* h, int T, int N, int for_backward);
+/* feat [T*N, S*S, C] NHWC (bf16 if feat_bf16 else f32); goal int64 [T*N]; h0 f32 [N,H];
+ * masks f32 [T*N] (h is multiplied by masks[t] before step t: episode reset);
+ * hv f32 [T*N, A+1] out: logits in cols 0..A-1, value in col A; h_final f32 [N,H] or NULL.
+ * The workspace keeps every activation the backward needs. */
+int ec_policy_forward(const ec_policy_t* h, const float* params, const void* feat, int feat_bf16,
+                      const int64_t* goal, const float* h0, const float* masks, int T, int N,
+                      void* workspace, size_t ws_bytes, float* hv, float* h_final, ec_stream_t stream);
+/* dhv f32 [T*N, A+1] = dLoss/dhv; dh_final [N,H] or NULL; grads += dLoss/dparams.
+ * `workspace` must be the one the matching ec_policy_forward filled (for_backward size). */
+int ec_policy_backward(const ec_policy_t* h, const float* params, const void* feat, int feat_bf16,
+                       const float* masks, int T, int N, void* workspace, size_t ws_bytes, const float* dhv,
+                       const float* dh_final, float* grads, ec_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Rollout post-processing and the PPO update ([U] allenact onpolicy_sync:
+ * storage.py RolloutStorage.compute_returns, losses/ppo.py PPO.loss,
+ * distributions.py CategoricalDistr, engine.py backprop_step).
+ * ---------------------------------------------------------------------- */
+/* rewards [T,N]; values, masks [T+1,N]; returns [T+1,N]; adv [T,N]; norm_adv [T,N] or NULL
+ * ((adv-mean)/(unbiased std + eps) over the T*N local steps); stats2: 2 doubles scratch. */
+int ec_gae(const float* rewards, const float* values, const float* masks, float* returns, float* adv,
+           float* norm_adv, double* stats2, int T, int N, float gamma, float tau, float eps, ec_stream_t stream);
+/* hv [B,A+1]; actions int64 [B]; old_logp, old_values, returns, norm_adv f32 [B];
+ * dhv [B,A+1] out = grad_scale * d(total)/d(hv); sums4 out (doubles): sum over B of
+ * {action loss, value loss, -entropy, ratio}; total = (s0 + vcoef*s1 + ecoef*s2)/B. */
+int ec_ppo_loss(const float* hv, const int64_t* actions, const float* old_logp, const float* old_values,
+                const float* returns, const float* norm_adv, float* dhv, double* sums4, long B, int A,
+                float clip, float vcoef, float ecoef, float grad_scale, ec_stream_t stream);
+/* actions ~ Categorical(logits = hv[:, :A]); logp = log_prob(actions); values = hv[:, A] (or NULL). */
+int ec_sample_actions(const float* hv, int64_t* actions, float* logp, float* values, int N, int A,
+                      uint64_t seed, uint64_t step, ec_stream_t stream);
+/* clip_grad_norm_(max_grad_norm) (<=0 disables) then Adam (1-based `step`) over n floats;
+ * sumsq1: 1 double scratch that receives ||grads||^2. */
+int ec_clip_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, double* sumsq1,
+                      long n, float max_grad_norm, float lr, float beta1, float beta2, float eps, int step,
+                      ec_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -64,8 +64,8 @@ def ppo_loss(logits: torch.Tensor, values: torch.Tensor, actions: torch.Tensor,
     ent_loss = -ent
     la, lv, le = action_loss.mean(), value_loss.mean(), ent_loss.mean()
     total = la + value_loss_coef * lv + entropy_coef * le
-    info = {"ppo_total": float(total), "value": float(lv), "action": float(la), "entropy": float(le),
-            "ratio_mean": float(ratio.mean())}
+    info = {"ppo_total": float(total.detach()), "value": float(lv.detach()), "action": float(la.detach()),
+            "entropy": float(le.detach()), "ratio_mean": float(ratio.mean().detach())}
     return total, info
 
 

@@ -1,0 +1,230 @@
+"""GPU parity: policy forward/backward, GAE, PPO loss, clip+Adam (through the C-ABI) vs the CPU oracle.
+
+Tolerance (all-fp32 path; the MFMA is an exact fp32 fmaf chain, only the summation ORDER differs from
+torch-CPU): forward rel-L2 <= 2e-5; gradients rel-L2 <= 2e-4 per tensor (K up to T*N*49 terms, fp32 atomics).
+With bf16-stored features both sides see identical (bf16-representable) inputs, so the same bounds hold.
+"""
+import pytest
+import torch
+
+from embodied_clip_amd import synthetic as syn
+from oracle import policy as opol
+from oracle import ppo as oppo
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-20)).item()
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _gemm(dev, A, B, C, M, N, K, sam, sak, sbk, sbn, ldc, flags=0, bias=None, gbias=None, gidx=None, group=0,
+          dmask=None, rowscale=None, splitk=1):
+    from embodied_clip_amd import _lib
+    lib = _lib.load()
+    _lib.check(lib.ec_gemm_f32(A.data_ptr(), B.data_ptr(), C.data_ptr(), M, N, K, sam, sak, sbk, sbn, ldc, flags,
+                               _lib.ptr(bias), _lib.ptr(gbias), _lib.ptr(gidx), group, _lib.ptr(dmask),
+                               _lib.ptr(rowscale), splitk, 0))
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("M,N,K", [(200, 128, 2048), (147, 32, 128), (50, 1536, 1568), (5, 7, 512), (300, 96, 20)])
+def test_gemm_f32_nt(dev, M, N, K):
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g); w = torch.randn(N, K, generator=g) * K ** -0.5; b = torch.randn(N, generator=g)
+    ref = torch.relu(a @ w.t() + b)
+    ad, wd, bd = a.to(dev), w.to(dev), b.to(dev)
+    c = torch.empty(M, N, device=dev)
+    _gemm(dev, ad, wd, c, M, N, K, K, 1, 1, K, N, flags=4, bias=bd)
+    assert _rel(c, ref) < 2e-5, _rel(c, ref)
+
+
+def test_gemm_f32_bf16_operands_nn_tn_epilogues(dev):
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 333, 200, 260
+    # NN with accumulate + rowscale + dmask
+    a = torch.randn(M, K, generator=g); b = torch.randn(K, N, generator=g) * K ** -0.5
+    c0 = torch.randn(M, N, generator=g); rs = torch.rand(M, generator=g); dm = torch.randn(M, N, generator=g)
+    # epilogue order: rowscale -> dmask -> accumulate
+    ref = c0 + torch.where(dm > 0, (a @ b) * rs[:, None], torch.zeros(()))
+    ad, bd, cd, rsd, dmd = a.to(dev), b.to(dev), c0.clone().to(dev), rs.to(dev), dm.to(dev)
+    _gemm(dev, ad, bd, cd, M, N, K, K, 1, N, 1, N, flags=8, dmask=dmd, rowscale=rsd)
+    assert _rel(cd, ref) < 2e-5
+    # TN split-K with a bf16 B operand (dW1 = dc1^T feat): out[m,n] = sum_k dY[k,m] X[k,n]
+    Kb = 5000
+    dy = torch.randn(Kb, 128, generator=g); x = torch.randn(Kb, 256, generator=g).to(torch.bfloat16)
+    ref = dy.t() @ x.float()
+    dyd, xd = dy.to(dev), x.to(dev)
+    out = torch.zeros(128, 256, device=dev)
+    _gemm(dev, dyd, xd, out, 128, 256, Kb, 1, 128, 256, 1, 256, flags=2 | 8, splitk=7)
+    assert _rel(out, ref) < 5e-5
+    # NT with a bf16 A operand and a row-group bias table indexed through gidx
+    feat = torch.randn(98, 64, generator=g).to(torch.bfloat16); w = torch.randn(32, 64, generator=g)
+    tab = torch.randn(5, 32, generator=g); gi = torch.tensor([3, 1], dtype=torch.int32)
+    ref = feat.float() @ w.t() + tab[gi.long()].repeat_interleave(49, 0)
+    fd, wd, td, gid = feat.to(dev), w.to(dev), tab.to(dev), gi.to(dev)
+    o = torch.empty(98, 32, device=dev)
+    _gemm(dev, fd, wd, o, 98, 32, 64, 64, 1, 1, 64, 32, flags=1, gbias=td, gidx=gid, group=49)
+    assert _rel(o, ref) < 2e-5
+
+
+def _policy_case(T, N, C=64, S=3, H=32, seed=0, bf16=False):
+    cfg = dict(in_channels=C, spatial=S, hidden=H)
+    sd = syn.policy_state_dict(seed, **cfg)
+    g = torch.Generator().manual_seed(seed + 1)
+    feat = torch.randn(T, N, C, S, S, generator=g).abs()       # post-ReLU features are non-negative
+    if bf16:
+        feat = feat.to(torch.bfloat16).float()
+    goal = syn.synthetic_goals(seed + 2, (T, N))
+    h0 = torch.randn(1, N, H, generator=g) * 0.5
+    masks = syn.synthetic_masks(seed + 3, T, N, p_reset=0.2)
+    return cfg, sd, feat, goal, h0, masks
+
+
+@pytest.mark.parametrize("T,N,bf16", [(1, 5, False), (6, 4, False), (5, 3, True)])
+def test_policy_forward_matches_oracle(dev, T, N, bf16):
+    from embodied_clip_amd.policy import PolicyHandle
+    cfg, sd, feat, goal, h0, masks = _policy_case(T, N, bf16=bf16)
+    ref_logits, ref_values, ref_h = opol.actor_critic_forward(feat, goal, h0, masks, sd)
+    h = PolicyHandle(**cfg)
+    flat = h.flatten(sd, dev)
+    rows = feat.permute(0, 1, 3, 4, 2).reshape(T * N, cfg["spatial"] ** 2, cfg["in_channels"]).contiguous()
+    rows = rows.to(torch.bfloat16) if bf16 else rows
+    ws = torch.empty(h.workspace_bytes(T, N, False), dtype=torch.uint8, device=dev)
+    hv, hf = h.forward(flat, rows.to(dev), goal.reshape(-1).to(dev), h0[0].contiguous().to(dev),
+                       masks.reshape(-1).to(dev), T, N, ws)
+    torch.cuda.synchronize()
+    hv = hv.view(T, N, -1)
+    assert _rel(hv[..., :6], ref_logits) < 2e-5
+    assert _rel(hv[..., 6:], ref_values) < 2e-5
+    assert _rel(hf, ref_h[0]) < 2e-5
+
+
+def _loss_inputs(T, N, seed):
+    g = torch.Generator().manual_seed(seed)
+    actions = torch.randint(0, 6, (T, N), generator=g)
+    old_lp = -torch.rand(T, N, 1, generator=g) * 2.5
+    old_v = torch.randn(T, N, 1, generator=g)
+    returns = torch.randn(T, N, 1, generator=g)
+    nadv = torch.randn(T, N, 1, generator=g)
+    return actions, old_lp, old_v, returns, nadv
+
+
+def test_ppo_loss_forward_backward_matches_oracle(dev):
+    from embodied_clip_amd import ppo
+    T, N, A = 7, 9, 6
+    g = torch.Generator().manual_seed(2)
+    logits = torch.randn(T, N, A, generator=g, requires_grad=True)
+    values = torch.randn(T, N, 1, generator=g, requires_grad=True)
+    actions, old_lp, old_v, returns, nadv = _loss_inputs(T, N, 3)
+    # put old_log_probs near the new ones so both clip branches are exercised
+    with torch.no_grad():
+        old_lp = opol.categorical_log_prob(logits, actions).unsqueeze(-1) + 0.25 * torch.randn(T, N, 1, generator=g)
+        old_v = values + 0.2 * torch.randn(T, N, 1, generator=g)
+    total, info = oppo.ppo_loss(logits, values, actions, old_lp, old_v, returns, nadv)
+    total.backward()
+    hv = torch.cat([logits, values], -1).detach().reshape(T * N, A + 1).contiguous().to(dev)
+    f = lambda t: t.reshape(-1).contiguous().to(dev)
+    dhv, sums = ppo.ppo_loss_raw(hv, f(actions), f(old_lp), f(old_v), f(returns), f(nadv), A)
+    torch.cuda.synchronize()
+    s = (sums / (T * N)).cpu()
+    assert abs(s[0].item() - info["action"]) < 1e-5 and abs(s[1].item() - info["value"]) < 1e-5
+    assert abs(s[2].item() - info["entropy"]) < 1e-5 and abs(s[3].item() - info["ratio_mean"]) < 1e-5
+    ref = torch.cat([logits.grad, values.grad], -1).reshape(T * N, A + 1)
+    assert _rel(dhv, ref) < 1e-5, _rel(dhv, ref)
+
+
+def test_gae_matches_oracle(dev):
+    from embodied_clip_amd import ppo
+    T, N = 16, 4
+    masks = torch.cat([torch.ones(1, N, 1), syn.synthetic_masks(4, T, N, p_reset=0.15)], 0)
+    rewards = syn.synthetic_rewards(5, masks[1:])
+    values = torch.randn(T + 1, N, 1, generator=torch.Generator().manual_seed(6))
+    R = oppo.compute_returns(rewards, values, masks)
+    adv, nadv = oppo.normalized_advantages(R, values)
+    r2, a2, n2 = ppo.compute_returns(rewards.to(dev), values.to(dev), masks.to(dev))
+    torch.cuda.synchronize()
+    assert _rel(r2, R) < 1e-6 and _rel(a2, adv) < 1e-5 and _rel(n2, nadv) < 1e-5
+
+
+@pytest.mark.parametrize("T,N,bf16", [(6, 4, False), (8, 4, True)])
+def test_policy_backward_and_update_step_match_oracle(dev, T, N, bf16):
+    """One full optimiser step of HOT LOOP B: forward, PPO loss, backward, clip, Adam."""
+    from embodied_clip_amd import ppo
+    from embodied_clip_amd.policy import PolicyHandle
+    cfg, sd, feat, goal, h0, masks = _policy_case(T, N, seed=7, bf16=bf16)
+    actions, old_lp, old_v, returns, nadv = _loss_inputs(T, N, 8)
+    with torch.no_grad():
+        lg, vv, _ = opol.actor_critic_forward(feat, goal, h0, masks, sd)
+        old_lp = opol.categorical_log_prob(lg, actions).unsqueeze(-1) + 0.2 * torch.randn(T, N, 1)
+        old_v = vv + 0.2 * torch.randn(T, N, 1)
+    sd_ref = {k: v.clone() for k, v in sd.items()}
+    batch = dict(feat=feat, goal=goal, h0=h0, masks=masks, actions=actions, old_log_probs=old_lp, old_values=old_v,
+                 returns=returns, norm_adv=nadv)
+    info, ref_grads = oppo.ppo_update_step(sd_ref, batch, {}, lr=3e-4, max_grad_norm=0.5)
+
+    h = PolicyHandle(**cfg)
+    flat = h.flatten(sd, dev)
+    rows = feat.permute(0, 1, 3, 4, 2).reshape(T * N, cfg["spatial"] ** 2, cfg["in_channels"]).contiguous()
+    rows = (rows.to(torch.bfloat16) if bf16 else rows).to(dev)
+    m = masks.reshape(-1).to(dev)
+    ws = torch.empty(h.workspace_bytes(T, N, True), dtype=torch.uint8, device=dev)
+    hv, _ = h.forward(flat, rows, goal.reshape(-1).to(dev), h0[0].contiguous().to(dev), m, T, N, ws)
+    f = lambda t: t.reshape(-1).contiguous().to(dev)
+    dhv, sums = ppo.ppo_loss_raw(hv, f(actions), f(old_lp), f(old_v), f(returns), f(nadv), 6)
+    grads = torch.zeros_like(flat)
+    h.backward(flat, rows, m, T, N, ws, dhv, None, grads)
+    torch.cuda.synchronize()
+    total = ((sums[0] + 0.5 * sums[1] + 0.01 * sums[2]) / (T * N)).item()
+    assert abs(total - info["ppo_total"]) < 1e-5 * max(1.0, abs(info["ppo_total"]))
+    gv = h.views(grads)
+    for name, gref in ref_grads.items():
+        assert _rel(gv[name], gref) < 2e-4, (name, _rel(gv[name], gref))
+    opt = ppo.FlatAdam(flat, lr=3e-4, max_grad_norm=0.5)
+    opt.step(grads)
+    torch.cuda.synchronize()
+    assert abs(opt.grad_norm() - info["grad_norm"]) < 1e-4 * info["grad_norm"]
+    pv = h.views(flat)
+    for name, pref in sd_ref.items():
+        # Adam's first step moves every weight by ~lr regardless of gradient scale: compare the UPDATE
+        upd, upd_ref = pv[name].cpu() - sd[name], pref - sd[name]
+        assert (upd - upd_ref).abs().max() < 0.05 * 3e-4 + 1e-7, name
+
+
+def test_actor_critic_module_autograd_surface(dev):
+    """The drop-in nn.Module: names, memory spec, autograd-visible forward, flat grad bucket."""
+    from embodied_clip_amd import spaces
+    from embodied_clip_amd.policy import Memory, ResnetTensorObjectNavActorCritic
+    from embodied_clip_amd.ppo import PPO
+    T, N = 4, 3
+    cfg, sd, feat, goal, h0, masks = _policy_case(T, N, C=64, S=3, H=32, seed=11)
+    obs_space = spaces.Dict({"rgb_clip_resnet": spaces.Box(-1e9, 1e9, (64, 3, 3)), "goal": spaces.Discrete(12)})
+    model = ResnetTensorObjectNavActorCritic(spaces.Discrete(6), obs_space, "goal", "rgb_clip_resnet", hidden_size=32,
+                                             state_dict=sd, device=dev)
+    assert [n for n, _ in model.named_parameters()] == list(syn.POLICY_PARAM_ORDER)
+    assert model._recurrent_memory_specification()["rnn"][0] == (("layer", 1), ("sampler", None), ("hidden", 32))
+    mem = Memory().check_append("rnn", h0.to(dev), 1)
+    out, mem2 = model({"rgb_clip_resnet": feat.to(dev), "goal": goal.to(dev)}, mem, None, masks.to(dev))
+    ref_logits, ref_values, ref_h = opol.actor_critic_forward(feat, goal, h0, masks, sd)
+    assert _rel(out.distributions.logits, ref_logits) < 2e-5 and _rel(out.values, ref_values) < 2e-5
+    assert _rel(mem2.tensor("rnn"), ref_h) < 2e-5
+    actions, old_lp, old_v, returns, nadv = _loss_inputs(T, N, 12)
+    batch = dict(actions=actions.to(dev), old_action_log_probs=old_lp.to(dev), values=old_v.to(dev),
+                 returns=returns.to(dev), norm_adv_targ=nadv.to(dev), adv_targ=nadv.to(dev))
+    total, info = PPO().loss(0, batch, out)
+    total.backward()
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    lg, vv, _ = opol.actor_critic_forward(feat, goal, h0, masks, leaves)
+    tref, iref = oppo.ppo_loss(lg, vv, actions, old_lp, old_v, returns, nadv)
+    tref.backward()
+    assert abs(float(total) - float(tref)) < 1e-5
+    for n, p in model.named_parameters():
+        assert p.grad is not None and _rel(p.grad, leaves[n].grad) < 2e-4, n
+    assert model.flat_grads.abs().sum() > 0          # grads landed in the single flat bucket
