@@ -1,0 +1,76 @@
+"""GPU parity of the whole worker iteration (engine) against the CPU oracle on identical frames/actions."""
+import pytest
+import torch
+
+from embodied_clip_amd import synthetic as syn
+from oracle import clip_resnet as ocr
+from oracle import policy as opol
+from oracle import ppo as oppo
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-20)).item()
+
+
+def test_worker_iteration_matches_oracle():
+    from embodied_clip_amd.engine import Worker
+    assert torch.cuda.is_available()
+    T, N, R = 3, 2, 2
+    enc_sd, pol_sd = syn.rn50_visual_state_dict(0), syn.policy_state_dict(0)
+    w = Worker(N, T=T, device="cuda:0", seed=3, update_repeats=R, encoder_sd=enc_sd, policy_sd=pol_sd)
+    w.collect_rollout()
+    w.compute_returns()
+    torch.cuda.synchronize()
+    S, C = w.S, w.C
+    # (1) encoder: every stored feature row vs the fp32 oracle on the same frames
+    frames = w.env.frames.cpu()
+    feat_gpu = w.feat.float().cpu().view(T + 1, N, S, S, C).permute(0, 1, 4, 2, 3).contiguous()   # [T+1,N,C,S,S]
+    for t in range(T + 1):
+        ref = ocr.clip_resnet_preprocessor(frames[t % frames.shape[0]], enc_sd)
+        assert _rel(feat_gpu[t], ref) < 2e-2, (t, _rel(feat_gpu[t], ref))
+    # (2) act steps: replay the oracle policy on the GPU's own (bf16-exact) features and actions
+    masks = w.env.masks.cpu().unsqueeze(-1)
+    goals = w.env.goals.cpu()
+    actions = w.actions.cpu()
+    assert int(actions.min()) >= 0 and int(actions.max()) < 6
+    h = torch.zeros(1, N, w.H)
+    vals, lps = [], []
+    with torch.no_grad():
+        for t in range(T + 1):
+            lg, v, h2 = opol.actor_critic_forward(feat_gpu[t][None], goals[t][None], h, masks[t][None], pol_sd)
+            vals.append(v[0])
+            if t < T:
+                lps.append(opol.categorical_log_prob(lg, actions[t][None])[0])
+                h = h2
+    vals, lps = torch.stack(vals), torch.stack(lps)
+    assert _rel(w.values.unsqueeze(-1), vals) < 1e-4
+    assert (w.logp.cpu() - lps).abs().max() < 1e-4
+    # (3) GAE + advantage normalisation
+    rewards = w.env.rewards.cpu().unsqueeze(-1)
+    Rr = oppo.compute_returns(rewards, vals, masks)
+    _, nadv = oppo.normalized_advantages(Rr, vals)
+    assert _rel(w.returns.unsqueeze(-1), Rr) < 1e-4
+    assert _rel(w.nadv.unsqueeze(-1), nadv) < 1e-3
+    # (4) update_repeats optimiser steps
+    sd_ref = {k: v.clone() for k, v in pol_sd.items()}
+    batch = dict(feat=feat_gpu[:T], goal=goals[:T], h0=torch.zeros(1, N, w.H), masks=masks[:T], actions=actions,
+                 old_log_probs=w.logp.cpu().unsqueeze(-1), old_values=w.values[:T].cpu().unsqueeze(-1),
+                 returns=w.returns[:T].cpu().unsqueeze(-1), norm_adv=w.nadv.cpu().unsqueeze(-1))
+    st = {}
+    for _ in range(R):
+        info, _ = oppo.ppo_update_step(sd_ref, batch, st)
+    w.update()
+    torch.cuda.synchronize()
+    got = w.loss_info()
+    assert abs(got["ppo_total"] - info["ppo_total"]) < 2e-4 * max(1.0, abs(info["ppo_total"]))
+    assert abs(got["grad_norm"] - info["grad_norm"]) < 2e-3 * info["grad_norm"]
+    pv = w.policy.views(w.params)
+    for name, pref in sd_ref.items():
+        upd, upd_ref = pv[name].cpu() - pol_sd[name], pref - pol_sd[name]
+        # R Adam steps of size <= lr each; the sign-like first steps amplify tiny gradient differences
+        assert (upd - upd_ref).abs().max() < 0.15 * R * 3e-4 + 1e-7, (name, (upd - upd_ref).abs().max())
+    w.after_update()
+    assert torch.equal(w.feat[0], w.feat[T])
