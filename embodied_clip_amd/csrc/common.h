@@ -20,8 +20,12 @@ __device__ __forceinline__ uint16_t ec_f2bf(float f) {
     return (uint16_t)(u >> 16);
 }
 __device__ __forceinline__ float ec_bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+typedef __bf16 ec_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float ec_f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t ec_pack2(float lo, float hi) {
-    return (uint32_t)ec_f2bf(lo) | ((uint32_t)ec_f2bf(hi) << 16);
+    // native conversion: one v_cvt_pk_bf16_f32 (round-to-nearest-even) for the pair
+    ec_f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, ec_bf16x2_t));
 }
 __device__ __forceinline__ float ec_lo(uint32_t p) { return __uint_as_float(p << 16); }
 __device__ __forceinline__ float ec_hi(uint32_t p) { return __uint_as_float(p & 0xffff0000u); }

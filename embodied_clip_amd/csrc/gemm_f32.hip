@@ -303,5 +303,9 @@ extern "C" int ec_gemm_f32(const void* A, const void* B, float* Cp, int M, int N
     hipStream_t s = (hipStream_t)stream;
     if (N <= 32) return launch_cfg<256, 32, 4, 1>(a, s);
     if (M <= 32) return launch_cfg<32, 256, 1, 4>(a, s);
+    // fp32 MFMA is 64 cycles per 32x32x2: a 128x128 tile is a long serial chain, so shapes that give
+    // fewer 128^2 tiles than ~2 per CU run on 64x64 tiles (4x the workgroups, 1/4 the chain).
+    const long blocks128 = (long)((M + 127) / 128) * ((N + 127) / 128) * a.splitk;
+    if (blocks128 < 512) return launch_cfg<64, 64, 2, 2>(a, s);
     return launch_cfg<128, 128, 2, 2>(a, s);
 }

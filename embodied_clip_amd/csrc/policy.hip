@@ -196,6 +196,16 @@ int pick_splitk(long M, long N, long K) {
     return (int)s;
 }
 
+// split-K for the small per-step GEMMs that only ever ACCUMULATE (atomics are fine): aim at ~1 workgroup
+// per CU on 64x64 tiles while keeping >= 4 K-tiles per slice.
+int step_splitk(long M, long N, long K) {
+    const long blocks = ((M + 63) / 64) * ((N + 63) / 64);
+    long s = 256 / (blocks > 0 ? blocks : 1);
+    const long nk = (K + 31) / 32;
+    if (s > nk / 4) s = nk / 4;
+    return (int)(s < 1 ? 1 : s);
+}
+
 #define RC(x) do { int rc__ = (x); if (rc__ != EC_OK) return rc__; } while (0)
 
 }  // namespace
@@ -339,7 +349,7 @@ extern "C" int ec_policy_backward(const ec_policy_t* h, const float* params, con
                            ws + w.dghb + o3, N, H);
         // dh_carry += m * (dghb @ W_hh)
         RC(ec_gemm_f32(ws + w.dghb + o3, W(P_WHH), ws + w.dhc, N, H, 3 * H, 3 * H, 1, H, 1, H, EC_GEMM_ACCUMULATE, nullptr,
-                       nullptr, nullptr, 0, nullptr, masks + (size_t)t * N, 1, stream));
+                       nullptr, nullptr, 0, nullptr, masks + (size_t)t * N, step_splitk(N, H, 3 * H), stream));
     }
     // weight grads of the recurrence / input projection (TN over all T*N rows)
     auto tn = [&](const float* dY, int ldy, const void* X, int ldx, int x_bf16, float* dW, int Mo, int No, long K,

@@ -134,6 +134,10 @@ extern "C" int ec_rn50_forward(const ec_rn50_t* h, const float* rgb, int batch, 
     if (!h || !rgb || !workspace || !feat) return EC_ERR_ARG;
     if (batch <= 0) return EC_ERR_SHAPE;
     if (chunk <= 0 || chunk > batch) chunk = batch;
+    {   // the conv kernels address activations through 32-bit buffer descriptors (< 2 GiB per tensor)
+        const long maxc = ((1L << 31) - 1) / (long)(h->max_elems_per_frame * 2);
+        if (chunk > maxc) chunk = (int)(maxc > 0 ? maxc : 1);
+    }
     if (ws_bytes < ec_rn50_workspace_bytes(h, chunk)) return EC_ERR_WORKSPACE;
     const size_t bufsz = align_up(h->max_elems_per_frame * 2 * (size_t)chunk, 256);
     unsigned char* base = (unsigned char*)workspace;

@@ -28,6 +28,7 @@ import torch
 
 from . import _lib
 from . import synthetic as syn
+from .dist import allreduce_flat
 from .encoder import RN50Trunk
 from .policy import PolicyHandle
 from .ppo import FlatAdam, linear_decay_lr, ppo_loss_raw
@@ -158,7 +159,7 @@ class Worker:
             self.grads.zero_()
             self.policy.backward(self.params, feat, masks, T, N, self.ws_learn, self.dhv, None, self.grads)
             if self.world > 1:
-                torch.distributed.all_reduce(self.grads)     # one flat 13.9 MB bucket over RCCL/xGMI
+                allreduce_flat(self.grads)                   # one flat 13.9 MB bucket over RCCL/xGMI
             self.opt.step(self.grads, lr=linear_decay_lr(self.base_lr, self.total_steps, self.lr_total_steps))
 
     def after_update(self):

@@ -1,0 +1,85 @@
+"""world_size=2 (gloo, CPU): actors sharded over ranks + one flat-bucket SUM all-reduce of
+(local/global)-scaled gradients == the unsharded gradient."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from embodied_clip_amd import synthetic as syn
+from embodied_clip_amd.dist import allreduce_flat, grad_scale, shard_actors
+from oracle import policy as opol
+from oracle import ppo as oppo
+
+CFG = dict(in_channels=32, spatial=2, hidden=16)
+T, N = 4, 6
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _case():
+    sd = syn.policy_state_dict(3, **CFG)
+    g = torch.Generator().manual_seed(0)
+    feat = torch.randn(T, N, 32, 2, 2, generator=g).abs()
+    goal = syn.synthetic_goals(1, (T, N)); h0 = torch.randn(1, N, 16, generator=g) * 0.3
+    masks = syn.synthetic_masks(2, T, N, 0.2)
+    actions = torch.randint(0, 6, (T, N), generator=g)
+    old_lp = -torch.rand(T, N, 1, generator=g); old_v = torch.randn(T, N, 1, generator=g)
+    ret = torch.randn(T, N, 1, generator=g); nadv = torch.randn(T, N, 1, generator=g)
+    return sd, feat, goal, h0, masks, actions, old_lp, old_v, ret, nadv
+
+
+def _grads(sd, feat, goal, h0, masks, actions, old_lp, old_v, ret, nadv, sl):
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    lg, vv, _ = opol.actor_critic_forward(feat[:, sl], goal[:, sl], h0[:, sl], masks[:, sl], leaves)
+    total, _ = oppo.ppo_loss(lg, vv, actions[:, sl], old_lp[:, sl], old_v[:, sl], ret[:, sl], nadv[:, sl])
+    gs = torch.autograd.grad(total, list(leaves.values()))
+    return dict(zip(leaves.keys(), gs))
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from embodied_clip_amd.policy import PolicyHandle   # host-only use: flat bucket layout
+        torch.set_num_threads(1)
+        case = _case()
+        start, cnt = shard_actors(N, rank, world)
+        g = _grads(*case, slice(start, start + cnt))
+        h = PolicyHandle(**CFG)
+        flat = h.flatten(g, "cpu") * grad_scale(T * cnt, T * N)
+        allreduce_flat(flat)
+        if rank == 0:
+            q.put(flat)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_actors_partition():
+    for n, w in [(256, 8), (10, 3), (512, 8), (5, 8)]:
+        parts = [shard_actors(n, r, w) for r in range(w)]
+        assert sum(c for _, c in parts) == n
+        assert all(parts[i][0] + parts[i][1] == parts[i + 1][0] for i in range(w - 1))
+
+
+@pytest.mark.timeout(180)
+def test_two_rank_flat_allreduce_equals_unsharded():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    flat = q.get()
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    from embodied_clip_amd.policy import PolicyHandle
+    h = PolicyHandle(**CFG)
+    ref = h.flatten(_grads(*_case(), slice(0, N)), "cpu")
+    assert flat.shape == ref.shape == (h.flat_size,)
+    assert torch.allclose(flat, ref, rtol=1e-4, atol=1e-7), (flat - ref).abs().max()
