@@ -48,6 +48,16 @@ SIGNATURES = {
     "ec_gae": (c_int, [c_void_p] * 7 + [c_int, c_int, c_float, c_float, c_float, c_void_p]),
     "ec_ppo_loss": (c_int, [c_void_p] * 8 + [C.c_long, c_int, c_float, c_float, c_float, c_float, c_void_p]),
     "ec_sample_actions": (c_int, [c_void_p] * 4 + [c_int, c_int, C.c_uint64, C.c_uint64, c_void_p]),
+    "ec_vit_create": (c_int, [C.POINTER(c_void_p), c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p,
+                              c_size_t]),
+    "ec_vit_destroy": (None, [c_void_p]),
+    "ec_vit_tokens": (c_int, [c_void_p]),
+    "ec_vit_workspace_bytes": (c_size_t, [c_void_p, c_int]),
+    "ec_vit_forward": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "ec_bf16_to_f32": (c_int, [c_void_p, c_void_p, C.c_long, C.c_long, C.c_long, c_void_p]),
+    "ec_attnpool_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "ec_attnpool_forward": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int] + [c_void_p] * 8 + [c_size_t, c_void_p,
+                                    c_void_p]),
     "ec_clip_adam_step": (c_int, [c_void_p] * 5 + [C.c_long, c_float, c_float, c_float, c_float, c_float, c_int,
                                   c_void_p]),
 }

@@ -115,3 +115,38 @@ class ClipResNetPreprocessor(_PreprocessorBase):
         """MI355X-native fast path: device fp32 NHWC frame -> bf16 NHWC [N,7,7,2048] written
         straight into ``out`` (a slice of the rollout feature buffer)."""
         return self.resnet.forward(rgb, out)
+
+
+class ClipViTPreprocessor(_PreprocessorBase):
+    """[U] ``ClipViTPreprocessor(rgb_input_uuid, clip_model_type, class_emb_only, device, device_ids, output_uuid)``
+    (allenact master; named by BASELINE.json).  ``process(obs)``: fp32 NHWC [N,224,224,3] ->
+    fp32 [N,50,768] tokens after ``resblocks[:-1]`` (``class_emb_only`` -> [N,768])."""
+
+    def __init__(self, rgb_input_uuid: str, clip_model_type: str, class_emb_only: bool = False,
+                 device: Optional[torch.device] = None, device_ids: Optional[List[torch.device]] = None,
+                 output_uuid: str = "rgb_clip_vit", state_dict=None, weights_path: Optional[str] = None, **kwargs: Any):
+        assert clip_model_type in ("ViT-B/32", "ViT-B/16", "ViT-L/14")
+        if clip_model_type != "ViT-B/32":
+            raise NotImplementedError("only ViT-B/32 (50 tokens) fits the 64-token LDS attention core for now")
+        output_shape = (768,) if class_emb_only else (50, 768)
+        self.clip_model_type = clip_model_type
+        self.class_emb_only = class_emb_only
+        self.device = torch.device("cuda") if device is None else torch.device(device)
+        self.device_ids = device_ids or []
+        self._state_dict, self._weights_path = state_dict, weights_path
+        self._model = None
+        super().__init__([rgb_input_uuid], output_uuid,
+                         spaces.Box(low=-np.inf, high=np.inf, shape=output_shape, dtype=np.float32))
+
+    @property
+    def vit(self):
+        if self._model is None:
+            from .encoder import ViTEmbedder
+            sd = _load_visual_state_dict(self.clip_model_type, self._state_dict, self._weights_path)
+            self._model = ViTEmbedder(sd, device=self.device)
+        return self._model
+
+    def process(self, obs: Dict[str, Any], *args: Any, **kwargs: Any) -> torch.Tensor:
+        x = obs[self.input_uuids[0]].to(self.device, dtype=torch.float32).contiguous()
+        m = self.vit
+        return m.to_f32(m.forward(x), self.class_emb_only)

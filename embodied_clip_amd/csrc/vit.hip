@@ -1,0 +1,427 @@
+// CLIP VisionTransformer embedder (ClipViTPreprocessor) and AttentionPool2d.
+//
+// Replaces ([U] openai/CLIP clip/model.py @40f5484c, pinned by
+// primitive_probing/environment.yml:22):
+//   * VisionTransformer.forward as driven by [U] allenact ClipViTEmbedder:
+//     conv1 patch-embed -> +class_embedding -> +positional_embedding -> ln_pre ->
+//     resblocks[:-1]  (no ln_post / proj)                     
+//   * ResidualAttentionBlock: x += out_proj(MHA(ln_1 x)); x += c_proj(QuickGELU(c_fc(ln_2 x)))
+//   * AttentionPool2d.forward, called detached at
+//     primitive_probing/generate_data/thor_image_features.py:62,112          (a6)
+//
+// All contractions (patch-embed, QKV, out-proj, MLP, k/v/q/c projections) run on
+// the bf16 MFMA GEMM of conv_igemm.hip with fused bias / QuickGELU / residual
+// epilogues; this file holds the bandwidth-bound glue (patchify, LayerNorm,
+// token assembly) and the attention cores, which keep the 50 KV rows of one
+// (frame, head) in LDS.  The residual stream is bf16, statistics are fp32.
+#include <new>
+
+#include "common.h"
+
+extern "C" int ec_gemm_bf16(const void* A, const void* Wt, const float* bias, const void* res, void* out, int M, int N,
+                            int K, int act, ec_stream_t stream);
+
+namespace {
+
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max_f(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// fp32 NHWC frame -> bf16 [B*G*G, P*P*3] rows, K ordered (ky, kx, c): each (patch, ky) is one
+// contiguous run of P*3 floats of an image row.
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ rgb, uint16_t* __restrict__ out, int R,
+                                                      int P, int G, long total4) {
+    const int run = P * 3;                 // floats per (patch, ky)
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+        long e = i * 4;                    // 4 consecutive K elements (run % 4 == 0)
+        const int k = (int)(e % ((long)P * run));
+        const long patch = e / ((long)P * run);
+        const int ky = k / run, rem = k - ky * run;
+        const int px = (int)(patch % G);
+        const long t = patch / G;
+        const int py = (int)(t % G);
+        const long b = t / G;
+        const float4 v = *reinterpret_cast<const float4*>(rgb + ((b * R + (long)py * P + ky) * R + (long)px * P) * 3 + rem);
+        uint2 o;
+        o.x = ec_pack2(v.x, v.y);
+        o.y = ec_pack2(v.z, v.w);
+        *reinterpret_cast<uint2*>(out + e) = o;
+    }
+}
+
+// LayerNorm over D (fp32 statistics), one wave per row.  MODE 0: in = bf16 rows.
+// MODE 1 (token assembly + ln_pre): row t of frame b is (t==0 ? cls : patch_emb[b, t-1]) + pos[t].
+template <int MODE>
+__global__ __launch_bounds__(256) void layernorm_kernel(const uint16_t* __restrict__ in, const float* __restrict__ cls,
+                                                       const float* __restrict__ pos, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, uint16_t* __restrict__ out,
+                                                       long rows, int D, int L, float eps) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    constexpr int MAXV = 16;               // D <= 1024
+    float v[MAXV];
+    const int per = D / 64;
+    float s = 0.f;
+    if (MODE == 0) {
+        const uint16_t* p = in + row * D;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i)
+            if (i < per) { v[i] = ec_bf2f(p[i * 64 + lane]); s += v[i]; }
+    } else {
+        const long b = row / L;
+        const int t = (int)(row - b * L);
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i)
+            if (i < per) {
+                const int d = i * 64 + lane;
+                const float base = (t == 0) ? cls[d] : ec_bf2f(in[(b * (L - 1) + (t - 1)) * D + d]);
+                v[i] = base + pos[(long)t * D + d];
+                s += v[i];
+            }
+    }
+    const float mean = wave_sum_f(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+        if (i < per) { const float d0 = v[i] - mean; q += d0 * d0; }
+    const float rstd = rsqrtf(wave_sum_f(q) / (float)D + eps);
+    uint16_t* o = out + row * D;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+        if (i < per) {
+            const int d = i * 64 + lane;
+            o[d] = (uint16_t)(ec_pack2((v[i] - mean) * rstd * gamma[d] + beta[d], 0.f) & 0xffffu);
+        }
+}
+
+// Multi-head self-attention core for L <= 64 tokens and head dim 64: one wave per (frame, head).
+// qkv bf16 [B*L, 3*D] (q | k | v, head h at columns h*64..), out bf16 [B*L, D].
+//   S^T[key][query] = K Q^T   (swapped operands: a lane owns ONE query column and 32 of the 64 keys,
+//                              so the softmax is in-lane + one exchange with the other half-wave)
+//   O[query][d]     = P V     (P stays in registers; V^T is read from LDS with the matching k-permutation)
+__global__ __launch_bounds__(64) void mha_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int L,
+                                                 int D, int heads, float scale) {
+    __shared__ __attribute__((aligned(16))) uint16_t sq[64 * 72];    // [token][d], row pitch 72 (144 B)
+    __shared__ __attribute__((aligned(16))) uint16_t sk[64 * 72];
+    __shared__ __attribute__((aligned(16))) uint16_t svt[64 * 72];   // V^T: [d][token]
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+    const uint16_t* base = qkv + (long)b * L * 3 * D + h * 64;
+    // stage Q, K (row-major) and V (transposed); tokens >= L are zero
+    for (int e = lane; e < 64 * 8; e += 64) {
+        const int t = e >> 3, c = e & 7;
+        uint4 q4 = make_uint4(0, 0, 0, 0), k4 = q4, v4 = q4;
+        if (t < L) {
+            const uint16_t* r = base + (long)t * 3 * D + c * 8;
+            q4 = *reinterpret_cast<const uint4*>(r);
+            k4 = *reinterpret_cast<const uint4*>(r + D);
+            v4 = *reinterpret_cast<const uint4*>(r + 2 * D);
+        }
+        *reinterpret_cast<uint4*>(sq + t * 72 + c * 8) = q4;
+        *reinterpret_cast<uint4*>(sk + t * 72 + c * 8) = k4;
+        const uint32_t vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            svt[(c * 8 + 2 * j) * 72 + t] = (uint16_t)(vv[j] & 0xffffu);
+            svt[(c * 8 + 2 * j + 1) * 72 + t] = (uint16_t)(vv[j] >> 16);
+        }
+    }
+    __syncthreads();
+    const int fr = lane & 31, fh = lane >> 5;
+    // ---- S^T = K Q^T : acc[kf][qf], rows = keys, cols = queries ----
+    f32x16_t st[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[a][c][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        s16x8_t kfv[2], qfv[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            kfv[a] = *reinterpret_cast<const s16x8_t*>(sk + (a * 32 + fr) * 72 + ks * 16 + fh * 8);
+            qfv[a] = *reinterpret_cast<const s16x8_t*>(sq + (a * 32 + fr) * 72 + ks * 16 + fh * 8);
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                st[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, kfv[a]),
+                                                                  __builtin_bit_cast(bf16x8_t, qfv[c]), st[a][c], 0, 0, 0);
+    }
+    // ---- softmax over keys, per query column (query = qf*32 + fr) ----
+    // this lane's keys: kf*32 + (r&3) + 8*(r>>2) + 4*fh
+    uint32_t pk[2][2][8];   // [qf][kf][pairs]: bf16 probabilities, packed in register order
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                const float s = (key < L) ? st[a][c][r] * scale : -INFINITY;
+                st[a][c][r] = s;
+                mx = fmaxf(mx, s);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = __expf(st[a][c][r] - mx);   // exp(-inf) = 0 for padded keys
+                st[a][c][r] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) pk[c][a][r >> 1] = ec_pack2(st[a][c][r] * inv, st[a][c][r + 1] * inv);
+    }
+    // ---- O = P V : per 16-key step s (keys 16s..16s+15) this lane holds, as MFMA k-slots e=0..7,
+    //      keys 16s + 8*(e>>2) + 4*fh + (e&3)  ==  registers r = 8*(s&1) + {0..3} and {4..7} of key-frag s>>1;
+    //      the B operand reads V^T[d][same keys] (two 8-byte pieces), so the permutation cancels. ----
+    f32x16_t oacc[2][2];   // [qf][df]
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[c][d][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int a = s >> 1, rb = 4 * (s & 1);      // pairs rb..rb+3 of pk[c][a]
+        s16x8_t vf[2];
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            const uint16_t* vrow = svt + (d * 32 + fr) * 72 + 16 * s + 4 * fh;
+            const uint2 lo = *reinterpret_cast<const uint2*>(vrow);
+            const uint2 hi = *reinterpret_cast<const uint2*>(vrow + 8);
+            const uint4 u = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            vf[d] = __builtin_bit_cast(s16x8_t, u);
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const uint4 pu = make_uint4(pk[c][a][rb], pk[c][a][rb + 1], pk[c][a][rb + 2], pk[c][a][rb + 3]);
+            const s16x8_t pf = __builtin_bit_cast(s16x8_t, pu);
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+                oacc[c][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, pf),
+                                                                    __builtin_bit_cast(bf16x8_t, vf[d]), oacc[c][d], 0, 0, 0);
+        }
+    }
+    // D[query][d]: col = d (lane&31), rows = queries (r&3) + 8*(r>>2) + 4*fh
+    uint16_t* ob = out + (long)b * L * D + h * 64;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int q = c * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                if (q < L) ob[(long)q * D + d * 32 + fr] = (uint16_t)(ec_pack2(oacc[c][d][r], 0.f) & 0xffffu);
+            }
+}
+
+__global__ void bf16_to_f32_kernel(const uint16_t* __restrict__ in, float* __restrict__ out, long n, long in_stride,
+                                   long row_len) {
+    // out[r, c] = in[r * in_stride + c], n = rows * row_len
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const long r = i / row_len, c = i - r * row_len;
+    out[i] = ec_bf2f(in[r * in_stride + c]);
+}
+
+// AttentionPool2d token assembly: tok[b,0] = mean_p feat[b,p] + pos[0]; tok[b,1+p] = feat[b,p] + pos[1+p];
+// cls[b] = tok[b,0] (dense copy for the q projection)
+__global__ __launch_bounds__(256) void attnpool_tokens_kernel(const uint16_t* __restrict__ feat,
+                                                             const float* __restrict__ pos, uint16_t* __restrict__ tok,
+                                                             uint16_t* __restrict__ cls, int HW, int C) {
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.f;
+        for (int p = 0; p < HW; ++p) {
+            const float v = ec_bf2f(feat[((long)b * HW + p) * C + c]);
+            s += v;
+            tok[((long)b * (HW + 1) + 1 + p) * C + c] = (uint16_t)(ec_pack2(v + pos[(long)(1 + p) * C + c], 0.f) & 0xffffu);
+        }
+        const uint16_t m = (uint16_t)(ec_pack2(s / (float)HW + pos[c], 0.f) & 0xffffu);
+        tok[(long)b * (HW + 1) * C + c] = m;
+        cls[(long)b * C + c] = m;
+    }
+}
+
+// CLS-only query attention (AttentionPool2d returns token 0): one wave per (frame, head), head dim 64.
+// q bf16 [B, C]; kv bf16 [B*L, 2C] (k | v); out bf16 [B, C]
+__global__ __launch_bounds__(64) void attnpool_core_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ kv,
+                                                          uint16_t* __restrict__ out, int L, int C, int heads,
+                                                          float scale) {
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+    const float qd = ec_bf2f(q[(long)b * C + h * 64 + lane]) * scale;   // q is scaled before the dot product
+    const uint16_t* kb = kv + (long)b * L * 2 * C + h * 64;
+    __shared__ float sc[64];
+    for (int t = 0; t < L; ++t) {
+        const float s = wave_sum_f(qd * ec_bf2f(kb[(long)t * 2 * C + lane]));
+        if (lane == 0) sc[t] = s;
+    }
+    __syncthreads();
+    const float mine = (lane < L) ? sc[lane] : -INFINITY;
+    const float mx = wave_max_f(mine);
+    const float e = (lane < L) ? __expf(mine - mx) : 0.f;
+    const float inv = 1.f / wave_sum_f(e);
+    __syncthreads();
+    sc[lane] = e * inv;
+    __syncthreads();
+    float o = 0.f;
+    for (int t = 0; t < L; ++t) o += sc[t] * ec_bf2f(kb[(long)t * 2 * C + C + lane]);
+    out[(long)b * C + h * 64 + lane] = (uint16_t)(ec_pack2(o, 0.f) & 0xffffu);
+}
+
+inline size_t al256(size_t v) { return (v + 255) / 256 * 256; }
+
+}  // namespace
+
+struct ec_vit {
+    int width, layers, heads, patch, res, grid, L;
+    const uint16_t* w;
+    const float* f;
+    size_t n_w, n_f;
+};
+
+#define RC(x) do { int rc__ = (x); if (rc__ != EC_OK) return rc__; } while (0)
+
+extern "C" int ec_vit_create(ec_vit_t** out, int width, int layers_run, int heads, int patch, int input_resolution,
+                             const void* w_bf16, size_t n_w, const float* params_f32, size_t n_f) {
+    if (!out || !w_bf16 || !params_f32) return EC_ERR_ARG;
+    if (width % 64 != 0 || width > 1024 || width / heads != 64 || input_resolution % patch != 0 || (patch * 3) % 4 != 0)
+        return EC_ERR_SHAPE;
+    const int G = input_resolution / patch, L = G * G + 1;
+    if (L > 64) return EC_ERR_SHAPE;   // attention core keeps <= 64 tokens per (frame, head) in LDS
+    const size_t D = width, Kp = (size_t)patch * patch * 3;
+    const size_t need_w = D * Kp + (size_t)layers_run * (3 * D * D + D * D + 4 * D * D + 4 * D * D);
+    const size_t need_f = D + L * D + 2 * D + (size_t)layers_run * (2 * D + 3 * D + D + 2 * D + 4 * D + D);
+    if (n_w != need_w || n_f != need_f) return EC_ERR_SHAPE;
+    ec_vit* h = new (std::nothrow) ec_vit();
+    if (!h) return EC_ERR_ALLOC;
+    h->width = width; h->layers = layers_run; h->heads = heads; h->patch = patch; h->res = input_resolution;
+    h->grid = G; h->L = L; h->w = (const uint16_t*)w_bf16; h->f = params_f32; h->n_w = n_w; h->n_f = n_f;
+    *out = h;
+    return EC_OK;
+}
+extern "C" void ec_vit_destroy(ec_vit_t* h) { delete h; }
+extern "C" int ec_vit_tokens(const ec_vit_t* h) { return h ? h->L : 0; }
+
+extern "C" size_t ec_vit_workspace_bytes(const ec_vit_t* h, int batch) {
+    if (!h || batch <= 0) return 0;
+    const size_t D = h->width, Kp = (size_t)h->patch * h->patch * 3, G2 = (size_t)h->grid * h->grid, L = h->L, B = batch;
+    return al256(B * G2 * Kp * 2) + al256(B * G2 * D * 2) + al256(B * L * D * 2) + al256(B * L * 3 * D * 2) +
+           al256(B * L * D * 2) + al256(B * L * 4 * D * 2);
+}
+
+extern "C" int ec_vit_forward(const ec_vit_t* h, const float* rgb, int batch, void* workspace, size_t ws_bytes,
+                              void* tokens_bf16, ec_stream_t stream) {
+    if (!h || !rgb || !workspace || !tokens_bf16) return EC_ERR_ARG;
+    if (batch <= 0) return EC_ERR_SHAPE;
+    if (ws_bytes < ec_vit_workspace_bytes(h, batch)) return EC_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const int D = h->width, P = h->patch, G = h->grid, L = h->L, B = batch;
+    const int Kp = P * P * 3, G2 = G * G;
+    if ((long)B * G2 * Kp * 2 >= (1L << 31) || (long)B * L * 4 * D * 2 >= (1L << 31)) return EC_ERR_SHAPE;
+    unsigned char* p = (unsigned char*)workspace;
+    uint16_t* patches = (uint16_t*)p; p += al256((size_t)B * G2 * Kp * 2);
+    uint16_t* pemb = (uint16_t*)p;    p += al256((size_t)B * G2 * D * 2);
+    uint16_t* hbuf = (uint16_t*)p;    p += al256((size_t)B * L * D * 2);
+    uint16_t* qkv = (uint16_t*)p;     p += al256((size_t)B * L * 3 * D * 2);
+    uint16_t* att = (uint16_t*)p;     p += al256((size_t)B * L * D * 2);
+    uint16_t* mlp = (uint16_t*)p;
+    uint16_t* x = (uint16_t*)tokens_bf16;   // residual stream lives in the output buffer
+    const uint16_t* w = h->w;
+    const float* f = h->f;
+    const float *cls = f, *pos = f + D, *lnpre_w = pos + (size_t)L * D, *lnpre_b = lnpre_w + D;
+    f = lnpre_b + D;
+    {
+        const long total4 = (long)B * G2 * Kp / 4;
+        long blocks = (total4 + 255) / 256;
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)blocks), dim3(256), 0, s, rgb, patches, h->res, P, G, total4);
+    }
+    RC(ec_gemm_bf16(patches, w, nullptr, nullptr, pemb, B * G2, D, Kp, EC_ACT_NONE, stream));
+    w += (size_t)D * Kp;
+    const long rows = (long)B * L;
+    const unsigned lnb = (unsigned)((rows + 3) / 4);
+    hipLaunchKernelGGL(layernorm_kernel<1>, dim3(lnb), dim3(256), 0, s, pemb, cls, pos, lnpre_w, lnpre_b, x, rows, D, L,
+                       1e-5f);
+    for (int l = 0; l < h->layers; ++l) {
+        const float *ln1w = f, *ln1b = f + D, *bqkv = f + 2 * D, *bo = bqkv + 3 * D, *ln2w = bo + D, *ln2b = ln2w + D;
+        const float *bfc = ln2b + D, *bpr = bfc + 4 * D;
+        f = bpr + D;
+        const uint16_t *wqkv = w, *wo = w + (size_t)3 * D * D, *wfc = wo + (size_t)D * D, *wpr = wfc + (size_t)4 * D * D;
+        w = wpr + (size_t)4 * D * D;
+        hipLaunchKernelGGL(layernorm_kernel<0>, dim3(lnb), dim3(256), 0, s, x, nullptr, nullptr, ln1w, ln1b, hbuf, rows, D,
+                           L, 1e-5f);
+        RC(ec_gemm_bf16(hbuf, wqkv, bqkv, nullptr, qkv, (int)rows, 3 * D, D, EC_ACT_NONE, stream));
+        hipLaunchKernelGGL(mha_kernel, dim3((unsigned)(B * h->heads)), dim3(64), 0, s, qkv, att, L, D, h->heads, 0.125f);
+        RC(ec_gemm_bf16(att, wo, bo, x, x, (int)rows, D, D, EC_ACT_NONE, stream));          // x += out_proj(...)
+        hipLaunchKernelGGL(layernorm_kernel<0>, dim3(lnb), dim3(256), 0, s, x, nullptr, nullptr, ln2w, ln2b, hbuf, rows, D,
+                           L, 1e-5f);
+        RC(ec_gemm_bf16(hbuf, wfc, bfc, nullptr, mlp, (int)rows, 4 * D, D, EC_ACT_QUICKGELU, stream));
+        RC(ec_gemm_bf16(mlp, wpr, bpr, x, x, (int)rows, D, 4 * D, EC_ACT_NONE, stream));     // x += c_proj(...)
+    }
+    EC_CHECK_LAUNCH();
+    return EC_OK;
+}
+
+extern "C" int ec_bf16_to_f32(const void* in, float* out, long rows, long row_len, long in_stride, ec_stream_t stream) {
+    if (!in || !out) return EC_ERR_ARG;
+    if (rows <= 0 || row_len <= 0) return EC_ERR_SHAPE;
+    const long n = rows * row_len;
+    hipLaunchKernelGGL(bf16_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t*)in, out, n, in_stride, row_len);
+    EC_CHECK_LAUNCH();
+    return EC_OK;
+}
+
+extern "C" size_t ec_attnpool_workspace_bytes(int batch, int HW, int C) {
+    if (batch <= 0 || HW <= 0 || C <= 0) return 0;
+    const size_t B = batch, L = HW + 1;
+    return al256(B * L * C * 2) + al256(B * C * 2) + al256(B * L * 2 * C * 2) + al256(B * C * 2) + al256(B * C * 2) +
+           al256(B * (size_t)C * 2);
+}
+
+extern "C" int ec_attnpool_forward(const void* feat, int batch, int HW, int C, int heads, int out_dim, const float* pos,
+                                   const void* wq, const float* bq, const void* wkv, const float* bkv, const void* wc,
+                                   const float* bc, void* workspace, size_t ws_bytes, float* out, ec_stream_t stream) {
+    if (!feat || !pos || !wq || !bq || !wkv || !bkv || !wc || !bc || !workspace || !out) return EC_ERR_ARG;
+    if (batch <= 0 || HW + 1 > 64 || C / heads != 64 || C % 64 != 0 || out_dim % 32 != 0 || out_dim > C) return EC_ERR_SHAPE;
+    if (ws_bytes < ec_attnpool_workspace_bytes(batch, HW, C)) return EC_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t B = batch, L = HW + 1;
+    unsigned char* p = (unsigned char*)workspace;
+    uint16_t* tok = (uint16_t*)p; p += al256(B * L * C * 2);
+    uint16_t* cls = (uint16_t*)p; p += al256(B * C * 2);
+    uint16_t* kv = (uint16_t*)p;  p += al256(B * L * 2 * C * 2);
+    uint16_t* q = (uint16_t*)p;   p += al256(B * C * 2);
+    uint16_t* att = (uint16_t*)p; p += al256(B * C * 2);
+    uint16_t* ob = (uint16_t*)p;
+    hipLaunchKernelGGL(attnpool_tokens_kernel, dim3((unsigned)B), dim3(256), 0, s, (const uint16_t*)feat, pos, tok, cls, HW, C);
+    RC(ec_gemm_bf16(tok, wkv, bkv, nullptr, kv, (int)(B * L), 2 * C, C, EC_ACT_NONE, stream));
+    RC(ec_gemm_bf16(cls, wq, bq, nullptr, q, (int)B, C, C, EC_ACT_NONE, stream));
+    hipLaunchKernelGGL(attnpool_core_kernel, dim3((unsigned)(B * heads)), dim3(64), 0, s, q, kv, att, (int)L, C, heads,
+                       0.125f);
+    RC(ec_gemm_bf16(att, wc, bc, nullptr, ob, (int)B, out_dim, C, EC_ACT_NONE, stream));
+    return ec_bf16_to_f32(ob, out, (long)B, out_dim, out_dim, stream);
+}

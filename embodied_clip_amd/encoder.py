@@ -142,6 +142,118 @@ class RN50Trunk:
         return o
 
 
+class AttentionPool:
+    """[U] CLIP ``AttentionPool2d`` on bf16 NHWC trunk features (the ``clip_pool`` the reference detaches at
+    primitive_probing/generate_data/thor_image_features.py:62 and calls at :112)."""
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], device="cuda", num_heads: int = 32, prefix="attnpool."):
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        sd = {k[len("visual."):] if k.startswith("visual.") else k: v for k, v in state_dict.items()}
+        g = lambda n: sd[prefix + n].detach().float()
+        bf = lambda t: t.to(torch.bfloat16).contiguous().to(self.device)
+        f32 = lambda t: t.float().contiguous().to(self.device)
+        self.pos = f32(g("positional_embedding"))
+        self.wq, self.bq = bf(g("q_proj.weight")), f32(g("q_proj.bias"))
+        self.wkv = bf(torch.cat([g("k_proj.weight"), g("v_proj.weight")], 0))
+        self.bkv = f32(torch.cat([g("k_proj.bias"), g("v_proj.bias")], 0))
+        self.wc, self.bc = bf(g("c_proj.weight")), f32(g("c_proj.bias"))
+        self.C = self.wq.shape[0]
+        self.out_dim = self.wc.shape[0]
+        self.heads = num_heads
+        self._ws = None
+
+    def forward(self, feat: torch.Tensor) -> torch.Tensor:
+        """feat bf16 [B,S,S,C] -> fp32 [B,out_dim]."""
+        B = feat.shape[0]
+        HW = feat.numel() // (B * self.C)
+        need = self.lib.ec_attnpool_workspace_bytes(B, HW, self.C)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        out = torch.empty((B, self.out_dim), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.ec_attnpool_forward(feat.data_ptr(), B, HW, self.C, self.heads, self.out_dim,
+                                                self.pos.data_ptr(), self.wq.data_ptr(), self.bq.data_ptr(),
+                                                self.wkv.data_ptr(), self.bkv.data_ptr(), self.wc.data_ptr(),
+                                                self.bc.data_ptr(), self._ws.data_ptr(), self._ws.numel(),
+                                                out.data_ptr(), _lib.stream_ptr()), "ec_attnpool_forward")
+        return out
+
+
+def pack_vit(sd: Dict[str, torch.Tensor], drop_last: int = 1):
+    """OpenAI-CLIP ``visual.state_dict()`` of a VisionTransformer -> (cfg, w bf16 flat, params f32 flat) in the
+    order ``ec_vit_create`` documents.  ``drop_last=1`` == ClipViTEmbedder (``resblocks[:-1]``)."""
+    sd = {k[len("visual."):] if k.startswith("visual.") else k: v.detach().cpu().float() for k, v in sd.items()}
+    D = sd["class_embedding"].numel()
+    patch = sd["conv1.weight"].shape[-1]
+    L = sd["positional_embedding"].shape[0]
+    n = 0
+    while f"transformer.resblocks.{n}.ln_1.weight" in sd:
+        n += 1
+    run = n - drop_last
+    ws = [sd["conv1.weight"].permute(0, 2, 3, 1).reshape(D, -1)]
+    fs = [sd["class_embedding"], sd["positional_embedding"].reshape(-1), sd["ln_pre.weight"], sd["ln_pre.bias"]]
+    for i in range(run):
+        p = f"transformer.resblocks.{i}."
+        ws += [sd[p + "attn.in_proj_weight"], sd[p + "attn.out_proj.weight"], sd[p + "mlp.c_fc.weight"],
+               sd[p + "mlp.c_proj.weight"]]
+        fs += [sd[p + "ln_1.weight"], sd[p + "ln_1.bias"], sd[p + "attn.in_proj_bias"], sd[p + "attn.out_proj.bias"],
+               sd[p + "ln_2.weight"], sd[p + "ln_2.bias"], sd[p + "mlp.c_fc.bias"], sd[p + "mlp.c_proj.bias"]]
+    w = torch.cat([t.reshape(-1) for t in ws]).to(torch.bfloat16)
+    f = torch.cat([t.reshape(-1) for t in fs]).float()
+    return dict(width=D, layers_run=run, patch=patch, tokens=L), w, f
+
+
+class ViTEmbedder:
+    """Frozen CLIP VisionTransformer run as [U] ``ClipViTEmbedder`` does: tokens after all but the last block."""
+
+    def __init__(self, state_dict, device="cuda", heads: int = 12, input_resolution: int = 224, drop_last: int = 1):
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        cfg, w, f = pack_vit(state_dict, drop_last)
+        self.w, self.f = w.to(self.device), f.to(self.device)
+        self.D, self.input_resolution = cfg["width"], input_resolution
+        h = C.c_void_p()
+        _lib.check(self.lib.ec_vit_create(C.byref(h), cfg["width"], cfg["layers_run"], heads, cfg["patch"],
+                                          input_resolution, self.w.data_ptr(), self.w.numel(), self.f.data_ptr(),
+                                          self.f.numel()), "ec_vit_create")
+        self.h = h
+        self.L = self.lib.ec_vit_tokens(h)
+        self._ws = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.ec_vit_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def forward(self, rgb: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """rgb device fp32 [B,R,R,3] -> tokens bf16 [B,L,D]."""
+        assert rgb.is_cuda and rgb.dtype == torch.float32 and rgb.is_contiguous()
+        B = rgb.shape[0]
+        need = self.lib.ec_vit_workspace_bytes(self.h, B)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        if out is None:
+            out = torch.empty((B, self.L, self.D), dtype=torch.bfloat16, device=self.device)
+        _lib.check(self.lib.ec_vit_forward(self.h, rgb.data_ptr(), B, self._ws.data_ptr(), self._ws.numel(),
+                                           out.data_ptr(), _lib.stream_ptr()), "ec_vit_forward")
+        return out
+
+    def to_f32(self, tokens: torch.Tensor, class_emb_only: bool = False) -> torch.Tensor:
+        B = tokens.shape[0]
+        if class_emb_only:
+            o = torch.empty((B, self.D), dtype=torch.float32, device=self.device)
+            _lib.check(self.lib.ec_bf16_to_f32(tokens.data_ptr(), o.data_ptr(), B, self.D, self.L * self.D,
+                                               _lib.stream_ptr()))
+        else:
+            o = torch.empty((B, self.L, self.D), dtype=torch.float32, device=self.device)
+            _lib.check(self.lib.ec_bf16_to_f32(tokens.data_ptr(), o.data_ptr(), B, self.L * self.D, self.L * self.D,
+                                               _lib.stream_ptr()))
+        return o
+
+
 # ---- thin op-level wrappers (used by the parity tests) -------------------------------------
 
 def conv_bf16(x, w, bias, res=None, ksize=1, pool=False, act=1):

@@ -126,11 +126,13 @@ def rn50_visual_state_dict(seed: int = 0, width: int = 64, layers: Sequence[int]
             _conv(sd, seed, p + ".conv2.weight", planes, planes, 3)
             _bn(sd, seed, p + ".bn2", planes)
             _conv(sd, seed, p + ".conv3.weight", planes * 4, planes, 1)
-            # damp the residual branch so 16 stacked blocks stay O(1)
-            _bn(sd, seed, p + ".bn3", planes * 4, gamma_scale=0.5)
+            # damp the residual branch (and the projection shortcut) so the 16 stacked blocks keep
+            # activations O(1) like the real CLIP tower; otherwise attention logits of AttentionPool2d
+            # reach the hundreds and the softmax becomes ill-conditioned under ANY reduced precision
+            _bn(sd, seed, p + ".bn3", planes * 4, gamma_scale=0.3)
             if stride > 1 or inplanes != planes * 4:
                 _conv(sd, seed, p + ".downsample.0.weight", planes * 4, inplanes, 1)
-                _bn(sd, seed, p + ".downsample.1", planes * 4)
+                _bn(sd, seed, p + ".downsample.1", planes * 4, gamma_scale=0.7)
             inplanes = planes * 4
     embed = width * 32
     sp = input_resolution // 32

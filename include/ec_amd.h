@@ -202,6 +202,40 @@ int ec_clip_adam_step(float* params, const float* grads, float* exp_avg, float* 
                       long n, float max_grad_norm, float lr, float beta1, float beta2, float eps, int step,
                       ec_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * CLIP VisionTransformer embedder == [U] allenact ClipViTEmbedder.forward over
+ * [U] openai/CLIP VisionTransformer: patch-embed, class +
+ * positional embedding, ln_pre, then `layers_run` ResidualAttentionBlocks
+ * (ClipViTPreprocessor runs all but the LAST block; no ln_post / proj).
+ * w_bf16 (concatenated): conv1 as [D][P*P*3] with K ordered (ky,kx,c); then per block
+ *   in_proj_weight [3D,D], out_proj.weight [D,D], mlp.c_fc.weight [4D,D], mlp.c_proj.weight [D,4D].
+ * params_f32: class_embedding [D], positional_embedding [L,D], ln_pre.{w,b}; then per block
+ *   ln_1.{w,b}, in_proj_bias [3D], out_proj.bias [D], ln_2.{w,b}, c_fc.bias [4D], c_proj.bias [D].
+ * ---------------------------------------------------------------------- */
+typedef struct ec_vit ec_vit_t;
+int ec_vit_create(ec_vit_t** out, int width, int layers_run, int heads, int patch, int input_resolution,
+                  const void* w_bf16, size_t n_w, const float* params_f32, size_t n_f);
+void ec_vit_destroy(ec_vit_t* h);
+int ec_vit_tokens(const ec_vit_t* h);                       /* L = (R/P)^2 + 1 */
+size_t ec_vit_workspace_bytes(const ec_vit_t* h, int batch);
+/* rgb f32 NHWC [B,R,R,3] -> tokens bf16 [B, L, D] */
+int ec_vit_forward(const ec_vit_t* h, const float* rgb_nhwc, int batch, void* workspace, size_t ws_bytes,
+                   void* tokens_bf16, ec_stream_t stream);
+/* out[r, c] = (float) in[r*in_stride + c]  -- the `.float()` at the API edge (e.g. class_emb_only: in_stride = L*D) */
+int ec_bf16_to_f32(const void* in, float* out, long rows, long row_len, long in_stride, ec_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * [U] openai/CLIP AttentionPool2d.forward, the module the reference detaches and calls on the conv
+ * features (primitive_probing/generate_data/thor_image_features.py:62,112): mean token + positional
+ * embedding, q/k/v projections, 64-wide heads, softmax, c_proj; returns token 0 only, so only the
+ * CLS query is computed.  feat bf16 NHWC [B,HW,C]; wkv = [k_proj.weight; v_proj.weight] ([2C,C]),
+ * bkv likewise; out f32 [B,out_dim].
+ * ---------------------------------------------------------------------- */
+size_t ec_attnpool_workspace_bytes(int batch, int HW, int C);
+int ec_attnpool_forward(const void* feat, int batch, int HW, int C, int heads, int out_dim, const float* pos,
+                        const void* wq, const float* bq, const void* wkv, const float* bkv, const void* wc,
+                        const float* bc, void* workspace, size_t ws_bytes, float* out, ec_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
