@@ -33,6 +33,9 @@ TRUNK_MAC_PER_FRAME = 5_367_226_368          # SURVEY.md §8d (RN50 trunk, 224x2
 POLICY_ACT_MAC = 16_846_336
 POLICY_UPDATE_MAC = 150_775_808              # 4 x (fwd + bwd)
 MFMA_BF16_PEAK_TFLOPS = 2500.0               # MI355X_MICROARCH.md: dense bf16 MFMA
+# HBM bytes per ec_rn50_forward launch at N=256 from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction +
+# WRITE_SIZE, separate --pmc passes): profiles/r01_trunk_b256_hbm_traffic.txt.  Algorithmic: 45.7 MB/frame.
+TRUNK_HBM_BYTES_PER_LAUNCH_N256 = 1.61e10
 
 
 def _usable_cpus() -> int:
@@ -169,7 +172,10 @@ def main():
                        "flop_per_frame": 2 * (TRUNK_MAC_PER_FRAME + POLICY_ACT_MAC + POLICY_UPDATE_MAC)},
             "roofline": {"bound": "mfma", "kernel": "ec_rn50_forward (conv_igemm_kernel family, 55 convs per call)",
                          "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
+                         "traffic": TRUNK_HBM_BYTES_PER_LAUNCH_N256 if a.actors == 256 else None,
+                         "traffic_note": "HBM bytes per launch, PMC-measured offline (profiles/r01_trunk_b256_hbm_traffic.txt); "
+                                         "algorithmic bytes 45.7 MB/frame x N",
                          "avg_launch_ms": round(avg_trunk_ms, 3), "launches_timed": len(trunk_ms),
                          "algorithmic_flop_per_launch": flops_call,
                          "encoder_share_of_step": round(sum(trunk_ms) / (dt * 1e3), 3)},

@@ -48,8 +48,10 @@ struct ConvArgs {
     int cin_log2;
     int act;
     int ntn;   // number of N tiles
+    int ntiles; // total output tiles
     int nbuf;  // LDS stages: 2 (double buffer) or 1
     unsigned in_bytes, w_bytes;   // buffer-descriptor extents (out-of-range loads return 0)
+    int ablate;                   // profiling only (EC_CONV_ABLATE): 1 no global loads, 2 no MFMA, 4 no LDS stores, 8 no epilogue
 };
 
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
@@ -65,13 +67,16 @@ __device__ __forceinline__ float dpp_quad_xor2(float v) {   // lane ^ 2 within a
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
 }
 
-template <int BM, int BN, int WM, int WN, int KS, bool POOL>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
+template <int BM, int BN, int WM, int WN, int KS, bool POOL, bool PF>
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_igemm_kernel(ConvArgs p) {
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int FM = TM / 32, FN = TN / 32;
-    constexpr int A_IT = BM / 32, B_IT = BN / 32;   // 16-B chunks per thread per tile
+    constexpr int NT = WM * WN * 64;                // threads per workgroup
+    constexpr int LR = NT / 8;                      // tile rows covered per loader pass (8 chunks per row)
+    constexpr int A_IT = BM / LR, B_IT = BN / LR;   // 16-B chunks per thread per tile
     constexpr int A_BYTES = BM * ROW_BYTES, B_BYTES = BN * ROW_BYTES;
-    static_assert(WM * WN == 4, "4 waves");
+    static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves");
+    static_assert(BM % LR == 0 && BN % LR == 0, "loader geometry");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
@@ -79,58 +84,64 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     const int wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
 
-    const unsigned nwg = gridDim.x;
-    const unsigned bid = ec_xcd_remap(blockIdx.x, nwg);
-    const int tile_n = bid % p.ntn;
-    const int tile_m = bid / p.ntn;
-    const int m0 = tile_m * BM;
-    const int n0 = tile_n * BN;
+    // Persistent workgroups: logical block lb walks tiles lb, lb+grid, lb+2*grid, ... (tile_n fastest, so the
+    // tiles in flight at any moment are neighbours and each XCD owns a contiguous run of them).
+    const unsigned grid = gridDim.x;
+    const unsigned lb = ec_xcd_remap(blockIdx.x, grid);
+    int tile = (int)lb;
+    if (tile >= p.ntiles) return;
+    int m0 = (tile / p.ntn) * BM;
+    int n0 = (tile % p.ntn) * BN;
 
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
 
     // ---- per-thread loader geometry (K-invariant): a byte offset and a 9-bit tap-validity mask per row ----
     const int chunk = tid & 7;     // which 16-B chunk of the 128-B K row
-    const int lrow = tid >> 3;     // 0..31
+    const int lrow = tid >> 3;     // 0..LR-1
     unsigned a_off[A_IT];          // byte offset of the row's centre-tap pixel, channel 0
     unsigned a_msk[A_IT];          // bit (ky*3+kx) set <=> that tap lies inside the frame (bit 0 only for 1x1)
-#pragma unroll
-    for (int i = 0; i < A_IT; ++i) {
-        const int m = m0 + lrow + 32 * i;
-        int pix, y = 0, x = 0;
-        if (POOL) {
-            const int q = m >> 2, s = m & 3;
-            const int Hp = p.H >> 1, Wp = p.W >> 1;
-            const int b = q / (Hp * Wp);
-            const int r2 = q - b * (Hp * Wp);
-            const int yp = r2 / Wp;
-            y = 2 * yp + (s >> 1);
-            x = 2 * (r2 - yp * Wp) + (s & 1);
-            pix = (b * p.H + y) * p.W + x;
-        } else if (KS == 1) {
-            pix = m;               // raster order: pixel index == m, no halo
-        } else {
-            const int b = m / (p.H * p.W);
-            const int r2 = m - b * (p.H * p.W);
-            y = r2 / p.W;
-            x = r2 - y * p.W;
-            pix = m;
-        }
-        unsigned msk = 1u;
-        if (KS == 3) {
-            const unsigned xm = (x > 0 ? 1u : 0u) | 2u | (x < p.W - 1 ? 4u : 0u);
-            msk = (y > 0 ? xm : 0u) | (xm << 3) | (y < p.H - 1 ? (xm << 6) : 0u);
-        }
-        a_msk[i] = (m < p.M) ? msk : 0u;
-        a_off[i] = (unsigned)pix * (unsigned)p.Cin * 2u;
-    }
     unsigned b_off[B_IT];
+    auto decode = [&]() {          // geometry of tile (m0, n0)
 #pragma unroll
-    for (int i = 0; i < B_IT; ++i) b_off[i] = ((unsigned)(n0 + lrow + 32 * i) * (unsigned)p.K + chunk * 8) * 2u;
+        for (int i = 0; i < A_IT; ++i) {
+            const int m = m0 + lrow + LR * i;
+            int pix, y = 0, x = 0;
+            if (POOL) {
+                const int q = m >> 2, s2 = m & 3;
+                const int Hp = p.H >> 1, Wp = p.W >> 1;
+                const int b = q / (Hp * Wp);
+                const int r2 = q - b * (Hp * Wp);
+                const int yp = r2 / Wp;
+                y = 2 * yp + (s2 >> 1);
+                x = 2 * (r2 - yp * Wp) + (s2 & 1);
+                pix = (b * p.H + y) * p.W + x;
+            } else if (KS == 1) {
+                pix = m;               // raster order: pixel index == m, no halo
+            } else {
+                const int b = m / (p.H * p.W);
+                const int r2 = m - b * (p.H * p.W);
+                y = r2 / p.W;
+                x = r2 - y * p.W;
+                pix = m;
+            }
+            unsigned msk = 1u;
+            if (KS == 3) {
+                const unsigned xm = (x > 0 ? 1u : 0u) | 2u | (x < p.W - 1 ? 4u : 0u);
+                msk = (y > 0 ? xm : 0u) | (xm << 3) | (y < p.H - 1 ? (xm << 6) : 0u);
+            }
+            a_msk[i] = (m < p.M) ? msk : 0u;
+            a_off[i] = (unsigned)pix * (unsigned)p.Cin * 2u;
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) b_off[i] = ((unsigned)(n0 + lrow + LR * i) * (unsigned)p.K + chunk * 8) * 2u;
+    };
+    decode();
 
-    u32x4_t ra[A_IT], rb[B_IT];
+    // register staging set for the NEXT K-tile (a second set, i.e. loads two tiles ahead, was measured: +-5%)
+    u32x4_t ra0[A_IT], rb0[B_IT];
 
-    auto load_tile = [&](int kt) {
+    auto load_tile = [&](int kt, u32x4_t (&ra)[A_IT], u32x4_t (&rb)[B_IT]) {
         const int k = kt * BK + chunk * 8;
         int tap = 0, toff = k * 2;
         if (KS == 3) {
@@ -150,93 +161,125 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, b_off[i] + kt * (BK * 2), 0, 0);
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, const u32x4_t (&ra)[A_IT], const u32x4_t (&rb)[B_IT]) {
         unsigned char* sa = smem + buf * (A_BYTES + B_BYTES);
         unsigned char* sb = sa + A_BYTES;
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i) *reinterpret_cast<u32x4_t*>(sa + lds_off(lrow + 32 * i, chunk)) = ra[i];
+        for (int i = 0; i < A_IT; ++i) *reinterpret_cast<u32x4_t*>(sa + lds_off(lrow + LR * i, chunk)) = ra[i];
 #pragma unroll
-        for (int i = 0; i < B_IT; ++i) *reinterpret_cast<u32x4_t*>(sb + lds_off(lrow + 32 * i, chunk)) = rb[i];
+        for (int i = 0; i < B_IT; ++i) *reinterpret_cast<u32x4_t*>(sb + lds_off(lrow + LR * i, chunk)) = rb[i];
     };
 
     f32x16_t acc[FM][FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // epilogue geometry (also used by the residual prefetch below)
+    // epilogue geometry
     constexpr int CH = BN / 8;                 // 16-B chunks per tile row
     constexpr int PITCH = BN * 2 + 16;         // bytes; +16 staggers banks between rows
-    constexpr int RPP = 256 / CH;              // rows per pass
+    constexpr int RPP = NT / CH;               // rows per pass
     constexpr int OUT_ROWS = POOL ? BM / 4 : BM;
     constexpr int NPASS = OUT_ROWS / RPP;
-    const int orow0 = POOL ? (m0 >> 2) : m0;
     const int Mout = POOL ? (p.M >> 2) : p.M;
     const int srow = tid / CH, schunk = tid % CH;
     const bool has_res = !POOL && (p.res != nullptr);
-    // residual tile: issued NOW so its HBM latency overlaps the whole K loop
-    uint4 rres[POOL ? 1 : NPASS];
-    if (has_res) {
-#pragma unroll
-        for (int i = 0; i < (POOL ? 1 : NPASS); ++i) {
-            const int row = i * RPP + srow;
-            rres[i] = make_uint4(0, 0, 0, 0);
-            if (orow0 + row < Mout)
-                rres[i] = *reinterpret_cast<const uint4*>(p.res + (long)(orow0 + row) * p.Cout + n0 + schunk * 8);
-        }
-    }
+    constexpr bool PREFETCH = PF && !POOL && (NPASS <= 8);   // PF: short-K (bandwidth-bound) launches only
+    uint4 rres[PREFETCH ? NPASS : 1];
 
     const int nk = (p.K + BK - 1) / BK;
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-
     const int frow = lane & 31;
     const int fhalf = lane >> 5;
-    const int bufmask = p.nbuf - 1;   // 1: ping-pong, 0: single stage
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & bufmask;
-        const bool more = (kt + 1) < nk;
-        if (more) load_tile(kt + 1);
-        const unsigned char* sa = smem + cur * (A_BYTES + B_BYTES);
+    auto compute = [&](int buf) {
+        const unsigned char* sa = smem + buf * (A_BYTES + B_BYTES);
         const unsigned char* sb = sa + A_BYTES;
+        // ALL fragments of the K-tile are read first, into distinct registers, so the LDS latency of the
+        // later k-steps hides behind the MFMAs of the earlier ones (left alone, hipcc recycles one fragment
+        // set and serialises ds_read -> lgkmcnt -> 4 MFMAs four times per tile).
+        s16x8_t af[BK / 16][FM], bfr[BK / 16][FN];
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
-            s16x8_t af[FM], bfr[FN];
             const int c = ks * 2 + fhalf;
 #pragma unroll
             for (int i = 0; i < FM; ++i)
-                af[i] = *reinterpret_cast<const s16x8_t*>(sa + lds_off(wm * TM + i * 32 + frow, c));
+                af[ks][i] = *reinterpret_cast<const s16x8_t*>(sa + lds_off(wm * TM + i * 32 + frow, c));
 #pragma unroll
             for (int j = 0; j < FN; ++j)
-                bfr[j] = *reinterpret_cast<const s16x8_t*>(sb + lds_off(wn * TN + j * 32 + frow, c));
-            // SWAPPED operands: D[n][m] = sum_k W[n][k] * A[m][k].  In the 32x32 C/D layout a lane then owns
-            // ONE pixel (col = lane&31) and channels (r&3) + 8*(r>>2) + 4*(lane>>5): every 4 accumulator
-            // registers are 4 consecutive channels -> 8-byte packed epilogue traffic.
+                bfr[ks][j] = *reinterpret_cast<const s16x8_t*>(sb + lds_off(wn * TN + j * 32 + frow, c));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // SWAPPED operands: D[n][m] = sum_k W[n][k] * A[m][k].  In the 32x32 C/D layout a lane then owns
+        // ONE pixel (col = lane&31) and channels (r&3) + 8*(r>>2) + 4*(lane>>5): every 4 accumulator
+        // registers are 4 consecutive channels -> 8-byte packed epilogue traffic.
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks)
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int j = 0; j < FN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                        __builtin_bit_cast(bf16x8_t, bfr[j]), __builtin_bit_cast(bf16x8_t, af[i]), acc[i][j], 0, 0, 0);
+                        __builtin_bit_cast(bf16x8_t, bfr[ks][j]), __builtin_bit_cast(bf16x8_t, af[ks][i]), acc[i][j], 0, 0, 0);
+    };
+    // K pipeline: tile t computes from LDS[t&1] while the global loads of tile t+1 are in flight in registers;
+    // they are written to LDS[(t+1)&1] after the MFMAs.  One barrier per K-tile.
+    // Tile pipeline: the first K-tile of the NEXT output tile is issued before this tile's epilogue, so the
+    // exposed first-load latency and the epilogue's HBM traffic overlap instead of adding up.
+    load_tile(0, ra0, rb0);
+    for (;;) {
+        const int e_m0 = m0, e_n0 = n0;                      // coordinates of the tile being finished
+        const int orow0 = POOL ? (e_m0 >> 2) : e_m0;
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        // residual tile of THIS output tile: issued now so its HBM latency overlaps the whole K loop
+        if (PREFETCH && has_res) {
+#pragma unroll
+            for (int i = 0; i < (PREFETCH ? NPASS : 1); ++i) {
+                const int row = i * RPP + srow;
+                rres[i] = make_uint4(0, 0, 0, 0);
+                if (orow0 + row < Mout)
+                    rres[i] = *reinterpret_cast<const uint4*>(p.res + (long)(orow0 + row) * p.Cout + e_n0 + schunk * 8);
+            }
         }
-        if (p.nbuf == 1) __syncthreads();          // everyone is done reading the only stage
-        if (more) store_tile((kt + 1) & bufmask);
+        store_tile(0, ra0, rb0);
         __syncthreads();
-    }
-
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            const bool more = (kt + 1) < nk;
+            if (more && !(p.ablate & 1)) load_tile(kt + 1, ra0, rb0);
+            if (!(p.ablate & 2)) compute(cur);
+            if (more && !(p.ablate & 4)) store_tile(cur ^ 1, ra0, rb0);
+            __syncthreads();
+        }
+        tile += (int)grid;
+        const bool has_next = tile < p.ntiles;
+        if (has_next) {
+            m0 = (tile / p.ntn) * BM;
+            n0 = (tile % p.ntn) * BN;
+            decode();
+            load_tile(0, ra0, rb0);                          // flies during the epilogue below
+        }
+        if (!(p.ablate & 8)) {
     // ---- epilogue: staged through LDS so every global access is a coalesced 16-B chunk ----
     //   1. prefetched residual tile -> LDS                [only with a residual]
     //   2. each lane folds bias/residual/activation (or the 2x2 pool) into 4 consecutive channels of its
     //      pixel in fp32, rounds ONCE to bf16 (v_cvt_pk_bf16_f32) and writes 8 bytes to its own LDS slot
     //   3. LDS -> global as 16-B row chunks
     if (has_res) {
+        if (PREFETCH) {
 #pragma unroll
-        for (int i = 0; i < (POOL ? 1 : NPASS); ++i)
-            *reinterpret_cast<uint4*>(smem + (i * RPP + srow) * PITCH + schunk * 16) = rres[i];
+            for (int i = 0; i < (PREFETCH ? NPASS : 1); ++i)
+                *reinterpret_cast<uint4*>(smem + (i * RPP + srow) * PITCH + schunk * 16) = rres[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < NPASS; ++i) {
+                const int row = i * RPP + srow;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (orow0 + row < Mout)
+                    v = *reinterpret_cast<const uint4*>(p.res + (long)(orow0 + row) * p.Cout + e_n0 + schunk * 8);
+                *reinterpret_cast<uint4*>(smem + row * PITCH + schunk * 16) = v;
+            }
+        }
         __syncthreads();
     }
 #pragma unroll
@@ -245,7 +288,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
         for (int g = 0; g < 4; ++g) {
             const int lcol = wn * TN + j * 32 + 8 * g + 4 * fhalf;          // 4 consecutive channels
             float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + n0 + lcol);
+            if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + e_n0 + lcol);
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
                 const int lrow_px = wm * TM + i * 32 + frow;                 // this lane's pixel (tile-local row)
@@ -287,39 +330,62 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     for (int r0 = 0; r0 < OUT_ROWS; r0 += RPP) {
         const int row = r0 + srow;
         if (orow0 + row < Mout)
-            *reinterpret_cast<uint4*>(p.out + (long)(orow0 + row) * p.Cout + n0 + schunk * 8) =
+            *reinterpret_cast<uint4*>(p.out + (long)(orow0 + row) * p.Cout + e_n0 + schunk * 8) =
                 *reinterpret_cast<const uint4*>(smem + row * PITCH + schunk * 16);
+    }
+        }   // !(ablate & 8)
+        if (!has_next) break;
+        __syncthreads();                                     // epilogue's LDS reads are done before the next store_tile
     }
 }
 
-template <int BM, int BN, int WM, int WN, int KS, bool POOL>
+template <int BM, int BN, int WM, int WN, int KS, bool POOL, bool PF = false>
 int launch(const ConvArgs& a, hipStream_t s) {
     ConvArgs p = a;
     p.ntn = a.Cout / BN;
     const int ntm = (a.M + BM - 1) / BM;
+    p.ntiles = ntm * p.ntn;
     const size_t lds_max = 2 * (size_t)(BM + BN) * ROW_BYTES;
     const size_t epi = (size_t)(POOL ? BM / 4 : BM) * (BN * 2 + 16);
     static const int nbuf_force = [] { const char* e = getenv("EC_CONV_NBUF"); return e ? atoi(e) : 0; }();
-    p.nbuf = nbuf_force ? nbuf_force : 1;   // single stage measured ~2% faster: more workgroups per CU
+    (void)nbuf_force;
+    p.nbuf = 2;
+    static const int ablate = [] { const char* e = getenv("EC_CONV_ABLATE"); return e ? atoi(e) : 0; }();
+    p.ablate = ablate;
     size_t lds = (size_t)p.nbuf * (BM + BN) * ROW_BYTES;
     if (lds < epi) lds = epi;
-    auto kern = conv_igemm_kernel<BM, BN, WM, WN, KS, POOL>;
+    auto kern = conv_igemm_kernel<BM, BN, WM, WN, KS, POOL, PF>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(lds_max > epi ? lds_max : epi));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(ntm * p.ntn)), dim3(256), lds, s, p);
+    // persistent: at most 2 workgroups per CU (register-limited residency), each walking several tiles
+    static const int wg_cap = [] { const char* e = getenv("EC_CONV_WGS"); return e ? atoi(e) : 512; }();
+    const int nwg = p.ntiles < wg_cap ? p.ntiles : wg_cap;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(WM * WN * 64), lds, s, p);
     EC_CHECK_LAUNCH();
     return EC_OK;
 }
 
 template <int KS, bool POOL>
 int dispatch_tile(const ConvArgs& a, hipStream_t s) {
-    if (a.Cout % 128 == 0) return launch<128, 128, 2, 2, KS, POOL>(a, s);
-    if (a.Cout % 64 == 0) return launch<256, 64, 4, 1, KS, POOL>(a, s);
-    if (a.Cout % 32 == 0) return launch<256, 32, 4, 1, KS, POOL>(a, s);
+    static const int force = [] { const char* e = getenv("EC_CONV_WAVES"); return e ? atoi(e) : 0; }();
+    // Tile choice: 128x128 wherever Cout allows; 256-row tiles for the narrow early layers.
+    // (Fatter 128x256 / 256x128 tiles were measured: no gain, and they spill once loads run two tiles ahead.)
+    if (a.Cout % 128 == 0) {
+        // residual register prefetch only for the short-K, bandwidth-bound expanding 1x1 convs
+        if (force != 8) {
+            if (KS == 1 && !POOL && a.res && a.K <= 256) return launch<128, 128, 2, 2, KS, POOL, (KS == 1 && !POOL)>(a, s);
+            return launch<128, 128, 2, 2, KS, POOL>(a, s);
+        }
+        // 8 waves x (64x32): 32 accumulator registers per lane -> 4 waves/SIMD resident (2 workgroups per CU)
+        if (KS == 1 && !POOL && a.res && a.K <= 256) return launch<128, 128, 2, 4, KS, POOL, (KS == 1 && !POOL)>(a, s);
+        return launch<128, 128, 2, 4, KS, POOL>(a, s);
+    }
+    if (a.Cout % 64 == 0) return force != 8 ? launch<256, 64, 4, 1, KS, POOL>(a, s) : launch<256, 64, 8, 1, KS, POOL>(a, s);
+    if (a.Cout % 32 == 0) return launch<256, 32, 4, 1, KS, POOL>(a, s);   // (one stem layer; 32 B rows < 8-wave loader pass)
     return EC_ERR_SHAPE;
 }
 
