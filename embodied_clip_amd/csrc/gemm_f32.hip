@@ -245,6 +245,263 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16x3 path: exact-fp32-equivalent products on the bf16 MFMA.
+// An fp32 value is split while it is staged into LDS:  x = x0 + x1 + x2  (three bf16 planes, 8+8+8 mantissa
+// bits = all 24).  Each bf16*bf16 product is exact in fp32 and the MFMA accumulates in fp32, so
+//   a*b = sum_{i+j<=2} a_i*b_j  + O(2^-24 |a||b|)      (6 MFMAs; 3 when one operand is stored as bf16)
+// i.e. fp32-GEMM accuracy at 6/16 (3/16) of the fp32-MFMA pipe time.  Used for the aligned, regular
+// shapes (all the large policy GEMMs); irregular shapes stay on the fp32-MFMA kernel above.
+// LDS image per operand plane: [row][32 bf16] (64-B rows), 16-B chunk index XOR (row>>2)&3: conflict-free for
+// the 16-lane ds_read_b128 groups.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int xoff(int row, int c) { return row * 64 + ((c ^ ((row >> 2) & 3)) << 4); }
+
+__device__ __forceinline__ void split3x4(const float (&x)[4], uint2& p0, uint2& p1, uint2& p2) {
+    p0.x = ec_pack2(x[0], x[1]); p0.y = ec_pack2(x[2], x[3]);
+    const float r0 = x[0] - ec_lo(p0.x), r1 = x[1] - ec_hi(p0.x), r2 = x[2] - ec_lo(p0.y), r3 = x[3] - ec_hi(p0.y);
+    p1.x = ec_pack2(r0, r1); p1.y = ec_pack2(r2, r3);
+    p2.x = ec_pack2(r0 - ec_lo(p1.x), r1 - ec_hi(p1.x)); p2.y = ec_pack2(r2 - ec_lo(p1.y), r3 - ec_hi(p1.y));
+}
+
+// One operand tile (R rows x 32 k): global -> registers.  KC: k-contiguous source (4 consecutive k per lane),
+// else row-contiguous (a 4x4 (k x row) block per lane, transposed in registers on the way to LDS).
+template <int R, bool BF16, bool KC>
+struct XStage {
+    static constexpr int PASS = KC ? R / 32 : (R + 127) / 128;
+    float v[PASS][KC ? 4 : 16];
+    __device__ __forceinline__ void load(const void* src, long sr, long sk, int r0, int k0, int Rmax, int Kmax, int tid) {
+        const int kq = tid & 7, rr = tid >> 3;
+        if (KC) {
+            const int k = k0 + 4 * kq;
+#pragma unroll
+            for (int i = 0; i < PASS; ++i) {
+                const int r = r0 + rr + 32 * i;
+                float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+                if (r < Rmax && k < Kmax) {
+                    const long off = (long)r * sr + k;
+                    if (BF16) {
+                        const uint2 u = *reinterpret_cast<const uint2*>((const uint16_t*)src + off);
+                        t0 = ec_lo(u.x); t1 = ec_hi(u.x); t2 = ec_lo(u.y); t3 = ec_hi(u.y);
+                    } else {
+                        const float4 u = *reinterpret_cast<const float4*>((const float*)src + off);
+                        t0 = u.x; t1 = u.y; t2 = u.z; t3 = u.w;
+                    }
+                }
+                v[i][0] = t0; v[i][1] = t1; v[i][2] = t2; v[i][3] = t3;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < PASS; ++i) {
+                const int r = r0 + 4 * (rr + 32 * i);
+                const bool rin = (4 * (rr + 32 * i) < R) && (r < Rmax);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int k = k0 + 4 * kq + kk;
+                    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+                    if (rin && k < Kmax) {
+                        const long off = (long)k * sk + r;
+                        if (BF16) {
+                            const uint2 u = *reinterpret_cast<const uint2*>((const uint16_t*)src + off);
+                            t0 = ec_lo(u.x); t1 = ec_hi(u.x); t2 = ec_lo(u.y); t3 = ec_hi(u.y);
+                        } else {
+                            const float4 u = *reinterpret_cast<const float4*>((const float*)src + off);
+                            t0 = u.x; t1 = u.y; t2 = u.z; t3 = u.w;
+                        }
+                    }
+                    v[i][kk * 4 + 0] = t0; v[i][kk * 4 + 1] = t1; v[i][kk * 4 + 2] = t2; v[i][kk * 4 + 3] = t3;
+                }
+            }
+        }
+    }
+    // registers -> LDS planes (plane stride R*64 bytes); bf16 sources fill plane 0 only
+    __device__ __forceinline__ void store(unsigned char* S, int tid) const {
+        const int kq = tid & 7, rr = tid >> 3;
+        const int c = kq >> 1, half = (kq & 1) * 8;
+        constexpr int PL = R * 64;
+        if (KC) {
+#pragma unroll
+            for (int i = 0; i < PASS; ++i) {
+                const int row = rr + 32 * i;
+                unsigned char* d = S + xoff(row, c) + half;
+                const float x[4] = {v[i][0], v[i][1], v[i][2], v[i][3]};
+                if (BF16) {
+                    *reinterpret_cast<uint2*>(d) = make_uint2(ec_pack2(x[0], x[1]), ec_pack2(x[2], x[3]));
+                } else {
+                    uint2 p0, p1, p2;
+                    split3x4(x, p0, p1, p2);
+                    *reinterpret_cast<uint2*>(d) = p0;
+                    *reinterpret_cast<uint2*>(d + PL) = p1;
+                    *reinterpret_cast<uint2*>(d + 2 * PL) = p2;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < PASS; ++i) {
+                if (4 * (rr + 32 * i) >= R) continue;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int row = 4 * (rr + 32 * i) + j;
+                    unsigned char* d = S + xoff(row, c) + half;
+                    const float x[4] = {v[i][j], v[i][4 + j], v[i][8 + j], v[i][12 + j]};
+                    if (BF16) {
+                        *reinterpret_cast<uint2*>(d) = make_uint2(ec_pack2(x[0], x[1]), ec_pack2(x[2], x[3]));
+                    } else {
+                        uint2 p0, p1, p2;
+                        split3x4(x, p0, p1, p2);
+                        *reinterpret_cast<uint2*>(d) = p0;
+                        *reinterpret_cast<uint2*>(d + PL) = p1;
+                        *reinterpret_cast<uint2*>(d + 2 * PL) = p2;
+                    }
+                }
+            }
+        }
+    }
+};
+
+template <int BM, int BN, int WM, int WN, bool ABF, bool BBF, bool AKC, bool BKC>
+__global__ __launch_bounds__(256) void gemm_x3_kernel(GemmArgs p) {
+    constexpr int TM = BM / WM, TN = BN / WN;
+    constexpr int FM = TM / 32, FN = TN / 32;
+    constexpr int PA = ABF ? 1 : 3, PB = BBF ? 1 : 3;
+    constexpr int A_BYTES = PA * BM * 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char xsm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int tile_n = blockIdx.x % p.ntn, tile_m = blockIdx.x / p.ntn;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int nk_total = (p.K + GBK - 1) / GBK;
+    const int nk_per = (nk_total + p.splitk - 1) / p.splitk;
+    const int kt0 = blockIdx.z * nk_per;
+    const int kt1 = min(nk_total, kt0 + nk_per);
+    if (kt0 >= kt1) return;
+
+    XStage<BM, ABF, AKC> sa;
+    XStage<BN, BBF, BKC> sb;
+    f32x16_t acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    sa.load(p.A, p.sam, p.sak, m0, kt0 * GBK, p.M, p.K, tid);
+    sb.load(p.B, p.sbn, p.sbk, n0, kt0 * GBK, p.N, p.K, tid);
+    sa.store(xsm, tid);
+    sb.store(xsm + A_BYTES, tid);
+    __syncthreads();
+    const int fr = lane & 31, fh = lane >> 5;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const bool more = (kt + 1) < kt1;
+        if (more) {
+            sa.load(p.A, p.sam, p.sak, m0, (kt + 1) * GBK, p.M, p.K, tid);
+            sb.load(p.B, p.sbn, p.sbk, n0, (kt + 1) * GBK, p.N, p.K, tid);
+        }
+#pragma unroll
+        for (int ks = 0; ks < GBK / 16; ++ks) {
+            s16x8_t af[PA][FM], bf[PB][FN];
+            const int c = ks * 2 + fh;
+#pragma unroll
+            for (int pl = 0; pl < PA; ++pl)
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+                    af[pl][i] = *reinterpret_cast<const s16x8_t*>(xsm + pl * BM * 64 + xoff(wm * TM + i * 32 + fr, c));
+#pragma unroll
+            for (int pl = 0; pl < PB; ++pl)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    bf[pl][j] = *reinterpret_cast<const s16x8_t*>(xsm + A_BYTES + pl * BN * 64 + xoff(wn * TN + j * 32 + fr, c));
+            // smallest terms first
+#pragma unroll
+            for (int sum = 2; sum >= 0; --sum)
+#pragma unroll
+                for (int pa = 0; pa < PA; ++pa) {
+                    const int pb = sum - pa;
+                    if (pb < 0 || pb >= PB) continue;
+#pragma unroll
+                    for (int i = 0; i < FM; ++i)
+#pragma unroll
+                        for (int j = 0; j < FN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[pa][i]),
+                                                                               __builtin_bit_cast(bf16x8_t, bf[pb][j]),
+                                                                               acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+        if (more) {
+            sa.store(xsm, tid);
+            sb.store(xsm + A_BYTES, tid);
+        }
+        __syncthreads();
+    }
+
+    const bool first = (blockIdx.z == 0);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int col = n0 + wn * TN + j * 32 + fr;
+        if (col >= p.N) continue;
+        const float bv = (p.bias && first) ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                if (row >= p.M) continue;
+                float v = acc[i][j][r] + bv;
+                if (p.gbias && first) {
+                    const int g = row / p.group;
+                    v += p.gbias[(long)(p.gidx ? p.gidx[g] : g) * p.N + col];
+                }
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (p.rowscale) v *= p.rowscale[row];
+                const long o = (long)row * p.ldc + col;
+                if (p.dmask) v = (p.dmask[o] > 0.f) ? v : 0.f;
+                if (p.splitk > 1) atomicAdd(p.C + o, v);
+                else if (p.accumulate) p.C[o] += v;
+                else p.C[o] = v;
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_x3(GemmArgs& a, hipStream_t s) {
+    a.ntn = (a.N + BN - 1) / BN;
+    const int ntm = (a.M + BM - 1) / BM;
+    const int pa = a.a_bf16 ? 1 : 3, pb = a.b_bf16 ? 1 : 3;
+    const size_t lds = (size_t)(pa * BM + pb * BN) * 64;
+    dim3 grid((unsigned)(ntm * a.ntn), 1, (unsigned)a.splitk);
+    const bool akc = (a.sak == 1), bkc = (a.sbk == 1);
+#define EC_X3(ABF, BBF, AKC, BKC)                                                                            \
+    do {                                                                                                     \
+        auto kern = gemm_x3_kernel<BM, BN, WM, WN, ABF, BBF, AKC, BKC>;                                      \
+        static bool attr_set = false;                                                                        \
+        if (!attr_set) {                                                                                     \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                   \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)((3 * BM + 3 * BN) * 64)); \
+            attr_set = true;                                                                                 \
+        }                                                                                                    \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);                                                \
+    } while (0)
+    if (a.a_bf16 && a.b_bf16) return EC_ERR_UNSUPPORTED;
+    if (a.a_bf16) {            // bf16 A is always k-contiguous here (feature rows)
+        if (!akc) return EC_ERR_UNSUPPORTED;
+        if (bkc) EC_X3(true, false, true, true); else EC_X3(true, false, true, false);
+    } else if (a.b_bf16) {     // bf16 B is row(n)-contiguous (features as the TN right operand)
+        if (bkc) return EC_ERR_UNSUPPORTED;
+        if (akc) EC_X3(false, true, true, false); else EC_X3(false, true, false, false);
+    } else {
+        if (akc && bkc) EC_X3(false, false, true, true);
+        else if (akc) EC_X3(false, false, true, false);
+        else if (bkc) EC_X3(false, false, false, true);
+        else EC_X3(false, false, false, false);
+    }
+#undef EC_X3
+    EC_CHECK_LAUNCH();
+    return EC_OK;
+}
+
 template <int BM, int BN, int WM, int WN>
 int launch_cfg(GemmArgs& a, hipStream_t s) {
     a.ntn = (a.N + BN - 1) / BN;
@@ -301,6 +558,15 @@ extern "C" int ec_gemm_f32(const void* A, const void* B, float* Cp, int M, int N
     a.a_vec = (sak == 1) ? vec_ok(A, sak, sam, a.a_bf16) : vec_ok(A, sam, sak, a.a_bf16);
     a.b_vec = (sbk == 1) ? vec_ok(B, sbk, sbn, a.b_bf16) : vec_ok(B, sbn, sbk, a.b_bf16);
     hipStream_t s = (hipStream_t)stream;
+    // bf16x3 path for regular shapes: vector-loadable operands, contiguous extents multiple of 4, not tiny
+    static const int x3_off = [] { const char* e = getenv("EC_GEMM_NO_X3"); return e ? atoi(e) : 0; }();
+    const bool a_ok = a.a_vec && ((sak == 1) ? (K % 4 == 0) : (M % 4 == 0 && sam == 1));
+    const bool b_ok = a.b_vec && ((sbk == 1) ? (K % 4 == 0) : (N % 4 == 0 && sbn == 1));
+    if (!x3_off && a_ok && b_ok && M >= 32 && N >= 32 && K >= 32 && !(a.a_bf16 && sak != 1) && !(a.b_bf16 && sbk == 1)) {
+        const long blocks128 = (long)((M + 127) / 128) * ((N + 127) / 128) * a.splitk;
+        if (blocks128 < 512) return launch_x3<64, 64, 2, 2>(a, s);
+        return launch_x3<128, 128, 2, 2>(a, s);
+    }
     if (N <= 32) return launch_cfg<256, 32, 4, 1>(a, s);
     if (M <= 32) return launch_cfg<32, 256, 1, 4>(a, s);
     // fp32 MFMA is 64 cycles per 32x32x2: a 128x128 tile is a long serial chain, so shapes that give
