@@ -15,21 +15,37 @@
 // nn.Linear / in_proj / out_proj GEMMs of ResidualAttentionBlock and
 // AttentionPool2d.
 //
-// Tiling (wave64, v_mfma_f32_32x32x16_bf16):
-//   workgroup = 4 waves (WM x WN), tile BM x BN x 64; each wave owns
-//   (BM/WM) x (BN/WN) as FM x FN 32x32 accumulators (fp32, 16 regs each).
-//   A/B K-tiles are register-staged (global_load_dwordx4 -> ds_write_b128)
-//   into a double-buffered LDS image with 128-byte rows and the 16-byte chunk
-//   index XOR-swizzled by (row>>1)&7, which makes both the ds_write_b128
-//   (8-lane groups = one row) and the fragment ds_read_b128 (16-lane groups
-//   {0-3,12-15,20-27},...) conflict-free.  One barrier per K-tile.
+// Structure (wave64, v_mfma_f32_32x32x16_bf16):
+//   * persistent workgroups of 4 waves; tile BM x BN x 64 (128x128, or 256x64 / 256x32 for narrow Cout);
+//     each wave owns (BM/WM) x (BN/WN) as FM x FN 32x32 fp32 accumulators.
+//   * operands go global -> LDS directly (LDS-DMA, `global_load_lds_dwordx4`): no staging registers, no
+//     ds_write pass.  The LDS image has 128-byte rows; LDS-DMA writes are lane-linear, so the XOR swizzle
+//     ((row>>1)&7 on the 16-byte chunk index) is applied to the SOURCE chunk each lane fetches and again
+//     on the fragment ds_read_b128 (conflict-free for the 16-lane groups {0-3,12-15,20-27},...).
+//     Padding / ragged-K chunks read a zero page, selected per row from a 9-bit tap-validity mask that is
+//     computed once per tile -- the 3x3 halo costs one v_cndmask per chunk, no branches.
+//   * SWAPPED MFMA operands (D[n][m]): a lane owns ONE pixel and, per 4 accumulator registers, 4
+//     consecutive channels -> bias/residual/activation/bf16-rounding work on packed 8-byte LDS slots
+//     (v_cvt_pk_bf16_f32), and the tile leaves as coalesced 16-byte row chunks.
+//   * single 32-KB LDS stage + 35-KB epilogue image, <= 168 VGPRs: 3 workgroups per CU; the load latency
+//     of one workgroup hides behind the MFMAs of the other two (two barriers per K-tile).
 //
-// Fused AvgPool2d(2) (CLIP's anti-aliased stride): in POOL mode row m is
-// ordered  m = 4*q + (dy*2+dx)  with q the pooled raster index, so the four
-// pixels of a pooling window are accumulator registers r&3 = 0..3 of ONE lane
-// (32x32 C/D layout: row = (r&3) + 8*(r>>2) + 4*(lane>>5)); the pool is an
-// in-register sum after bias+ReLU -- no extra pass over HBM.
+// Fused AvgPool2d(2) (CLIP's anti-aliased stride): in POOL mode row m is ordered m = 4*q + (dy*2+dx) with
+// q the pooled raster index, so the four pixels of a pooling window are the four lanes of a quad; the pool
+// is two DPP quad-permute adds after bias+ReLU -- the full-resolution output never touches HBM.
+//
+// What the round-1 measurements say (profiles/): the compute-bound layers plateau at
+// ~570-660 TFLOP/s.  Ablation of one such layer (3x3 256->256 @14x14, B=256): MFMA-only 33 us (81 % of the
+// pipe at the sustained clock), operand loads-only 42 us (~21 TB/s L2->LDS), both together ~100 us, i.e.
+// the two phases barely overlap.  Tried without effect on that sum: loads two tiles ahead (second register
+// set), double vs single LDS stage, fat 128x256 / 256x128 tiles, 8-wave workgroups, all-fragments-up-front
+// MFMA scheduling, interleaving the LDS-DMA pieces between MFMA groups, start skew between co-resident
+// workgroups, persistent tiles with next-tile prefetch.  Next: cut the L2->LDS bytes per flop (halo reuse
+// for 3x3, 256-row tiles) and a wave-specialised (loader / MFMA) pipeline.
 #include <stdlib.h>
+
+#include <type_traits>
+#include <utility>
 
 #include "common.h"
 
@@ -51,11 +67,14 @@ struct ConvArgs {
     int ntiles; // total output tiles
     int nbuf;  // LDS stages: 2 (double buffer) or 1
     unsigned in_bytes, w_bytes;   // buffer-descriptor extents (out-of-range loads return 0)
+    int skew;                     // start-skew range in units of 256 cycles (0 = off)
     int ablate;                   // profiling only (EC_CONV_ABLATE): 1 no global loads, 2 no MFMA, 4 no LDS stores, 8 no epilogue
 };
 
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-constexpr unsigned OOB = 0xFFFFFF00u;   // voffset beyond any descriptor extent -> hardware returns zeros
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+__device__ uint4 ec_zero_page[8];   // source for padded / out-of-range 16-byte chunks of LDS-DMA loads
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {
     return row * ROW_BYTES + ((chunk ^ ((row >> 1) & 7)) << 4);
@@ -68,7 +87,7 @@ __device__ __forceinline__ float dpp_quad_xor2(float v) {   // lane ^ 2 within a
 }
 
 template <int BM, int BN, int WM, int WN, int KS, bool POOL, bool PF>
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_igemm_kernel(ConvArgs p) {
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 3) void conv_igemm_kernel(ConvArgs p) {
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int FM = TM / 32, FN = TN / 32;
     constexpr int NT = WM * WN * 64;                // threads per workgroup
@@ -93,11 +112,11 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_ige
     int m0 = (tile / p.ntn) * BM;
     int n0 = (tile % p.ntn) * BN;
 
-    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
 
     // ---- per-thread loader geometry (K-invariant): a byte offset and a 9-bit tap-validity mask per row ----
-    const int chunk = tid & 7;     // which 16-B chunk of the 128-B K row
+    // LDS-DMA writes lane l of a wave at (wave-uniform base + 16*l): the LDS image is lane-linear, so the XOR
+    // swizzle is applied to the SOURCE chunk each lane fetches (and again on the fragment reads).
+    const int chunk = (tid & 7) ^ ((tid >> 4) & 7);   // source 16-B chunk of the 128-B K row for LDS position tid&7
     const int lrow = tid >> 3;     // 0..LR-1
     unsigned a_off[A_IT];          // byte offset of the row's centre-tap pixel, channel 0
     unsigned a_msk[A_IT];          // bit (ky*3+kx) set <=> that tap lies inside the frame (bit 0 only for 1x1)
@@ -138,36 +157,46 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_ige
     };
     decode();
 
-    // register staging set for the NEXT K-tile (a second set, i.e. loads two tiles ahead, was measured: +-5%)
-    u32x4_t ra0[A_IT], rb0[B_IT];
-
-    auto load_tile = [&](int kt, u32x4_t (&ra)[A_IT], u32x4_t (&rb)[B_IT]) {
+    // direct global -> LDS (LDS-DMA): no staging registers, no ds_write pass
+    const unsigned char* in_b = reinterpret_cast<const unsigned char*>(p.in);
+    const unsigned char* w_b = reinterpret_cast<const unsigned char*>(p.w);
+    const unsigned char* zp = reinterpret_cast<const unsigned char*>(ec_zero_page);
+    const int wave_lds = wave * 1024;                       // 64 lanes x 16 B
+    // per-K-tile addressing state shared by the pieces of one tile
+    int g_toff = 0; unsigned g_tapbit = 0; bool g_kin = false; int g_kt = 0;
+    unsigned char* g_sa = smem; unsigned char* g_sb = smem;
+    auto glds_begin = [&](int kt, int buf) {
+        g_sa = smem + buf * (A_BYTES + B_BYTES) + wave_lds;
+        g_sb = g_sa + A_BYTES;
         const int k = kt * BK + chunk * 8;
-        int tap = 0, toff = k * 2;
+        int tap = 0;
+        g_toff = k * 2;
         if (KS == 3) {
             tap = k >> p.cin_log2;
             const int ci = k & (p.Cin - 1);
             const int ky = (tap * 11) >> 5;   // tap / 3 for tap in 0..8
-            toff = (((ky - 1) * p.W + (tap - ky * 3 - 1)) * p.Cin + ci) * 2;
+            g_toff = (((ky - 1) * p.W + (tap - ky * 3 - 1)) * p.Cin + ci) * 2;
         }
-        const unsigned tapbit = (k < p.K) ? (1u << tap) : 0u;
-#pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            const unsigned vo = (a_msk[i] & tapbit) ? (a_off[i] + (unsigned)toff) : OOB;
-            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rin, vo, 0, 0);
-        }
-        // (k >= K only on a ragged last tile: A is zero there, so whatever finite weight bytes B
-        //  picks up are multiplied by zero; beyond the weight buffer the descriptor returns zeros)
-#pragma unroll
-        for (int i = 0; i < B_IT; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, b_off[i] + kt * (BK * 2), 0, 0);
+        g_kin = k < p.K;
+        g_tapbit = g_kin ? (1u << tap) : 0u;
+        g_kt = kt;
     };
-    auto store_tile = [&](int buf, const u32x4_t (&ra)[A_IT], const u32x4_t (&rb)[B_IT]) {
-        unsigned char* sa = smem + buf * (A_BYTES + B_BYTES);
-        unsigned char* sb = sa + A_BYTES;
-#pragma unroll
-        for (int i = 0; i < A_IT; ++i) *reinterpret_cast<u32x4_t*>(sa + lds_off(lrow + LR * i, chunk)) = ra[i];
-#pragma unroll
-        for (int i = 0; i < B_IT; ++i) *reinterpret_cast<u32x4_t*>(sb + lds_off(lrow + LR * i, chunk)) = rb[i];
+    // piece q of the tile begun last: q < A_IT -> A rows, else B rows (each piece = one 1-KiB wave LDS-DMA)
+    auto glds_piece = [&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        if constexpr (q < A_IT) {
+            const unsigned char* src = (a_msk[q] & g_tapbit) ? in_b + (a_off[q] + (unsigned)g_toff) : zp;
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(g_sa + q * (LR * ROW_BYTES)), 16, 0, 0);
+        } else {
+            constexpr int i = q - A_IT;
+            const unsigned char* src = g_kin ? w_b + (b_off[i] + (unsigned)(g_kt * (BK * 2))) : zp;
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(g_sb + i * (LR * ROW_BYTES)), 16, 0, 0);
+        }
+    };
+    auto glds_tile = [&](int kt, int buf) {
+        glds_begin(kt, buf);
+        [&]<int... Q>(std::integer_sequence<int, Q...>) { (glds_piece(std::integral_constant<int, Q>{}), ...); }
+        (std::make_integer_sequence<int, A_IT + B_IT>{});
     };
 
     f32x16_t acc[FM][FN];
@@ -187,41 +216,34 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_ige
     const int nk = (p.K + BK - 1) / BK;
     const int frow = lane & 31;
     const int fhalf = lane >> 5;
-    auto compute = [&](int buf) {
+    auto compute = [&](int buf, bool issue_next) {
         const unsigned char* sa = smem + buf * (A_BYTES + B_BYTES);
         const unsigned char* sb = sa + A_BYTES;
-        // ALL fragments of the K-tile are read first, into distinct registers, so the LDS latency of the
-        // later k-steps hides behind the MFMAs of the earlier ones (left alone, hipcc recycles one fragment
-        // set and serialises ds_read -> lgkmcnt -> 4 MFMAs four times per tile).
-        s16x8_t af[BK / 16][FM], bfr[BK / 16][FN];
-#pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-            const int c = ks * 2 + fhalf;
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-                af[ks][i] = *reinterpret_cast<const s16x8_t*>(sa + lds_off(wm * TM + i * 32 + frow, c));
-#pragma unroll
-            for (int j = 0; j < FN; ++j)
-                bfr[ks][j] = *reinterpret_cast<const s16x8_t*>(sb + lds_off(wn * TN + j * 32 + frow, c));
-        }
-        __builtin_amdgcn_sched_barrier(0);
         // SWAPPED operands: D[n][m] = sum_k W[n][k] * A[m][k].  In the 32x32 C/D layout a lane then owns
         // ONE pixel (col = lane&31) and channels (r&3) + 8*(r>>2) + 4*(lane>>5): every 4 accumulator
         // registers are 4 consecutive channels -> 8-byte packed epilogue traffic.
 #pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks)
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            s16x8_t af[FM], bfr[FN];
+            const int c = ks * 2 + fhalf;
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+                af[i] = *reinterpret_cast<const s16x8_t*>(sa + lds_off(wm * TM + i * 32 + frow, c));
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                bfr[j] = *reinterpret_cast<const s16x8_t*>(sb + lds_off(wn * TN + j * 32 + frow, c));
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int j = 0; j < FN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                        __builtin_bit_cast(bf16x8_t, bfr[ks][j]), __builtin_bit_cast(bf16x8_t, af[ks][i]), acc[i][j], 0, 0, 0);
+                        __builtin_bit_cast(bf16x8_t, bfr[j]), __builtin_bit_cast(bf16x8_t, af[i]), acc[i][j], 0, 0, 0);
+        }
+        (void)issue_next;
     };
-    // K pipeline: tile t computes from LDS[t&1] while the global loads of tile t+1 are in flight in registers;
-    // they are written to LDS[(t+1)&1] after the MFMAs.  One barrier per K-tile.
-    // Tile pipeline: the first K-tile of the NEXT output tile is issued before this tile's epilogue, so the
-    // exposed first-load latency and the epilogue's HBM traffic overlap instead of adding up.
-    load_tile(0, ra0, rb0);
+
+    // K pipeline: LDS-DMA of tile t+1 into LDS[(t+1)&1] is in flight while tile t computes from LDS[t&1];
+    // the barrier at the end of the iteration carries the vmcnt(0) that lands it.  One barrier per K-tile.
     for (;;) {
         const int e_m0 = m0, e_n0 = n0;                      // coordinates of the tile being finished
         const int orow0 = POOL ? (e_m0 >> 2) : e_m0;
@@ -241,15 +263,27 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_ige
                     rres[i] = *reinterpret_cast<const uint4*>(p.res + (long)(orow0 + row) * p.Cout + e_n0 + schunk * 8);
             }
         }
-        store_tile(0, ra0, rb0);
+        glds_tile(0, 0);
         __syncthreads();
-        for (int kt = 0; kt < nk; ++kt) {
-            const int cur = kt & 1;
-            const bool more = (kt + 1) < nk;
-            if (more && !(p.ablate & 1)) load_tile(kt + 1, ra0, rb0);
-            if (!(p.ablate & 2)) compute(cur);
-            if (more && !(p.ablate & 4)) store_tile(cur ^ 1, ra0, rb0);
-            __syncthreads();
+        if (p.nbuf == 1) {
+            // single LDS stage, two barriers per K-tile: smallest footprint (3 workgroups per CU); the load
+            // latency of one workgroup is covered by the MFMAs of the other two
+            for (int kt = 0; kt < nk; ++kt) {
+                if (!(p.ablate & 2)) compute(0, false);
+                if (kt + 1 < nk) {
+                    __syncthreads();
+                    if (!(p.ablate & 1)) glds_tile(kt + 1, 0);
+                }
+                __syncthreads();
+            }
+        } else {
+            for (int kt = 0; kt < nk; ++kt) {
+                const int cur = kt & 1;
+                const bool more = (kt + 1) < nk;
+                if (more && !(p.ablate & 1)) glds_tile(kt + 1, cur ^ 1);
+                if (!(p.ablate & 2)) compute(cur, false);
+                __syncthreads();
+            }
         }
         tile += (int)grid;
         const bool has_next = tile < p.ntiles;
@@ -257,7 +291,6 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_ige
             m0 = (tile / p.ntn) * BM;
             n0 = (tile % p.ntn) * BN;
             decode();
-            load_tile(0, ra0, rb0);                          // flies during the epilogue below
         }
         if (!(p.ablate & 8)) {
     // ---- epilogue: staged through LDS so every global access is a coalesced 16-B chunk ----
@@ -348,11 +381,12 @@ int launch(const ConvArgs& a, hipStream_t s) {
     const size_t lds_max = 2 * (size_t)(BM + BN) * ROW_BYTES;
     const size_t epi = (size_t)(POOL ? BM / 4 : BM) * (BN * 2 + 16);
     static const int nbuf_force = [] { const char* e = getenv("EC_CONV_NBUF"); return e ? atoi(e) : 0; }();
-    (void)nbuf_force;
-    p.nbuf = 2;
+    p.nbuf = nbuf_force ? nbuf_force : 1;
     static const int ablate = [] { const char* e = getenv("EC_CONV_ABLATE"); return e ? atoi(e) : 0; }();
     p.ablate = ablate;
-    size_t lds = (size_t)p.nbuf * (BM + BN) * ROW_BYTES;
+    static const int skew = [] { const char* e = getenv("EC_CONV_SKEW"); return e ? atoi(e) : 0; }();
+    p.skew = skew;
+    size_t lds = (size_t)p.nbuf * (BM + BN) * ROW_BYTES;   // (set after nbuf below)
     if (lds < epi) lds = epi;
     auto kern = conv_igemm_kernel<BM, BN, WM, WN, KS, POOL, PF>;
     static bool attr_set = false;
@@ -361,8 +395,8 @@ int launch(const ConvArgs& a, hipStream_t s) {
                                   (int)(lds_max > epi ? lds_max : epi));
         attr_set = true;
     }
-    // persistent: at most 2 workgroups per CU (register-limited residency), each walking several tiles
-    static const int wg_cap = [] { const char* e = getenv("EC_CONV_WGS"); return e ? atoi(e) : 512; }();
+    // persistent: 3 workgroups per CU (<= 168 VGPRs, single 35-KB LDS stage), each walking several tiles
+    static const int wg_cap = [] { const char* e = getenv("EC_CONV_WGS"); return e ? atoi(e) : 768; }();
     const int nwg = p.ntiles < wg_cap ? p.ntiles : wg_cap;
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(WM * WN * 64), lds, s, p);
     EC_CHECK_LAUNCH();
