@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 TRUNK_MAC_PER_FRAME = 5_367_226_368          # SURVEY.md §8d (RN50 trunk, 224x224)
+VIT_MAC_PER_FRAME = 4_050_683_904            # SURVEY.md §8d (ViT-B/32, 11 of 12 blocks)
 POLICY_ACT_MAC = 16_846_336
 POLICY_UPDATE_MAC = 150_775_808              # 4 x (fwd + bwd)
 MFMA_BF16_PEAK_TFLOPS = 2500.0               # MI355X_MICROARCH.md: dense bf16 MFMA
@@ -108,6 +109,8 @@ def main():
     ap.add_argument("--rollout", type=int, default=128)
     ap.add_argument("--update-repeats", type=int, default=4)
     ap.add_argument("--encoder-chunk", type=int, default=0)
+    ap.add_argument("--encoder", choices=("rn50", "vit"), default="rn50",
+                    help="rn50 = BASELINE headline config; vit = config 3 (ViT-B/32, parity-unpinned fusion)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-actors", type=int, default=32)
     ap.add_argument("--cpu-rollout", type=int, default=8)
@@ -129,7 +132,7 @@ def main():
 
     from embodied_clip_amd.engine import Worker
     w = Worker(a.actors, T=a.rollout, device=dev, seed=0, rank=rank, world=world, update_repeats=a.update_repeats,
-               encoder_chunk=a.encoder_chunk)
+               encoder_chunk=a.encoder_chunk, encoder=a.encoder)
 
     def barrier():
         if world > 1:
@@ -157,23 +160,28 @@ def main():
     if rank == 0:
         frames = a.rollout * a.actors * world * a.steps
         value = frames / dt
-        flops_call = 2.0 * TRUNK_MAC_PER_FRAME * a.actors
+        enc_mac = TRUNK_MAC_PER_FRAME if a.encoder == "rn50" else VIT_MAC_PER_FRAME
+        flops_call = 2.0 * enc_mac * a.actors
         achieved = flops_call / (avg_trunk_ms * 1e-3) / 1e12
         out = {
             "metric": "env-frames/sec (CLIP encode + policy fwd/bwd + PPO update)",
             "value": round(value, 1), "unit": "env-frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "RoboTHOR ObjectNav: frozen CLIP-RN50 encoder (bf16 MFMA, fp32 accumulate) + "
+            "config": {"workload": ("RoboTHOR ObjectNav: frozen CLIP-RN50 encoder" if a.encoder == "rn50" else
+                                    "RoboTHOR ObjectNav: frozen CLIP ViT-B/32 encoder (11 blocks)") +
+                                   " (bf16 MFMA, fp32 accumulate) + "
                                    "1-layer GRU actor-critic PPO (fp32), synthetic 224x224 RGB + random goal ids",
                        "actors_per_gpu": a.actors, "global_actors": a.actors * world, "rollout": a.rollout,
                        "update_repeats": a.update_repeats, "num_mini_batch": 1,
                        "parallelism": f"dp{world} (actors sharded; one flat 13.9 MB grad all-reduce per optimiser step)",
-                       "flop_per_frame": 2 * (TRUNK_MAC_PER_FRAME + POLICY_ACT_MAC + POLICY_UPDATE_MAC)},
-            "roofline": {"bound": "mfma", "kernel": "ec_rn50_forward (conv_igemm_kernel family, 55 convs per call)",
+                       "flop_per_frame": 2 * ((TRUNK_MAC_PER_FRAME + POLICY_ACT_MAC + POLICY_UPDATE_MAC)
+                                             if a.encoder == "rn50" else VIT_MAC_PER_FRAME)},
+            "roofline": {"bound": "mfma", "kernel": ("ec_rn50_forward (conv_igemm_kernel family, 55 convs per call)" if a.encoder == "rn50"
+                                    else "ec_vit_forward (conv_igemm GEMMs + mha/layernorm kernels)"),
                          "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
-                         "traffic": TRUNK_HBM_BYTES_PER_LAUNCH_N256 if a.actors == 256 else None,
+                         "traffic": TRUNK_HBM_BYTES_PER_LAUNCH_N256 if (a.actors == 256 and a.encoder == "rn50") else None,
                          "traffic_note": "HBM bytes per launch, PMC-measured offline (profiles/r01_trunk_b256_hbm_traffic.txt); "
                                          "algorithmic bytes 45.7 MB/frame x N",
                          "avg_launch_ms": round(avg_trunk_ms, 3), "launches_timed": len(trunk_ms),

@@ -29,7 +29,7 @@ import torch
 from . import _lib
 from . import synthetic as syn
 from .dist import allreduce_flat
-from .encoder import RN50Trunk
+from .encoder import RN50Trunk, ViTEmbedder
 from .policy import PolicyHandle
 from .ppo import FlatAdam, linear_decay_lr, ppo_loss_raw
 
@@ -64,18 +64,31 @@ class Worker:
     def __init__(self, n_actors: int, T: int = 128, device="cuda:0", seed: int = 0, rank: int = 0, world: int = 1,
                  update_repeats: int = 4, lr: float = 3e-4, max_grad_norm: float = 0.5, gamma: float = 0.99,
                  tau: float = 0.95, encoder_sd=None, policy_sd=None, lr_total_steps: int = 300_000_000,
-                 encoder_chunk: int = 0):
+                 encoder_chunk: int = 0, encoder: str = "rn50"):
         self.lib = _lib.load()
         self.dev = torch.device(device)
         self.N, self.T, self.rank, self.world = n_actors, T, rank, world
         self.update_repeats, self.gamma, self.tau = update_repeats, gamma, tau
         self.base_lr, self.lr_total_steps = lr, lr_total_steps
-        self.trunk = RN50Trunk(encoder_sd if encoder_sd is not None else syn.rn50_visual_state_dict(0),
-                               device=self.dev, chunk=encoder_chunk)
-        self.S, self.C = self.trunk.out_spatial, self.trunk.out_channels
-        self.policy = PolicyHandle(in_channels=self.C, spatial=self.S)
+        self.encoder = encoder
+        if encoder == "rn50":
+            self.trunk = RN50Trunk(encoder_sd if encoder_sd is not None else syn.rn50_visual_state_dict(0),
+                                   device=self.dev, chunk=encoder_chunk)
+            self.S, self.C = self.trunk.out_spatial, self.trunk.out_channels
+        elif encoder == "vit":
+            # BASELINE config 3 (builder-defined fusion, SURVEY.md §8d note): ClipViTEmbedder tokens, CLS dropped,
+            # the 49 patch tokens are the 7x7 channels-last "feature map" [N,49,768] of the goal encoder
+            self.vit = ViTEmbedder(encoder_sd if encoder_sd is not None else syn.vit_visual_state_dict(0),
+                                   device=self.dev)
+            self.S, self.C = 7, self.vit.D
+            self._tok = torch.empty((n_actors, self.vit.L, self.vit.D), dtype=torch.bfloat16, device=self.dev)
+        else:
+            raise ValueError(encoder)
+        pkw = dict(in_channels=self.C, spatial=self.S)
+        self.policy = PolicyHandle(**pkw)
         self.H, self.A = self.policy.H, self.policy.A
-        self.params = self.policy.flatten(policy_sd if policy_sd is not None else syn.policy_state_dict(0), self.dev)
+        self.params = self.policy.flatten(policy_sd if policy_sd is not None else syn.policy_state_dict(0, **pkw),
+                                          self.dev)
         self.grads = torch.zeros_like(self.params)
         self.opt = FlatAdam(self.params, lr=lr, max_grad_norm=max_grad_norm)
         N, S2 = n_actors, self.S * self.S
@@ -104,19 +117,26 @@ class Worker:
         self.trunk_events: List = []     # (start, end) HIP event pairs around ec_rn50_forward
         self.time_trunk = False
         # first observation of the first rollout
-        self.trunk.forward(self.env.observe(), self.feat[0])
+        self._encode_raw(self.env.observe(), self.feat[0])
         self.last_info: Dict[str, float] = {}
 
     # ---- HOT LOOP A ---------------------------------------------------------------------------
+    def _encode_raw(self, rgb: torch.Tensor, out: torch.Tensor):
+        if self.encoder == "rn50":
+            self.trunk.forward(rgb, out)              # last conv writes straight into the rollout slice
+        else:
+            self.vit.forward(rgb, self._tok)
+            out.copy_(self._tok[:, 1:, :])            # drop CLS: [N,49,768] channels-last rows
+
     def _encode(self, rgb: torch.Tensor, out: torch.Tensor):
         if self.time_trunk:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            self.trunk.forward(rgb, out)
+            self._encode_raw(rgb, out)
             e1.record()
             self.trunk_events.append((e0, e1))
         else:
-            self.trunk.forward(rgb, out)
+            self._encode_raw(rgb, out)
 
     def _act(self, t: int, sample: bool = True):
         N, sp = self.N, _lib.stream_ptr()
