@@ -74,3 +74,17 @@ def test_worker_iteration_matches_oracle():
         assert (upd - upd_ref).abs().max() < 0.15 * R * 3e-4 + 1e-7, (name, (upd - upd_ref).abs().max())
     w.after_update()
     assert torch.equal(w.feat[0], w.feat[T])
+
+
+def test_two_stream_encode_is_bit_identical():
+    """Encoding the two halves of the actor batch on two HIP streams is a pure scheduling choice."""
+    from embodied_clip_amd.engine import Worker
+    enc_sd = syn.rn50_visual_state_dict(0)
+    w1 = Worker(64, T=1, device="cuda:0", seed=3, update_repeats=1, encoder_sd=enc_sd, encoder_streams=1)
+    w2 = Worker(64, T=1, device="cuda:0", seed=3, update_repeats=1, encoder_sd=enc_sd, encoder_streams=2)
+    assert not w1.enc_streams and len(w2.enc_streams) == 2
+    w1.iteration(); w2.iteration()
+    torch.cuda.synchronize()
+    assert torch.equal(w1.feat, w2.feat)
+    assert torch.equal(w1.actions, w2.actions)
+    assert torch.allclose(w1.params, w2.params, rtol=0, atol=1e-6)   # fp32 atomics order may differ in the last bit
