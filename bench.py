@@ -113,6 +113,7 @@ def main():
     ap.add_argument("--encoder", choices=("rn50", "vit"), default="rn50",
                     help="rn50 = BASELINE headline config; vit = config 3 (ViT-B/32, parity-unpinned fusion)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--phase-times", action="store_true", help="extra untimed iteration with per-phase sync timing")
     ap.add_argument("--cpu-actors", type=int, default=32)
     ap.add_argument("--cpu-rollout", type=int, default=8)
     a = ap.parse_args()
@@ -158,12 +159,23 @@ def main():
     avg_trunk_ms = sum(trunk_ms) / max(1, len(trunk_ms))
     info = w.loss_info()
 
+    phases = None
+    if a.phase_times:
+        torch.cuda.synchronize(); p0 = time.perf_counter()
+        w.collect_rollout(); torch.cuda.synchronize(); p1 = time.perf_counter()
+        w.compute_returns(); torch.cuda.synchronize(); p2 = time.perf_counter()
+        w.update(); w.after_update(); torch.cuda.synchronize(); p3 = time.perf_counter()
+        phases = {"rollout_ms": round((p1 - p0) * 1e3, 1), "gae_ms": round((p2 - p1) * 1e3, 2),
+                  "update_ms": round((p3 - p2) * 1e3, 1)}
     if rank == 0:
         frames = a.rollout * a.actors * world * a.steps
         value = frames / dt
         enc_mac = TRUNK_MAC_PER_FRAME if a.encoder == "rn50" else VIT_MAC_PER_FRAME
-        flops_call = 2.0 * enc_mac * a.actors
-        achieved = flops_call / (avg_trunk_ms * 1e-3) / 1e12
+        flops_call = 2.0 * enc_mac * w.encode_frames     # one timed launch = one (slice of the) encoder forward
+        # encoder launches run `n_conc` at a time (one per HIP stream): the chip-level rate is the aggregate
+        n_conc = max(1, a.actors // w.encode_frames)
+        achieved_launch = flops_call / (avg_trunk_ms * 1e-3) / 1e12
+        achieved = achieved_launch * n_conc
         out = {
             "metric": "env-frames/sec (CLIP encode + policy fwd/bwd + PPO update)",
             "value": round(value, 1), "unit": "env-frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -182,13 +194,17 @@ def main():
                                     else "ec_vit_forward (conv_igemm GEMMs + mha/layernorm kernels)"),
                          "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
-                         "traffic": TRUNK_HBM_BYTES_PER_LAUNCH_N256 if (a.actors == 256 and a.encoder == "rn50") else None,
+                         "traffic": (TRUNK_HBM_BYTES_PER_LAUNCH_N256 * w.encode_frames / 256.0
+                                     if (a.actors == 256 and a.encoder == "rn50") else None),
                          "traffic_note": "HBM bytes per launch, PMC-measured offline (profiles/r01_trunk_b256_hbm_traffic.txt); "
                                          "algorithmic bytes 45.7 MB/frame x N",
                          "avg_launch_ms": round(avg_trunk_ms, 3), "launches_timed": len(trunk_ms),
+                         "frames_per_launch": w.encode_frames, "concurrent_launches": n_conc,
+                         "achieved_per_launch": round(achieved_launch, 1),
                          "algorithmic_flop_per_launch": flops_call,
-                         "encoder_share_of_step": round(sum(trunk_ms) / (dt * 1e3), 3)},
+                         "encoder_share_of_step": round(sum(trunk_ms) / (dt * 1e3) * w.encode_frames / a.actors, 3)},
             "loss": {k: round(v, 6) for k, v in info.items()},
+            **({"phases": phases} if phases else {}),
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_actors, a.cpu_rollout, a.update_repeats)

@@ -47,7 +47,7 @@ SIGNATURES = {
                                    c_void_p, c_void_p, c_void_p, c_void_p]),
     "ec_gae": (c_int, [c_void_p] * 7 + [c_int, c_int, c_float, c_float, c_float, c_void_p]),
     "ec_ppo_loss": (c_int, [c_void_p] * 8 + [C.c_long, c_int, c_float, c_float, c_float, c_float, c_void_p]),
-    "ec_sample_actions": (c_int, [c_void_p] * 4 + [c_int, c_int, C.c_uint64, C.c_uint64, c_void_p]),
+    "ec_sample_actions": (c_int, [c_void_p] * 4 + [c_int, c_int, C.c_uint64, C.c_uint64, c_int, c_void_p]),
     "ec_vit_create": (c_int, [C.POINTER(c_void_p), c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p,
                               c_size_t]),
     "ec_vit_destroy": (None, [c_void_p]),

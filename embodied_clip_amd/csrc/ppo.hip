@@ -147,7 +147,7 @@ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
 // CategoricalDistr.sample() + log_prob(): inverse-CDF on a counter-based uniform.
 template <int MAXA>
 __global__ void sample_kernel(const float* __restrict__ hv, long long* __restrict__ actions, float* __restrict__ logp,
-                              float* __restrict__ values, int N, int A, uint64_t seed, uint64_t step) {
+                              float* __restrict__ values, int N, int A, uint64_t seed, uint64_t step, int first_actor) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= N) return;
     const float* row = hv + (long)n * (A + 1);
@@ -156,7 +156,7 @@ __global__ void sample_kernel(const float* __restrict__ hv, long long* __restric
     float se = 0.f;
     for (int k = 0; k < A; ++k) se += expf(row[k] - mx);
     const float lse = mx + logf(se);
-    const uint64_t h = mix64(mix64(seed) ^ (step * 0x100000001B3ull + (uint64_t)n));
+    const uint64_t h = mix64(mix64(seed) ^ (step * 0x100000001B3ull + (uint64_t)(n + first_actor)));   // keyed by GLOBAL actor id
     const float u = (float)((h >> 40) * (1.0 / 16777216.0));   // [0,1) with 24 bits
     float cdf = 0.f;
     int a = A - 1;
@@ -233,11 +233,11 @@ extern "C" int ec_ppo_loss(const float* hv, const int64_t* actions, const float*
 }
 
 extern "C" int ec_sample_actions(const float* hv, int64_t* actions, float* logp, float* values, int N, int A,
-                                 uint64_t seed, uint64_t step, ec_stream_t stream) {
+                                 uint64_t seed, uint64_t step, int first_actor, ec_stream_t stream) {
     if (!hv || !actions || !logp) return EC_ERR_ARG;
     if (N <= 0 || A <= 0) return EC_ERR_SHAPE;
     hipLaunchKernelGGL(sample_kernel<16>, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, hv,
-                       (long long*)actions, logp, values, N, A, seed, step);
+                       (long long*)actions, logp, values, N, A, seed, step, first_actor);
     EC_CHECK_LAUNCH();
     return EC_OK;
 }

@@ -92,6 +92,8 @@ class Worker:
             self._tok = torch.empty((n_actors, self.vit.L, self.vit.D), dtype=torch.bfloat16, device=self.dev)
         else:
             raise ValueError(encoder)
+        if not hasattr(self, 'enc_streams'):
+            self.enc_streams = []
         pkw = dict(in_channels=self.C, spatial=self.S)
         self.policy = PolicyHandle(**pkw)
         self.H, self.A = self.policy.H, self.policy.A
@@ -117,6 +119,9 @@ class Worker:
         self.sums = torch.zeros(4, dtype=torch.float64, device=d)
         self.stats = torch.zeros(2, dtype=torch.float64, device=d)
         self.ws_act = torch.empty(self.policy.workspace_bytes(1, N, False), dtype=torch.uint8, device=d)
+        self.ws_act_half = [torch.empty(self.policy.workspace_bytes(1, N, False), dtype=torch.uint8, device=d)
+                            for _ in range(len(getattr(self, 'enc_streams', [])))]
+        self.encode_frames = N // max(1, len(getattr(self, 'enc_streams', [])))   # frames per timed encoder launch
         self.ws_learn = torch.empty(self.policy.workspace_bytes(T, N, True), dtype=torch.uint8, device=d)
         self.env = SyntheticEnv(N, T, d, seed=1000 + rank)
         self.seed = seed + 7919 * rank
@@ -156,25 +161,59 @@ class Worker:
         else:
             self._encode_raw(rgb, out)
 
-    def _act(self, t: int, sample: bool = True):
-        N, sp = self.N, _lib.stream_ptr()
-        self.policy.forward(self.params, self.feat[t].view(N, self.S * self.S, self.C), self.env.goals[t], self.h,
-                            self.env.masks[t], 1, N, self.ws_act, hv=self.hv_act, h_final=self.h_next)
+    def _act(self, t: int, sample: bool = True, o: int = 0, n: Optional[int] = None, ws=None):
+        """Policy act step for actors [o, o+n) on the current stream (T=1, no grad)."""
+        n = self.N if n is None else n
+        ws = self.ws_act if ws is None else ws
+        sp = _lib.stream_ptr()
+        sl = slice(o, o + n)
+        h_in, h_out = (self.h, self.h_next) if (t & 1) == 0 else (self.h_next, self.h)   # ping-pong by step parity
+        self.policy.forward(self.params, self.feat[t][sl].view(n, self.S * self.S, self.C), self.env.goals[t][sl],
+                            h_in[sl], self.env.masks[t][sl], 1, n, ws, hv=self.hv_act[sl], h_final=h_out[sl])
         if sample:
-            _lib.check(self.lib.ec_sample_actions(self.hv_act.data_ptr(), self.actions[t].data_ptr(),
-                                                  self.logp[t].data_ptr(), self.values[t].data_ptr(), N, self.A,
-                                                  self.seed, self.iter * (self.T + 1) + t, sp), "ec_sample_actions")
-            self.h, self.h_next = self.h_next, self.h
+            _lib.check(self.lib.ec_sample_actions(self.hv_act[sl].data_ptr(), self.actions[t][sl].data_ptr(),
+                                                  self.logp[t][sl].data_ptr(), self.values[t][sl].data_ptr(), n, self.A,
+                                                  self.seed, self.iter * (self.T + 1) + t, o, sp), "ec_sample_actions")
         else:   # bootstrap value of the last observation; memory is NOT advanced
-            self.values[t].copy_(self.hv_act[:, self.A])
+            self.values[t][sl].copy_(self.hv_act[sl, self.A])
 
     def collect_rollout(self):
+        T = self.T
         self.h_start.copy_(self.h)
-        for t in range(self.T):
-            self._act(t)
-            # env.step(actions[t]) happens here in the real system; its frames arrive as fp32 NHWC
-            self._encode(self.env.observe(), self.feat[t + 1])
-        self._act(self.T, sample=False)
+        if self.enc_streams and self.encoder == "rn50":
+            # each slice of the actor batch runs its own act -> (env.step) -> encode chain on its own stream: the small
+            # act-step kernels of one slice overlap the encoder of the other; per-actor results are unchanged
+            cur = torch.cuda.current_stream()
+            ns = len(self.enc_streams)
+            hN = self.N // ns
+            for st in self.enc_streams:
+                st.wait_stream(cur)
+            for t in range(T):
+                rgb = self.env.observe()
+                for i, st in enumerate(self.enc_streams):
+                    with torch.cuda.stream(st):
+                        self._act(t, True, i * hN, hN, self.ws_act_half[i])
+                        sl = slice(i * hN, (i + 1) * hN)
+                        if self.time_trunk:
+                            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                            e0.record(st)
+                            self.trunks[i].forward(rgb[sl], self.feat[t + 1][sl])
+                            e1.record(st)
+                            self.trunk_events.append((e0, e1))
+                        else:
+                            self.trunks[i].forward(rgb[sl], self.feat[t + 1][sl])
+            for i, st in enumerate(self.enc_streams):
+                with torch.cuda.stream(st):
+                    self._act(T, False, i * hN, hN, self.ws_act_half[i])
+                cur.wait_stream(st)
+        else:
+            for t in range(T):
+                self._act(t)
+                # env.step(actions[t]) happens here in the real system; its frames arrive as fp32 NHWC
+                self._encode(self.env.observe(), self.feat[t + 1])
+            self._act(T, sample=False)
+        if (T & 1) == 1:   # after an odd number of advancing steps the live memory sits in h_next
+            self.h, self.h_next = self.h_next, self.h
 
     def compute_returns(self):
         _lib.check(self.lib.ec_gae(self.env.rewards.data_ptr(), self.values.data_ptr(), self.env.masks.data_ptr(),

@@ -193,9 +193,11 @@ int ec_gae(const float* rewards, const float* values, const float* masks, float*
 int ec_ppo_loss(const float* hv, const int64_t* actions, const float* old_logp, const float* old_values,
                 const float* returns, const float* norm_adv, float* dhv, double* sums4, long B, int A,
                 float clip, float vcoef, float ecoef, float grad_scale, ec_stream_t stream);
-/* actions ~ Categorical(logits = hv[:, :A]); logp = log_prob(actions); values = hv[:, A] (or NULL). */
+/* actions ~ Categorical(logits = hv[:, :A]); logp = log_prob(actions); values = hv[:, A] (or NULL).
+ * The counter-based uniform of row n is keyed by (seed, step, first_actor + n), so a batch may be sampled in
+ * slices (e.g. one per HIP stream) with identical results. */
 int ec_sample_actions(const float* hv, int64_t* actions, float* logp, float* values, int N, int A,
-                      uint64_t seed, uint64_t step, ec_stream_t stream);
+                      uint64_t seed, uint64_t step, int first_actor, ec_stream_t stream);
 /* clip_grad_norm_(max_grad_norm) (<=0 disables) then Adam (1-based `step`) over n floats;
  * sumsq1: 1 double scratch that receives ||grads||^2. */
 int ec_clip_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, double* sumsq1,
