@@ -60,7 +60,18 @@ class SyntheticEnv:
         return f
 
 
+class _Slice:
+    """Per-slice state: a contiguous group of actors with its own stream, encoder handle and buffers."""
+    pass
+
+
 class Worker:
+    """One DD-PPO worker.  The actor batch is processed as ``n_slices`` independent slices (default 2), each with its
+    own HIP stream, encoder handle, rollout feature buffer ``[T+1, n, S*S, C]``, policy workspaces and gradient
+    bucket.  Slices only meet at the GAE/advantage normalisation and at the gradient sum, so the HBM-bound and
+    MFMA-bound launches of one slice overlap the small / latency-bound launches (policy act step, GRU recurrence)
+    of the other.  Per-actor arithmetic does not depend on the slicing (tests assert identical features/actions)."""
+
     def __init__(self, n_actors: int, T: int = 128, device="cuda:0", seed: int = 0, rank: int = 0, world: int = 1,
                  update_repeats: int = 4, lr: float = 3e-4, max_grad_norm: float = 0.5, gamma: float = 0.99,
                  tau: float = 0.95, encoder_sd=None, policy_sd=None, lr_total_steps: int = 300_000_000,
@@ -71,39 +82,30 @@ class Worker:
         self.update_repeats, self.gamma, self.tau = update_repeats, gamma, tau
         self.base_lr, self.lr_total_steps = lr, lr_total_steps
         self.encoder = encoder
+        ns = encoder_streams if (encoder_streams > 1 and n_actors >= 64 and n_actors % encoder_streams == 0) else 1
+        self.ns = ns
+        n = n_actors // ns
+        d = self.dev
         if encoder == "rn50":
-            self.trunk = RN50Trunk(encoder_sd if encoder_sd is not None else syn.rn50_visual_state_dict(0),
-                                   device=self.dev, chunk=encoder_chunk)
-            self.S, self.C = self.trunk.out_spatial, self.trunk.out_channels
-            # Two halves of the actor batch are encoded concurrently on two HIP streams: bandwidth-bound and
-            # MFMA-bound conv launches of the two halves overlap on the chip (+11 % measured at N=256).
-            self.enc_streams = []
-            if encoder_streams > 1 and n_actors >= 64 and n_actors % encoder_streams == 0:
-                self.enc_streams = [torch.cuda.Stream(device=self.dev) for _ in range(encoder_streams)]
-                self.trunks = [self.trunk] + [RN50Trunk(encoder_sd if encoder_sd is not None
-                                                        else syn.rn50_visual_state_dict(0), device=self.dev,
-                                                        chunk=encoder_chunk) for _ in range(encoder_streams - 1)]
+            sd = encoder_sd if encoder_sd is not None else syn.rn50_visual_state_dict(0)
+            encs = [RN50Trunk(sd, device=d, chunk=encoder_chunk) for _ in range(ns)]
+            self.S, self.C = encs[0].out_spatial, encs[0].out_channels
         elif encoder == "vit":
             # BASELINE config 3 (builder-defined fusion, SURVEY.md §8d note): ClipViTEmbedder tokens, CLS dropped,
-            # the 49 patch tokens are the 7x7 channels-last "feature map" [N,49,768] of the goal encoder
-            self.vit = ViTEmbedder(encoder_sd if encoder_sd is not None else syn.vit_visual_state_dict(0),
-                                   device=self.dev)
-            self.S, self.C = 7, self.vit.D
-            self._tok = torch.empty((n_actors, self.vit.L, self.vit.D), dtype=torch.bfloat16, device=self.dev)
+            # the 49 patch tokens are the 7x7 channels-last "feature map" [n,49,768] of the goal encoder
+            sd = encoder_sd if encoder_sd is not None else syn.vit_visual_state_dict(0)
+            encs = [ViTEmbedder(sd, device=d) for _ in range(ns)]
+            self.S, self.C = 7, encs[0].D
         else:
             raise ValueError(encoder)
-        if not hasattr(self, 'enc_streams'):
-            self.enc_streams = []
         pkw = dict(in_channels=self.C, spatial=self.S)
         self.policy = PolicyHandle(**pkw)
         self.H, self.A = self.policy.H, self.policy.A
-        self.params = self.policy.flatten(policy_sd if policy_sd is not None else syn.policy_state_dict(0, **pkw),
-                                          self.dev)
+        self.params = self.policy.flatten(policy_sd if policy_sd is not None else syn.policy_state_dict(0, **pkw), d)
         self.grads = torch.zeros_like(self.params)
         self.opt = FlatAdam(self.params, lr=lr, max_grad_norm=max_grad_norm)
         N, S2 = n_actors, self.S * self.S
-        d = self.dev
-        self.feat = torch.empty((T + 1, N, S2, self.C), dtype=torch.bfloat16, device=d)
+        # [T, N] rollout scalars (global; tiny)
         self.actions = torch.zeros((T, N), dtype=torch.int64, device=d)
         self.logp = torch.zeros((T, N), dtype=torch.float32, device=d)
         self.values = torch.zeros((T + 1, N), dtype=torch.float32, device=d)
@@ -114,104 +116,105 @@ class Worker:
         self.h = torch.zeros((N, self.H), dtype=torch.float32, device=d)
         self.h_next = torch.zeros((N, self.H), dtype=torch.float32, device=d)
         self.hv_act = torch.empty((N, self.A + 1), dtype=torch.float32, device=d)
-        self.hv = torch.empty((T * N, self.A + 1), dtype=torch.float32, device=d)
-        self.dhv = torch.empty_like(self.hv)
-        self.sums = torch.zeros(4, dtype=torch.float64, device=d)
         self.stats = torch.zeros(2, dtype=torch.float64, device=d)
-        self.ws_act = torch.empty(self.policy.workspace_bytes(1, N, False), dtype=torch.uint8, device=d)
-        self.ws_act_half = [torch.empty(self.policy.workspace_bytes(1, N, False), dtype=torch.uint8, device=d)
-                            for _ in range(len(getattr(self, 'enc_streams', [])))]
-        self.encode_frames = N // max(1, len(getattr(self, 'enc_streams', [])))   # frames per timed encoder launch
-        self.ws_learn = torch.empty(self.policy.workspace_bytes(T, N, True), dtype=torch.uint8, device=d)
+        self.sums = torch.zeros(4, dtype=torch.float64, device=d)
         self.env = SyntheticEnv(N, T, d, seed=1000 + rank)
+        self.slices: List[_Slice] = []
+        for i in range(ns):
+            sl = _Slice()
+            sl.o, sl.n, sl.enc = i * n, n, encs[i]
+            sl.stream = torch.cuda.Stream(device=d) if ns > 1 else None
+            sl.feat = torch.empty((T + 1, n, S2, self.C), dtype=torch.bfloat16, device=d)
+            sl.tok = (torch.empty((n, encs[i].L, encs[i].D), dtype=torch.bfloat16, device=d) if encoder == "vit" else None)
+            sl.ws_act = torch.empty(self.policy.workspace_bytes(1, n, False), dtype=torch.uint8, device=d)
+            sl.ws_learn = torch.empty(self.policy.workspace_bytes(T, n, True), dtype=torch.uint8, device=d)
+            sl.hv = torch.empty((T * n, self.A + 1), dtype=torch.float32, device=d)
+            sl.dhv = torch.empty_like(sl.hv)
+            sl.grads = self.grads if ns == 1 else torch.zeros_like(self.params)
+            sl.sums = torch.zeros(4, dtype=torch.float64, device=d)
+            sl.goal = sl.masks = sl.actions = sl.logp = sl.old_v = sl.ret = sl.nadv = None
+            self.slices.append(sl)
+        self.encode_frames = n                    # frames per timed encoder launch
         self.seed = seed + 7919 * rank
         self.total_steps = 0
         self.iter = 0
-        self.trunk_events: List = []     # (start, end) HIP event pairs around ec_rn50_forward
+        self.trunk_events: List = []             # (start, end) HIP event pairs around the encoder launches
         self.time_trunk = False
         # first observation of the first rollout
-        self._encode_raw(self.env.observe(), self.feat[0])
-        self.last_info: Dict[str, float] = {}
+        rgb = self.env.observe()
+        for sl in self.slices:
+            self._encode_slice(sl, rgb, 0)
+        torch.cuda.synchronize(d)
+
+    # ---- helpers ------------------------------------------------------------------------------
+    @property
+    def feat(self) -> torch.Tensor:
+        """[T+1, N, S*S, C] view for tests / inspection (concatenates the slices)."""
+        return self.slices[0].feat if self.ns == 1 else torch.cat([sl.feat for sl in self.slices], dim=1)
+
+    @property
+    def enc_streams(self):
+        return [sl.stream for sl in self.slices if sl.stream is not None]
+
+    def _on(self, sl):
+        return torch.cuda.stream(sl.stream) if sl.stream is not None else _NullCtx()
+
+    def _fork(self):
+        if self.ns > 1:
+            cur = torch.cuda.current_stream()
+            for sl in self.slices:
+                sl.stream.wait_stream(cur)
+
+    def _join(self):
+        if self.ns > 1:
+            cur = torch.cuda.current_stream()
+            for sl in self.slices:
+                cur.wait_stream(sl.stream)
 
     # ---- HOT LOOP A ---------------------------------------------------------------------------
-    def _encode_raw(self, rgb: torch.Tensor, out: torch.Tensor):
-        if self.encoder == "rn50":
-            if self.enc_streams:
-                cur = torch.cuda.current_stream()
-                h = self.N // len(self.enc_streams)
-                for i, (tr, st) in enumerate(zip(self.trunks, self.enc_streams)):
-                    st.wait_stream(cur)
-                    with torch.cuda.stream(st):
-                        tr.forward(rgb[i * h:(i + 1) * h], out[i * h:(i + 1) * h])
-                for st in self.enc_streams:
-                    cur.wait_stream(st)
-            else:
-                self.trunk.forward(rgb, out)          # last conv writes straight into the rollout slice
-        else:
-            self.vit.forward(rgb, self._tok)
-            out.copy_(self._tok[:, 1:, :])            # drop CLS: [N,49,768] channels-last rows
-
-    def _encode(self, rgb: torch.Tensor, out: torch.Tensor):
-        if self.time_trunk:
+    def _encode_slice(self, sl, rgb: torch.Tensor, t: int):
+        src = rgb[sl.o:sl.o + sl.n]
+        timed = self.time_trunk
+        if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            self._encode_raw(rgb, out)
-            e1.record()
-            self.trunk_events.append((e0, e1))
+            e0.record(torch.cuda.current_stream())
+        if self.encoder == "rn50":
+            sl.enc.forward(src, sl.feat[t])           # the last conv writes straight into the rollout slice
         else:
-            self._encode_raw(rgb, out)
+            sl.enc.forward(src, sl.tok)
+            sl.feat[t].copy_(sl.tok[:, 1:, :])        # drop CLS: [n,49,768] channels-last rows
+        if timed:
+            e1.record(torch.cuda.current_stream())
+            self.trunk_events.append((e0, e1))
 
-    def _act(self, t: int, sample: bool = True, o: int = 0, n: Optional[int] = None, ws=None):
-        """Policy act step for actors [o, o+n) on the current stream (T=1, no grad)."""
-        n = self.N if n is None else n
-        ws = self.ws_act if ws is None else ws
-        sp = _lib.stream_ptr()
-        sl = slice(o, o + n)
+    def _act_slice(self, sl, t: int, sample: bool = True):
+        """Policy act step (T=1, no grad) for the slice's actors on the current stream."""
+        o, n, sp = sl.o, sl.n, _lib.stream_ptr()
+        rs = slice(o, o + n)
         h_in, h_out = (self.h, self.h_next) if (t & 1) == 0 else (self.h_next, self.h)   # ping-pong by step parity
-        self.policy.forward(self.params, self.feat[t][sl].view(n, self.S * self.S, self.C), self.env.goals[t][sl],
-                            h_in[sl], self.env.masks[t][sl], 1, n, ws, hv=self.hv_act[sl], h_final=h_out[sl])
+        self.policy.forward(self.params, sl.feat[t], self.env.goals[t][rs], h_in[rs], self.env.masks[t][rs], 1, n,
+                            sl.ws_act, hv=self.hv_act[rs], h_final=h_out[rs])
         if sample:
-            _lib.check(self.lib.ec_sample_actions(self.hv_act[sl].data_ptr(), self.actions[t][sl].data_ptr(),
-                                                  self.logp[t][sl].data_ptr(), self.values[t][sl].data_ptr(), n, self.A,
+            _lib.check(self.lib.ec_sample_actions(self.hv_act[rs].data_ptr(), self.actions[t][rs].data_ptr(),
+                                                  self.logp[t][rs].data_ptr(), self.values[t][rs].data_ptr(), n, self.A,
                                                   self.seed, self.iter * (self.T + 1) + t, o, sp), "ec_sample_actions")
         else:   # bootstrap value of the last observation; memory is NOT advanced
-            self.values[t][sl].copy_(self.hv_act[sl, self.A])
+            self.values[t][rs].copy_(self.hv_act[rs, self.A])
 
     def collect_rollout(self):
         T = self.T
         self.h_start.copy_(self.h)
-        if self.enc_streams and self.encoder == "rn50":
-            # each slice of the actor batch runs its own act -> (env.step) -> encode chain on its own stream: the small
-            # act-step kernels of one slice overlap the encoder of the other; per-actor results are unchanged
-            cur = torch.cuda.current_stream()
-            ns = len(self.enc_streams)
-            hN = self.N // ns
-            for st in self.enc_streams:
-                st.wait_stream(cur)
-            for t in range(T):
-                rgb = self.env.observe()
-                for i, st in enumerate(self.enc_streams):
-                    with torch.cuda.stream(st):
-                        self._act(t, True, i * hN, hN, self.ws_act_half[i])
-                        sl = slice(i * hN, (i + 1) * hN)
-                        if self.time_trunk:
-                            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                            e0.record(st)
-                            self.trunks[i].forward(rgb[sl], self.feat[t + 1][sl])
-                            e1.record(st)
-                            self.trunk_events.append((e0, e1))
-                        else:
-                            self.trunks[i].forward(rgb[sl], self.feat[t + 1][sl])
-            for i, st in enumerate(self.enc_streams):
-                with torch.cuda.stream(st):
-                    self._act(T, False, i * hN, hN, self.ws_act_half[i])
-                cur.wait_stream(st)
-        else:
-            for t in range(T):
-                self._act(t)
-                # env.step(actions[t]) happens here in the real system; its frames arrive as fp32 NHWC
-                self._encode(self.env.observe(), self.feat[t + 1])
-            self._act(T, sample=False)
+        self._fork()
+        for t in range(T):
+            rgb = self.env.observe()      # env.step(actions[t]) happens here in the real system (fp32 NHWC frames)
+            for sl in self.slices:
+                with self._on(sl):
+                    self._act_slice(sl, t)
+                    self._encode_slice(sl, rgb, t + 1)
+        for sl in self.slices:
+            with self._on(sl):
+                self._act_slice(sl, T, sample=False)
+        self._join()
         if (T & 1) == 1:   # after an odd number of advancing steps the live memory sits in h_next
             self.h, self.h_next = self.h_next, self.h
 
@@ -222,25 +225,46 @@ class Worker:
                                    _lib.stream_ptr()), "ec_gae")
 
     # ---- HOT LOOP B ---------------------------------------------------------------------------
+    def _gather_slice_batches(self):
+        """Contiguous [T*n] copies of the slice's columns of the [T, N] rollout scalars (once per iteration)."""
+        T = self.T
+        for sl in self.slices:
+            rs = slice(sl.o, sl.o + sl.n)
+            c = lambda x: x[:T, rs].reshape(-1).contiguous()
+            sl.goal, sl.masks = c(self.env.goals), c(self.env.masks)
+            sl.actions, sl.logp, sl.old_v = c(self.actions), c(self.logp), c(self.values)
+            sl.ret, sl.nadv = c(self.returns), c(self.nadv)
+
     def update(self):
-        T, N = self.T, self.N
-        feat = self.feat[:T].view(T * N, self.S * self.S, self.C)
-        goal = self.env.goals[:T].reshape(-1)
-        masks = self.env.masks[:T].reshape(-1)
-        grad_scale = 1.0 / self.world        # local_bsize / global_bsize: SUM all-reduce -> global mean
+        T = self.T
+        self._gather_slice_batches()
+        # d(total)/d(hv) carries 1/B_slice inside the loss kernel: rescale to the mean over the WHOLE local batch,
+        # then local_bsize / global_bsize for the SUM all-reduce (global mean gradient)
+        grad_scale = (1.0 / self.ns) * (1.0 / self.world)
         for _ in range(self.update_repeats):
-            self.policy.forward(self.params, feat, goal, self.h_start, masks, T, N, self.ws_learn, hv=self.hv)
-            ppo_loss_raw(self.hv, self.actions.view(-1), self.logp.view(-1), self.values[:T].reshape(-1),
-                         self.returns[:T].reshape(-1), self.nadv.view(-1), self.A, grad_scale=grad_scale,
-                         dhv=self.dhv, sums=self.sums)
-            self.grads.zero_()
-            self.policy.backward(self.params, feat, masks, T, N, self.ws_learn, self.dhv, None, self.grads)
+            self._fork()
+            for sl in self.slices:
+                with self._on(sl):
+                    n = sl.n
+                    self.policy.forward(self.params, sl.feat[:T].view(T * n, self.S * self.S, self.C), sl.goal,
+                                        self.h_start[sl.o:sl.o + n], sl.masks, T, n, sl.ws_learn, hv=sl.hv)
+                    ppo_loss_raw(sl.hv, sl.actions, sl.logp, sl.old_v, sl.ret, sl.nadv, self.A, grad_scale=grad_scale,
+                                 dhv=sl.dhv, sums=sl.sums)
+                    sl.grads.zero_()
+                    self.policy.backward(self.params, sl.feat[:T].view(T * n, self.S * self.S, self.C), sl.masks, T, n,
+                                         sl.ws_learn, sl.dhv, None, sl.grads)
+            self._join()
+            if self.ns > 1:
+                torch.add(self.slices[0].grads, self.slices[1].grads, out=self.grads)
+                for sl in self.slices[2:]:
+                    self.grads.add_(sl.grads)
             if self.world > 1:
                 allreduce_flat(self.grads)                   # one flat 13.9 MB bucket over RCCL/xGMI
             self.opt.step(self.grads, lr=linear_decay_lr(self.base_lr, self.total_steps, self.lr_total_steps))
 
     def after_update(self):
-        self.feat[0].copy_(self.feat[self.T])
+        for sl in self.slices:
+            sl.feat[0].copy_(sl.feat[self.T])
         self.total_steps += self.T * self.N * self.world
         self.iter += 1
 
@@ -251,6 +275,15 @@ class Worker:
         self.after_update()
 
     def loss_info(self) -> Dict[str, float]:
-        s = (self.sums / (self.T * self.N)).tolist()
+        tot = sum(sl.sums for sl in self.slices)
+        s = (tot / (self.T * self.N)).tolist()
         return {"action": s[0], "value": s[1], "entropy": s[2], "ratio": s[3],
                 "ppo_total": s[0] + 0.5 * s[1] + 0.01 * s[2], "grad_norm": self.opt.grad_norm()}
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
