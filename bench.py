@@ -110,6 +110,9 @@ def main():
     ap.add_argument("--update-repeats", type=int, default=4)
     ap.add_argument("--encoder-chunk", type=int, default=0)
     ap.add_argument("--encoder-streams", type=int, default=2, help="concurrent HIP streams for the RN50 encoder")
+    ap.add_argument("--frames-u8", action="store_true",
+                    help="raw uint8 frames in HBM (normalisation fused into the stem); default is the reference "
+                         "sensor's wire form, fp32 normalised HWC")
     ap.add_argument("--encoder", choices=("rn50", "vit"), default="rn50",
                     help="rn50 = BASELINE headline config; vit = config 3 (ViT-B/32, parity-unpinned fusion)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -134,7 +137,8 @@ def main():
 
     from embodied_clip_amd.engine import Worker
     w = Worker(a.actors, T=a.rollout, device=dev, seed=0, rank=rank, world=world, update_repeats=a.update_repeats,
-               encoder_chunk=a.encoder_chunk, encoder=a.encoder, encoder_streams=a.encoder_streams)
+               encoder_chunk=a.encoder_chunk, encoder=a.encoder, encoder_streams=a.encoder_streams,
+               frames_u8=a.frames_u8)
 
     def barrier():
         if world > 1:
@@ -187,6 +191,7 @@ def main():
                                    "1-layer GRU actor-critic PPO (fp32), synthetic 224x224 RGB + random goal ids",
                        "actors_per_gpu": a.actors, "global_actors": a.actors * world, "rollout": a.rollout,
                        "update_repeats": a.update_repeats, "num_mini_batch": 1, "encoder_streams": a.encoder_streams,
+                       "frames": "uint8 HWC (normalisation fused)" if a.frames_u8 else "fp32 normalised HWC",
                        "parallelism": f"dp{world} (actors sharded; one flat 13.9 MB grad all-reduce per optimiser step)",
                        "flop_per_frame": 2 * ((TRUNK_MAC_PER_FRAME + POLICY_ACT_MAC + POLICY_UPDATE_MAC)
                                              if a.encoder == "rn50" else VIT_MAC_PER_FRAME)},

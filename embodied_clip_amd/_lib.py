@@ -33,6 +33,10 @@ SIGNATURES = {
     "ec_rn50_out_spatial": (c_int, [c_void_p]),
     "ec_rn50_forward": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p, c_int, c_void_p]),
     "ec_rn50_num_ops": (c_int, [c_void_p]),
+    "ec_stem_conv1_u8": (c_int, [c_void_p, C.POINTER(c_float), C.POINTER(c_float), c_void_p, c_void_p, c_void_p]
+                         + [c_int] * 4 + [c_void_p]),
+    "ec_rn50_forward_u8": (c_int, [c_void_p, c_void_p, C.POINTER(c_float), C.POINTER(c_float), c_int, c_void_p,
+                                   c_size_t, c_void_p, c_int, c_void_p]),
     "ec_gemm_f32": (c_int, [c_void_p] * 3 + [c_int] * 3 + [C.c_long] * 4 + [c_int, c_int] + [c_void_p] * 3 + [c_int]
                     + [c_void_p] * 2 + [c_int, c_void_p]),
     "ec_policy_create": (c_int, [C.POINTER(c_void_p), c_void_p]),

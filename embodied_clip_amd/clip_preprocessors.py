@@ -106,9 +106,11 @@ class ClipResNetPreprocessor(_PreprocessorBase):
         x = obs[self.input_uuids[0]]
         if x.shape[-1] == 1:      # depth input: repeated to 3 channels, as upstream does
             x = x.expand(*x.shape[:-1], 3)
-        x = x.to(self.device, dtype=torch.float32).contiguous()
         trunk = self.resnet
-        feat = trunk.forward(x)
+        if x.dtype == torch.uint8:   # raw frames: /255 and CLIP mean/std are fused into the stem kernel
+            feat = trunk.forward_u8(x.to(self.device).contiguous(), mean=self.CLIP_RGB_MEANS, std=self.CLIP_RGB_STDS)
+        else:
+            feat = trunk.forward(x.to(self.device, dtype=torch.float32).contiguous())
         return trunk.spatial_mean(feat) if self.pool else trunk.to_nchw_f32(feat)
 
     def process_bf16_nhwc(self, rgb: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:

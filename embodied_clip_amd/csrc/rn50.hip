@@ -129,8 +129,29 @@ extern "C" size_t ec_rn50_workspace_bytes(const ec_rn50_t* h, int batch) {
     return NBUF * align_up(h->max_elems_per_frame * 2 * (size_t)batch, 256);
 }
 
+extern "C" int ec_stem_conv1_u8(const uint8_t* rgb_u8, const float* mean3, const float* std3, const float* w,
+                                const float* bias, void* out, int B, int H, int W, int Cout, ec_stream_t stream);
+
+namespace {
+int rn50_run(const ec_rn50_t* h, const void* rgb, bool u8, const float* mean3, const float* std3, int batch,
+             void* workspace, size_t ws_bytes, void* feat, int chunk, ec_stream_t stream);
+}
+
 extern "C" int ec_rn50_forward(const ec_rn50_t* h, const float* rgb, int batch, void* workspace, size_t ws_bytes,
                                void* feat, int chunk, ec_stream_t stream) {
+    return rn50_run(h, rgb, false, nullptr, nullptr, batch, workspace, ws_bytes, feat, chunk, stream);
+}
+
+extern "C" int ec_rn50_forward_u8(const ec_rn50_t* h, const uint8_t* rgb_u8, const float* h_mean3, const float* h_std3,
+                                  int batch, void* workspace, size_t ws_bytes, void* feat, int chunk,
+                                  ec_stream_t stream) {
+    if (!h_mean3 || !h_std3) return EC_ERR_ARG;
+    return rn50_run(h, rgb_u8, true, h_mean3, h_std3, batch, workspace, ws_bytes, feat, chunk, stream);
+}
+
+namespace {
+int rn50_run(const ec_rn50_t* h, const void* rgb, bool u8, const float* mean3, const float* std3, int batch,
+             void* workspace, size_t ws_bytes, void* feat, int chunk, ec_stream_t stream) {
     if (!h || !rgb || !workspace || !feat) return EC_ERR_ARG;
     if (batch <= 0) return EC_ERR_SHAPE;
     if (chunk <= 0 || chunk > batch) chunk = batch;
@@ -153,8 +174,12 @@ extern "C" int ec_rn50_forward(const ec_rn50_t* h, const float* rgb, int batch, 
             int rc;
             switch (o.kind) {
                 case OP_STEM1:
-                    rc = ec_stem_conv1(rgb + (size_t)b0 * rgb_stride, h->stem_w, h->bias + o.b_off, buf(o.dst), nb, o.H,
-                                       o.W, o.Cout, stream);
+                    if (u8)
+                        rc = ec_stem_conv1_u8((const uint8_t*)rgb + (size_t)b0 * rgb_stride, mean3, std3, h->stem_w,
+                                              h->bias + o.b_off, buf(o.dst), nb, o.H, o.W, o.Cout, stream);
+                    else
+                        rc = ec_stem_conv1((const float*)rgb + (size_t)b0 * rgb_stride, h->stem_w, h->bias + o.b_off,
+                                           buf(o.dst), nb, o.H, o.W, o.Cout, stream);
                     break;
                 case OP_POOL:
                     rc = ec_avgpool2_bf16(buf(o.src), buf(o.dst), nb, o.H, o.W, o.Cin, stream);
@@ -168,3 +193,4 @@ extern "C" int ec_rn50_forward(const ec_rn50_t* h, const float* rgb, int batch, 
     }
     return EC_OK;
 }
+}  // namespace

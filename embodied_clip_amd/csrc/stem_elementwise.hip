@@ -21,10 +21,14 @@ constexpr int ST = 16;                 // output tile edge
 constexpr int SP = 2 * ST + 1;         // input patch edge (33)
 constexpr int SROW = SP * 3;           // floats per patch row (99)
 
-template <int COUT>
-__global__ __launch_bounds__(256) void stem_conv1_kernel(const float* __restrict__ rgb, const float* __restrict__ w,
+// U8: the frame is the raw uint8 HWC image; ToTensor (/255) and Normalize(mean, std) of the reference's
+// `clip_preprocess` (thor_image_features.py:108; constants CLIP_RGB_MEANS/STDS of the plugin) are applied while the
+// patch is staged into LDS, so padding stays exactly zero in the NORMALISED domain as in the reference.
+template <int COUT, bool U8>
+__global__ __launch_bounds__(256) void stem_conv1_kernel(const void* __restrict__ rgb_, const float* __restrict__ w,
                                                          const float* __restrict__ bias, uint16_t* __restrict__ out,
-                                                         int H, int W, int Ho, int Wo, int tiles_x, int tiles_y) {
+                                                         int H, int W, int Ho, int Wo, int tiles_x, int tiles_y,
+                                                         float3 nscale, float3 nshift) {
     __shared__ float patch[SP * SROW + 1];
     int bid = blockIdx.x;
     const int tx = bid % tiles_x; bid /= tiles_x;
@@ -32,13 +36,23 @@ __global__ __launch_bounds__(256) void stem_conv1_kernel(const float* __restrict
     const int b = bid / tiles_y;
     const int oy0 = ty * ST, ox0 = tx * ST;
     const int iy0 = 2 * oy0 - 1, ix0 = 2 * ox0 - 1;
-    const float* img = rgb + (long)b * H * W * 3;
+    const long img_off = (long)b * H * W * 3;
     for (int e = threadIdx.x; e < SP * SROW; e += 256) {
         const int r = e / SROW, c = e - r * SROW;
         const int iy = iy0 + r;
-        const int ixc = ix0 * 3 + c;   // float index within the image row
+        const int ixc = ix0 * 3 + c;   // element index within the image row
         float v = 0.f;
-        if (iy >= 0 && iy < H && ixc >= 0 && ixc < W * 3) v = img[(long)iy * W * 3 + ixc];
+        if (iy >= 0 && iy < H && ixc >= 0 && ixc < W * 3) {
+            const long idx = img_off + (long)iy * W * 3 + ixc;
+            if (U8) {
+                const int ch = ((ixc % 3) + 3) % 3;
+                const float sc = ch == 0 ? nscale.x : (ch == 1 ? nscale.y : nscale.z);
+                const float sh = ch == 0 ? nshift.x : (ch == 1 ? nshift.y : nshift.z);
+                v = (float)reinterpret_cast<const unsigned char*>(rgb_)[idx] * sc + sh;
+            } else {
+                v = reinterpret_cast<const float*>(rgb_)[idx];
+            }
+        }
         patch[e] = v;
     }
     __syncthreads();
@@ -142,10 +156,36 @@ extern "C" int ec_stem_conv1(const float* rgb, const float* w, const float* bias
     const int tx = (Wo + ST - 1) / ST, ty = (Ho + ST - 1) / ST;
     dim3 grid((unsigned)(B * tx * ty));
     hipStream_t s = (hipStream_t)stream;
+    const float3 z = make_float3(0.f, 0.f, 0.f);
     if (Cout == 32)
-        hipLaunchKernelGGL(stem_conv1_kernel<32>, grid, dim3(256), 0, s, rgb, w, bias, (uint16_t*)out, H, W, Ho, Wo, tx, ty);
+        hipLaunchKernelGGL((stem_conv1_kernel<32, false>), grid, dim3(256), 0, s, (const void*)rgb, w, bias, (uint16_t*)out, H, W,
+                           Ho, Wo, tx, ty, z, z);
     else if (Cout == 48)
-        hipLaunchKernelGGL(stem_conv1_kernel<48>, grid, dim3(256), 0, s, rgb, w, bias, (uint16_t*)out, H, W, Ho, Wo, tx, ty);
+        hipLaunchKernelGGL((stem_conv1_kernel<48, false>), grid, dim3(256), 0, s, (const void*)rgb, w, bias, (uint16_t*)out, H, W,
+                           Ho, Wo, tx, ty, z, z);
+    else
+        return EC_ERR_SHAPE;
+    EC_CHECK_LAUNCH();
+    return EC_OK;
+}
+
+extern "C" int ec_stem_conv1_u8(const uint8_t* rgb_u8, const float* mean3, const float* std3, const float* w,
+                                const float* bias, void* out, int B, int H, int W, int Cout, ec_stream_t stream) {
+    if (!rgb_u8 || !mean3 || !std3 || !w || !bias || !out) return EC_ERR_ARG;   // mean3/std3 are HOST pointers
+    if (B <= 0 || H < 2 || W < 2) return EC_ERR_SHAPE;
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const int tx = (Wo + ST - 1) / ST, ty = (Ho + ST - 1) / ST;
+    dim3 grid((unsigned)(B * tx * ty));
+    hipStream_t s = (hipStream_t)stream;
+    // (u8/255 - mean)/std == u8 * (1/(255 std)) - mean/std
+    const float3 sc = make_float3(1.f / (255.f * std3[0]), 1.f / (255.f * std3[1]), 1.f / (255.f * std3[2]));
+    const float3 sh = make_float3(-mean3[0] / std3[0], -mean3[1] / std3[1], -mean3[2] / std3[2]);
+    if (Cout == 32)
+        hipLaunchKernelGGL((stem_conv1_kernel<32, true>), grid, dim3(256), 0, s, (const void*)rgb_u8, w, bias, (uint16_t*)out, H,
+                           W, Ho, Wo, tx, ty, sc, sh);
+    else if (Cout == 48)
+        hipLaunchKernelGGL((stem_conv1_kernel<48, true>), grid, dim3(256), 0, s, (const void*)rgb_u8, w, bias, (uint16_t*)out, H,
+                           W, Ho, Wo, tx, ty, sc, sh);
     else
         return EC_ERR_SHAPE;
     EC_CHECK_LAUNCH();

@@ -125,6 +125,22 @@ class RN50Trunk:
                                             chunk, _lib.stream_ptr()), "ec_rn50_forward")
         return out
 
+    def forward_u8(self, rgb_u8: torch.Tensor, out: Optional[torch.Tensor] = None,
+                   mean=(0.48145466, 0.4578275, 0.40821073), std=(0.26862954, 0.26130258, 0.27577711)) -> torch.Tensor:
+        """rgb_u8: device uint8 [B, R, R, 3] raw frames; CLIP normalisation is fused into the stem kernel."""
+        assert rgb_u8.is_cuda and rgb_u8.dtype == torch.uint8 and rgb_u8.is_contiguous()
+        B, R = rgb_u8.shape[0], rgb_u8.shape[1]
+        assert R == self.input_resolution and rgb_u8.shape[3] == 3
+        S, Cc = self.out_spatial, self.out_channels
+        if out is None:
+            out = torch.empty((B, S, S, Cc), dtype=torch.bfloat16, device=self.device)
+        chunk = self.chunk if self.chunk > 0 else B
+        ws = self._workspace(min(chunk, B))
+        m3, s3 = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
+        _lib.check(self.lib.ec_rn50_forward_u8(self.h, rgb_u8.data_ptr(), m3, s3, B, ws.data_ptr(), ws.numel(),
+                                               out.data_ptr(), chunk, _lib.stream_ptr()), "ec_rn50_forward_u8")
+        return out
+
     def to_nchw_f32(self, feat: torch.Tensor) -> torch.Tensor:
         B = feat.shape[0]
         S, Cc = self.out_spatial, self.out_channels

@@ -38,15 +38,17 @@ class SyntheticEnv:
     """N synthetic actors: a pool of pre-rendered, CLIP-normalised 224x224 frames in HBM,
     random goal ids, episode resets w.p. 1/100, RoboTHOR-style rewards."""
 
-    def __init__(self, n_actors: int, T: int, device, seed: int, pool_steps: int = 4, res: int = 224):
+    def __init__(self, n_actors: int, T: int, device, seed: int, pool_steps: int = 4, res: int = 224,
+                 frames_u8: bool = False):
         self.N, self.T = n_actors, T
-        base = syn.synthetic_rgb(seed, min(n_actors, 32), res)
+        # frames_u8: raw uint8 frames (what the simulator renders); normalisation is then fused into the stem kernel
+        base = (syn.synthetic_rgb_u8 if frames_u8 else syn.synthetic_rgb)(seed, min(n_actors, 32), res)
         reps = (n_actors + base.shape[0] - 1) // base.shape[0]
         frames = []
         for s in range(pool_steps):   # distinct frame batches so consecutive steps differ
             f = base.roll(shifts=s + 1, dims=0).roll(shifts=7 * (s + 1), dims=2)
             frames.append(f.repeat(reps, 1, 1, 1)[:n_actors])
-        self.frames = torch.stack(frames).to(device).contiguous()      # [P, N, R, R, 3] fp32
+        self.frames = torch.stack(frames).to(device).contiguous()      # [P, N, R, R, 3] fp32 | uint8
         self.pool_steps = pool_steps
         masks = torch.cat([torch.ones(1, n_actors, 1), syn.synthetic_masks(seed + 1, T, n_actors)], 0)
         self.masks = masks.reshape(T + 1, n_actors).to(device).contiguous()
@@ -75,7 +77,7 @@ class Worker:
     def __init__(self, n_actors: int, T: int = 128, device="cuda:0", seed: int = 0, rank: int = 0, world: int = 1,
                  update_repeats: int = 4, lr: float = 3e-4, max_grad_norm: float = 0.5, gamma: float = 0.99,
                  tau: float = 0.95, encoder_sd=None, policy_sd=None, lr_total_steps: int = 300_000_000,
-                 encoder_chunk: int = 0, encoder: str = "rn50", encoder_streams: int = 2):
+                 encoder_chunk: int = 0, encoder: str = "rn50", encoder_streams: int = 2, frames_u8: bool = False):
         self.lib = _lib.load()
         self.dev = torch.device(device)
         self.N, self.T, self.rank, self.world = n_actors, T, rank, world
@@ -118,7 +120,7 @@ class Worker:
         self.hv_act = torch.empty((N, self.A + 1), dtype=torch.float32, device=d)
         self.stats = torch.zeros(2, dtype=torch.float64, device=d)
         self.sums = torch.zeros(4, dtype=torch.float64, device=d)
-        self.env = SyntheticEnv(N, T, d, seed=1000 + rank)
+        self.env = SyntheticEnv(N, T, d, seed=1000 + rank, frames_u8=frames_u8)
         self.slices: List[_Slice] = []
         for i in range(ns):
             sl = _Slice()
@@ -179,7 +181,8 @@ class Worker:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream())
         if self.encoder == "rn50":
-            sl.enc.forward(src, sl.feat[t])           # the last conv writes straight into the rollout slice
+            # the last conv writes straight into the rollout slice
+            (sl.enc.forward_u8 if src.dtype == torch.uint8 else sl.enc.forward)(src, sl.feat[t])
         else:
             sl.enc.forward(src, sl.tok)
             sl.feat[t].copy_(sl.tok[:, 1:, :])        # drop CLS: [n,49,768] channels-last rows

@@ -78,6 +78,12 @@ int ec_gemm_bf16(const void* A, const void* W, const float* bias, const void* re
 int ec_stem_conv1(const float* rgb_nhwc, const float* w, const float* bias, void* out,
                   int B, int H, int W, int Cout, ec_stream_t stream);
 
+/* Same, on the RAW uint8 HWC frame (thor_frames.py:33-34,96 writes uint8 frames): ToTensor (/255) and
+ * Normalize(mean, std) of `clip_preprocess` (thor_image_features.py:108) are fused into the LDS staging.
+ * h_mean3 / h_std3 are HOST pointers to 3 floats (CLIP_RGB_MEANS / CLIP_RGB_STDS). */
+int ec_stem_conv1_u8(const uint8_t* rgb_u8_nhwc, const float* h_mean3, const float* h_std3, const float* w,
+                     const float* bias, void* out, int B, int H, int W, int Cout, ec_stream_t stream);
+
 /* AvgPool2d(2) on bf16 NHWC ([U] Bottleneck downsample "-1"). C multiple of 8. */
 int ec_avgpool2_bf16(const void* in, void* out, int B, int H, int W, int C, ec_stream_t stream);
 
@@ -112,6 +118,10 @@ int ec_rn50_out_spatial(const ec_rn50_t* h);
  * of `chunk` frames so intermediates stay Infinity-Cache resident. */
 int ec_rn50_forward(const ec_rn50_t* h, const float* rgb_nhwc, int batch, void* workspace, size_t ws_bytes,
                     void* feat_bf16_nhwc, int chunk, ec_stream_t stream);
+/* uint8 frames in (fused input pipeline; 4x fewer input bytes, no fp32 frame tensor). */
+int ec_rn50_forward_u8(const ec_rn50_t* h, const uint8_t* rgb_u8_nhwc, const float* h_mean3, const float* h_std3,
+                       int batch, void* workspace, size_t ws_bytes, void* feat_bf16_nhwc, int chunk,
+                       ec_stream_t stream);
 /* debugging / parity: copy of an intermediate stage of the LAST forward is not
  * kept; instead run only the first `n_ops` ops and return the op's output dims. */
 int ec_rn50_num_ops(const ec_rn50_t* h);

@@ -159,3 +159,40 @@ def test_preprocessor_api_surface(dev):
     outp = pre_p.process({"rgb_lowres": rgb})
     assert outp.shape == (2, 2048)
     assert _rel(outp.cpu(), ocr.clip_resnet_preprocessor(rgb, sd, pool=True)) < 2e-2
+
+
+def test_uint8_input_path_matches_normalised_fp32_path(dev):
+    """raw uint8 frames in, CLIP normalisation fused into the stem kernel."""
+    from embodied_clip_amd.clip_preprocessors import ClipResNetPreprocessor
+    from embodied_clip_amd.encoder import RN50Trunk
+    sd = syn.rn50_visual_state_dict(0)
+    u8 = syn.synthetic_rgb_u8(77, 3)
+    trunk = RN50Trunk(sd, device=dev)
+    a = trunk.forward(syn.normalize_rgb(u8).to(dev)).cpu()
+    b = trunk.forward_u8(u8.to(dev)).cpu()
+    # same math up to fp32 rounding of the normalisation; 1-ulp input differences flip bf16 roundings that
+    # propagate through 50 layers, so the bound is the bf16 noise floor of the trunk, not fp32
+    assert _rel(b, a) < 1e-2, _rel(b, a)
+    # stem conv1 alone (one bf16 rounding): tight
+    import ctypes as C
+    from embodied_clip_amd import _lib
+    lib = _lib.load()
+    w = torch.randn(27, 32, device=dev) * 0.2
+    bias = torch.randn(32, device=dev) * 0.1
+    xf = syn.normalize_rgb(u8).to(dev).contiguous()
+    xu = u8.to(dev).contiguous()
+    o1 = torch.empty(3, 112, 112, 32, dtype=torch.bfloat16, device=dev)
+    o2 = torch.empty_like(o1)
+    _lib.check(lib.ec_stem_conv1(xf.data_ptr(), w.data_ptr(), bias.data_ptr(), o1.data_ptr(), 3, 224, 224, 32,
+                                 _lib.stream_ptr()), "stem")
+    m3 = (C.c_float * 3)(*syn.CLIP_RGB_MEANS)
+    s3 = (C.c_float * 3)(*syn.CLIP_RGB_STDS)
+    _lib.check(lib.ec_stem_conv1_u8(xu.data_ptr(), m3, s3, w.data_ptr(), bias.data_ptr(), o2.data_ptr(), 3, 224, 224,
+                                    32, _lib.stream_ptr()), "stem_u8")
+    torch.cuda.synchronize()
+    d = (o1.float() - o2.float()).abs()
+    assert d.max().item() <= 2 ** -7 * o1.float().abs().max().item()      # at most one bf16 ulp
+    assert (d > 0).float().mean().item() < 0.01
+    ref = ocr.clip_resnet_preprocessor(syn.normalize_rgb(u8), sd)
+    pre = ClipResNetPreprocessor("rgb", "RN50", pool=False, state_dict=sd, device=dev)
+    assert _rel(pre.process({"rgb": u8}).cpu(), ref) < 2e-2
