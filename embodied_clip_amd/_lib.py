@@ -33,6 +33,9 @@ SIGNATURES = {
     "ec_rn50_out_spatial": (c_int, [c_void_p]),
     "ec_rn50_forward": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p, c_int, c_void_p]),
     "ec_rn50_num_ops": (c_int, [c_void_p]),
+    "ec_probe_head": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                              c_void_p, c_void_p]),
+    "ec_probe_pool3": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "ec_stem_conv1_u8": (c_int, [c_void_p, C.POINTER(c_float), C.POINTER(c_float), c_void_p, c_void_p, c_void_p]
                          + [c_int] * 4 + [c_void_p]),
     "ec_rn50_forward_u8": (c_int, [c_void_p, c_void_p, C.POINTER(c_float), C.POINTER(c_float), c_int, c_void_p,

@@ -248,6 +248,28 @@ int ec_attnpool_forward(const void* feat, int batch, int HW, int C, int heads, i
                         const void* wq, const float* bq, const void* wkv, const float* bkv, const void* wc,
                         const float* bc, void* workspace, size_t ws_bytes, float* out, ec_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * Linear probe heads (BASELINE config 1) == LinearEncoder of
+ * primitive_probing/train.py:14-113.  The Linear / Conv1x1 contraction is ec_gemm_f32; these are the
+ * activation + loss + metric counts + analytic backward of compute_loss (train.py:56-92):
+ *   EC_PROBE_SIGMOID_BCE         Sigmoid + F.binary_cross_entropy over [R,C]  (object_presence; object_localization
+ *                                with R = B*9 rows from ec_probe_pool3)                     train.py:29,31,44-49,76
+ *   EC_PROBE_SIGMOID_BCE_GATHER  Sigmoid, loss on column idx[r] only (reachability)         train.py:61-63,72,76
+ *   EC_PROBE_SOFTMAX_CE2         Softmax(dim=1) then F.cross_entropy ON THE PROBABILITIES   train.py:35,78
+ *                                (double softmax reproduced); labels > label_clamp are clamped (train.py:65)
+ * labels int64: [R,C] (mode 0) or [R] (modes 1,2); idx int64 [R] (mode 1).
+ * pred [R,C] (probabilities), dlogits [R,C] = d(mean loss)/d(logits), dbias [C] = column sums of dlogits:
+ * each may be NULL.  out5 (doubles): {sum of per-element losses, tp, pred_pos, true_pos, correct}; the mean
+ * loss is out5[0] / (R*C) (mode 0) or / R (modes 1,2); micro-F1 = 2 tp / (pred_pos + true_pos) (train.py:86),
+ * accuracy = correct / count (train.py:88,90). */
+enum { EC_PROBE_SIGMOID_BCE = 0, EC_PROBE_SIGMOID_BCE_GATHER = 1, EC_PROBE_SOFTMAX_CE2 = 2 };
+int ec_probe_head(int mode, const float* logits, const int64_t* labels, const int64_t* idx, int R, int C,
+                  int label_clamp, float* pred, float* dlogits, float* dbias, double* out5, ec_stream_t stream);
+/* nn.AdaptiveAvgPool2d((3,3)) (train.py:45) of the cached fp32 NCHW conv features [B,C,H,W] ->
+ * rows [B*9, C] so the Conv1x1 (train.py:46) is a row GEMM whose [B*9,52] output equals
+ * y_pred.permute(0,2,1).flatten(1) (train.py:70). */
+int ec_probe_pool3(const float* conv_nchw, float* rows, int B, int C, int H, int W, ec_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

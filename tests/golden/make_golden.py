@@ -32,6 +32,26 @@ def policy_case(T=8, N=4, seed=21):
     return sd, feat, goal, h0, masks, actions, u(6), u(7), u(8), u(9)
 
 
+def probe_cases():
+    """Seeded (x, y, weight, bias) for the four probe tasks (clip_avgpool / clip_conv embeddings)."""
+    cases = {}
+    x = torch.from_numpy(syn.hash_normal(41, 8 * 2048).astype("float32")).reshape(8, 2048)
+    xc = torch.from_numpy(syn.hash_normal(44, 8 * 2048 * 49).astype("float32")).reshape(8, 2048, 7, 7)
+    for task, odim in (("object_presence", 52), ("free_space", 11), ("reachability", 110), ("object_localization", 52)):
+        w = torch.from_numpy(syn.hash_normal(42, odim * 2048).astype("float32")).reshape(odim, 2048) * 0.02
+        bb = torch.zeros(odim)
+        if task == "object_presence":
+            y = syn.synthetic_goals(43, (8, odim), 2)
+        elif task == "free_space":
+            y = syn.synthetic_goals(43, (8,), 14)
+        elif task == "reachability":
+            y = (syn.synthetic_goals(45, (8,), 110), syn.synthetic_goals(46, (8,), 2))
+        else:
+            y = syn.synthetic_goals(47, (8, 9, odim), 2)
+        cases[task] = (xc if task == "object_localization" else x, y, w, bb)
+    return cases
+
+
 def main():
     g = {}
     # (1) RN50 trunk on 2 frames: pooled embedding + a slice of the conv features (fp32 oracle)
@@ -67,14 +87,7 @@ def main():
     adv, nadv = oppo.normalized_advantages(R, v)
     g["gae"] = {"seeds": (31, 32, 33), "returns": R.clone(), "norm_adv": nadv.clone()}
     # (5) linear-probe losses for the 4 tasks of primitive_probing/train.py (incl. the double softmax)
-    x = torch.from_numpy(syn.hash_normal(41, 8 * 2048).astype("float32")).reshape(8, 2048)
-    pr = {}
-    for task, odim in (("object_presence", 52), ("free_space", 11)):
-        w = torch.from_numpy(syn.hash_normal(42, odim * 2048).astype("float32")).reshape(odim, 2048) * 0.02
-        bb = torch.zeros(odim)
-        y = (syn.synthetic_goals(43, (8, odim), 2) if task == "object_presence" else syn.synthetic_goals(43, (8,), 14))
-        pr[task] = float(oprobe.compute_loss(x, y, w, bb, task))
-    g["probe"] = pr
+    g["probe"] = {task: float(oprobe.compute_loss(x, y, w, bb, task)) for task, (x, y, w, bb) in probe_cases().items()}
     torch.save(g, os.path.join(OUT, "oracle_golden.pt"))
     print("wrote", os.path.join(OUT, "oracle_golden.pt"), os.path.getsize(os.path.join(OUT, "oracle_golden.pt")), "bytes")
 

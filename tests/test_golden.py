@@ -42,3 +42,11 @@ def test_oracle_policy_and_gae_reproduce_golden():
     v = torch.from_numpy(syn.hash_normal(33, (T + 1) * N).astype("float32")).reshape(T + 1, N, 1)
     R = oppo.compute_returns(r, v, m)
     assert torch.allclose(R, G["gae"]["returns"], rtol=1e-5, atol=1e-6)
+
+
+def test_oracle_probe_reproduces_golden():
+    from oracle import probe as oprobe
+    gold = torch.load(os.path.join(os.path.dirname(__file__), "golden", "oracle_golden.pt"))["probe"]
+    assert set(gold) == {"object_presence", "free_space", "reachability", "object_localization"}
+    for task, (x, y, w, bb) in mg.probe_cases().items():
+        assert abs(float(oprobe.compute_loss(x, y, w, bb, task)) - gold[task]) < 1e-6, task
