@@ -1,0 +1,261 @@
+// Fused pair of 1x1 convolutions across a Bottleneck boundary of CLIP-RN50 layer1 (bf16 MFMA, gfx950):
+//
+//   y = relu( a0 . w0^T + b0  [+ a1 . w1^T + b1]  [+ res] )      [M, 256]   conv3+bn3 (+ downsample conv+bn) + identity + ReLU
+//   z = relu( y . w2^T + b2 )                                     [M, N2]    the NEXT block's conv1+bn1+ReLU (N2 = 64 | 128)
+//
+// Replaces, per boundary, two (three with the downsample) launches of `conv_igemm` and the HBM round trip of
+// y between them ([U] openai/CLIP clip/model.py Bottleneck.forward: `out = relu(bn3(conv3(out)) + identity)`
+// followed by the next block's `relu(bn1(conv1(x)))`; reached from
+// primitive_probing/generate_data/thor_image_features.py:109).  At 56x56 these 1x1 convs are bandwidth-bound
+// (K = 64: 0.5 flop/B), so the win is bytes: y is written once and never re-read by conv1, and with the
+// downsample fused the 256-channel identity tensor of block 0 is never materialised at all.
+//
+// Design (one workgroup of 4 waves per CU, persistent; everything wave-private after the prologue):
+//   * all weights stay resident in LDS for the lifetime of the workgroup (w0|w1: 32-64 KB, w2: 32-64 KB);
+//   * a wave owns a 32-pixel tile.  Pixel operands (a0, a1) are loaded straight into MFMA operand layout,
+//     the residual tile as coalesced 16-B row chunks; both are PREFETCHED one tile ahead into registers
+//     (1 wave/SIMD => 512 VGPRs), so ~20 KB per wave are always in flight and no barrier is ever needed;
+//   * swapped MFMA operands (D[channel][pixel]): a lane owns one pixel and 4 consecutive channels per 4
+//     accumulator registers.  After bias/residual/ReLU/bf16 rounding, 8 consecutive accumulator registers
+//     ARE the k-slots a lane must supply for one K-step of the second GEMM -- y never leaves registers on its
+//     way into conv1; the matching K permutation is applied to w2 once, while it is staged into LDS;
+//   * y and z leave through a small per-wave LDS staging image so every global access is a 16-B row chunk.
+#include <type_traits>
+#include <utility>
+
+#include "common.h"
+
+namespace {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // native vector: plain loads/stores, SROA-friendly
+constexpr int PX = 32;         // pixels per wave tile
+constexpr int NY = 256;        // channels of y
+constexpr int KA = 64;         // channels of a0 / a1
+constexpr int SP = 272;        // staging pitch in bytes of a 128-channel half row (+16: 2-way instead of 32-way conflicts)
+constexpr int STG = PX * SP;   // staging bytes per wave
+
+struct PairArgs {
+    const uint16_t *a0, *a1, *w0, *w1, *w2, *res;
+    const float *b0, *b1, *b2;
+    uint16_t *y, *z;
+    int ntiles;
+};
+
+__device__ __forceinline__ int pw_off(int row, int chunk) {   // 128-B rows, XOR swizzle on the 16-B chunk
+    return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+
+template <bool TWO, bool RES, int N2>
+__global__ __launch_bounds__(256, 1) void conv1x1_pair_kernel(PairArgs p) {
+    constexpr int W0_BYTES = (TWO ? 2 : 1) * NY * 128;
+    constexpr int W2_BYTES = 4 * N2 * 128;
+    constexpr int FN2 = N2 / 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    unsigned char* sW0 = sm;
+    unsigned char* sW2 = sm + W0_BYTES;
+    float* sBy = reinterpret_cast<float*>(sm + W0_BYTES + W2_BYTES);
+    float* sBz = sBy + NY;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned char* stg = sm + W0_BYTES + W2_BYTES + (NY + N2) * 4 + wave * STG;
+    const int px = lane & 31, h = lane >> 5;
+
+    // ---- prologue: weights -> LDS (once per workgroup) ----
+    for (int idx = tid; idx < (TWO ? 2 : 1) * NY * 8; idx += 256) {
+        const int kt = idx / (NY * 8), r = (idx / 8) % NY, c = idx & 7;
+        const uint16_t* src = (kt == 0 ? p.w0 : p.w1) + r * KA + c * 8;
+        *reinterpret_cast<uint4*>(sW0 + kt * (NY * 128) + pw_off(r, c)) = *reinterpret_cast<const uint4*>(src);
+    }
+    // w2 with the K permutation of the register-chained operand: K-step s = (j, gp), half hh, element e
+    //   <->  channel 32 j + 16 gp + 8 (e >> 2) + 4 hh + (e & 3)
+    for (int idx = tid; idx < N2 * 32; idx += 256) {
+        const int n = idx >> 5, q = idx & 31;
+        const int s = q >> 1, hh = q & 1;
+        const int c0 = 32 * (s >> 1) + 16 * (s & 1) + 4 * hh;
+        const uint2 lo = *reinterpret_cast<const uint2*>(p.w2 + n * NY + c0);
+        const uint2 hi = *reinterpret_cast<const uint2*>(p.w2 + n * NY + c0 + 8);
+        *reinterpret_cast<uint4*>(sW2 + (s >> 2) * (N2 * 128) + pw_off(n, 2 * (s & 3) + hh)) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    }
+    for (int i = tid; i < NY; i += 256) sBy[i] = p.b0[i] + (TWO ? p.b1[i] : 0.f);
+    for (int i = tid; i < N2; i += 256) sBz[i] = p.b2[i];
+    __syncthreads();
+
+    const int gw = blockIdx.x * 4 + wave, GW = gridDim.x * 4;
+    int t = gw;
+    if (t >= p.ntiles) return;
+
+    // ---- register prefetch of the next tile ----
+    u32x4 a0n[4], a1n[TWO ? 4 : 1], rn[RES ? 16 : 1];
+    auto prefetch = [&](int tile) {
+        const long m0 = (long)tile * PX;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            a0n[ks] = *reinterpret_cast<const u32x4*>(p.a0 + (m0 + px) * KA + (2 * ks + h) * 8);
+            if (TWO) a1n[ks] = *reinterpret_cast<const u32x4*>(p.a1 + (m0 + px) * KA + (2 * ks + h) * 8);
+        }
+        if constexpr (RES) {   // fold over compile-time indices: keeps the array in registers (a runtime-indexed loop lands in scratch)
+            [&]<int... I>(std::integer_sequence<int, I...>) {
+                ((rn[I] = *reinterpret_cast<const u32x4*>(p.res + (m0 + (((I & 7) * 64 + lane) >> 4)) * NY + (I >> 3) * 128 +
+                                                          (((I & 7) * 64 + lane) & 15) * 8)), ...);
+            }(std::make_integer_sequence<int, 16>{});
+        }
+    };
+    prefetch(t);
+
+    for (;;) {
+        const long m0 = (long)t * PX;
+        u32x4 a0c[4], a1c[TWO ? 4 : 1], rc[RES ? 16 : 1];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { a0c[ks] = a0n[ks]; if (TWO) a1c[ks] = a1n[ks]; }
+        if constexpr (RES) {
+            [&]<int... I>(std::integer_sequence<int, I...>) { ((rc[I] = rn[I]), ...); }(std::make_integer_sequence<int, 16>{});
+        }
+        const int tn = t + GW;
+        const bool more = tn < p.ntiles;
+        if (more) prefetch(tn);
+
+        // ---- GEMM 1: acc[j] = D[channel 32j..][pixel] ----
+        f32x16_t acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const s16x8_t wf = *reinterpret_cast<const s16x8_t*>(sW0 + pw_off(32 * j + px, 2 * ks + h));
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf),
+                                                                 __builtin_bit_cast(bf16x8_t, a0c[ks]), acc[j], 0, 0, 0);
+            }
+            if (TWO) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const s16x8_t wf = *reinterpret_cast<const s16x8_t*>(sW0 + NY * 128 + pw_off(32 * j + px, 2 * ks + h));
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf),
+                                                                     __builtin_bit_cast(bf16x8_t, a1c[ks]), acc[j], 0, 0, 0);
+                }
+            }
+        }
+
+        // ---- epilogue 1 (two 128-channel halves) + the packed operand of GEMM 2 ----
+        uint4 P[8][2];
+        auto half_epilogue = [&](auto hfc) {
+            constexpr int hf = decltype(hfc)::value;   // compile-time: keeps rc[] / acc[] / P[] in registers
+            if constexpr (RES) {
+                [&]<int... I>(std::integer_sequence<int, I...>) {
+                    ((*reinterpret_cast<u32x4*>(stg + ((I * 64 + lane) >> 4) * SP + ((I * 64 + lane) & 15) * 16) = rc[hf * 8 + I]), ...);
+                }(std::make_integer_sequence<int, 8>{});
+            }
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int j = hf * 4 + jj;
+                unsigned pk[8];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int lc = 32 * jj + 8 * g + 4 * h;                       // channel within the half
+                    const float4 bv = *reinterpret_cast<const float4*>(sBy + hf * 128 + lc);
+                    float v0 = acc[j][4 * g + 0] + bv.x, v1 = acc[j][4 * g + 1] + bv.y;
+                    float v2 = acc[j][4 * g + 2] + bv.z, v3 = acc[j][4 * g + 3] + bv.w;
+                    uint2* slot = reinterpret_cast<uint2*>(stg + px * SP + lc * 2);
+                    if (RES) {
+                        const uint2 rr = *slot;
+                        v0 += ec_lo(rr.x); v1 += ec_hi(rr.x); v2 += ec_lo(rr.y); v3 += ec_hi(rr.y);
+                    }
+                    v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+                    uint2 o;
+                    o.x = ec_pack2(v0, v1);
+                    o.y = ec_pack2(v2, v3);
+                    *slot = o;
+                    pk[2 * g] = o.x; pk[2 * g + 1] = o.y;
+                }
+                P[j][0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                P[j][1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int idx = i * 64 + lane;
+                const uint4 v = *reinterpret_cast<const uint4*>(stg + (idx >> 4) * SP + (idx & 15) * 16);
+                *reinterpret_cast<uint4*>(p.y + (m0 + (idx >> 4)) * NY + hf * 128 + (idx & 15) * 8) = v;
+            }
+        };
+        half_epilogue(std::integral_constant<int, 0>{});
+        half_epilogue(std::integral_constant<int, 1>{});
+
+        // ---- GEMM 2, pixel operand straight from registers: z[n][pixel] ----
+        f32x16_t acc2[FN2];
+#pragma unroll
+        for (int n = 0; n < FN2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[n][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const bf16x8_t bop = __builtin_bit_cast(bf16x8_t, P[s >> 1][s & 1]);
+#pragma unroll
+            for (int n = 0; n < FN2; ++n) {
+                const s16x8_t wf = *reinterpret_cast<const s16x8_t*>(sW2 + (s >> 2) * (N2 * 128) + pw_off(32 * n + px, 2 * (s & 3) + h));
+                acc2[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf), bop, acc2[n], 0, 0, 0);
+            }
+        }
+        // ---- epilogue 2 ----
+        constexpr int ZP = N2 * 2 + 16;            // staging pitch of a z row
+        constexpr int ZC = N2 / 8;                 // 16-B chunks per z row
+#pragma unroll
+        for (int n = 0; n < FN2; ++n)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int lc = 32 * n + 8 * g + 4 * h;
+                const float4 bv = *reinterpret_cast<const float4*>(sBz + lc);
+                uint2 o;
+                o.x = ec_pack2(fmaxf(acc2[n][4 * g + 0] + bv.x, 0.f), fmaxf(acc2[n][4 * g + 1] + bv.y, 0.f));
+                o.y = ec_pack2(fmaxf(acc2[n][4 * g + 2] + bv.z, 0.f), fmaxf(acc2[n][4 * g + 3] + bv.w, 0.f));
+                *reinterpret_cast<uint2*>(stg + px * ZP + lc * 2) = o;
+            }
+#pragma unroll
+        for (int i = 0; i < PX * ZC / 64; ++i) {
+            const int idx = i * 64 + lane;
+            const uint4 v = *reinterpret_cast<const uint4*>(stg + (idx / ZC) * ZP + (idx % ZC) * 16);
+            *reinterpret_cast<uint4*>(p.z + (m0 + idx / ZC) * N2 + (idx % ZC) * 8) = v;
+        }
+        if (!more) break;
+        t = tn;
+    }
+}
+
+template <bool TWO, bool RES, int N2>
+int launch_pair(const PairArgs& p, hipStream_t s) {
+    constexpr size_t lds = (size_t)(TWO ? 2 : 1) * NY * 128 + 4 * N2 * 128 + (NY + N2) * 4 + 4 * STG;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    auto kern = conv1x1_pair_kernel<TWO, RES, N2>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int wgs = (p.ntiles + 3) / 4 < 256 ? (p.ntiles + 3) / 4 : 256;
+    hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(256), lds, s, p);
+    EC_CHECK_LAUNCH();
+    return EC_OK;
+}
+
+}  // namespace
+
+extern "C" int ec_conv1x1_pair_bf16(const void* a0, const void* w0, const float* b0, const void* a1, const void* w1,
+                                    const float* b1, const void* res, void* y, const void* w2, const float* b2, void* z,
+                                    long M, int K0, int N, int N2, ec_stream_t stream) {
+    if (!a0 || !w0 || !b0 || !y || !w2 || !b2 || !z) return EC_ERR_ARG;
+    if ((a1 != nullptr) != (w1 != nullptr) || (a1 != nullptr) != (b1 != nullptr)) return EC_ERR_ARG;
+    if (K0 != KA || N != NY || (N2 != 64 && N2 != 128) || M <= 0 || (M % PX) != 0 || M / PX > 0x7fffffffL) return EC_ERR_SHAPE;
+    PairArgs p{(const uint16_t*)a0, (const uint16_t*)a1, (const uint16_t*)w0, (const uint16_t*)w1, (const uint16_t*)w2,
+               (const uint16_t*)res, b0, b1, b2, (uint16_t*)y, (uint16_t*)z, (int)(M / PX)};
+    hipStream_t s = (hipStream_t)stream;
+    const bool two = a1 != nullptr, hres = res != nullptr;
+    if (N2 == 64) {
+        if (two && hres) return launch_pair<true, true, 64>(p, s);
+        if (two) return launch_pair<true, false, 64>(p, s);
+        if (hres) return launch_pair<false, true, 64>(p, s);
+        return launch_pair<false, false, 64>(p, s);
+    }
+    if (two) return EC_ERR_SHAPE;           // w0|w1 (64 KB) + w2 (64 KB) + staging exceeds the 160-KB LDS
+    if (hres) return launch_pair<false, true, 128>(p, s);
+    return launch_pair<false, false, 128>(p, s);
+}

@@ -11,6 +11,8 @@
 // workspace.  CLIP's anti-aliased stride (3x3 conv at full resolution, then
 // AvgPool2d(2)) is fused into the 3x3 conv's epilogue; the residual add + ReLU
 // is fused into conv3's epilogue.
+#include <stdlib.h>
+
 #include <new>
 #include <vector>
 
@@ -18,13 +20,17 @@
 
 namespace {
 
-enum OpKind { OP_STEM1, OP_CONV, OP_POOL };
+enum OpKind { OP_STEM1, OP_CONV, OP_POOL, OP_PAIR };
 
 struct Op {
     OpKind kind;
     int src, dst, res;       // buffer ids; -1 = none; src -2 = rgb input; dst -3 = final output
     int H, W, Cin, Cout, ks, pool, act;
     size_t w_off, b_off;     // element offsets into w_bf16 / bias
+    // OP_PAIR (fused layer-1 block boundary, conv_pair.hip): y = relu(src.w + [src1.w1] + [res]) -> dst;
+    // z = relu(y.w2) -> dst2 (the next block's conv1 output, N2 channels)
+    int src1 = -1, dst2 = -1, N2 = 0;
+    size_t w1_off = 0, b1_off = 0, w2_off = 0, b2_off = 0;
 };
 
 }  // namespace
@@ -73,6 +79,12 @@ extern "C" int ec_rn50_create(ec_rn50_t** out, int width, const int* layers4, in
         conv(2, 0, -1, R, R, width / 2, width, 3, 1, EC_ACT_RELU);   // + fused AvgPool2d(2)
         R /= 2;
     }
+    // Layer-1 block boundaries (56x56, bandwidth-bound 1x1 convs) run as ONE fused launch per boundary:
+    // conv3 (+ the block-0 downsample conv) + identity + ReLU, chained in registers into the next block's conv1.
+    const char* fuse_e = getenv("EC_RN50_FUSE");   // read per handle so both plans can be compared in one process
+    const bool fuse_env = !fuse_e || atoi(fuse_e) != 0;
+    const bool fuse_l1 = fuse_env && width == 64 && (R % 8) == 0;   // K = 64, N = 256; 32-pixel tiles divide R*R
+    bool conv1_done = false;   // the previous boundary launch already produced this block's conv1 output in buffer 1
     int inplanes = width, x = 0;
     for (int li = 0; li < 4; ++li) {
         const int planes = width << li;
@@ -81,7 +93,13 @@ extern "C" int ec_rn50_create(ec_rn50_t** out, int width, const int* layers4, in
             const bool ds = stride > 1 || inplanes != planes * 4;
             const int y = (x == 0) ? 4 : 0;
             const int Ro = R / stride;
-            conv(x, 1, -1, R, R, inplanes, planes, 1, 0, EC_ACT_RELU);
+            if (conv1_done) {   // weights are still laid out conv1, conv2, conv3, downsample: skip the slot
+                wo += (size_t)planes * inplanes;
+                bo += planes;
+                conv1_done = false;
+            } else {
+                conv(x, 1, -1, R, R, inplanes, planes, 1, 0, EC_ACT_RELU);
+            }
             conv(1, 2, -1, R, R, planes, planes, 3, stride > 1 ? 1 : 0, EC_ACT_RELU);
             int idt = x;
             // weights are laid out conv1, conv2, conv3, downsample; the downsample conv
@@ -89,6 +107,26 @@ extern "C" int ec_rn50_create(ec_rn50_t** out, int width, const int* layers4, in
             // reserve conv3's weight slot first.
             const size_t w_c3 = wo, b_c3 = bo;
             wo += (size_t)planes * 4 * planes; bo += planes * 4;
+            // boundary fusion applies to every block of layer 1 that is followed by a 1x1 conv1 on its output
+            const bool last_of_layer = (b + 1 == layers4[li]);
+            const bool pair = fuse_l1 && li == 0 && stride == 1 && (!ds || (inplanes == planes && !last_of_layer)) &&
+                              (!last_of_layer || li + 1 < 4);   // (downsample + a 128-wide conv1 exceeds the LDS)
+            if (pair) {
+                Op o{OP_PAIR, 2, y, ds ? -1 : x, R, R, planes, planes * 4, 1, 0, EC_ACT_RELU, w_c3, b_c3};
+                if (ds) {   // block 0: the downsample conv (x -> 256) is folded in as a second K = 64 operand
+                    o.src1 = x; o.w1_off = wo; o.b1_off = bo;
+                    wo += (size_t)planes * 4 * inplanes; bo += planes * 4;
+                }
+                o.dst2 = 1;
+                o.N2 = last_of_layer ? planes * 2 : planes;          // next conv1: 256 -> planes (same layer) | 2*planes
+                o.w2_off = wo; o.b2_off = bo;                        // == the next block's conv1 slot
+                h->ops.push_back(o);
+                track(R, R, planes * 4);
+                conv1_done = true;
+                x = y;
+                inplanes = planes * 4;
+                continue;
+            }
             if (ds) {
                 int dsrc = x;
                 if (stride > 1) {
@@ -183,6 +221,13 @@ int rn50_run(const ec_rn50_t* h, const void* rgb, bool u8, const float* mean3, c
                     break;
                 case OP_POOL:
                     rc = ec_avgpool2_bf16(buf(o.src), buf(o.dst), nb, o.H, o.W, o.Cin, stream);
+                    break;
+                case OP_PAIR:
+                    rc = ec_conv1x1_pair_bf16(buf(o.src), h->w + o.w_off, h->bias + o.b_off,
+                                              o.src1 >= 0 ? buf(o.src1) : nullptr, o.src1 >= 0 ? h->w + o.w1_off : nullptr,
+                                              o.src1 >= 0 ? h->bias + o.b1_off : nullptr, o.res >= 0 ? buf(o.res) : nullptr,
+                                              buf(o.dst), h->w + o.w2_off, h->bias + o.b2_off, buf(o.dst2),
+                                              (long)nb * o.H * o.W, o.Cin, o.Cout, o.N2, stream);
                     break;
                 default:
                     rc = ec_conv_bf16(buf(o.src), h->w + o.w_off, h->bias + o.b_off, o.res >= 0 ? buf(o.res) : nullptr,

@@ -293,3 +293,17 @@ def gemm_bf16(a, w, bias=None, res=None, act=0):
     _lib.check(lib.ec_gemm_bf16(a.data_ptr(), w.data_ptr(), _lib.ptr(bias), _lib.ptr(res), out.data_ptr(), M, N, K,
                                 act, _lib.stream_ptr()), "ec_gemm_bf16")
     return out
+
+
+def conv1x1_pair_bf16(a0, w0, b0, w2, b2, a1=None, w1=None, b1=None, res=None):
+    """y = relu(a0 @ w0.T + b0 [+ a1 @ w1.T + b1] [+ res]) bf16 [M,256];  z = relu(y @ w2.T + b2) bf16 [M,N2].
+    a0/a1 bf16 [M,64], w0/w1 bf16 [256,64], res bf16 [M,256], w2 bf16 [N2,256] (layer-1 Bottleneck boundary)."""
+    lib = _lib.load()
+    M, K0 = a0.shape
+    N, N2 = w0.shape[0], w2.shape[0]
+    y = torch.empty((M, N), dtype=torch.bfloat16, device=a0.device)
+    z = torch.empty((M, N2), dtype=torch.bfloat16, device=a0.device)
+    _lib.check(lib.ec_conv1x1_pair_bf16(a0.data_ptr(), w0.data_ptr(), b0.data_ptr(), _lib.ptr(a1), _lib.ptr(w1),
+                                        _lib.ptr(b1), _lib.ptr(res), y.data_ptr(), w2.data_ptr(), b2.data_ptr(),
+                                        z.data_ptr(), M, K0, N, N2, _lib.stream_ptr()), "ec_conv1x1_pair_bf16")
+    return y, z

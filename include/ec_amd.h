@@ -78,6 +78,17 @@ int ec_gemm_bf16(const void* A, const void* W, const float* bias, const void* re
 int ec_stem_conv1(const float* rgb_nhwc, const float* w, const float* bias, void* out,
                   int B, int H, int W, int Cout, ec_stream_t stream);
 
+/* Fused pair of 1x1 convolutions across a Bottleneck boundary of layer1 (bandwidth-bound at 56x56):
+ *   y = relu(a0 . w0^T + b0 [+ a1 . w1^T + b1] [+ res])   [M,256]  == relu(bn3(conv3(out)) + identity), the identity
+ *                                                                    being `res` or the fused downsample conv (a1,w1,b1)
+ *   z = relu(y . w2^T + b2)                               [M,N2]   == the next block's relu(bn1(conv1(x)))
+ * ([U] openai/CLIP clip/model.py Bottleneck.forward; call site thor_image_features.py:109).
+ * a0,a1 bf16 [M,64]; w0,w1 bf16 [256,64]; res,y bf16 [M,256]; w2 bf16 [N2,256]; z bf16 [M,N2].
+ * K0 must be 64, N 256, N2 64 or 128 (64 only with a1), M a multiple of 32; else EC_ERR_SHAPE. */
+int ec_conv1x1_pair_bf16(const void* a0, const void* w0, const float* b0, const void* a1, const void* w1,
+                         const float* b1, const void* res, void* y, const void* w2, const float* b2, void* z,
+                         long M, int K0, int N, int N2, ec_stream_t stream);
+
 /* Same, on the RAW uint8 HWC frame (thor_frames.py:33-34,96 writes uint8 frames): ToTensor (/255) and
  * Normalize(mean, std) of `clip_preprocess` (thor_image_features.py:108) are fused into the LDS staging.
  * h_mean3 / h_std3 are HOST pointers to 3 floats (CLIP_RGB_MEANS / CLIP_RGB_STDS). */

@@ -196,3 +196,67 @@ def test_uint8_input_path_matches_normalised_fp32_path(dev):
     ref = ocr.clip_resnet_preprocessor(syn.normalize_rgb(u8), sd)
     pre = ClipResNetPreprocessor("rgb", "RN50", pool=False, state_dict=sd, device=dev)
     assert _rel(pre.process({"rgb": u8}).cpu(), ref) < 2e-2
+
+
+@pytest.mark.parametrize("two,res,N2,M", [(False, True, 64, 32 * 7), (True, False, 64, 32 * 1031), (False, True, 128, 32 * 300),
+                                          (False, False, 64, 32), (True, True, 64, 32 * 130), (False, False, 128, 32 * 1025)])
+def test_conv1x1_pair_matches_two_conv_launches_and_fp32(dev, two, res, N2, M):
+    """Fused layer-1 block boundary (conv3 [+downsample] + identity + ReLU -> next conv1 + ReLU) vs the same math as
+    separate ec_gemm_bf16 launches (same bf16 roundings; fp32 summation order differs) and vs an fp32 reference."""
+    from embodied_clip_amd.encoder import conv1x1_pair_bf16, gemm_bf16
+    g = torch.Generator().manual_seed(M + N2 + 2 * two + res)
+    bf = lambda t: t.to(torch.bfloat16).to(dev)  # noqa: E731
+    a0, a1 = bf(torch.randn(M, 64, generator=g).relu()), bf(torch.randn(M, 64, generator=g).relu())
+    w0, w1 = bf(torch.randn(256, 64, generator=g) * 0.15), bf(torch.randn(256, 64, generator=g) * 0.15)
+    w2 = bf(torch.randn(N2, 256, generator=g) * 0.08)
+    b0, b1, b2 = (torch.randn(n, generator=g).mul(0.3).to(dev) for n in (256, 256, N2))
+    r = bf(torch.randn(M, 256, generator=g).relu()) if res else None
+    y, z = conv1x1_pair_bf16(a0, w0, b0, w2, b2, a1=a1 if two else None, w1=w1 if two else None,
+                             b1=b1 if two else None, res=r)
+    # fp32 reference on the same bf16 inputs
+    yf = a0.float() @ w0.float().t() + b0
+    if two:
+        yf = yf + a1.float() @ w1.float().t() + b1
+    if res:
+        yf = yf + r.float()
+    yf = yf.relu()
+    assert _rel(y.float().cpu(), yf.cpu()) < 3e-3
+    zf = (y.float() @ w2.float().t() + b2).relu()            # z from the kernel's OWN bf16 y: isolates GEMM 2
+    assert _rel(z.float().cpu(), zf.cpu()) < 3e-3
+    zz = z.float() - zf
+    assert zz.abs().max().item() <= 2 ** -7 * max(1.0, zf.abs().max().item())       # <= 1 bf16 ulp of the largest value
+    if not two:
+        # bit-level agreement with the unfused launches up to rare 1-ulp rounding flips
+        y2 = gemm_bf16(a0, w0, b0, res=r, act=1)
+        z2 = gemm_bf16(y2, w2, b2, act=1)
+        assert (y2 != y).float().mean().item() < 1e-3
+        assert _rel(z.float().cpu(), z2.float().cpu()) < 2e-3
+
+
+def test_conv1x1_pair_rejects_unsupported_shapes(dev):
+    from embodied_clip_amd import _lib
+    lib = _lib.load()
+    t = torch.zeros(64, 256, dtype=torch.bfloat16, device=dev)
+    f = torch.zeros(256, device=dev)
+    args = lambda M, K0, N, N2: lib.ec_conv1x1_pair_bf16(t.data_ptr(), t.data_ptr(), f.data_ptr(), None, None, None, None,  # noqa: E731
+                                                         t.data_ptr(), t.data_ptr(), f.data_ptr(), t.data_ptr(), M, K0, N, N2, 0)
+    assert args(33, 64, 256, 64) == _lib.EC_ERR_SHAPE if hasattr(_lib, "EC_ERR_SHAPE") else args(33, 64, 256, 64) != 0
+    assert args(32, 128, 256, 64) != 0 and args(32, 64, 512, 64) != 0 and args(32, 64, 256, 32) != 0
+
+
+def test_rn50_fused_layer1_boundaries_match_unfused_plan(dev, monkeypatch):
+    """EC_RN50_FUSE=0 builds the plain one-launch-per-conv plan; the default plan fuses the three layer-1 block
+    boundaries (conv_pair.hip).  Same bf16 roundings except the block-0 identity, which the fused plan keeps in fp32."""
+    from embodied_clip_amd.encoder import RN50Trunk
+    sd = syn.rn50_visual_state_dict(0)
+    x = syn.synthetic_rgb(5, 3).to(dev)
+    fused = RN50Trunk(sd, device=dev)
+    monkeypatch.setenv("EC_RN50_FUSE", "0")
+    plain = RN50Trunk(sd, device=dev)
+    monkeypatch.delenv("EC_RN50_FUSE")
+    assert fused.lib.ec_rn50_num_ops(fused.h) == plain.lib.ec_rn50_num_ops(plain.h) - 4   # 3 conv1 + 1 downsample launches gone
+    a, b = fused.forward(x).float().cpu(), plain.forward(x).float().cpu()
+    assert _rel(a, b) < 1e-2, _rel(a, b)
+    ref = ocr.clip_resnet_preprocessor(x.cpu(), sd)
+    ra, rb = _rel(fused.to_nchw_f32(fused.forward(x)).cpu(), ref), _rel(plain.to_nchw_f32(plain.forward(x)).cpu(), ref)
+    assert ra < 2e-2 and rb < 2e-2, (ra, rb)
