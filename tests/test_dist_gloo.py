@@ -17,8 +17,11 @@ CFG = dict(in_channels=32, spatial=2, hidden=16)
 T, N = 4, 6
 
 
-def _free_port():
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+def _rendezvous():
+    """File-store rendezvous: no TCP port to race for (a freshly probed 'free' port can be taken before bind)."""
+    import tempfile
+    fd, path = tempfile.mkstemp(prefix="ec_gloo_"); os.close(fd); os.unlink(path)
+    return path
 
 
 def _case():
@@ -42,8 +45,8 @@ def _grads(sd, feat, goal, h0, masks, actions, old_lp, old_v, ret, nadv, sl):
 
 
 def _worker(rank, world, port, q):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["GLOO_SOCKET_IFNAME"] = "lo"
+    dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)
     try:
         from embodied_clip_amd.policy import PolicyHandle   # host-only use: flat bucket layout
         torch.set_num_threads(1)
@@ -68,7 +71,7 @@ def test_shard_actors_partition():
 
 @pytest.mark.timeout(180)
 def test_two_rank_flat_allreduce_equals_unsharded():
-    world, port = 2, _free_port()
+    world, port = 2, _rendezvous()
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
