@@ -1,0 +1,211 @@
+// 3x3 convolution (pad 1, stride 1) + folded BN + ReLU [+ fused AvgPool2d(2)] for the NARROW early layers of
+// CLIP-RN50 (Cin, Cout in {32, 64}: stem conv2 / conv3, layer-1 conv2), bf16 NHWC, gfx950 MFMA.
+//
+// Replaces the cuDNN conv + BatchNorm(eval) + ReLU (+ AvgPool2d) of [U] openai/CLIP clip/model.py
+// ModifiedResNet.stem / Bottleneck.conv2 reached from primitive_probing/generate_data/thor_image_features.py:109.
+//
+// Why a second kernel: these layers have huge M (B*112*112 or B*56*56 rows), tiny N and K <= 576.  In the tiled
+// `conv_igemm` kernel every workgroup re-stages the same <= 72 KB of weights per tile and pays two barriers per
+// 64-wide K-tile for 4.5-9 K-tiles of work.  Here
+//   * the whole weight tensor is staged into LDS ONCE per (persistent) workgroup, per-K-step rows of 32 B with an
+//     XOR swizzle that makes the 16-lane ds_read_b128 groups conflict-free;
+//   * each wave owns a 32-pixel tile and fetches its im2col operand straight from global memory in MFMA operand
+//     layout (lane = pixel x 8-channel half): no LDS staging of activations, no barriers; padding taps point at a
+//     zero page.  The 9x re-read of every input pixel is served by the L1/L2;
+//   * 16 waves per CU (4 per SIMD, <= 128 VGPRs): one wave's loads fly under the others' MFMAs;
+//   * swapped MFMA operands (D[channel][pixel]) -> 8-byte packed epilogue, 2x2 pooling as two DPP quad adds
+//     (rows are ordered m = 4 q + (dy*2+dx) in POOL mode), output through a per-wave LDS image as 16-B row chunks.
+#include <stdlib.h>
+
+#include <type_traits>
+#include <utility>
+
+#include "common.h"
+
+namespace {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int PX = 32;
+__device__ u32x4 ec_zero_page3[4];   // 64 zero bytes: source of padding taps
+
+struct N3Args {
+    const uint16_t *in, *w;
+    const float* bias;
+    uint16_t* out;
+    int H, W, ntiles;
+};
+
+__device__ __forceinline__ float dppq_xor1(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dppq_xor2(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+}
+// 16-B unit of weight row n, half hh inside a K-step block of COUT x 32 B
+__device__ __forceinline__ int wunit(int n, int hh) { return ((2 * n + hh) ^ ((n >> 3) & 1)) << 4; }
+
+template <int CIN, int COUT, bool POOL, int NW>
+__global__ __launch_bounds__(NW * 64, 1) void conv3x3_narrow_kernel(N3Args p) {
+    constexpr int KSTEPS = 9 * CIN / 16;        // 16 input channels of one tap per MFMA K-step
+    constexpr int CB = CIN / 16;                // K-steps per tap
+    constexpr int FN = COUT / 32;
+    constexpr int K = 9 * CIN;
+    constexpr int W_BYTES = KSTEPS * COUT * 32;
+    constexpr int OP = COUT * 2 + 16;           // staging pitch
+    constexpr int STG = (POOL ? PX / 4 : PX) * OP;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    float* sB = reinterpret_cast<float*>(sm + W_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned char* stg = sm + W_BYTES + COUT * 4 + wave * STG;
+    const int px = lane & 31, h = lane >> 5;
+
+    // ---- weights -> LDS once: w[n][k], k = (tap, ci);  K-step ks = k / 16, half = (k / 8) & 1 ----
+    for (int idx = tid; idx < COUT * (K / 8); idx += NW * 64) {
+        const int n = idx / (K / 8), c = idx % (K / 8);
+        const u32x4 v = *reinterpret_cast<const u32x4*>(p.w + (long)n * K + c * 8);
+        *reinterpret_cast<u32x4*>(sm + (c >> 1) * (COUT * 32) + wunit(n, c & 1)) = v;
+    }
+    for (int i = tid; i < COUT; i += NW * 64) sB[i] = p.bias[i];
+    __syncthreads();
+
+    const int GW = gridDim.x * NW;
+    const unsigned char* in_b = reinterpret_cast<const unsigned char*>(p.in);
+    const unsigned char* zp = reinterpret_cast<const unsigned char*>(ec_zero_page3);
+    const int HW = p.H * p.W;
+
+    for (int t = blockIdx.x * NW + wave; t < p.ntiles; t += GW) {
+        // ---- this lane's pixel and its 9-bit tap validity mask ----
+        const int m = t * PX + px;
+        int y, x, pix;
+        if (POOL) {
+            const int q = m >> 2, s2 = m & 3;
+            const int Hp = p.H >> 1, Wp = p.W >> 1;
+            const int b = q / (Hp * Wp);
+            const int r2 = q - b * (Hp * Wp);
+            const int yp = r2 / Wp;
+            y = 2 * yp + (s2 >> 1);
+            x = 2 * (r2 - yp * Wp) + (s2 & 1);
+            pix = (b * p.H + y) * p.W + x;
+        } else {
+            const int b = m / HW;
+            const int r2 = m - b * HW;
+            y = r2 / p.W;
+            x = r2 - y * p.W;
+            pix = m;
+        }
+        const unsigned xm = (x > 0 ? 1u : 0u) | 2u | (x < p.W - 1 ? 4u : 0u);
+        const unsigned msk = (y > 0 ? xm : 0u) | (xm << 3) | (y < p.H - 1 ? (xm << 6) : 0u);
+        const unsigned char* base = in_b + ((long)pix * CIN + h * 8) * 2;
+
+        // ---- im2col operand straight into MFMA layout: K-step (tap, cb) = 16 B of pixel (y+dy, x+dx) ----
+        // K is walked in phases of <= 18 K-steps (72 VGPRs of operands) so that 4 waves per SIMD stay resident;
+        // within a phase every load is issued before the first MFMA waits on one.
+        f32x16_t acc[FN];
+#pragma unroll
+        for (int n = 0; n < FN; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+        constexpr int PH = (KSTEPS + 17) / 18, PS = KSTEPS / PH;
+        static_assert(PS * PH == KSTEPS, "phase split");
+        auto phase = [&](auto phc) {
+            constexpr int S0 = decltype(phc)::value * PS;
+            u32x4 a[PS];
+            [&]<int... I>(std::integer_sequence<int, I...>) {
+                ((a[I] = *reinterpret_cast<const u32x4*>(
+                      ((msk >> ((S0 + I) / CB)) & 1u)
+                          ? base + (((((S0 + I) / CB) / 3 - 1) * p.W + (((S0 + I) / CB) % 3 - 1)) * CIN + ((S0 + I) % CB) * 16) * 2
+                          : zp + h * 16)),
+                 ...);
+            }(std::make_integer_sequence<int, PS>{});
+            __builtin_amdgcn_sched_barrier(0);
+            [&]<int... I>(std::integer_sequence<int, I...>) {
+                (([&] {
+                     const bf16x8_t aop = __builtin_bit_cast(bf16x8_t, a[I]);
+#pragma unroll
+                     for (int n = 0; n < FN; ++n) {
+                         const s16x8_t wf = *reinterpret_cast<const s16x8_t*>(sm + (S0 + I) * (COUT * 32) + wunit(32 * n + px, h));
+                         acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf), aop, acc[n], 0, 0, 0);
+                     }
+                 }()),
+                 ...);
+            }(std::make_integer_sequence<int, PS>{});
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        [&]<int... P>(std::integer_sequence<int, P...>) { (phase(std::integral_constant<int, P>{}), ...); }
+        (std::make_integer_sequence<int, PH>{});
+
+        // ---- epilogue: bias + ReLU (+ 2x2 mean over the lane quad) -> bf16 -> staging -> 16-B row chunks ----
+#pragma unroll
+        for (int n = 0; n < FN; ++n)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int lc = 32 * n + 8 * g + 4 * h;
+                const float4 bv = *reinterpret_cast<const float4*>(sB + lc);
+                float v0 = fmaxf(acc[n][4 * g + 0] + bv.x, 0.f), v1 = fmaxf(acc[n][4 * g + 1] + bv.y, 0.f);
+                float v2 = fmaxf(acc[n][4 * g + 2] + bv.z, 0.f), v3 = fmaxf(acc[n][4 * g + 3] + bv.w, 0.f);
+                if (POOL) {
+                    v0 += dppq_xor1(v0); v1 += dppq_xor1(v1); v2 += dppq_xor1(v2); v3 += dppq_xor1(v3);
+                    v0 += dppq_xor2(v0); v1 += dppq_xor2(v1); v2 += dppq_xor2(v2); v3 += dppq_xor2(v3);
+                    if ((lane & 3) == 0) {
+                        uint2 o;
+                        o.x = ec_pack2(0.25f * v0, 0.25f * v1);
+                        o.y = ec_pack2(0.25f * v2, 0.25f * v3);
+                        *reinterpret_cast<uint2*>(stg + (px >> 2) * OP + lc * 2) = o;
+                    }
+                } else {
+                    uint2 o;
+                    o.x = ec_pack2(v0, v1);
+                    o.y = ec_pack2(v2, v3);
+                    *reinterpret_cast<uint2*>(stg + px * OP + lc * 2) = o;
+                }
+            }
+        constexpr int ORows = POOL ? PX / 4 : PX;
+        constexpr int ZC = COUT / 8;                          // 16-B chunks per output row
+        const long orow0 = (long)t * ORows;
+#pragma unroll
+        for (int i = 0; i < (ORows * ZC + 63) / 64; ++i) {
+            const int idx = i * 64 + lane;
+            if (ORows * ZC >= 64 || idx < ORows * ZC) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(stg + (idx / ZC) * OP + (idx % ZC) * 16);
+                *reinterpret_cast<u32x4*>(p.out + (orow0 + idx / ZC) * COUT + (idx % ZC) * 8) = v;
+            }
+        }
+    }
+}
+
+template <int CIN, int COUT, bool POOL, int NW = 16>
+int launch_n3(const N3Args& p, hipStream_t s) {
+    constexpr size_t lds = (size_t)(9 * CIN / 16) * COUT * 32 + COUT * 4 + NW * (size_t)((POOL ? PX / 4 : PX) * (COUT * 2 + 16));
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    auto kern = conv3x3_narrow_kernel<CIN, COUT, POOL, NW>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int wgs = (p.ntiles + NW - 1) / NW < 256 ? (p.ntiles + NW - 1) / NW : 256;
+    hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(NW * 64), lds, s, p);
+    EC_CHECK_LAUNCH();
+    return EC_OK;
+}
+
+}  // namespace
+
+// Returns EC_OK when it ran, EC_ERR_SHAPE when the shape is not one it handles (the caller then uses conv_igemm).
+int ec_conv3x3_narrow(const void* in, const void* w, const float* bias, void* out, int B, int H, int W, int Cin, int Cout,
+                      int pool, hipStream_t s) {
+    static const bool on = [] { const char* e = getenv("EC_CONV_NARROW"); return !e || atoi(e) != 0; }();
+    const long M = (long)B * H * W;
+    if (!on || !bias || (M % PX) != 0 || M / PX > 0x7fffffffL || (pool && ((H | W) & 1))) return EC_ERR_SHAPE;
+    N3Args p{(const uint16_t*)in, (const uint16_t*)w, bias, (uint16_t*)out, H, W, (int)(M / PX)};
+    if (Cin == 32 && Cout == 32 && !pool) return launch_n3<32, 32, false>(p, s);
+    if (Cin == 32 && Cout == 64 && pool) return launch_n3<32, 64, true>(p, s);
+    if (Cin == 32 && Cout == 64 && !pool) return launch_n3<32, 64, false>(p, s);
+    // Cin = 64 (layer-1 conv2) stays on conv_igemm: with one 128-B cache line per pixel the direct operand fetch
+    // touches 32 lines per load instruction and becomes L1-tag bound (measured 157 us vs 106 us at B = 256); the
+    // instantiation is kept for EC_CONV_NARROW=2 experiments.
+    static const bool all = [] { const char* e = getenv("EC_CONV_NARROW"); return e && atoi(e) == 2; }();
+    if (all && Cin == 64 && Cout == 64 && !pool) return launch_n3<64, 64, false>(p, s);
+    if (all && Cin == 64 && Cout == 64 && pool) return launch_n3<64, 64, true>(p, s);
+    return EC_ERR_SHAPE;
+}

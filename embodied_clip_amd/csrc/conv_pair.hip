@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256, 1) void conv1x1_pair_kernel(PairArgs p) {
             for (int i = 0; i < 8; ++i) {
                 const int idx = i * 64 + lane;
                 const uint4 v = *reinterpret_cast<const uint4*>(stg + (idx >> 4) * SP + (idx & 15) * 16);
-                *reinterpret_cast<uint4*>(p.y + (m0 + (idx >> 4)) * NY + hf * 128 + (idx & 15) * 8) = v;
+                __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(p.y + (m0 + (idx >> 4)) * NY + hf * 128 + (idx & 15) * 8));
             }
         };
         half_epilogue(std::integral_constant<int, 0>{});
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256, 1) void conv1x1_pair_kernel(PairArgs p) {
         for (int i = 0; i < PX * ZC / 64; ++i) {
             const int idx = i * 64 + lane;
             const uint4 v = *reinterpret_cast<const uint4*>(stg + (idx / ZC) * ZP + (idx % ZC) * 16);
-            *reinterpret_cast<uint4*>(p.z + (m0 + idx / ZC) * N2 + (idx % ZC) * 8) = v;
+            __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(p.z + (m0 + idx / ZC) * N2 + (idx % ZC) * 8));
         }
         if (!more) break;
         t = tn;

@@ -63,6 +63,13 @@ def _conv_case(dev, B, H, W, Cin, Cout, ks, pool, res, act, seed):
     (5, 7, 7, 64, 256, 1, False, True, 0),       # residual, no activation
     (1, 10, 6, 128, 384, 1, False, False, 2),    # QuickGELU epilogue, non-square
     (2, 6, 10, 16, 96, 3, False, False, 1),      # Cin=16, Cout=96 (32-wide tile)
+    # narrow early 3x3 layers -> conv3x3_narrow.hip (M % 32 == 0); tiles straddle rows and frames, all borders hit
+    (2, 12, 12, 64, 64, 3, False, False, 1),     # layer-1 conv2
+    (2, 12, 12, 64, 64, 3, True, False, 1),
+    (2, 12, 12, 32, 64, 3, False, False, 1),
+    (4, 16, 8, 32, 32, 3, False, False, 1),      # non-square
+    (1, 4, 8, 64, 64, 3, False, False, 1),       # a single 32-pixel tile
+    (3, 20, 20, 32, 64, 3, True, False, 1),      # M = 1200 is not a multiple of 32 -> falls back to conv_igemm
 ])
 def test_conv_bf16_matches_oracle(dev, B, H, W, Cin, Cout, ks, pool, res, act):
     got, ref = _conv_case(dev, B, H, W, Cin, Cout, ks, pool, res, act, seed=B * 1000 + Cin + Cout + ks)
