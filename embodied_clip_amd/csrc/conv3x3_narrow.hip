@@ -73,7 +73,10 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_narrow_kernel(N3Args p) {
     const unsigned char* zp = reinterpret_cast<const unsigned char*>(ec_zero_page3);
     const int HW = p.H * p.W;
 
-    for (int t = blockIdx.x * NW + wave; t < p.ntiles; t += GW) {
+    // XCD-aware: each XCD (own L2) walks a contiguous run of logical blocks, so the halo rows shared by neighbouring
+    // bands of pixels are fetched into ONE L2 instead of eight
+    const int lb = (int)ec_xcd_remap(blockIdx.x, gridDim.x);
+    for (int t = lb * NW + wave; t < p.ntiles; t += GW) {
         // ---- this lane's pixel and its 9-bit tap validity mask ----
         const int m = t * PX + px;
         int y, x, pix;
