@@ -78,8 +78,8 @@ class ClipResNetPreprocessor(_PreprocessorBase):
         assert clip_model_type in ("RN50", "RN50x16")
         if clip_model_type == "RN50":
             output_shape = (2048, 7, 7)
-        else:
-            raise NotImplementedError("RN50x16 (width 96) is not supported by the gfx950 kernels yet")
+        else:   # width 96, layers (6, 8, 18, 8); the plugin feeds it the same 224x224 frames -> 7x7 map
+            output_shape = (3072, 7, 7)
         if pool:
             output_shape = output_shape[:1]
         self.clip_model_type = clip_model_type

@@ -172,8 +172,14 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 3) void conv_ige
         int tap = 0;
         g_toff = k * 2;
         if (KS == 3) {
-            tap = k >> p.cin_log2;
-            const int ci = k & (p.Cin - 1);
+            int ci;
+            if (p.cin_log2 >= 0) {            // power-of-two Cin (RN50): shift / mask
+                tap = k >> p.cin_log2;
+                ci = k & (p.Cin - 1);
+            } else {                          // e.g. the 96 k channels of RN50x16
+                tap = k / p.Cin;
+                ci = k - tap * p.Cin;
+            }
             const int ky = (tap * 11) >> 5;   // tap / 3 for tap in 0..8
             g_toff = (((ky - 1) * p.W + (tap - ky * 3 - 1)) * p.Cin + ci) * 2;
         }
@@ -434,7 +440,7 @@ extern "C" int ec_conv_bf16(const void* in, const void* w, const float* bias, co
     if (!in || !w || !out) return EC_ERR_ARG;
     if (B <= 0 || H <= 0 || W <= 0) return EC_ERR_SHAPE;
     if (ksize != 1 && ksize != 3) return EC_ERR_SHAPE;
-    if (Cin < 8 || (Cin & (Cin - 1)) != 0 || Cout % 32 != 0) return EC_ERR_SHAPE;
+    if (Cin < 8 || Cin % 8 != 0 || Cout % 32 != 0) return EC_ERR_SHAPE;
     if (pool && ((H & 1) || (W & 1) || res != nullptr || act != EC_ACT_RELU)) return EC_ERR_SHAPE;
     if (H >= 4096 || W >= 65536) return EC_ERR_SHAPE;
     if ((long)B * H * W >= (1L << 31) / 4) return EC_ERR_SHAPE;
@@ -447,7 +453,7 @@ extern "C" int ec_conv_bf16(const void* in, const void* w, const float* bias, co
     a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     a.K = ksize * ksize * Cin;
     a.M = B * H * W;
-    a.cin_log2 = ec_ilog2(Cin);
+    a.cin_log2 = (Cin & (Cin - 1)) == 0 ? ec_ilog2(Cin) : -1;
     a.act = act;
     a.ntn = 0;
     if ((long)B * H * W * Cin * 2 >= (1L << 31) || (long)Cout * a.K * 2 >= (1L << 31)) return EC_ERR_SHAPE;

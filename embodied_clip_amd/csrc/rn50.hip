@@ -54,7 +54,10 @@ extern "C" int ec_rn50_create(ec_rn50_t** out, int width, const int* layers4, in
                               const float* stem_w_f32, const void* w_bf16, size_t n_w, const float* bias,
                               size_t n_bias) {
     if (!out || !layers4 || !stem_w_f32 || !w_bf16 || !bias) return EC_ERR_ARG;
-    if (width % 32 != 0 || (width & (width - 1)) != 0 || input_resolution % 32 != 0) return EC_ERR_SHAPE;
+    if (width % 32 != 0 || width < 32 || input_resolution % 32 != 0) return EC_ERR_SHAPE;
+    // stem channels: width/2, rounded up to the 32-channel granule of the conv kernels (RN50x16: 48 -> 64; the
+    // packer zero-pads the weights, so the padded channels are exactly 0 after ReLU and contribute nothing)
+    const int sc = (width / 2 + 31) / 32 * 32;
     ec_rn50* h = new (std::nothrow) ec_rn50();
     if (!h) return EC_ERR_ALLOC;
     h->width = width; h->res = input_resolution;
@@ -71,12 +74,12 @@ extern "C" int ec_rn50_create(ec_rn50_t** out, int width, const int* layers4, in
     int R = input_resolution / 2;
     // buffers: 0 = X (block input / output), 1,2 = temporaries, 3 = identity path, 4 = Y
     {   // stem
-        Op o{OP_STEM1, -2, 1, -1, input_resolution, input_resolution, 3, width / 2, 3, 0, EC_ACT_RELU, 0, bo};
-        bo += width / 2;
+        Op o{OP_STEM1, -2, 1, -1, input_resolution, input_resolution, 3, sc, 3, 0, EC_ACT_RELU, 0, bo};
+        bo += sc;
         h->ops.push_back(o);
-        track(R, R, width / 2);
-        conv(1, 2, -1, R, R, width / 2, width / 2, 3, 0, EC_ACT_RELU);
-        conv(2, 0, -1, R, R, width / 2, width, 3, 1, EC_ACT_RELU);   // + fused AvgPool2d(2)
+        track(R, R, sc);
+        conv(1, 2, -1, R, R, sc, sc, 3, 0, EC_ACT_RELU);
+        conv(2, 0, -1, R, R, sc, width, 3, 1, EC_ACT_RELU);   // + fused AvgPool2d(2)
         R /= 2;
     }
     // Layer-1 block boundaries (56x56, bandwidth-bound 1x1 convs) run as ONE fused launch per boundary:

@@ -163,6 +163,9 @@ extern "C" int ec_stem_conv1(const float* rgb, const float* w, const float* bias
     else if (Cout == 48)
         hipLaunchKernelGGL((stem_conv1_kernel<48, false>), grid, dim3(256), 0, s, (const void*)rgb, w, bias, (uint16_t*)out, H, W,
                            Ho, Wo, tx, ty, z, z);
+    else if (Cout == 64)   // RN50x16: 48 real channels zero-padded to the 32-channel granule of the conv kernels
+        hipLaunchKernelGGL((stem_conv1_kernel<64, false>), grid, dim3(256), 0, s, (const void*)rgb, w, bias, (uint16_t*)out, H, W,
+                           Ho, Wo, tx, ty, z, z);
     else
         return EC_ERR_SHAPE;
     EC_CHECK_LAUNCH();
@@ -185,6 +188,9 @@ extern "C" int ec_stem_conv1_u8(const uint8_t* rgb_u8, const float* mean3, const
                            W, Ho, Wo, tx, ty, sc, sh);
     else if (Cout == 48)
         hipLaunchKernelGGL((stem_conv1_kernel<48, true>), grid, dim3(256), 0, s, (const void*)rgb_u8, w, bias, (uint16_t*)out, H,
+                           W, Ho, Wo, tx, ty, sc, sh);
+    else if (Cout == 64)
+        hipLaunchKernelGGL((stem_conv1_kernel<64, true>), grid, dim3(256), 0, s, (const void*)rgb_u8, w, bias, (uint16_t*)out, H,
                            W, Ho, Wo, tx, ty, sc, sh);
     else
         return EC_ERR_SHAPE;

@@ -53,10 +53,32 @@ def pack_rn50(sd: Dict[str, torch.Tensor]):
         ws.append(w.reshape(-1).to(torch.bfloat16))
         return None
 
-    w1 = add("conv1", "bn1", keep_f32=True)          # [Cout, 3, 3, 3]
-    stem_w = w1.reshape(w1.shape[0], 27).t().contiguous()   # [(ky,kx,ci), Cout]
-    add("conv2", "bn2")
-    add("conv3", "bn3")
+    # Stem channels are padded to the 32-channel granule of the conv kernels (RN50x16: 48 -> 64) with zero weights
+    # and biases: a padded channel is exactly relu(0) = 0 and multiplies zero weights downstream.
+    sc_real = sd["conv1.weight"].shape[0]
+    sc = (sc_real + 31) // 32 * 32
+
+    def pad_out(w, b):      # [Cout, ...] -> [sc, ...]
+        if w.shape[0] == sc:
+            return w, b
+        return (torch.cat([w, w.new_zeros((sc - w.shape[0],) + tuple(w.shape[1:]))]), torch.cat([b, b.new_zeros(sc - b.shape[0])]))
+
+    def pad_in(w):          # [Cout, kh, kw, Cin] -> [Cout, kh, kw, sc]
+        if w.shape[3] == sc:
+            return w
+        return torch.cat([w, w.new_zeros(tuple(w.shape[:3]) + (sc - w.shape[3],))], dim=3)
+
+    w1, b1 = _fold(sd["conv1.weight"], sd, "bn1")
+    w1, b1 = pad_out(w1.permute(0, 2, 3, 1).contiguous(), b1)          # [sc, 3, 3, 3]
+    bs.append(b1)
+    stem_w = w1.reshape(sc, 27).t().contiguous()                        # [(ky,kx,ci), sc]
+    w2, b2 = _fold(sd["conv2.weight"], sd, "bn2")
+    w2, b2 = pad_out(pad_in(w2.permute(0, 2, 3, 1).contiguous()), b2)  # [sc, 3, 3, sc]
+    bs.append(b2)
+    ws.append(w2.reshape(-1).to(torch.bfloat16))
+    w3, b3 = _fold(sd["conv3.weight"], sd, "bn3")
+    bs.append(b3)
+    ws.append(pad_in(w3.permute(0, 2, 3, 1).contiguous()).reshape(-1).to(torch.bfloat16))
     for li, n in enumerate(layers, start=1):
         for b in range(n):
             p = f"layer{li}.{b}"

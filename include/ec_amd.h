@@ -113,10 +113,13 @@ int ec_spatial_mean_bf16(const void* in, float* out, int B, int HW, int C, ec_st
  * ---------------------------------------------------------------------- */
 typedef struct ec_rn50 ec_rn50_t;
 
-/* Weight order contract (execution order): stem conv1 (f32, [27][w/2]) is
+/* Weight order contract (execution order): stem conv1 (f32, [27][sc]) is
  * passed separately; `w_bf16` holds, concatenated, stem conv2, conv3, then per
  * block conv1, conv2, conv3, [downsample] as [Cout][k*k*Cin] bf16;
  * `bias` holds stem conv1..3 then the same per-block order, f32.
+ * `width` is a multiple of 32 (64 = RN50, 96 = RN50x16).  The stem's w/2 channels are carried at
+ * sc = roundup(w/2, 32) (RN50x16: 48 -> 64): stem conv1 is [27][sc], conv2 [sc][9*sc], conv3 [w][9*sc], with zero
+ * weights / biases in the padding (exactly neutral after ReLU).
  * The handle borrows the device pointers (caller keeps them alive). */
 int ec_rn50_create(ec_rn50_t** out, int width, const int* layers4, int input_resolution,
                    const float* stem_w_f32, const void* w_bf16, size_t n_w, const float* bias, size_t n_bias);

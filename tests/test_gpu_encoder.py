@@ -267,3 +267,23 @@ def test_rn50_fused_layer1_boundaries_match_unfused_plan(dev, monkeypatch):
     ref = ocr.clip_resnet_preprocessor(x.cpu(), sd)
     ra, rb = _rel(fused.to_nchw_f32(fused.forward(x)).cpu(), ref), _rel(plain.to_nchw_f32(plain.forward(x)).cpu(), ref)
     assert ra < 2e-2 and rb < 2e-2, (ra, rb)
+
+
+def test_rn50x16_style_width96_trunk_and_preprocessor(dev):
+    """ClipResNetPreprocessor('RN50x16'): width 96 (non-power-of-two channels, 48-channel stem zero-padded to 64).
+    A shallow width-96 tower (1 block per layer) keeps the CPU oracle fast; channel arithmetic is the x16 one."""
+    from embodied_clip_amd.clip_preprocessors import ClipResNetPreprocessor
+    sd = syn.rn50_visual_state_dict(11, width=96, layers=(1, 1, 1, 1), output_dim=768, heads=48)
+    x = syn.synthetic_rgb(9, 2)
+    ref = ocr.clip_resnet_preprocessor(x, sd)
+    assert ref.shape == (2, 3072, 7, 7)
+    pre = ClipResNetPreprocessor("rgb", "RN50x16", pool=False, state_dict=sd, device=dev)
+    assert pre.observation_space.shape == (3072, 7, 7)
+    got = pre.process({"rgb": x}).cpu()
+    assert got.shape == ref.shape
+    assert _rel(got, ref) < 2e-2, _rel(got, ref)
+    cos = torch.nn.functional.cosine_similarity(got.flatten(1), ref.flatten(1)).min().item()
+    assert cos > 0.999, cos
+    pooled = ClipResNetPreprocessor("rgb", "RN50x16", pool=True, state_dict=sd, device=dev)
+    assert pooled.observation_space.shape == (3072,)
+    assert _rel(pooled.process({"rgb": x}).cpu(), ref.mean(dim=(2, 3))) < 2e-2
