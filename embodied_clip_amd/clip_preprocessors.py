@@ -128,9 +128,11 @@ class ClipViTPreprocessor(_PreprocessorBase):
                  device: Optional[torch.device] = None, device_ids: Optional[List[torch.device]] = None,
                  output_uuid: str = "rgb_clip_vit", state_dict=None, weights_path: Optional[str] = None, **kwargs: Any):
         assert clip_model_type in ("ViT-B/32", "ViT-B/16", "ViT-L/14")
-        if clip_model_type != "ViT-B/32":
-            raise NotImplementedError("only ViT-B/32 (50 tokens) fits the 64-token LDS attention core for now")
-        output_shape = (768,) if class_emb_only else (50, 768)
+        # (tokens, width, heads): ViT-B/32 runs the 64-token MFMA attention core (benchmarked); B/16 and L/14 run the
+        # general LDS attention core -- functional, not tuned
+        tokens, width, self._heads = {"ViT-B/32": (50, 768, 12), "ViT-B/16": (197, 768, 12),
+                                      "ViT-L/14": (257, 1024, 16)}[clip_model_type]
+        output_shape = (width,) if class_emb_only else (tokens, width)
         self.clip_model_type = clip_model_type
         self.class_emb_only = class_emb_only
         self.device = torch.device("cuda") if device is None else torch.device(device)
@@ -145,7 +147,7 @@ class ClipViTPreprocessor(_PreprocessorBase):
         if self._model is None:
             from .encoder import ViTEmbedder
             sd = _load_visual_state_dict(self.clip_model_type, self._state_dict, self._weights_path)
-            self._model = ViTEmbedder(sd, device=self.device)
+            self._model = ViTEmbedder(sd, device=self.device, heads=self._heads)
         return self._model
 
     def process(self, obs: Dict[str, Any], *args: Any, **kwargs: Any) -> torch.Tensor:

@@ -21,6 +21,8 @@
 extern "C" int ec_gemm_bf16(const void* A, const void* Wt, const float* bias, const void* res, void* out, int M, int N,
                             int K, int act, ec_stream_t stream);
 
+extern "C" int ec_bf16_to_f32(const void* in, float* out, long rows, long row_len, long in_stride, ec_stream_t stream);
+
 namespace {
 
 __device__ __forceinline__ float wave_sum_f(float v) {
@@ -291,6 +293,124 @@ __global__ __launch_bounds__(64) void attnpool_core_kernel(const uint16_t* __res
     out[(long)b * C + h * 64 + lane] = (uint16_t)(ec_pack2(o, 0.f) & 0xffffu);
 }
 
+// General multi-head self-attention core: any number of tokens (K/V of one head fit the LDS up to ~500 tokens),
+// head dim 64, optional causal mask (the CLIP text tower's `build_attention_mask`).  One workgroup of 4 waves per
+// (sequence, head); K and V rows live in LDS as bf16 (pitch 72), each wave walks query rows: lane j scores keys
+// j, j+64, ..., the softmax is a wave reduction, then lane d accumulates output dim d.  Same rounding points as
+// mha_kernel (P and O rounded to bf16).  Used for L > 64 (ViT-B/16, ViT-L/14) and for the text tower -- functional
+// coverage, not a tuned kernel (the 50-token ViT-B/32 path keeps the MFMA core above).
+template <bool CAUSAL>
+__global__ __launch_bounds__(256) void mha_general_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out,
+                                                         int L, int D, int heads, float scale) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
+    uint16_t* sk = reinterpret_cast<uint16_t*>(gsm);
+    uint16_t* sv = sk + (size_t)L * 72;
+    const int Lp = (L + 63) / 64 * 64;
+    float* sq = reinterpret_cast<float*>(sv + (size_t)L * 72);      // [4][64] scaled query
+    float* sp = sq + 4 * 64;                                         // [4][Lp] probabilities
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+    const uint16_t* base = qkv + (long)b * L * 3 * D + h * 64;
+    for (int e = tid; e < L * 8; e += 256) {
+        const int t = e >> 3, c = e & 7;
+        const uint16_t* r = base + (long)t * 3 * D + c * 8;
+        *reinterpret_cast<uint4*>(sk + t * 72 + c * 8) = *reinterpret_cast<const uint4*>(r + D);
+        *reinterpret_cast<uint4*>(sv + t * 72 + c * 8) = *reinterpret_cast<const uint4*>(r + 2 * D);
+    }
+    __syncthreads();
+    float* q = sq + wave * 64;
+    float* pr = sp + wave * Lp;
+    constexpr int MAXJ = 8;                                          // L <= 512
+    for (int qi = wave; qi < L; qi += 4) {
+        q[lane] = ec_bf2f(base[(long)qi * 3 * D + lane]) * scale;
+        __builtin_amdgcn_wave_barrier();
+        const int nk = CAUSAL ? qi + 1 : L;
+        float sc[MAXJ];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < MAXJ; ++i) {
+            const int j = i * 64 + lane;
+            sc[i] = -INFINITY;
+            if (i * 64 < nk && j < nk) {
+                float a = 0.f;
+                const uint16_t* kr = sk + j * 72;
+#pragma unroll 8
+                for (int d = 0; d < 64; ++d) a += q[d] * ec_bf2f(kr[d]);
+                sc[i] = a;
+                mx = fmaxf(mx, a);
+            }
+        }
+        mx = wave_max_f(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXJ; ++i) {
+            const int j = i * 64 + lane;
+            if (i * 64 < nk) {
+                const float e = (j < nk) ? __expf(sc[i] - mx) : 0.f;
+                sc[i] = e;
+                sum += e;
+            }
+        }
+        const float inv = 1.f / wave_sum_f(sum);
+#pragma unroll
+        for (int i = 0; i < MAXJ; ++i) {
+            const int j = i * 64 + lane;
+            if (i * 64 < nk && j < nk) pr[j] = ec_bf2f((uint16_t)(ec_pack2(sc[i] * inv, 0.f) & 0xffffu));   // P in bf16
+        }
+        __builtin_amdgcn_wave_barrier();
+        float o = 0.f;
+        for (int j = 0; j < nk; ++j) o += pr[j] * ec_bf2f(sv[j * 72 + lane]);
+        out[((long)b * L + qi) * D + h * 64 + lane] = (uint16_t)(ec_pack2(o, 0.f) & 0xffffu);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// text tower input: x[b, t, :] = token_embedding[tokens[b, t]] + positional_embedding[t]   (bf16 residual stream)
+__global__ __launch_bounds__(256) void embed_tokens_kernel(const int32_t* __restrict__ tokens, const float* __restrict__ emb,
+                                                          const float* __restrict__ pos, uint16_t* __restrict__ x,
+                                                          long rows, int ctx, int D, int vocab) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * (D / 2)) return;
+    const long row = i / (D / 2);
+    const int d = (int)(i - row * (D / 2)) * 2;
+    const int t = (int)(row % ctx);
+    int tok = tokens[row];
+    tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
+    const float a = emb[(long)tok * D + d] + pos[(long)t * D + d], bq = emb[(long)tok * D + d + 1] + pos[(long)t * D + d + 1];
+    reinterpret_cast<uint32_t*>(x)[i] = ec_pack2(a, bq);
+}
+
+// ln_final on the EOT row (first arg-max of the token ids, as torch.argmax) of every sequence: one wave per sequence
+__global__ __launch_bounds__(64) void eot_layernorm_kernel(const int32_t* __restrict__ tokens, const uint16_t* __restrict__ x,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          uint16_t* __restrict__ out, int ctx, int D, float eps) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    int best = -1, at = 0;
+    for (int t = 0; t < ctx; ++t) {            // uniform over the wave
+        const int v = tokens[(long)b * ctx + t];
+        if (v > best) { best = v; at = t; }
+    }
+    const uint16_t* p = x + ((long)b * ctx + at) * D;
+    float v[16];
+    const int per = D / 64;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if (i < per) { v[i] = ec_bf2f(p[i * 64 + lane]); s += v[i]; }
+    const float mean = wave_sum_f(s) / (float)D;
+    float qq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if (i < per) { const float d0 = v[i] - mean; qq += d0 * d0; }
+    const float rstd = rsqrtf(wave_sum_f(qq) / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if (i < per) {
+            const int d = i * 64 + lane;
+            out[(long)b * D + d] = (uint16_t)(ec_pack2((v[i] - mean) * rstd * gamma[d] + beta[d], 0.f) & 0xffffu);
+        }
+}
+
 inline size_t al256(size_t v) { return (v + 255) / 256 * 256; }
 
 }  // namespace
@@ -304,13 +424,62 @@ struct ec_vit {
 
 #define RC(x) do { int rc__ = (x); if (rc__ != EC_OK) return rc__; } while (0)
 
+namespace {
+constexpr int MHA_GENERAL_MAX_TOKENS = 512;
+size_t mha_general_lds(int L) { return (size_t)L * 72 * 2 * 2 + 4 * 64 * 4 + 4 * (size_t)((L + 63) / 64 * 64) * 4; }
+
+// `layers` ResidualAttentionBlocks ([U] clip/model.py) on the bf16 residual stream x [B*L, D]; w / f point at the
+// first block's weights (wqkv, wo, wfc, wpr) / params (ln1 w,b, bqkv, bo, ln2 w,b, bfc, bpr) and are advanced.
+int run_blocks(const uint16_t*& w, const float*& f, int layers, int heads, uint16_t* x, uint16_t* hbuf, uint16_t* qkv,
+               uint16_t* att, uint16_t* mlp, int B, int L, int D, bool causal, ec_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    const long rows = (long)B * L;
+    const unsigned lnb = (unsigned)((rows + 3) / 4);
+    const bool general = causal || L > 64;
+    if (general) {
+        if (L > MHA_GENERAL_MAX_TOKENS) return EC_ERR_SHAPE;
+        static bool attr_set = false;
+        if (!attr_set) {
+            const int mx = (int)mha_general_lds(MHA_GENERAL_MAX_TOKENS);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mha_general_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mha_general_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+            attr_set = true;
+        }
+    }
+    for (int l = 0; l < layers; ++l) {
+        const float *ln1w = f, *ln1b = f + D, *bqkv = f + 2 * D, *bo = bqkv + 3 * D, *ln2w = bo + D, *ln2b = ln2w + D;
+        const float *bfc = ln2b + D, *bpr = bfc + 4 * D;
+        f = bpr + D;
+        const uint16_t *wqkv = w, *wo = w + (size_t)3 * D * D, *wfc = wo + (size_t)D * D, *wpr = wfc + (size_t)4 * D * D;
+        w = wpr + (size_t)4 * D * D;
+        hipLaunchKernelGGL(layernorm_kernel<0>, dim3(lnb), dim3(256), 0, s, x, nullptr, nullptr, ln1w, ln1b, hbuf, rows, D,
+                           L, 1e-5f);
+        RC(ec_gemm_bf16(hbuf, wqkv, bqkv, nullptr, qkv, (int)rows, 3 * D, D, EC_ACT_NONE, stream));
+        if (!general)
+            hipLaunchKernelGGL(mha_kernel, dim3((unsigned)(B * heads)), dim3(64), 0, s, qkv, att, L, D, heads, 0.125f);
+        else if (causal)
+            hipLaunchKernelGGL(mha_general_kernel<true>, dim3((unsigned)(B * heads)), dim3(256), mha_general_lds(L), s, qkv, att,
+                               L, D, heads, 0.125f);
+        else
+            hipLaunchKernelGGL(mha_general_kernel<false>, dim3((unsigned)(B * heads)), dim3(256), mha_general_lds(L), s, qkv, att,
+                               L, D, heads, 0.125f);
+        RC(ec_gemm_bf16(att, wo, bo, x, x, (int)rows, D, D, EC_ACT_NONE, stream));          // x += out_proj(...)
+        hipLaunchKernelGGL(layernorm_kernel<0>, dim3(lnb), dim3(256), 0, s, x, nullptr, nullptr, ln2w, ln2b, hbuf, rows, D,
+                           L, 1e-5f);
+        RC(ec_gemm_bf16(hbuf, wfc, bfc, nullptr, mlp, (int)rows, 4 * D, D, EC_ACT_QUICKGELU, stream));
+        RC(ec_gemm_bf16(mlp, wpr, bpr, x, x, (int)rows, D, 4 * D, EC_ACT_NONE, stream));     // x += c_proj(...)
+    }
+    return EC_OK;
+}
+}  // namespace
+
 extern "C" int ec_vit_create(ec_vit_t** out, int width, int layers_run, int heads, int patch, int input_resolution,
                              const void* w_bf16, size_t n_w, const float* params_f32, size_t n_f) {
     if (!out || !w_bf16 || !params_f32) return EC_ERR_ARG;
     if (width % 64 != 0 || width > 1024 || width / heads != 64 || input_resolution % patch != 0 || (patch * 3) % 4 != 0)
         return EC_ERR_SHAPE;
     const int G = input_resolution / patch, L = G * G + 1;
-    if (L > 64) return EC_ERR_SHAPE;   // attention core keeps <= 64 tokens per (frame, head) in LDS
+    if (L > MHA_GENERAL_MAX_TOKENS) return EC_ERR_SHAPE;   // <= 64 tokens: MFMA core; above: general LDS core
     const size_t D = width, Kp = (size_t)patch * patch * 3;
     const size_t need_w = D * Kp + (size_t)layers_run * (3 * D * D + D * D + 4 * D * D + 4 * D * D);
     const size_t need_f = D + L * D + 2 * D + (size_t)layers_run * (2 * D + 3 * D + D + 2 * D + 4 * D + D);
@@ -365,22 +534,76 @@ extern "C" int ec_vit_forward(const ec_vit_t* h, const float* rgb, int batch, vo
     const unsigned lnb = (unsigned)((rows + 3) / 4);
     hipLaunchKernelGGL(layernorm_kernel<1>, dim3(lnb), dim3(256), 0, s, pemb, cls, pos, lnpre_w, lnpre_b, x, rows, D, L,
                        1e-5f);
-    for (int l = 0; l < h->layers; ++l) {
-        const float *ln1w = f, *ln1b = f + D, *bqkv = f + 2 * D, *bo = bqkv + 3 * D, *ln2w = bo + D, *ln2b = ln2w + D;
-        const float *bfc = ln2b + D, *bpr = bfc + 4 * D;
-        f = bpr + D;
-        const uint16_t *wqkv = w, *wo = w + (size_t)3 * D * D, *wfc = wo + (size_t)D * D, *wpr = wfc + (size_t)4 * D * D;
-        w = wpr + (size_t)4 * D * D;
-        hipLaunchKernelGGL(layernorm_kernel<0>, dim3(lnb), dim3(256), 0, s, x, nullptr, nullptr, ln1w, ln1b, hbuf, rows, D,
-                           L, 1e-5f);
-        RC(ec_gemm_bf16(hbuf, wqkv, bqkv, nullptr, qkv, (int)rows, 3 * D, D, EC_ACT_NONE, stream));
-        hipLaunchKernelGGL(mha_kernel, dim3((unsigned)(B * h->heads)), dim3(64), 0, s, qkv, att, L, D, h->heads, 0.125f);
-        RC(ec_gemm_bf16(att, wo, bo, x, x, (int)rows, D, D, EC_ACT_NONE, stream));          // x += out_proj(...)
-        hipLaunchKernelGGL(layernorm_kernel<0>, dim3(lnb), dim3(256), 0, s, x, nullptr, nullptr, ln2w, ln2b, hbuf, rows, D,
-                           L, 1e-5f);
-        RC(ec_gemm_bf16(hbuf, wfc, bfc, nullptr, mlp, (int)rows, 4 * D, D, EC_ACT_QUICKGELU, stream));
-        RC(ec_gemm_bf16(mlp, wpr, bpr, x, x, (int)rows, D, 4 * D, EC_ACT_NONE, stream));     // x += c_proj(...)
-    }
+    RC(run_blocks(w, f, h->layers, h->heads, x, hbuf, qkv, att, mlp, B, L, D, false, stream));
+    EC_CHECK_LAUNCH();
+    return EC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// CLIP text tower == CLIP.encode_text ([U] openai/CLIP clip/model.py): the goal-embedding source of the zero-shot
+// ObjectNav variant (readme_files/zeroshot_objectnav.md:3-8).  Only a handful of goal strings exist, so this runs
+// once per experiment to build a [num_goals, embed_dim] table -- correctness path, not a throughput path.
+// ---------------------------------------------------------------------------------------------------------------
+struct ec_text {
+    int width, layers, heads, ctx, vocab, embed;
+    const uint16_t* w;
+    const float* f;
+};
+
+extern "C" int ec_text_create(ec_text_t** out, int width, int layers, int heads, int context_length, int vocab_size,
+                              int embed_dim, const void* w_bf16, size_t n_w, const float* params_f32, size_t n_f) {
+    if (!out || !w_bf16 || !params_f32) return EC_ERR_ARG;
+    if (width % 64 != 0 || width > 1024 || width / heads != 64 || context_length <= 0 ||
+        context_length > MHA_GENERAL_MAX_TOKENS || vocab_size <= 0 || embed_dim % 32 != 0 || layers < 0)
+        return EC_ERR_SHAPE;
+    const size_t D = width;
+    const size_t need_w = (size_t)layers * 12 * D * D + (size_t)embed_dim * D;
+    const size_t need_f = (size_t)vocab_size * D + (size_t)context_length * D + (size_t)layers * 13 * D + 2 * D;
+    if (n_w != need_w || n_f != need_f) return EC_ERR_SHAPE;
+    ec_text* h = new (std::nothrow) ec_text();
+    if (!h) return EC_ERR_ALLOC;
+    h->width = width; h->layers = layers; h->heads = heads; h->ctx = context_length; h->vocab = vocab_size;
+    h->embed = embed_dim; h->w = (const uint16_t*)w_bf16; h->f = params_f32;
+    *out = h;
+    return EC_OK;
+}
+extern "C" void ec_text_destroy(ec_text_t* h) { delete h; }
+
+extern "C" size_t ec_text_workspace_bytes(const ec_text_t* h, int batch) {
+    if (!h || batch <= 0) return 0;
+    const size_t D = h->width, L = h->ctx, B = batch;
+    return al256(B * L * D * 2) * 3 + al256(B * L * 3 * D * 2) + al256(B * L * 4 * D * 2) + al256(B * D * 2) +
+           al256(B * (size_t)h->embed * 2);
+}
+
+extern "C" int ec_text_forward(const ec_text_t* h, const int32_t* tokens, int batch, void* workspace, size_t ws_bytes,
+                               float* out, ec_stream_t stream) {
+    if (!h || !tokens || !workspace || !out) return EC_ERR_ARG;
+    if (batch <= 0) return EC_ERR_SHAPE;
+    if (ws_bytes < ec_text_workspace_bytes(h, batch)) return EC_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const int D = h->width, L = h->ctx, B = batch, E = h->embed;
+    if ((long)B * L * 4 * D * 2 >= (1L << 31)) return EC_ERR_SHAPE;
+    unsigned char* p = (unsigned char*)workspace;
+    uint16_t* x = (uint16_t*)p;    p += al256((size_t)B * L * D * 2);
+    uint16_t* hbuf = (uint16_t*)p; p += al256((size_t)B * L * D * 2);
+    uint16_t* att = (uint16_t*)p;  p += al256((size_t)B * L * D * 2);
+    uint16_t* qkv = (uint16_t*)p;  p += al256((size_t)B * L * 3 * D * 2);
+    uint16_t* mlp = (uint16_t*)p;  p += al256((size_t)B * L * 4 * D * 2);
+    uint16_t* eot = (uint16_t*)p;  p += al256((size_t)B * D * 2);
+    uint16_t* emb = (uint16_t*)p;
+    const float* f = h->f;
+    const float *tok_emb = f, *pos = f + (size_t)h->vocab * D;
+    f = pos + (size_t)L * D;
+    const uint16_t* w = h->w;
+    const long rows = (long)B * L;
+    const long n2 = rows * (D / 2);
+    hipLaunchKernelGGL(embed_tokens_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, s, tokens, tok_emb, pos, x, rows, L,
+                       D, h->vocab);
+    RC(run_blocks(w, f, h->layers, h->heads, x, hbuf, qkv, att, mlp, B, L, D, true, stream));
+    hipLaunchKernelGGL(eot_layernorm_kernel, dim3((unsigned)B), dim3(64), 0, s, tokens, x, f, f + D, eot, L, D, 1e-5f);
+    RC(ec_gemm_bf16(eot, w, nullptr, nullptr, emb, B, E, D, EC_ACT_NONE, stream));          // @ text_projection
+    RC(ec_bf16_to_f32(emb, out, B, E, E, stream));
     EC_CHECK_LAUNCH();
     return EC_OK;
 }

@@ -329,3 +329,74 @@ def conv1x1_pair_bf16(a0, w0, b0, w2, b2, a1=None, w1=None, b1=None, res=None):
                                         _lib.ptr(b1), _lib.ptr(res), y.data_ptr(), w2.data_ptr(), b2.data_ptr(),
                                         z.data_ptr(), M, K0, N, N2, _lib.stream_ptr()), "ec_conv1x1_pair_bf16")
     return y, z
+
+
+def pack_text(sd: Dict[str, torch.Tensor]):
+    """OpenAI-CLIP ``state_dict()`` entries of the text tower (``token_embedding.weight``, ``positional_embedding``,
+    ``transformer.resblocks.*``, ``ln_final.*``, ``text_projection``) -> (cfg, w bf16 flat, params f32 flat) in the
+    order ``ec_text_create`` documents."""
+    sd = {k: v.detach().cpu().float() for k, v in sd.items()}
+    vocab, D = sd["token_embedding.weight"].shape
+    ctx = sd["positional_embedding"].shape[0]
+    E = sd["text_projection"].shape[1]
+    n = 0
+    while f"transformer.resblocks.{n}.ln_1.weight" in sd:
+        n += 1
+    ws, fs = [], [sd["token_embedding.weight"].reshape(-1), sd["positional_embedding"].reshape(-1)]
+    for i in range(n):
+        p = f"transformer.resblocks.{i}."
+        ws += [sd[p + "attn.in_proj_weight"], sd[p + "attn.out_proj.weight"], sd[p + "mlp.c_fc.weight"],
+               sd[p + "mlp.c_proj.weight"]]
+        fs += [sd[p + "ln_1.weight"], sd[p + "ln_1.bias"], sd[p + "attn.in_proj_bias"], sd[p + "attn.out_proj.bias"],
+               sd[p + "ln_2.weight"], sd[p + "ln_2.bias"], sd[p + "mlp.c_fc.bias"], sd[p + "mlp.c_proj.bias"]]
+    ws.append(sd["text_projection"].t().contiguous())
+    fs += [sd["ln_final.weight"], sd["ln_final.bias"]]
+    w = torch.cat([t.reshape(-1) for t in ws]).to(torch.bfloat16)
+    f = torch.cat([t.reshape(-1) for t in fs]).float()
+    return dict(width=D, layers=n, context_length=ctx, vocab_size=vocab, embed_dim=E), w, f
+
+
+class ClipTextEncoder:
+    """Frozen CLIP text tower on one MI355X: ``encode_text(tokens int [B, ctx]) -> fp32 [B, embed_dim]``
+    (== ``clip_model.encode_text``).  In the zero-shot ObjectNav variant it is run once over the goal strings to
+    build the goal-embedding table that replaces ``nn.Embedding`` (readme_files/zeroshot_objectnav.md)."""
+
+    def __init__(self, state_dict, device="cuda", heads: Optional[int] = None):
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        cfg, w, f = pack_text(state_dict)
+        self.cfg = cfg
+        self.w, self.f = w.to(self.device), f.to(self.device)
+        heads = cfg["width"] // 64 if heads is None else heads        # CLIP: transformer_heads = transformer_width // 64
+        h = C.c_void_p()
+        _lib.check(self.lib.ec_text_create(C.byref(h), cfg["width"], cfg["layers"], heads, cfg["context_length"],
+                                           cfg["vocab_size"], cfg["embed_dim"], self.w.data_ptr(), self.w.numel(),
+                                           self.f.data_ptr(), self.f.numel()), "ec_text_create")
+        self.h = h
+        self._ws = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.ec_text_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    @torch.no_grad()
+    def encode_text(self, tokens: torch.Tensor) -> torch.Tensor:
+        assert tokens.dim() == 2 and tokens.shape[1] == self.cfg["context_length"], tokens.shape
+        t = tokens.to(self.device, torch.int32).contiguous()
+        B = t.shape[0]
+        need = self.lib.ec_text_workspace_bytes(self.h, B)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        out = torch.empty((B, self.cfg["embed_dim"]), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.ec_text_forward(self.h, t.data_ptr(), B, self._ws.data_ptr(), self._ws.numel(),
+                                            out.data_ptr(), _lib.stream_ptr()), "ec_text_forward")
+        return out
+
+    def goal_table(self, goal_tokens: torch.Tensor, normalize: bool = True) -> torch.Tensor:
+        """[num_goals, ctx] token ids -> [num_goals, embed_dim] (L2-normalised like CLIP's zero-shot classifier)."""
+        e = self.encode_text(goal_tokens)
+        return e / e.norm(dim=-1, keepdim=True) if normalize else e

@@ -185,6 +185,48 @@ def vit_visual_state_dict(seed: int = 0, width: int = 768, layers: int = 12, hea
     return sd
 
 
+def text_state_dict(seed: int = 0, width: int = 512, layers: int = 12, heads: int = 8, context_length: int = 77,
+                    vocab_size: int = 49408, embed_dim: int = 1024) -> "OrderedDict[str, torch.Tensor]":
+    """Synthetic CLIP text tower (``token_embedding`` .. ``text_projection``) with CLIP's init scales
+    (``CLIP.initialize_parameters``).  RN50 CLIP: width 512, 12 layers, 8 heads, ctx 77, vocab 49,408, out 1024."""
+    sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    sd["token_embedding.weight"] = _normal(seed, "token_embedding.weight", (vocab_size, width), 0.02)
+    sd["positional_embedding"] = _normal(seed, "text.positional_embedding", (context_length, width), 0.01)
+    attn_std = width ** -0.5
+    proj_std = attn_std * ((2 * layers) ** -0.5)
+    fc_std = (2 * width) ** -0.5
+    for i in range(layers):
+        p = f"transformer.resblocks.{i}"
+        sd[p + ".attn.in_proj_weight"] = _normal(seed, "text." + p + ".attn.in_proj_weight", (3 * width, width), attn_std)
+        sd[p + ".attn.in_proj_bias"] = _normal(seed, "text." + p + ".attn.in_proj_bias", (3 * width,), 0.02)
+        sd[p + ".attn.out_proj.weight"] = _normal(seed, "text." + p + ".attn.out_proj.weight", (width, width), proj_std)
+        sd[p + ".attn.out_proj.bias"] = _normal(seed, "text." + p + ".attn.out_proj.bias", (width,), 0.02)
+        sd[p + ".ln_1.weight"] = _uniform(seed, "text." + p + ".ln_1.weight", (width,), 0.8, 1.2)
+        sd[p + ".ln_1.bias"] = _normal(seed, "text." + p + ".ln_1.bias", (width,), 0.05)
+        sd[p + ".mlp.c_fc.weight"] = _normal(seed, "text." + p + ".mlp.c_fc.weight", (4 * width, width), fc_std)
+        sd[p + ".mlp.c_fc.bias"] = _normal(seed, "text." + p + ".mlp.c_fc.bias", (4 * width,), 0.02)
+        sd[p + ".mlp.c_proj.weight"] = _normal(seed, "text." + p + ".mlp.c_proj.weight", (width, 4 * width), proj_std)
+        sd[p + ".mlp.c_proj.bias"] = _normal(seed, "text." + p + ".mlp.c_proj.bias", (width,), 0.02)
+        sd[p + ".ln_2.weight"] = _uniform(seed, "text." + p + ".ln_2.weight", (width,), 0.8, 1.2)
+        sd[p + ".ln_2.bias"] = _normal(seed, "text." + p + ".ln_2.bias", (width,), 0.05)
+    sd["ln_final.weight"] = _uniform(seed, "ln_final.weight", (width,), 0.8, 1.2)
+    sd["ln_final.bias"] = _normal(seed, "ln_final.bias", (width,), 0.05)
+    sd["text_projection"] = _normal(seed, "text_projection", (width, embed_dim), attn_std)
+    return sd
+
+
+def synthetic_tokens(seed: int, n: int, context_length: int = 77, vocab_size: int = 49408) -> torch.Tensor:
+    """CLIP-tokenizer-shaped ids: <SOT> = vocab-2, 1..8 word tokens, <EOT> = vocab-1 (the arg-max), zero padding."""
+    k = hash_u64(seed, n * (context_length + 1), stream=9).reshape(n, context_length + 1)
+    out = np.zeros((n, context_length), dtype=np.int64)
+    for i in range(n):
+        nw = 1 + int(k[i, 0] % np.uint64(8))
+        out[i, 0] = vocab_size - 2
+        out[i, 1:1 + nw] = (k[i, 1:1 + nw] % np.uint64(vocab_size - 2)).astype(np.int64)
+        out[i, 1 + nw] = vocab_size - 1
+    return torch.from_numpy(out)
+
+
 # --------------------------------------------------------------------------
 # AllenAct ResnetTensorObjectNavActorCritic policy (SURVEY.md §8a a11-a14, §9)
 # --------------------------------------------------------------------------

@@ -263,6 +263,23 @@ int ec_attnpool_forward(const void* feat, int batch, int HW, int C, int heads, i
                         const float* bc, void* workspace, size_t ws_bytes, float* out, ec_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * CLIP text tower == CLIP.encode_text ([U] openai/CLIP clip/model.py; the goal embedding of the zero-shot
+ * ObjectNav variant, readme_files/zeroshot_objectnav.md:3-8): token + positional embedding, `layers` causal
+ * ResidualAttentionBlocks, ln_final, features at the EOT token (arg-max id) @ text_projection.
+ * w_bf16: per block in_proj [3D][D], out_proj [D][D], c_fc [4D][D], c_proj [D][4D]; then text_projection^T [E][D].
+ * params_f32: token_embedding [vocab][D], positional_embedding [ctx][D], per block ln_1 w,b, in_proj_bias [3D],
+ * out_proj.bias, ln_2 w,b, c_fc.bias [4D], c_proj.bias; then ln_final w,b.  tokens int32 [B][ctx] (the BPE tokenizer
+ * is host string processing, not part of this path); out f32 [B][E].  width/heads must be 64, ctx <= 512.
+ * ---------------------------------------------------------------------- */
+typedef struct ec_text ec_text_t;
+int ec_text_create(ec_text_t** out, int width, int layers, int heads, int context_length, int vocab_size,
+                   int embed_dim, const void* w_bf16, size_t n_w, const float* params_f32, size_t n_f);
+void ec_text_destroy(ec_text_t* h);
+size_t ec_text_workspace_bytes(const ec_text_t* h, int batch);
+int ec_text_forward(const ec_text_t* h, const int32_t* tokens, int batch, void* workspace, size_t ws_bytes,
+                    float* out, ec_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * Linear probe heads (BASELINE config 1) == LinearEncoder of
  * primitive_probing/train.py:14-113.  The Linear / Conv1x1 contraction is ec_gemm_f32; these are the
  * activation + loss + metric counts + analytic backward of compute_loss (train.py:56-92):

@@ -40,10 +40,11 @@ def num_blocks(sd: Dict[str, torch.Tensor]) -> int:
     return n
 
 
-def residual_attention_block(x_lnd, sd, p, heads, emulate=False):
+def residual_attention_block(x_lnd, sd, p, heads, emulate=False, attn_mask=None):
     """``x = x + attn(ln_1(x)); x = x + mlp(ln_2(x))`` with
     nn.MultiheadAttention (fused in_proj, softmax(QK^T/sqrt(64)), out_proj)
-    and mlp = c_proj(QuickGELU(c_fc(.))).  x: [L, N, D]."""
+    and mlp = c_proj(QuickGELU(c_fc(.))).  x: [L, N, D].  ``attn_mask``: additive [L, L] (the text tower's
+    causal mask), None for the vision tower."""
     e = emulate
     D = x_lnd.shape[-1]
     h = _r(F.layer_norm(x_lnd, (D,), sd[p + ".ln_1.weight"].float(), sd[p + ".ln_1.bias"].float(), LN_EPS), e)
@@ -51,7 +52,7 @@ def residual_attention_block(x_lnd, sd, p, heads, emulate=False):
         a, _ = F.multi_head_attention_forward(
             h, h, h, D, heads, _r(sd[p + ".attn.in_proj_weight"].float(), e), sd[p + ".attn.in_proj_bias"].float(),
             None, None, False, 0.0, _r(sd[p + ".attn.out_proj.weight"].float(), e),
-            sd[p + ".attn.out_proj.bias"].float(), training=False, need_weights=False)
+            sd[p + ".attn.out_proj.bias"].float(), training=False, need_weights=False, attn_mask=attn_mask)
     else:
         # same math with the bf16 rounding points of the HIP path made explicit
         L, N, _ = h.shape
@@ -62,6 +63,8 @@ def residual_attention_block(x_lnd, sd, p, heads, emulate=False):
         k = k.reshape(L, N * heads, dh).transpose(0, 1)
         v = v.reshape(L, N * heads, dh).transpose(0, 1)
         s = torch.bmm(q, k.transpose(1, 2)) * (dh ** -0.5)
+        if attn_mask is not None:
+            s = s + attn_mask
         pr = _r(torch.softmax(s, dim=-1), e)
         o = _r(torch.bmm(pr, v), e).transpose(0, 1).reshape(L, N, D)
         a = F.linear(o, _r(sd[p + ".attn.out_proj.weight"].float(), e), sd[p + ".attn.out_proj.bias"].float())

@@ -14,7 +14,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from embodied_clip_amd import synthetic as syn  # noqa: E402
-from oracle import clip_resnet as ocr, clip_vit as ovit, policy as opol, ppo as oppo, probe as oprobe  # noqa: E402
+from oracle import clip_resnet as ocr, clip_text as otxt, clip_vit as ovit, policy as opol, ppo as oppo, probe as oprobe  # noqa: E402
 
 OUT = os.path.dirname(os.path.abspath(__file__))
 
@@ -30,6 +30,12 @@ def policy_case(T=8, N=4, seed=21):
     actions = syn.synthetic_goals(seed + 5, (T, N), num_goals=6)
     u = lambda s: torch.from_numpy(syn.hash_normal(seed + s, T * N).astype("float32")).reshape(T, N, 1)
     return sd, feat, goal, h0, masks, actions, u(6), u(7), u(8), u(9)
+
+
+def text_case():
+    """Seeded text tower (width 512, 8 heads, ctx 77, 2 blocks, vocab 1000, out 1024) and 12 'goal' token rows."""
+    sd = syn.text_state_dict(21, width=512, layers=2, heads=8, context_length=77, vocab_size=1000, embed_dim=1024)
+    return sd, syn.synthetic_tokens(22, 12, 77, 1000)
 
 
 def probe_cases():
@@ -65,6 +71,9 @@ def main():
     vsd = syn.vit_visual_state_dict(0)
     tok = ovit.clip_vit_preprocessor(rgb, vsd)
     g["vit"] = {"seed_weights": 0, "seed_rgb": 1000, "tokens": tok[:, :9].clone(), "norm": tok.flatten(1).norm(dim=1).clone()}
+    # (2b) CLIP text tower (goal embeddings of the zero-shot variant): RN50-CLIP geometry, reduced depth / vocabulary
+    tsd, ttok = text_case()
+    g["text"] = {"embeds": otxt.encode_text(ttok, tsd, heads=8).clone()}
     # (3) policy forward + PPO loss + gradients for a T=8, N=4 minibatch
     psd, feat, goal, h0, masks, actions, a, b, c, d = policy_case()
     with torch.no_grad():

@@ -50,3 +50,11 @@ def test_oracle_probe_reproduces_golden():
     assert set(gold) == {"object_presence", "free_space", "reachability", "object_localization"}
     for task, (x, y, w, bb) in mg.probe_cases().items():
         assert abs(float(oprobe.compute_loss(x, y, w, bb, task)) - gold[task]) < 1e-6, task
+
+
+def test_oracle_text_reproduces_golden():
+    from oracle import clip_text as otxt
+    gold = torch.load(os.path.join(os.path.dirname(__file__), "golden", "oracle_golden.pt"))["text"]["embeds"]
+    sd, tok = mg.text_case()
+    assert tok.shape == (12, 77) and int(tok.max()) == 999          # <EOT> = vocab-1 is the arg-max
+    assert torch.allclose(otxt.encode_text(tok, sd, heads=8), gold, atol=1e-5)

@@ -65,3 +65,14 @@ def test_policy_loss_grads_gae_against_golden():
     v = torch.from_numpy(syn.hash_normal(33, (Tg + 1) * Ng).astype("float32")).reshape(Tg + 1, Ng, 1)
     R, _, nadv = ppo.compute_returns(r.to(dev), v.to(dev), mm.to(dev))
     assert _rel(R, G["gae"]["returns"]) < 1e-6 and _rel(nadv, G["gae"]["norm_adv"]) < 1e-5
+
+
+def test_text_tower_against_golden():
+    """CLIP.encode_text on HIP vs the committed oracle embeddings of 12 goal-token rows (bf16 tolerance)."""
+    from embodied_clip_amd.encoder import ClipTextEncoder
+    gold = G["text"]["embeds"]
+    sd, tok = mg.text_case()
+    got = ClipTextEncoder(sd, device="cuda:0").encode_text(tok).cpu()
+    rel = float((got - gold).norm() / gold.norm())
+    assert rel < 2e-2, rel
+    assert torch.nn.functional.cosine_similarity(got, gold).min().item() > 0.999

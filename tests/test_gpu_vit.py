@@ -78,3 +78,45 @@ def test_attnpool_matches_oracle_and_golden(dev):
     assert _rel(out, ref_same_in) < 1.5e-2, _rel(out, ref_same_in)
     # end to end vs the fp32 golden (thor_image_features.py:112 `clip_attnpool`)
     assert _rel(out, G["rn50"]["attnpool"]) < 3e-2, _rel(out, G["rn50"]["attnpool"])
+
+
+def test_vit_b16_style_197_tokens_general_attention(dev):
+    """ClipViTPreprocessor('ViT-B/16'): 14x14+1 = 197 tokens run the general LDS attention core (L > 64)."""
+    from embodied_clip_amd.clip_preprocessors import ClipViTPreprocessor
+    from oracle import clip_vit as ovit
+    sd = syn.vit_visual_state_dict(4, width=768, layers=3, heads=12, patch_size=16, input_resolution=224, output_dim=64)
+    x = syn.synthetic_rgb(6, 2)
+    ref = ovit.vit_embedder(x.permute(0, 3, 1, 2).contiguous(), sd, heads=12, drop_last=1)
+    pre = ClipViTPreprocessor("rgb", "ViT-B/16", class_emb_only=False, state_dict=sd, device=dev)
+    assert pre.observation_space.shape == (197, 768)
+    got = pre.process({"rgb": x}).cpu()
+    assert got.shape == ref.shape == (2, 197, 768)
+    rel = float((got - ref).norm() / ref.norm())
+    assert rel < 2e-2, rel
+
+
+def test_text_tower_matches_oracle_and_is_causal(dev):
+    """CLIP.encode_text on HIP (ec_text_forward) vs oracle/clip_text.py: small tower and the RN50-CLIP geometry
+    (width 512, 8 heads, ctx 77) with a reduced vocabulary / depth to keep the CPU oracle quick."""
+    from embodied_clip_amd.encoder import ClipTextEncoder
+    from oracle import clip_text as otxt
+    for (width, layers, ctx, vocab, out, n) in ((128, 2, 20, 300, 64, 5), (512, 3, 77, 2000, 1024, 12)):
+        sd = syn.text_state_dict(3, width=width, layers=layers, heads=width // 64, context_length=ctx,
+                                 vocab_size=vocab, embed_dim=out)
+        tokens = syn.synthetic_tokens(5, n, ctx, vocab)
+        ref = otxt.encode_text(tokens, sd, heads=width // 64)
+        enc = ClipTextEncoder(sd, device=dev)
+        got = enc.encode_text(tokens).cpu()
+        assert got.shape == ref.shape == (n, out)
+        rel = float((got - ref).norm() / ref.norm())
+        assert rel < 2e-2, (width, rel)
+        cos = torch.nn.functional.cosine_similarity(got, ref).min().item()
+        assert cos > 0.999, cos
+        # padding after EOT never reaches the EOT feature (causal mask): garbage in the padded tail changes nothing
+        t2 = tokens.clone()
+        eot = tokens.argmax(dim=-1)
+        for i in range(n):
+            t2[i, int(eot[i]) + 1:] = 1
+        assert torch.equal(enc.encode_text(t2).cpu(), got)
+        tab = enc.goal_table(tokens).cpu()
+        assert torch.allclose(tab.norm(dim=-1), torch.ones(n), atol=1e-5)
