@@ -58,9 +58,11 @@ __global__ __launch_bounds__(256) void stem_conv1_kernel(const void* __restrict_
     __syncthreads();
     const int ly = threadIdx.x / ST, lx = threadIdx.x % ST;
     const int oy = oy0 + ly, ox = ox0 + lx;
-    float acc[COUT];
+    // packed fp32 FMAs (v_pk_fma_f32: two channels per instruction); weights are wave-uniform (scalar loads)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 acc2[COUT / 2];
 #pragma unroll
-    for (int c = 0; c < COUT; ++c) acc[c] = bias[c];
+    for (int c = 0; c < COUT / 2; ++c) acc2[c] = *reinterpret_cast<const f32x2*>(bias + 2 * c);
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -68,10 +70,14 @@ __global__ __launch_bounds__(256) void stem_conv1_kernel(const void* __restrict_
 #pragma unroll
             for (int ci = 0; ci < 3; ++ci) {
                 const float v = patch[(2 * ly + ky) * SROW + (2 * lx + kx) * 3 + ci];
-                const float* wr = w + ((ky * 3 + kx) * 3 + ci) * COUT;
+                const f32x2 v2 = {v, v};
+                const f32x2* wr = reinterpret_cast<const f32x2*>(w + ((ky * 3 + kx) * 3 + ci) * COUT);
 #pragma unroll
-                for (int c = 0; c < COUT; ++c) acc[c] = fmaf(v, wr[c], acc[c]);
+                for (int c = 0; c < COUT / 2; ++c) acc2[c] = __builtin_elementwise_fma(v2, wr[c], acc2[c]);
             }
+    float acc[COUT];
+#pragma unroll
+    for (int c = 0; c < COUT / 2; ++c) { acc[2 * c] = acc2[c][0]; acc[2 * c + 1] = acc2[c][1]; }
     if (oy < Ho && ox < Wo) {
         uint4* dst = reinterpret_cast<uint4*>(out + ((long)(b * Ho + oy) * Wo + ox) * COUT);
 #pragma unroll
