@@ -196,6 +196,41 @@ int pick_splitk(long M, long N, long K) {
     return (int)s;
 }
 
+// LinearActorHead + LinearCriticHead ([U] allenact basic_models.py): hv[b, :A] = hs[b] . Wa^T + ba, hv[b, A] = hs[b] . wc + bc.
+// A+1 <= 8 outputs of a 512-long dot product per row: one wave per row (the tiled GEMM would run this as ONE
+// workgroup -- 44 us for 128 rows).  Lane l owns elements l, l+64, ... of the row; fixed-order wave reduction.
+template <int MAXO>
+__global__ __launch_bounds__(256) void heads_fwd_kernel(const float* __restrict__ hs, const float* __restrict__ Wa,
+                                                       const float* __restrict__ ba, const float* __restrict__ Wc,
+                                                       const float* __restrict__ bc, float* __restrict__ hv, long B,
+                                                       int H, int A) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= B) return;
+    float acc[MAXO];
+#pragma unroll
+    for (int o = 0; o < MAXO; ++o) acc[o] = 0.f;
+    const float* x = hs + row * H;
+    for (int k = lane; k < H; k += 64) {
+        const float v = x[k];
+#pragma unroll
+        for (int o = 0; o < MAXO; ++o)
+            if (o <= A) acc[o] = fmaf(v, (o < A ? Wa[(long)o * H + k] : Wc[k]), acc[o]);
+    }
+#pragma unroll
+    for (int o = 0; o < MAXO; ++o) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc[o] += __shfl_xor(acc[o], off, 64);
+    }
+    if (lane <= A) {
+        float r = 0.f;
+#pragma unroll
+        for (int o = 0; o < MAXO; ++o)
+            if (o == lane) r = acc[o];
+        hv[row * (A + 1) + lane] = r + (lane < A ? ba[lane] : bc[0]);
+    }
+}
+
 // split-K for the small per-step GEMMs that only ever ACCUMULATE (atomics are fine): aim at ~1 workgroup
 // per CU on 64x64 tiles while keeping >= 4 K-tiles per slice.
 int step_splitk(long M, long N, long K) {
@@ -286,6 +321,7 @@ extern "C" int ec_policy_forward(const ec_policy_t* h, const float* params, cons
                            S, c.comb_out, total);
     }
     // GRU: input projection for all T at once, then the sequential recurrence
+    // (no split-K here: the act step stays free of float atomics, so rollouts are bit-reproducible)
     RC(ec_gemm_f32(ws + w.x, W(P_WIH), ws + w.gi, B, 3 * H, flat, flat, 1, 1, flat, 3 * H, 0, W(P_BIH), nullptr,
                    nullptr, 0, nullptr, nullptr, 1, stream));
     for (int t = 0; t < T; ++t) {
@@ -298,10 +334,15 @@ extern "C" int ec_policy_forward(const ec_policy_t* h, const float* params, cons
                            ws + w.hp + o1, N, H);
     }
     // heads: hv[:, :A] = actor logits, hv[:, A] = critic value
-    RC(ec_gemm_f32(ws + w.hs, W(P_WA), hv, B, c.num_actions, H, H, 1, 1, H, A1, 0, W(P_BA), nullptr, nullptr, 0,
-                   nullptr, nullptr, 1, stream));
-    RC(ec_gemm_f32(ws + w.hs, W(P_WC), hv + c.num_actions, B, 1, H, H, 1, 1, H, A1, 0, W(P_BC), nullptr, nullptr, 0,
-                   nullptr, nullptr, 1, stream));
+    if (A1 <= 8) {
+        hipLaunchKernelGGL(heads_fwd_kernel<8>, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s, ws + w.hs, W(P_WA), W(P_BA),
+                           W(P_WC), W(P_BC), hv, (long)B, H, c.num_actions);
+    } else {
+        RC(ec_gemm_f32(ws + w.hs, W(P_WA), hv, B, c.num_actions, H, H, 1, 1, H, A1, 0, W(P_BA), nullptr, nullptr, 0,
+                       nullptr, nullptr, 1, stream));
+        RC(ec_gemm_f32(ws + w.hs, W(P_WC), hv + c.num_actions, B, 1, H, H, 1, 1, H, A1, 0, W(P_BC), nullptr, nullptr, 0,
+                       nullptr, nullptr, 1, stream));
+    }
     if (h_final)
         (void)hipMemcpyAsync(h_final, ws + w.hs + (size_t)(T - 1) * N * H, (size_t)N * H * 4, hipMemcpyDeviceToDevice, s);
     EC_CHECK_LAUNCH();
