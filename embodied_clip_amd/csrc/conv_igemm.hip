@@ -86,8 +86,10 @@ __device__ __forceinline__ float dpp_quad_xor2(float v) {   // lane ^ 2 within a
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
 }
 
-template <int BM, int BN, int WM, int WN, int KS, bool POOL, bool PF>
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 3) void conv_igemm_kernel(ConvArgs p) {
+// MV = rows of the tile that are real output rows (tile stride in M); MV < BM pads the tile (see dispatch_tile:
+// 196-of-224-row tiles make every RN50 layer's tile count a multiple of the CU count).
+template <int BM, int BN, int WM, int WN, int KS, bool POOL, bool PF, int MV>
+__global__ __launch_bounds__(WM * WN * 64, (BM > 192) ? 2 : ((WM * WN == 8) ? 4 : 3)) void conv_igemm_kernel(ConvArgs p) {
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int FM = TM / 32, FN = TN / 32;
     constexpr int NT = WM * WN * 64;                // threads per workgroup
@@ -109,7 +111,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 3) void conv_ige
     const unsigned lb = ec_xcd_remap(blockIdx.x, grid);
     int tile = (int)lb;
     if (tile >= p.ntiles) return;
-    int m0 = (tile / p.ntn) * BM;
+    static_assert(MV <= BM && (MV == BM || !POOL), "padded tiles: non-pooled only");
+    int m0 = (tile / p.ntn) * MV;
     int n0 = (tile % p.ntn) * BN;
 
 
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 3) void conv_ige
                 const unsigned xm = (x > 0 ? 1u : 0u) | 2u | (x < p.W - 1 ? 4u : 0u);
                 msk = (y > 0 ? xm : 0u) | (xm << 3) | (y < p.H - 1 ? (xm << 6) : 0u);
             }
-            a_msk[i] = (m < p.M) ? msk : 0u;
+            a_msk[i] = (m < p.M && (MV == BM || lrow + LR * i < MV)) ? msk : 0u;
             a_off[i] = (unsigned)pix * (unsigned)p.Cin * 2u;
         }
 #pragma unroll
@@ -265,7 +268,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 3) void conv_ige
             for (int i = 0; i < (PREFETCH ? NPASS : 1); ++i) {
                 const int row = i * RPP + srow;
                 rres[i] = make_uint4(0, 0, 0, 0);
-                if (orow0 + row < Mout)
+                if (orow0 + row < Mout && (MV == BM || row < MV))
                     rres[i] = *reinterpret_cast<const uint4*>(p.res + (long)(orow0 + row) * p.Cout + e_n0 + schunk * 8);
             }
         }
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 3) void conv_ige
         tile += (int)grid;
         const bool has_next = tile < p.ntiles;
         if (has_next) {
-            m0 = (tile / p.ntn) * BM;
+            m0 = (tile / p.ntn) * MV;
             n0 = (tile % p.ntn) * BN;
             decode();
         }
@@ -314,7 +317,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 3) void conv_ige
             for (int i = 0; i < NPASS; ++i) {
                 const int row = i * RPP + srow;
                 uint4 v = make_uint4(0, 0, 0, 0);
-                if (orow0 + row < Mout)
+                if (orow0 + row < Mout && (MV == BM || row < MV))
                     v = *reinterpret_cast<const uint4*>(p.res + (long)(orow0 + row) * p.Cout + e_n0 + schunk * 8);
                 *reinterpret_cast<uint4*>(smem + row * PITCH + schunk * 16) = v;
             }
@@ -368,7 +371,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 3) void conv_ige
 #pragma unroll
     for (int r0 = 0; r0 < OUT_ROWS; r0 += RPP) {
         const int row = r0 + srow;
-        if (orow0 + row < Mout)
+        if (orow0 + row < Mout && (MV == BM || row < MV))
             *reinterpret_cast<uint4*>(p.out + (long)(orow0 + row) * p.Cout + e_n0 + schunk * 8) =
                 *reinterpret_cast<const uint4*>(smem + row * PITCH + schunk * 16);
     }
@@ -378,11 +381,11 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 3) void conv_ige
     }
 }
 
-template <int BM, int BN, int WM, int WN, int KS, bool POOL, bool PF = false>
+template <int BM, int BN, int WM, int WN, int KS, bool POOL, bool PF = false, int MV = BM>
 int launch(const ConvArgs& a, hipStream_t s) {
     ConvArgs p = a;
     p.ntn = a.Cout / BN;
-    const int ntm = (a.M + BM - 1) / BM;
+    const int ntm = (a.M + MV - 1) / MV;
     p.ntiles = ntm * p.ntn;
     const size_t lds_max = 2 * (size_t)(BM + BN) * ROW_BYTES;
     const size_t epi = (size_t)(POOL ? BM / 4 : BM) * (BN * 2 + 16);
@@ -394,7 +397,7 @@ int launch(const ConvArgs& a, hipStream_t s) {
     p.skew = skew;
     size_t lds = (size_t)p.nbuf * (BM + BN) * ROW_BYTES;   // (set after nbuf below)
     if (lds < epi) lds = epi;
-    auto kern = conv_igemm_kernel<BM, BN, WM, WN, KS, POOL, PF>;
+    auto kern = conv_igemm_kernel<BM, BN, WM, WN, KS, POOL, PF, MV>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -415,6 +418,20 @@ int dispatch_tile(const ConvArgs& a, hipStream_t s) {
     // Tile choice: 128x128 wherever Cout allows; 256-row tiles for the narrow early layers.
     // (Fatter 128x256 / 256x128 tiles were measured: no gain, and they spill once loads run two tiles ahead.)
     if (a.Cout % 128 == 0) {
+        // 196-of-224-row tiles: 196 = 14^2 divides every RN50 feature map (56^2, 28^2, 14^2, 4 x 7^2), so the tile count
+        // becomes a multiple of the frame count -- e.g. layer 3 at 256 frames: 512 tiles = 2 per CU instead of 784
+        // tiles on 768 workgroups (16 tail tiles running alone).  Costs 12.5 % padding and runs 2 workgroups per CU, so
+        // it only pays where quantisation hurts most: measured 3x3 256->256 @14x14 100.9 -> 79.3 us, 1x1 1024->256
+        // 49.6 -> 39.2 us (B = 256); slower on short-K / residual convs and on 256-tile launches.
+        // EC_CONV_T224: 0 off, 1 everywhere (tests/experiments), 2 (default) the rule below, 3 also 256-tile launches.
+        static const int t224 = [] { const char* e = getenv("EC_CONV_T224"); return e ? atoi(e) : 2; }();
+        if constexpr (!POOL) {
+            const long t196 = (long)(a.M / 196) * (a.Cout / 128), t128 = (long)((a.M + 127) / 128) * (a.Cout / 128);
+            if (a.M % 196 == 0 &&
+                (t224 == 1 || (t224 >= 2 && !a.res && a.K >= 1024 && (t196 == 256 || t196 == 512) && (t128 % 768) != 0 &&
+                               (t224 == 3 || t196 == 512))))
+                return launch<224, 128, 1, 4, KS, POOL, false, 196>(a, s);
+        }
         // residual register prefetch only for the short-K, bandwidth-bound expanding 1x1 convs
         if (force != 8) {
             if (KS == 1 && !POOL && a.res && a.K <= 256) return launch<128, 128, 2, 2, KS, POOL, (KS == 1 && !POOL)>(a, s);
