@@ -1,0 +1,100 @@
+"""The hot path at BASELINE.json's full size (256 actors, rollout 128, CLIP-RN50, 4 PPO epochs) checked through
+size-independent properties -- the oracle would need hours on CPU for this configuration:
+
+  * the encoder is a pure function of the frame: the synthetic env replays a pool of 4 frame batches, so
+    feat[t] == feat[t + 4] bit for bit, and a frame encoded inside the 128-frame launch equals the same frame
+    encoded alone;
+  * stored log-probs are log_softmax(logits)[action] of the stored actions; the first PPO epoch sees ratio == 1;
+  * GAE: R[t] - V[t] == adv[t]; normalised advantages have zero mean / unit (unbiased) std over the local batch;
+  * the softmax-gradient rows of d(loss)/d(logits) sum to zero; Adam with a zero gradient leaves parameters unchanged;
+  * gradient clipping: the applied update is bounded by lr per parameter.
+"""
+import os
+import sys
+
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def worker():
+    from embodied_clip_amd.engine import Worker
+    w = Worker(256, T=128, device="cuda:0", seed=0)
+    w.collect_rollout()
+    w.compute_returns()
+    torch.cuda.synchronize()
+    return w
+
+
+def test_encoder_is_a_pure_function_of_the_frame(worker):
+    w = worker
+    for sl in w.slices:
+        assert torch.equal(sl.feat[1], sl.feat[5]) and torch.equal(sl.feat[2], sl.feat[126])     # pool of 4 frame batches
+        assert not torch.equal(sl.feat[1], sl.feat[2])
+    # frame 37 of slice 0 at step 1, encoded alone (different launch geometry, same arithmetic per pixel)
+    sl = w.slices[0]
+    b = sl.feat[1][37].float().reshape(-1)
+    rels = []
+    for pidx in range(w.env.pool_steps):        # which pool batch fed step 1 depends on how many observations preceded
+        alone = sl.enc.forward(w.env.frames[pidx][sl.o + 37:sl.o + 38].contiguous())
+        torch.cuda.synchronize()
+        a = alone[0].float().reshape(-1)
+        rels.append((((a - b).norm() / b.norm()).item(), (a != b).float().mean().item()))
+    best = min(rels)
+    assert best[0] < 2e-3 and best[1] < 1e-3, rels                      # bit-equal up to rare 1-ulp rounding flips
+    assert sorted(rels)[1][0] > 0.01, rels                              # ... and only for the right frame (the others are shifted copies)
+    assert torch.isfinite(w.feat.float()).all() and (w.feat >= 0).all()  # post-ReLU
+
+
+def test_rollout_bookkeeping_is_consistent(worker):
+    w = worker
+    T, N = w.T, w.N
+    assert w.actions.min() >= 0 and w.actions.max() < w.A
+    assert torch.isfinite(w.logp).all() and (w.logp <= 0).all()
+    assert torch.isfinite(w.values).all() and torch.isfinite(w.returns).all()
+    # every action occurs (6 actions, 32768 draws from a near-uniform initial policy)
+    assert torch.bincount(w.actions.reshape(-1), minlength=w.A).min().item() > T * N // 20
+    # GAE identities
+    adv = w.returns[:T] - w.values[:T]
+    assert torch.allclose(adv, w.adv, atol=1e-5)
+    assert abs(w.nadv.mean().item()) < 1e-4 and abs(w.nadv.std(unbiased=True).item() - 1.0) < 1e-3
+    # terminal bootstrap: where the next step is a reset the return does not look past it
+    m1 = w.env.masks[1:T + 1]
+    idx = (m1 == 0)
+    assert torch.allclose(w.returns[:T][idx], w.env.rewards[idx], atol=1e-5)
+
+
+def test_first_epoch_ratio_is_one_and_update_is_bounded(worker):
+    w = worker
+    p0 = w.params.clone()
+    w.update_repeats, saved = 1, w.update_repeats
+    try:
+        w.update()
+        torch.cuda.synchronize()
+    finally:
+        w.update_repeats = saved
+    info = w.loss_info()
+    assert abs(info["ratio"] - 1.0) < 1e-4, info                         # same parameters as the rollout's act steps
+    assert abs(info["action"]) < 1e-3                                    # mean(-ratio * normalised advantage) ~ 0
+    assert 0.0 < info["grad_norm"] < 1e3
+    step = (w.params - p0).abs().max().item()
+    assert 0.0 < step <= 3e-4 * 1.001                                    # Adam's first step: at most lr per parameter
+    # d(loss)/d(logits) rows sum to zero (softmax), checked on the stored per-slice gradient
+    for sl in w.slices:
+        g = sl.dhv[:, :w.A]
+        assert g.sum(dim=1).abs().max().item() < 1e-6 + 1e-4 * g.abs().max().item()
+
+
+def test_adam_with_zero_gradient_is_a_no_op():
+    from embodied_clip_amd.ppo import FlatAdam
+    p = torch.randn(100_003, device="cuda:0")
+    p0 = p.clone()
+    opt = FlatAdam(p, lr=3e-4, max_grad_norm=0.5)
+    for _ in range(3):
+        opt.step(torch.zeros_like(p))
+    torch.cuda.synchronize()
+    assert torch.equal(p, p0)
