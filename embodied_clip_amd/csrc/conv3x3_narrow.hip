@@ -176,6 +176,206 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_narrow_kernel(N3Args p) {
     }
 }
 
+
+// -----------------------------------------------------------------------------------------------------------------
+// Row-tile variant: the activations of a tile go through a WAVE-PRIVATE LDS image instead of being gathered per
+// K-step from global memory.  A wave owns 28 pixels of one image row (POOL: a 2 x 14 block = 7 pooling windows), its
+// input footprint is 3 rows x 30 pixels (4 x 16), i.e. 3-4 contiguous runs that are fetched with coalesced 16-B
+// loads (6-12 load instructions per tile instead of 18-36 gathers that each touch 16-32 cache lines -- the L1-tag
+// bound of the kernel above), prefetched one tile ahead into registers.  The 9 taps then read the image with
+// ds_read_b128 at compile-time offsets; pixel pitches of 80 B / 144 B (+128 B row skew in POOL mode) make every
+// 16-lane read group conflict-free.  28 of 32 MFMA rows are real (12.5 % padding): these layers are not MFMA-bound.
+// -----------------------------------------------------------------------------------------------------------------
+// (Keeping the weight fragments in registers instead of LDS -- 72-144 VGPRs for 32 input channels -- was measured:
+// no gain; the kernel is VALU-issue bound, not LDS bound.)
+template <int CIN, int COUT, bool POOL, int NW>
+__global__ __launch_bounds__(NW * 64, 1) void conv3x3_rows_kernel(N3Args p) {
+    constexpr int KSTEPS = 9 * CIN / 16, CB = CIN / 16, FN = COUT / 32, K = 9 * CIN;
+    constexpr int CPP = CIN / 8;                              // 16-B chunks per pixel
+    constexpr int PITCH = CIN * 2 + 16;                       // bytes per pixel in the LDS image
+    constexpr int RW = POOL ? 16 : 30;                        // pixels per image row of the footprint
+    constexpr int RPB = POOL ? RW * PITCH + 128 : RW * PITCH; // row pitch in bytes
+    constexpr int NR = POOL ? 4 : 3;
+    constexpr int REGION = NR * RPB + 4 * PITCH;              // + overrun of the 4 padding lanes
+    constexpr int NCH = NR * RW * CPP;                        // 16-B chunks of the footprint
+    constexpr int IT = (NCH + 63) / 64;
+    constexpr int W_BYTES = KSTEPS * COUT * 32;
+    constexpr int OP = COUT * 2 + 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    float* sB = reinterpret_cast<float*>(sm + W_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned char* img = sm + W_BYTES + COUT * 4 + wave * REGION;
+    const int px = lane & 31, h = lane >> 5;
+
+    for (int idx = tid; idx < COUT * (K / 8); idx += NW * 64) {
+        const int n = idx / (K / 8), c = idx % (K / 8);
+        const u32x4 v = *reinterpret_cast<const u32x4*>(p.w + (long)n * K + c * 8);
+        *reinterpret_cast<u32x4*>(sm + (c >> 1) * (COUT * 32) + wunit(n, c & 1)) = v;
+    }
+    for (int i = tid; i < COUT; i += NW * 64) sB[i] = p.bias[i];
+    __syncthreads();
+
+    const int GW = gridDim.x * NW;
+    const int lb = (int)ec_xcd_remap(blockIdx.x, gridDim.x);
+    const int nseg = POOL ? p.W / 14 : p.W / 28;
+    const int nrow = POOL ? p.H / 2 : p.H;
+
+    // per-lane footprint geometry (tile-invariant): row / pixel / sub-chunk of the chunks this lane fetches
+    int f_r[IT], f_px[IT], f_lds[IT], f_goff[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int g = i * 64 + lane;
+        const int r = g / (RW * CPP), rem = g - r * (RW * CPP);
+        f_r[i] = (g < NCH) ? r : -100000;                     // invalid chunk: row test fails below
+        f_px[i] = rem / CPP;
+        f_lds[i] = r * RPB + (rem / CPP) * PITCH + (rem % CPP) * 16;
+        f_goff[i] = ((r * p.W + rem / CPP) * CIN + (rem % CPP) * 8) * 2;   // bytes from the footprint's first pixel
+    }
+    // this lane's MFMA-operand base in the image
+    int obase;
+    if (POOL) obase = ((px >> 1) & 1) * RPB + (2 * (px >> 2) + (px & 1)) * PITCH + h * 16;
+    else obase = px * PITCH + h * 16;
+
+    // this lane's 4 x 4 x FN output channels never change: keep their biases in registers and START the accumulators
+    // from them (one v_mov instead of a zero + an LDS read + an add per value)
+    f32x16_t bias_acc[FN];
+#pragma unroll
+    for (int n = 0; n < FN; ++n)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 bv = *reinterpret_cast<const float4*>(sB + 32 * n + 8 * g + 4 * h);
+            bias_acc[n][4 * g + 0] = bv.x; bias_acc[n][4 * g + 1] = bv.y; bias_acc[n][4 * g + 2] = bv.z; bias_acc[n][4 * g + 3] = bv.w;
+        }
+
+    u32x4 nxt[IT];
+    const unsigned char* in_b = reinterpret_cast<const unsigned char*>(p.in);
+    // The tile index is wave-uniform: decode it on the scalar unit (readfirstlane) so that the per-lane work of a
+    // fetch is one add + two unsigned range checks per 16-B chunk (these layers are VALU-issue bound).
+    // tile coordinates (segment, row, frame) are carried incrementally: t advances by a constant stride, so the three
+    // integer divisions per tile become a few scalar adds and compares
+    struct Coord { int sg, rr, b; };
+    auto decode = [&](int t_) {
+        const int t = __builtin_amdgcn_readfirstlane(t_);
+        return Coord{t % nseg, (t / nseg) % nrow, t / (nseg * nrow)};
+    };
+    const Coord step = decode(GW);
+    auto advance = [&](Coord c) {
+        c.sg += step.sg; c.rr += step.rr; c.b += step.b;
+        if (c.sg >= nseg) { c.sg -= nseg; ++c.rr; }
+        if (c.rr >= nrow) { c.rr -= nrow; ++c.b; }
+        return c;
+    };
+    auto fetch = [&](Coord c) {
+        const int sgi = __builtin_amdgcn_readfirstlane(c.sg), rr = __builtin_amdgcn_readfirstlane(c.rr);
+        const int b = __builtin_amdgcn_readfirstlane(c.b);
+        const int y0 = POOL ? 2 * rr - 1 : rr - 1, x0 = (POOL ? 14 : 28) * sgi - 1;
+        const unsigned char* base = in_b + (((long)b * p.H + y0) * p.W + x0) * (CIN * 2);     // scalar (may point before
+                                                                                              // the tensor: masked)
+        [&]<int... I>(std::integer_sequence<int, I...>) {
+            (([&] {
+                 const bool ok = (unsigned)(y0 + f_r[I]) < (unsigned)p.H && (unsigned)(x0 + f_px[I]) < (unsigned)p.W;
+                 const u32x4 z = {0u, 0u, 0u, 0u};
+                 nxt[I] = ok ? *reinterpret_cast<const u32x4*>(base + f_goff[I]) : z;
+             }()),
+             ...);
+        }(std::make_integer_sequence<int, IT>{});
+    };
+
+    int t = lb * NW + wave;
+    if (t >= p.ntiles) return;
+    Coord cn = decode(t);
+    fetch(cn);
+    for (;;) {
+        // registers -> wave-private image (in-order LDS: earlier reads of the previous tile are already done)
+        [&]<int... I>(std::integer_sequence<int, I...>) {
+            (([&] {
+                 if (I * 64 + lane < NCH) *reinterpret_cast<u32x4*>(img + f_lds[I]) = nxt[I];
+             }()),
+             ...);
+        }(std::make_integer_sequence<int, IT>{});
+        const Coord cc = cn;
+        t += GW;
+        const bool more = t < p.ntiles;
+        if (more) { cn = advance(cn); fetch(cn); }
+
+        f32x16_t acc[FN];
+#pragma unroll
+        for (int n = 0; n < FN; ++n) acc[n] = bias_acc[n];
+        [&]<int... S>(std::integer_sequence<int, S...>) {
+            (([&] {
+                 constexpr int tap = S / CB, cb = S % CB, ky = tap / 3, kx = tap % 3;
+                 const s16x8_t av = *reinterpret_cast<const s16x8_t*>(img + obase + ky * RPB + kx * PITCH + cb * 32);
+#pragma unroll
+                 for (int n = 0; n < FN; ++n) {
+                     const s16x8_t wf = *reinterpret_cast<const s16x8_t*>(sm + S * (COUT * 32) + wunit(32 * n + px, h));
+                     acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf),
+                                                                      __builtin_bit_cast(bf16x8_t, av), acc[n], 0, 0, 0);
+                 }
+             }()),
+             ...);
+        }(std::make_integer_sequence<int, KSTEPS>{});
+
+        // epilogue through the (now free) image region
+        unsigned char* stg = img;
+#pragma unroll
+        for (int n = 0; n < FN; ++n)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int lc = 32 * n + 8 * g + 4 * h;
+                float v0 = fmaxf(acc[n][4 * g + 0], 0.f), v1 = fmaxf(acc[n][4 * g + 1], 0.f);
+                float v2 = fmaxf(acc[n][4 * g + 2], 0.f), v3 = fmaxf(acc[n][4 * g + 3], 0.f);
+                if (POOL) {
+                    v0 += dppq_xor1(v0); v1 += dppq_xor1(v1); v2 += dppq_xor1(v2); v3 += dppq_xor1(v3);
+                    v0 += dppq_xor2(v0); v1 += dppq_xor2(v1); v2 += dppq_xor2(v2); v3 += dppq_xor2(v3);
+                    if ((lane & 3) == 0) {
+                        uint2 o;
+                        o.x = ec_pack2(0.25f * v0, 0.25f * v1);
+                        o.y = ec_pack2(0.25f * v2, 0.25f * v3);
+                        *reinterpret_cast<uint2*>(stg + (px >> 2) * OP + lc * 2) = o;
+                    }
+                } else {
+                    uint2 o;
+                    o.x = ec_pack2(v0, v1);
+                    o.y = ec_pack2(v2, v3);
+                    *reinterpret_cast<uint2*>(stg + px * OP + lc * 2) = o;
+                }
+            }
+        {
+            const int sgi = __builtin_amdgcn_readfirstlane(cc.sg), rr = __builtin_amdgcn_readfirstlane(cc.rr);
+            const int b = __builtin_amdgcn_readfirstlane(cc.b);
+            constexpr int ORows = POOL ? 7 : 28, ZC = COUT / 8;
+            const long opix = POOL ? ((long)b * (p.H / 2) + rr) * (p.W / 2) + 7 * sgi : ((long)b * p.H + rr) * p.W + 28 * sgi;
+#pragma unroll
+            for (int i = 0; i < (ORows * ZC + 63) / 64; ++i) {
+                const int idx = i * 64 + lane;
+                if (idx < ORows * ZC) {
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(stg + (idx / ZC) * OP + (idx % ZC) * 16);
+                    *reinterpret_cast<u32x4*>(p.out + (opix + idx / ZC) * COUT + (idx % ZC) * 8) = v;
+                }
+            }
+        }
+        if (!more) break;
+    }
+}
+
+template <int CIN, int COUT, bool POOL, int NW>
+int launch_rows(const N3Args& p, hipStream_t s) {
+    constexpr int PITCH = CIN * 2 + 16, RW = POOL ? 16 : 30, RPB = POOL ? RW * PITCH + 128 : RW * PITCH, NR = POOL ? 4 : 3;
+    constexpr size_t lds = (size_t)(9 * CIN / 16) * COUT * 32 + COUT * 4 + (size_t)NW * (NR * RPB + 4 * PITCH);
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    static_assert((NR * RPB + 4 * PITCH) % 16 == 0, "image alignment");
+    auto kern = conv3x3_rows_kernel<CIN, COUT, POOL, NW>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int wgs = (p.ntiles + NW - 1) / NW < 256 ? (p.ntiles + NW - 1) / NW : 256;
+    hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(NW * 64), lds, s, p);
+    EC_CHECK_LAUNCH();
+    return EC_OK;
+}
+
 template <int CIN, int COUT, bool POOL, int NW = 16>
 int launch_n3(const N3Args& p, hipStream_t s) {
     constexpr size_t lds = (size_t)(9 * CIN / 16) * COUT * 32 + COUT * 4 + NW * (size_t)((POOL ? PX / 4 : PX) * (COUT * 2 + 16));
@@ -197,18 +397,31 @@ int launch_n3(const N3Args& p, hipStream_t s) {
 // Returns EC_OK when it ran, EC_ERR_SHAPE when the shape is not one it handles (the caller then uses conv_igemm).
 int ec_conv3x3_narrow(const void* in, const void* w, const float* bias, void* out, int B, int H, int W, int Cin, int Cout,
                       int pool, hipStream_t s) {
-    static const bool on = [] { const char* e = getenv("EC_CONV_NARROW"); return !e || atoi(e) != 0; }();
+    // EC_CONV_NARROW: 0 off; 1 gather kernel only; 2 gather kernel also for Cin = 64; 3 (default) row-tile kernel
+    // where the image width allows (W % 28 == 0, POOL: W % 14 == 0), gather kernel for the other 32-channel layers
+    static const int mode = [] { const char* e = getenv("EC_CONV_NARROW"); return e ? atoi(e) : 3; }();
     const long M = (long)B * H * W;
-    if (!on || !bias || (M % PX) != 0 || M / PX > 0x7fffffffL || (pool && ((H | W) & 1))) return EC_ERR_SHAPE;
+    if (!mode || !bias || (pool && ((H | W) & 1))) return EC_ERR_SHAPE;
+    if (mode >= 3) {
+        const bool fits = pool ? (W % 14 == 0) : (W % 28 == 0);
+        const long nt = pool ? (long)B * (H / 2) * (W / 14) : (long)B * H * (W / 28);
+        if (fits && nt <= 0x7fffffffL) {
+            N3Args p{(const uint16_t*)in, (const uint16_t*)w, bias, (uint16_t*)out, H, W, (int)nt};
+            if (Cin == 32 && Cout == 32 && !pool) return launch_rows<32, 32, false, 16>(p, s);
+            if (Cin == 32 && Cout == 64 && pool) return launch_rows<32, 64, true, 16>(p, s);
+            if (Cin == 32 && Cout == 64 && !pool) return launch_rows<32, 64, false, 16>(p, s);
+            if (Cin == 64 && Cout == 64 && !pool) return launch_rows<64, 64, false, 6>(p, s);
+            if (Cin == 64 && Cout == 64 && pool) return launch_rows<64, 64, true, 8>(p, s);
+        }
+    }
+    if ((M % PX) != 0 || M / PX > 0x7fffffffL) return EC_ERR_SHAPE;
     N3Args p{(const uint16_t*)in, (const uint16_t*)w, bias, (uint16_t*)out, H, W, (int)(M / PX)};
     if (Cin == 32 && Cout == 32 && !pool) return launch_n3<32, 32, false>(p, s);
     if (Cin == 32 && Cout == 64 && pool) return launch_n3<32, 64, true>(p, s);
     if (Cin == 32 && Cout == 64 && !pool) return launch_n3<32, 64, false>(p, s);
-    // Cin = 64 (layer-1 conv2) stays on conv_igemm: with one 128-B cache line per pixel the direct operand fetch
-    // touches 32 lines per load instruction and becomes L1-tag bound (measured 157 us vs 106 us at B = 256); the
-    // instantiation is kept for EC_CONV_NARROW=2 experiments.
-    static const bool all = [] { const char* e = getenv("EC_CONV_NARROW"); return e && atoi(e) == 2; }();
-    if (all && Cin == 64 && Cout == 64 && !pool) return launch_n3<64, 64, false>(p, s);
-    if (all && Cin == 64 && Cout == 64 && pool) return launch_n3<64, 64, true>(p, s);
+    // Cin = 64 on the gather kernel: one 128-B cache line per pixel -> 32 lines per load instruction, L1-tag bound
+    // (measured 157 us vs 106 us for conv_igemm at B = 256); kept for EC_CONV_NARROW=2 experiments only.
+    if (mode == 2 && Cin == 64 && Cout == 64 && !pool) return launch_n3<64, 64, false>(p, s);
+    if (mode == 2 && Cin == 64 && Cout == 64 && pool) return launch_n3<64, 64, true>(p, s);
     return EC_ERR_SHAPE;
 }

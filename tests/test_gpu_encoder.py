@@ -70,6 +70,13 @@ def _conv_case(dev, B, H, W, Cin, Cout, ks, pool, res, act, seed):
     (4, 16, 8, 32, 32, 3, False, False, 1),      # non-square
     (1, 4, 8, 64, 64, 3, False, False, 1),       # a single 32-pixel tile
     (3, 20, 20, 32, 64, 3, True, False, 1),      # M = 1200 is not a multiple of 32 -> falls back to conv_igemm
+    # row-tile kernel (W % 28 == 0 / POOL: W % 14 == 0): image borders, several segments per row, several frames
+    (2, 6, 28, 32, 32, 3, False, False, 1),
+    (3, 5, 56, 32, 64, 3, False, False, 1),
+    (2, 8, 28, 32, 64, 3, True, False, 1),
+    (1, 4, 14, 32, 64, 3, True, False, 1),
+    (2, 7, 56, 64, 64, 3, False, False, 1),
+    (3, 6, 28, 64, 64, 3, True, False, 1),
     # 256 frames of 14x14: 512 padded (196-of-224-row) tiles -> the quantisation-friendly tile config of conv_igemm
     (256, 14, 14, 1024, 256, 1, False, False, 1),
     (256, 14, 14, 128, 256, 3, False, False, 1),

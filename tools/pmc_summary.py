@@ -12,7 +12,7 @@ for p in sorted(os.listdir(root)):
         d = int(r['Dispatch_Id'])
         disp.setdefault(d, {'name': r['Kernel_Name'], 'grid': int(r['Grid_Size']) // max(1, int(r['Workgroup_Size']))})
         disp[d][r['Counter_Name']] = float(r['Counter_Value'])
-    ids = [d for d in disp if any(k in disp[d]['name'] for k in ('conv_igemm', 'stem', 'avgpool', 'conv1x1_pair', 'conv3x3_narrow'))]
+    ids = [d for d in disp if any(k in disp[d]['name'] for k in ('conv_igemm', 'stem', 'avgpool', 'conv1x1_pair', 'conv3x3_narrow', 'conv3x3_rows'))]
     ids = ids[-n_last:]
     for i, d in enumerate(ids):
         per.setdefault(i, {}).update(disp[d])
