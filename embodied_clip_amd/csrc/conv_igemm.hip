@@ -67,7 +67,6 @@ struct ConvArgs {
     int ntiles; // total output tiles
     int nbuf;  // LDS stages: 2 (double buffer) or 1
     unsigned in_bytes, w_bytes;   // buffer-descriptor extents (out-of-range loads return 0)
-    int skew;                     // start-skew range in units of 256 cycles (0 = off)
     int ablate;                   // profiling only (EC_CONV_ABLATE): 1 no global loads, 2 no MFMA, 4 no LDS stores, 8 no epilogue
 };
 
@@ -225,7 +224,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM > 192) ? 2 : ((WM * WN == 8) ? 4 
     const int nk = (p.K + BK - 1) / BK;
     const int frow = lane & 31;
     const int fhalf = lane >> 5;
-    auto compute = [&](int buf, bool issue_next) {
+    auto compute = [&](int buf) {
         const unsigned char* sa = smem + buf * (A_BYTES + B_BYTES);
         const unsigned char* sb = sa + A_BYTES;
         // SWAPPED operands: D[n][m] = sum_k W[n][k] * A[m][k].  In the 32x32 C/D layout a lane then owns
@@ -248,7 +247,6 @@ __global__ __launch_bounds__(WM * WN * 64, (BM > 192) ? 2 : ((WM * WN == 8) ? 4 
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                         __builtin_bit_cast(bf16x8_t, bfr[j]), __builtin_bit_cast(bf16x8_t, af[i]), acc[i][j], 0, 0, 0);
         }
-        (void)issue_next;
     };
 
     // K pipeline: LDS-DMA of tile t+1 into LDS[(t+1)&1] is in flight while tile t computes from LDS[t&1];
@@ -278,7 +276,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM > 192) ? 2 : ((WM * WN == 8) ? 4 
             // single LDS stage, two barriers per K-tile: smallest footprint (3 workgroups per CU); the load
             // latency of one workgroup is covered by the MFMAs of the other two
             for (int kt = 0; kt < nk; ++kt) {
-                if (!(p.ablate & 2)) compute(0, false);
+                if (!(p.ablate & 2)) compute(0);
                 if (kt + 1 < nk) {
                     __syncthreads();
                     if (!(p.ablate & 1)) glds_tile(kt + 1, 0);
@@ -290,7 +288,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM > 192) ? 2 : ((WM * WN == 8) ? 4 
                 const int cur = kt & 1;
                 const bool more = (kt + 1) < nk;
                 if (more && !(p.ablate & 1)) glds_tile(kt + 1, cur ^ 1);
-                if (!(p.ablate & 2)) compute(cur, false);
+                if (!(p.ablate & 2)) compute(cur);
                 __syncthreads();
             }
         }
@@ -393,8 +391,6 @@ int launch(const ConvArgs& a, hipStream_t s) {
     p.nbuf = nbuf_force ? nbuf_force : 1;
     static const int ablate = [] { const char* e = getenv("EC_CONV_ABLATE"); return e ? atoi(e) : 0; }();
     p.ablate = ablate;
-    static const int skew = [] { const char* e = getenv("EC_CONV_SKEW"); return e ? atoi(e) : 0; }();
-    p.skew = skew;
     size_t lds = (size_t)p.nbuf * (BM + BN) * ROW_BYTES;   // (set after nbuf below)
     if (lds < epi) lds = epi;
     auto kern = conv_igemm_kernel<BM, BN, WM, WN, KS, POOL, PF, MV>;
