@@ -105,7 +105,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--actors", type=int, default=256, help="synthetic actors per GPU")
+    ap.add_argument("--actors", type=int, default=256, help="synthetic actors per GPU (weak) / in total (strong)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default, DD-PPO convention): --actors per GPU; strong: --actors in total, sharded")
     ap.add_argument("--rollout", type=int, default=128)
     ap.add_argument("--update-repeats", type=int, default=4)
     ap.add_argument("--encoder-chunk", type=int, default=0)
@@ -136,6 +138,10 @@ def main():
         torch.distributed.init_process_group("nccl", rank=rank, world_size=world)   # RCCL over xGMI
 
     from embodied_clip_amd.engine import Worker
+    if a.scaling == "strong":          # the same global actor list sharded over the ranks (N/G each)
+        if a.actors % world != 0:
+            raise SystemExit(f"--scaling strong needs --actors ({a.actors}) divisible by the world size ({world})")
+        a.actors //= world
     w = Worker(a.actors, T=a.rollout, device=dev, seed=0, rank=rank, world=world, update_repeats=a.update_repeats,
                encoder_chunk=a.encoder_chunk, encoder=a.encoder, encoder_streams=a.encoder_streams,
                frames_u8=a.frames_u8)
@@ -194,7 +200,7 @@ def main():
         out = {
             "metric": "env-frames/sec (CLIP encode + policy fwd/bwd + PPO update)",
             "value": round(value, 1), "unit": "env-frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": a.scaling,
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": ("RoboTHOR ObjectNav: frozen CLIP-RN50 encoder" if a.encoder == "rn50" else
                                     "RoboTHOR ObjectNav: frozen CLIP ViT-B/32 encoder (11 blocks)") +
