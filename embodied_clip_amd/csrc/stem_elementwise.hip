@@ -20,6 +20,7 @@ namespace {
 constexpr int ST = 16;                 // output tile edge
 constexpr int SP = 2 * ST + 1;         // input patch edge (33)
 constexpr int SROW = SP * 3;           // floats per patch row (99)
+constexpr int SROW4 = 104;             // vectorised staging: rows start one float early (16-B aligned) and span 26 float4
 
 // U8: the frame is the raw uint8 HWC image; ToTensor (/255) and Normalize(mean, std) of the reference's
 // `clip_preprocess` (thor_image_features.py:108; constants CLIP_RGB_MEANS/STDS of the plugin) are applied while the
@@ -29,7 +30,10 @@ __global__ __launch_bounds__(256) void stem_conv1_kernel(const void* __restrict_
                                                          const float* __restrict__ bias, uint16_t* __restrict__ out,
                                                          int H, int W, int Ho, int Wo, int tiles_x, int tiles_y,
                                                          float3 nscale, float3 nshift) {
-    __shared__ float patch[SP * SROW + 1];
+    // Staging: the patch rows are fetched as 26 aligned 4-element vectors per row (the row origin 6*ox0 - 4 is a
+    // multiple of 4 and W*3 is a multiple of 4 when W % 4 == 0, so a vector is entirely inside or outside the frame)
+    // -- 4 wide loads per thread instead of 13 scalar ones with a div/mod each (the kernel is VALU-issue bound).
+    __shared__ __attribute__((aligned(16))) float patch[SP * SROW4];
     int bid = blockIdx.x;
     const int tx = bid % tiles_x; bid /= tiles_x;
     const int ty = bid % tiles_y;
@@ -37,23 +41,49 @@ __global__ __launch_bounds__(256) void stem_conv1_kernel(const void* __restrict_
     const int oy0 = ty * ST, ox0 = tx * ST;
     const int iy0 = 2 * oy0 - 1, ix0 = 2 * ox0 - 1;
     const long img_off = (long)b * H * W * 3;
-    for (int e = threadIdx.x; e < SP * SROW; e += 256) {
-        const int r = e / SROW, c = e - r * SROW;
-        const int iy = iy0 + r;
-        const int ixc = ix0 * 3 + c;   // element index within the image row
-        float v = 0.f;
-        if (iy >= 0 && iy < H && ixc >= 0 && ixc < W * 3) {
-            const long idx = img_off + (long)iy * W * 3 + ixc;
-            if (U8) {
-                const int ch = ((ixc % 3) + 3) % 3;
-                const float sc = ch == 0 ? nscale.x : (ch == 1 ? nscale.y : nscale.z);
-                const float sh = ch == 0 ? nshift.x : (ch == 1 ? nshift.y : nshift.z);
-                v = (float)reinterpret_cast<const unsigned char*>(rgb_)[idx] * sc + sh;
-            } else {
-                v = reinterpret_cast<const float*>(rgb_)[idx];
+    const int c0 = ix0 * 3 - 1;            // first staged element of a row (multiple of 4)
+    const bool vec = (W & 3) == 0;
+    if (vec) {
+        for (int e = threadIdx.x; e < SP * 26; e += 256) {
+            const int r = e / 26, q = e - r * 26;
+            const int iy = iy0 + r, col = c0 + 4 * q;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (iy >= 0 && iy < H && col >= 0 && col < W * 3) {
+                const long idx = img_off + (long)iy * W * 3 + col;
+                if (U8) {
+                    const unsigned u = *reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned char*>(rgb_) + idx);
+                    const int ch0 = col % 3;     // channel of element 0 (col >= 0 here)
+                    const float sc[3] = {nscale.x, nscale.y, nscale.z}, sh[3] = {nshift.x, nshift.y, nshift.z};
+                    const int c1 = ch0 == 2 ? 0 : ch0 + 1, c2 = c1 == 2 ? 0 : c1 + 1;
+                    v.x = (float)(u & 0xffu) * sc[ch0] + sh[ch0];
+                    v.y = (float)((u >> 8) & 0xffu) * sc[c1] + sh[c1];
+                    v.z = (float)((u >> 16) & 0xffu) * sc[c2] + sh[c2];
+                    v.w = (float)(u >> 24) * sc[ch0] + sh[ch0];
+                } else {
+                    v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(rgb_) + idx);
+                }
             }
+            *reinterpret_cast<float4*>(patch + r * SROW4 + 4 * q) = v;
         }
-        patch[e] = v;
+    } else {
+        for (int e = threadIdx.x; e < SP * SROW; e += 256) {
+            const int r = e / SROW, c = e - r * SROW;
+            const int iy = iy0 + r;
+            const int ixc = ix0 * 3 + c;   // element index within the image row
+            float v = 0.f;
+            if (iy >= 0 && iy < H && ixc >= 0 && ixc < W * 3) {
+                const long idx = img_off + (long)iy * W * 3 + ixc;
+                if (U8) {
+                    const int ch = ixc % 3;
+                    const float sc = ch == 0 ? nscale.x : (ch == 1 ? nscale.y : nscale.z);
+                    const float sh = ch == 0 ? nshift.x : (ch == 1 ? nshift.y : nshift.z);
+                    v = (float)reinterpret_cast<const unsigned char*>(rgb_)[idx] * sc + sh;
+                } else {
+                    v = reinterpret_cast<const float*>(rgb_)[idx];
+                }
+            }
+            patch[r * SROW4 + c + 1] = v;  // same image as the vector path: element c sits at column c + 1
+        }
     }
     __syncthreads();
     const int ly = threadIdx.x / ST, lx = threadIdx.x % ST;
@@ -69,7 +99,7 @@ __global__ __launch_bounds__(256) void stem_conv1_kernel(const void* __restrict_
         for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
             for (int ci = 0; ci < 3; ++ci) {
-                const float v = patch[(2 * ly + ky) * SROW + (2 * lx + kx) * 3 + ci];
+                const float v = patch[(2 * ly + ky) * SROW4 + (2 * lx + kx) * 3 + ci + 1];
                 const f32x2 v2 = {v, v};
                 const f32x2* wr = reinterpret_cast<const f32x2*>(w + ((ky * 3 + kx) * 3 + ci) * COUT);
 #pragma unroll
