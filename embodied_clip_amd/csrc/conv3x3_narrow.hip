@@ -41,6 +41,9 @@ __device__ __forceinline__ float dppq_xor1(float v) {
 __device__ __forceinline__ float dppq_xor2(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
 }
+// ReLU as ONE instruction: v_med3_f32(x, 0, +inf).  (fmaxf costs a canonicalising v_max first; an inline-asm
+// v_max_f32 is NOT safe here -- the hazard recogniser does not see that it reads an MFMA result.)
+__device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, __builtin_inff()); }
 // 16-B unit of weight row n, half hh inside a K-step block of COUT x 32 B
 __device__ __forceinline__ int wunit(int n, int hh) { return ((2 * n + hh) ^ ((n >> 3) & 1)) << 4; }
 
@@ -249,6 +252,7 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_rows_kernel(N3Args p) {
 
     u32x4 nxt[IT];
     const unsigned char* in_b = reinterpret_cast<const unsigned char*>(p.in);
+    const unsigned char* zp = reinterpret_cast<const unsigned char*>(ec_zero_page3);
     // The tile index is wave-uniform: decode it on the scalar unit (readfirstlane) so that the per-lane work of a
     // fetch is one add + two unsigned range checks per 16-B chunk (these layers are VALU-issue bound).
     // tile coordinates (segment, row, frame) are carried incrementally: t advances by a constant stride, so the three
@@ -274,8 +278,7 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_rows_kernel(N3Args p) {
         [&]<int... I>(std::integer_sequence<int, I...>) {
             (([&] {
                  const bool ok = (unsigned)(y0 + f_r[I]) < (unsigned)p.H && (unsigned)(x0 + f_px[I]) < (unsigned)p.W;
-                 const u32x4 z = {0u, 0u, 0u, 0u};
-                 nxt[I] = ok ? *reinterpret_cast<const u32x4*>(base + f_goff[I]) : z;
+                 nxt[I] = *reinterpret_cast<const u32x4*>(ok ? base + f_goff[I] : zp);   // padding reads a zero page
              }()),
              ...);
         }(std::make_integer_sequence<int, IT>{});
@@ -299,8 +302,6 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_rows_kernel(N3Args p) {
         if (more) { cn = advance(cn); fetch(cn); }
 
         f32x16_t acc[FN];
-#pragma unroll
-        for (int n = 0; n < FN; ++n) acc[n] = bias_acc[n];
         [&]<int... S>(std::integer_sequence<int, S...>) {
             (([&] {
                  constexpr int tap = S / CB, cb = S % CB, ky = tap / 3, kx = tap % 3;
@@ -308,8 +309,10 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_rows_kernel(N3Args p) {
 #pragma unroll
                  for (int n = 0; n < FN; ++n) {
                      const s16x8_t wf = *reinterpret_cast<const s16x8_t*>(sm + S * (COUT * 32) + wunit(32 * n + px, h));
+                     // the first K-step takes the bias registers as its C operand: no accumulator init at all
                      acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf),
-                                                                      __builtin_bit_cast(bf16x8_t, av), acc[n], 0, 0, 0);
+                                                                      __builtin_bit_cast(bf16x8_t, av),
+                                                                      S == 0 ? bias_acc[n] : acc[n], 0, 0, 0);
                  }
              }()),
              ...);
@@ -322,8 +325,8 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_rows_kernel(N3Args p) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int lc = 32 * n + 8 * g + 4 * h;
-                float v0 = fmaxf(acc[n][4 * g + 0], 0.f), v1 = fmaxf(acc[n][4 * g + 1], 0.f);
-                float v2 = fmaxf(acc[n][4 * g + 2], 0.f), v3 = fmaxf(acc[n][4 * g + 3], 0.f);
+                float v0 = relu1(acc[n][4 * g + 0]), v1 = relu1(acc[n][4 * g + 1]);
+                float v2 = relu1(acc[n][4 * g + 2]), v3 = relu1(acc[n][4 * g + 3]);
                 if (POOL) {
                     v0 += dppq_xor1(v0); v1 += dppq_xor1(v1); v2 += dppq_xor1(v2); v3 += dppq_xor1(v3);
                     v0 += dppq_xor2(v0); v1 += dppq_xor2(v1); v2 += dppq_xor2(v2); v3 += dppq_xor2(v3);
