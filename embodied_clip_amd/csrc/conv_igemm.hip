@@ -34,14 +34,14 @@
 // q the pooled raster index, so the four pixels of a pooling window are the four lanes of a quad; the pool
 // is two DPP quad-permute adds after bias+ReLU -- the full-resolution output never touches HBM.
 //
-// What the round-1 measurements say (profiles/): the compute-bound layers plateau at
-// ~570-660 TFLOP/s.  Ablation of one such layer (3x3 256->256 @14x14, B=256): MFMA-only 33 us (81 % of the
-// pipe at the sustained clock), operand loads-only 42 us (~21 TB/s L2->LDS), both together ~100 us, i.e.
-// the two phases barely overlap.  Tried without effect on that sum: loads two tiles ahead (second register
-// set), double vs single LDS stage, fat 128x256 / 256x128 tiles, 8-wave workgroups, all-fragments-up-front
-// MFMA scheduling, interleaving the LDS-DMA pieces between MFMA groups, start skew between co-resident
-// workgroups, persistent tiles with next-tile prefetch.  Next: cut the L2->LDS bytes per flop (halo reuse
-// for 3x3, 256-row tiles) and a wave-specialised (loader / MFMA) pipeline.
+// What the round-1 measurements say (profiles/): with many tiles per launch the kernel runs
+// at 760-850 TFLOP/s; the mid-size layers sit at 570-680 because of (a) the L2->LDS operand feed (3x3 256->256
+// @14x14, B=256: MFMA alone 33 us, operand loads alone 42 us, together ~the sum) and (b) tile quantisation (784 tiles
+// on 768 workgroups cost 98 us where 766 tiles cost 72 us).  (b) is what the 196-of-224-row tile configuration
+// (template parameter MV, see dispatch_tile) removes for single 256-frame launches.  Measured without effect:
+// loads two tiles ahead, double vs single LDS stage, fat 128x256 / 256x128 tiles, 8-wave workgroups,
+// all-fragments-up-front MFMA scheduling, LDS-DMA pieces interleaved between MFMA groups, start skew between
+// co-resident workgroups, wave specialisation, a split-K tail reduced by the last arriver, 64-row tiles.
 #include <stdlib.h>
 
 #include <type_traits>
