@@ -41,6 +41,7 @@ SIGNATURES = {
     "ec_probe_head": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                               c_void_p, c_void_p]),
     "ec_probe_pool3": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "ec_conv1x1_pair_pool_bf16": (c_int, [c_void_p] * 9 + [c_int] * 6 + [c_void_p]),
     "ec_conv1x1_pair_bf16": (c_int, [c_void_p] * 11 + [C.c_long, c_int, c_int, c_int, c_void_p]),
     "ec_stem_conv1_u8": (c_int, [c_void_p, C.POINTER(c_float), C.POINTER(c_float), c_void_p, c_void_p, c_void_p]
                          + [c_int] * 4 + [c_void_p]),

@@ -39,14 +39,28 @@ struct PairArgs {
     const float *b0, *b1, *b2;
     uint16_t *y, *z;
     int ntiles;
+    uint16_t* yp;   // PL: AvgPool2d(2) of y, [B, H/2, W/2, 256]
+    int H, W;       // PL: frame geometry (tiles are 4 x 8 pixel blocks = 8 pooling windows)
 };
+
+__device__ __forceinline__ float pq_xor1(float v) {   // lane ^ 1 within a quad
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float pq_xor2(float v) {   // lane ^ 2 within a quad
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+}
 
 __device__ __forceinline__ int pw_off(int row, int chunk) {   // 128-B rows, XOR swizzle on the 16-B chunk
     return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
 
-template <bool TWO, bool RES, int N2>
+// PL: the tile is a 4 x 8 block of pixels in quad order (row r of the tile = window (r >> 2), corner r & 3), so a 2 x 2
+// pooling window is one lane quad and the kernel also emits AvgPool2d(2)(y) -- the input of the next layer's
+// downsample path -- instead of a separate pooling pass over y.
+template <bool TWO, bool RES, int N2, bool PL>
 __global__ __launch_bounds__(256, 1) void conv1x1_pair_kernel(PairArgs p) {
+    static_assert(!PL || N2 == 128, "pooled variant: the layer-1 -> layer-2 boundary");
+    constexpr int PP = NY * 2 + 16;            // pooled staging pitch
     constexpr int W0_BYTES = (TWO ? 2 : 1) * NY * 128;
     constexpr int W2_BYTES = 4 * N2 * 128;
     constexpr int FN2 = N2 / 32;
@@ -57,7 +71,24 @@ __global__ __launch_bounds__(256, 1) void conv1x1_pair_kernel(PairArgs p) {
     float* sBz = sBy + NY;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     unsigned char* stg = sm + W0_BYTES + W2_BYTES + (NY + N2) * 4 + wave * STG;
+    unsigned char* pstg = sm + W0_BYTES + W2_BYTES + (NY + N2) * 4 + 4 * STG + wave * (8 * PP);   // PL only
     const int px = lane & 31, h = lane >> 5;
+    // tile row r -> pixel offset from the tile's first pixel
+    auto roff = [&](int r) -> int {
+        if (!PL) return r;
+        return (2 * (r >> 4) + ((r >> 1) & 1)) * p.W + 2 * ((r >> 2) & 3) + (r & 1);
+    };
+    const int roff_px = roff(px);
+    int rrow[8];                               // rows touched by the coalesced 16-lanes-per-row accesses
+#pragma unroll
+    for (int j = 0; j < 8; ++j) rrow[j] = roff(4 * j + (lane >> 4));
+    auto tile_base = [&](int tile) -> long {   // first pixel of the tile (wave-uniform)
+        if (!PL) return (long)tile * PX;
+        const int t = __builtin_amdgcn_readfirstlane(tile);
+        const int tpr = p.W / 8, tpi = (p.H / 4) * tpr;
+        const int b = t / tpi, rem = t - b * tpi, ty = rem / tpr, tx = rem - ty * tpr;
+        return ((long)b * p.H + 4 * ty) * p.W + 8 * tx;
+    };
 
     // ---- prologue: weights -> LDS (once per workgroup) ----
     for (int idx = tid; idx < (TWO ? 2 : 1) * NY * 8; idx += 256) {
@@ -86,15 +117,15 @@ __global__ __launch_bounds__(256, 1) void conv1x1_pair_kernel(PairArgs p) {
     // ---- register prefetch of the next tile ----
     u32x4 a0n[4], a1n[TWO ? 4 : 1], rn[RES ? 16 : 1];
     auto prefetch = [&](int tile) {
-        const long m0 = (long)tile * PX;
+        const long m0 = tile_base(tile);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            a0n[ks] = *reinterpret_cast<const u32x4*>(p.a0 + (m0 + px) * KA + (2 * ks + h) * 8);
-            if (TWO) a1n[ks] = *reinterpret_cast<const u32x4*>(p.a1 + (m0 + px) * KA + (2 * ks + h) * 8);
+            a0n[ks] = *reinterpret_cast<const u32x4*>(p.a0 + (m0 + roff_px) * KA + (2 * ks + h) * 8);
+            if (TWO) a1n[ks] = *reinterpret_cast<const u32x4*>(p.a1 + (m0 + roff_px) * KA + (2 * ks + h) * 8);
         }
         if constexpr (RES) {   // fold over compile-time indices: keeps the array in registers (a runtime-indexed loop lands in scratch)
             [&]<int... I>(std::integer_sequence<int, I...>) {
-                ((rn[I] = *reinterpret_cast<const u32x4*>(p.res + (m0 + (((I & 7) * 64 + lane) >> 4)) * NY + (I >> 3) * 128 +
+                ((rn[I] = *reinterpret_cast<const u32x4*>(p.res + (m0 + rrow[I & 7]) * NY + (I >> 3) * 128 +
                                                           (((I & 7) * 64 + lane) & 15) * 8)), ...);
             }(std::make_integer_sequence<int, 16>{});
         }
@@ -102,7 +133,7 @@ __global__ __launch_bounds__(256, 1) void conv1x1_pair_kernel(PairArgs p) {
     prefetch(t);
 
     for (;;) {
-        const long m0 = (long)t * PX;
+        const long m0 = tile_base(t);
         u32x4 a0c[4], a1c[TWO ? 4 : 1], rc[RES ? 16 : 1];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) { a0c[ks] = a0n[ks]; if (TWO) a1c[ks] = a1n[ks]; }
@@ -167,6 +198,17 @@ __global__ __launch_bounds__(256, 1) void conv1x1_pair_kernel(PairArgs p) {
                     o.y = ec_pack2(v2, v3);
                     *slot = o;
                     pk[2 * g] = o.x; pk[2 * g + 1] = o.y;
+                    if constexpr (PL) {   // mean of the ROUNDED bf16 values of the window, as avgpool2 on y would compute
+                        float q0 = ec_lo(o.x), q1 = ec_hi(o.x), q2 = ec_lo(o.y), q3 = ec_hi(o.y);
+                        q0 += pq_xor1(q0); q1 += pq_xor1(q1); q2 += pq_xor1(q2); q3 += pq_xor1(q3);
+                        q0 += pq_xor2(q0); q1 += pq_xor2(q1); q2 += pq_xor2(q2); q3 += pq_xor2(q3);
+                        if ((lane & 3) == 0) {
+                            uint2 po;
+                            po.x = ec_pack2(0.25f * q0, 0.25f * q1);
+                            po.y = ec_pack2(0.25f * q2, 0.25f * q3);
+                            *reinterpret_cast<uint2*>(pstg + (px >> 2) * PP + (hf * 128 + lc) * 2) = po;
+                        }
+                    }
                 }
                 P[j][0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
                 P[j][1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
@@ -175,11 +217,23 @@ __global__ __launch_bounds__(256, 1) void conv1x1_pair_kernel(PairArgs p) {
             for (int i = 0; i < 8; ++i) {
                 const int idx = i * 64 + lane;
                 const uint4 v = *reinterpret_cast<const uint4*>(stg + (idx >> 4) * SP + (idx & 15) * 16);
-                __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(p.y + (m0 + (idx >> 4)) * NY + hf * 128 + (idx & 15) * 8));
+                __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(p.y + (m0 + rrow[i]) * NY + hf * 128 + (idx & 15) * 8));
             }
         };
         half_epilogue(std::integral_constant<int, 0>{});
         half_epilogue(std::integral_constant<int, 1>{});
+        if constexpr (PL) {   // 8 pooled pixels x 256 channels leave as 16-B row chunks
+            const int tt = __builtin_amdgcn_readfirstlane(t);
+            const int tpr = p.W / 8, tpi = (p.H / 4) * tpr;
+            const int b = tt / tpi, rem = tt - b * tpi, ty = rem / tpr, tx = rem - ty * tpr;
+            const long pb = ((long)b * (p.H / 2) + 2 * ty) * (p.W / 2) + 4 * tx;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = i * 64 + lane, prow = idx >> 5, c = idx & 31;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(pstg + prow * PP + c * 16);
+                *reinterpret_cast<u32x4*>(p.yp + (pb + (prow >> 2) * (p.W / 2) + (prow & 3)) * NY + c * 8) = v;
+            }
+        }
 
         // ---- GEMM 2, pixel operand straight from registers: z[n][pixel] ----
         f32x16_t acc2[FN2];
@@ -214,18 +268,19 @@ __global__ __launch_bounds__(256, 1) void conv1x1_pair_kernel(PairArgs p) {
         for (int i = 0; i < PX * ZC / 64; ++i) {
             const int idx = i * 64 + lane;
             const uint4 v = *reinterpret_cast<const uint4*>(stg + (idx / ZC) * ZP + (idx % ZC) * 16);
-            __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(p.z + (m0 + idx / ZC) * N2 + (idx % ZC) * 8));
+            __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(p.z + (m0 + (PL ? rrow[i] : idx / ZC)) * N2 + (idx % ZC) * 8));
         }
         if (!more) break;
         t = tn;
     }
 }
 
-template <bool TWO, bool RES, int N2>
+template <bool TWO, bool RES, int N2, bool PL = false>
 int launch_pair(const PairArgs& p, hipStream_t s) {
-    constexpr size_t lds = (size_t)(TWO ? 2 : 1) * NY * 128 + 4 * N2 * 128 + (NY + N2) * 4 + 4 * STG;
+    constexpr size_t lds = (size_t)(TWO ? 2 : 1) * NY * 128 + 4 * N2 * 128 + (NY + N2) * 4 + 4 * STG +
+                           (PL ? 4 * 8 * (NY * 2 + 16) : 0);
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kern = conv1x1_pair_kernel<TWO, RES, N2>;
+    auto kern = conv1x1_pair_kernel<TWO, RES, N2, PL>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -246,7 +301,7 @@ extern "C" int ec_conv1x1_pair_bf16(const void* a0, const void* w0, const float*
     if ((a1 != nullptr) != (w1 != nullptr) || (a1 != nullptr) != (b1 != nullptr)) return EC_ERR_ARG;
     if (K0 != KA || N != NY || (N2 != 64 && N2 != 128) || M <= 0 || (M % PX) != 0 || M / PX > 0x7fffffffL) return EC_ERR_SHAPE;
     PairArgs p{(const uint16_t*)a0, (const uint16_t*)a1, (const uint16_t*)w0, (const uint16_t*)w1, (const uint16_t*)w2,
-               (const uint16_t*)res, b0, b1, b2, (uint16_t*)y, (uint16_t*)z, (int)(M / PX)};
+               (const uint16_t*)res, b0, b1, b2, (uint16_t*)y, (uint16_t*)z, (int)(M / PX), nullptr, 0, 0};
     hipStream_t s = (hipStream_t)stream;
     const bool two = a1 != nullptr, hres = res != nullptr;
     if (N2 == 64) {
@@ -258,4 +313,16 @@ extern "C" int ec_conv1x1_pair_bf16(const void* a0, const void* w0, const float*
     if (two) return EC_ERR_SHAPE;           // w0|w1 (64 KB) + w2 (64 KB) + staging exceeds the 160-KB LDS
     if (hres) return launch_pair<false, true, 128>(p, s);
     return launch_pair<false, false, 128>(p, s);
+}
+
+extern "C" int ec_conv1x1_pair_pool_bf16(const void* a0, const void* w0, const float* b0, const void* res, void* y,
+                                         void* y_pooled, const void* w2, const float* b2, void* z, int B, int H, int W,
+                                         int K0, int N, int N2, ec_stream_t stream) {
+    if (!a0 || !w0 || !b0 || !res || !y || !y_pooled || !w2 || !b2 || !z) return EC_ERR_ARG;
+    if (K0 != KA || N != NY || N2 != 128 || B <= 0 || H <= 0 || W <= 0 || (H % 4) != 0 || (W % 8) != 0) return EC_ERR_SHAPE;
+    const long tiles = (long)B * (H / 4) * (W / 8);
+    if (tiles > 0x7fffffffL) return EC_ERR_SHAPE;
+    PairArgs p{(const uint16_t*)a0, nullptr, (const uint16_t*)w0, nullptr, (const uint16_t*)w2, (const uint16_t*)res, b0,
+               nullptr, b2, (uint16_t*)y, (uint16_t*)z, (int)tiles, (uint16_t*)y_pooled, H, W};
+    return launch_pair<false, true, 128, true>(p, (hipStream_t)stream);
 }

@@ -30,6 +30,7 @@ struct Op {
     // OP_PAIR (fused layer-1 block boundary, conv_pair.hip): y = relu(src.w + [src1.w1] + [res]) -> dst;
     // z = relu(y.w2) -> dst2 (the next block's conv1 output, N2 channels)
     int src1 = -1, dst2 = -1, N2 = 0;
+    int dst3 = -1;           // OP_PAIR at the layer-1 -> layer-2 boundary: AvgPool2d(2)(y) for the downsample path
     size_t w1_off = 0, b1_off = 0, w2_off = 0, b2_off = 0;
 };
 
@@ -88,6 +89,7 @@ extern "C" int ec_rn50_create(ec_rn50_t** out, int width, const int* layers4, in
     const bool fuse_env = !fuse_e || atoi(fuse_e) != 0;
     const bool fuse_l1 = fuse_env && width == 64 && (R % 8) == 0;   // K = 64, N = 256; 32-pixel tiles divide R*R
     bool conv1_done = false;   // the previous boundary launch already produced this block's conv1 output in buffer 1
+    int pooled_in = -1;        // ... and (layer-1 -> layer-2) the pooled block input for the downsample path, in this buffer
     int inplanes = width, x = 0;
     for (int li = 0; li < 4; ++li) {
         const int planes = width << li;
@@ -122,6 +124,11 @@ extern "C" int ec_rn50_create(ec_rn50_t** out, int width, const int* layers4, in
                 }
                 o.dst2 = 1;
                 o.N2 = last_of_layer ? planes * 2 : planes;          // next conv1: 256 -> planes (same layer) | 2*planes
+                if (last_of_layer && !ds && (R % 8) == 0) {          // the next block pools its input: emit it here
+                    o.dst3 = 3;
+                    pooled_in = 3;
+                    track(R / 2, R / 2, planes * 4);
+                }
                 o.w2_off = wo; o.b2_off = bo;                        // == the next block's conv1 slot
                 h->ops.push_back(o);
                 track(R, R, planes * 4);
@@ -131,15 +138,19 @@ extern "C" int ec_rn50_create(ec_rn50_t** out, int width, const int* layers4, in
                 continue;
             }
             if (ds) {
-                int dsrc = x;
-                if (stride > 1) {
+                int dsrc = x, ddst = 3;
+                if (stride > 1 && pooled_in >= 0) {   // pooled input came with the previous boundary launch (buffer 3);
+                    dsrc = pooled_in;                 // buffer 1 (this block's conv1 output) is free after conv2
+                    ddst = 1;
+                    pooled_in = -1;
+                } else if (stride > 1) {
                     Op o{OP_POOL, x, 1, -1, R, R, inplanes, inplanes, 0, 0, 0, 0, 0};
                     h->ops.push_back(o);
                     track(Ro, Ro, inplanes);
                     dsrc = 1;
                 }
-                conv(dsrc, 3, -1, Ro, Ro, inplanes, planes * 4, 1, 0, EC_ACT_NONE);
-                idt = 3;
+                conv(dsrc, ddst, -1, Ro, Ro, inplanes, planes * 4, 1, 0, EC_ACT_NONE);
+                idt = ddst;
             }
             {
                 Op o{OP_CONV, 2, y, idt, Ro, Ro, planes, planes * 4, 1, 0, EC_ACT_RELU, w_c3, b_c3};
@@ -226,6 +237,12 @@ int rn50_run(const ec_rn50_t* h, const void* rgb, bool u8, const float* mean3, c
                     rc = ec_avgpool2_bf16(buf(o.src), buf(o.dst), nb, o.H, o.W, o.Cin, stream);
                     break;
                 case OP_PAIR:
+                    if (o.dst3 >= 0) {
+                        rc = ec_conv1x1_pair_pool_bf16(buf(o.src), h->w + o.w_off, h->bias + o.b_off, buf(o.res), buf(o.dst),
+                                                       buf(o.dst3), h->w + o.w2_off, h->bias + o.b2_off, buf(o.dst2), nb, o.H,
+                                                       o.W, o.Cin, o.Cout, o.N2, stream);
+                        break;
+                    }
                     rc = ec_conv1x1_pair_bf16(buf(o.src), h->w + o.w_off, h->bias + o.b_off,
                                               o.src1 >= 0 ? buf(o.src1) : nullptr, o.src1 >= 0 ? h->w + o.w1_off : nullptr,
                                               o.src1 >= 0 ? h->bias + o.b1_off : nullptr, o.res >= 0 ? buf(o.res) : nullptr,

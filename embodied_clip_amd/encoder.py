@@ -400,3 +400,18 @@ class ClipTextEncoder:
         """[num_goals, ctx] token ids -> [num_goals, embed_dim] (L2-normalised like CLIP's zero-shot classifier)."""
         e = self.encode_text(goal_tokens)
         return e / e.norm(dim=-1, keepdim=True) if normalize else e
+
+
+def conv1x1_pair_pool_bf16(a0, w0, b0, res, w2, b2):
+    """Layer-1 -> layer-2 boundary with the pooled copy: a0 bf16 [B,H,W,64], res bf16 [B,H,W,256] ->
+    (y [B,H,W,256], AvgPool2d(2)(y) [B,H/2,W/2,256], z = relu(y @ w2.T + b2) [B,H,W,128])."""
+    lib = _lib.load()
+    B, H, W, K0 = a0.shape
+    N, N2 = w0.shape[0], w2.shape[0]
+    y = torch.empty((B, H, W, N), dtype=torch.bfloat16, device=a0.device)
+    yp = torch.empty((B, H // 2, W // 2, N), dtype=torch.bfloat16, device=a0.device)
+    z = torch.empty((B, H, W, N2), dtype=torch.bfloat16, device=a0.device)
+    _lib.check(lib.ec_conv1x1_pair_pool_bf16(a0.data_ptr(), w0.data_ptr(), b0.data_ptr(), res.data_ptr(), y.data_ptr(),
+                                             yp.data_ptr(), w2.data_ptr(), b2.data_ptr(), z.data_ptr(), B, H, W, K0, N,
+                                             N2, _lib.stream_ptr()), "ec_conv1x1_pair_pool_bf16")
+    return y, yp, z

@@ -89,6 +89,14 @@ int ec_conv1x1_pair_bf16(const void* a0, const void* w0, const float* b0, const 
                          const float* b1, const void* res, void* y, const void* w2, const float* b2, void* z,
                          long M, int K0, int N, int N2, ec_stream_t stream);
 
+/* Same fused pair at the layer-1 -> layer-2 boundary (res given, N2 = 128), which ALSO emits y_pooled =
+ * AvgPool2d(2)(y) bf16 [B, H/2, W/2, 256] -- the input of the next block's downsample path ([U] Bottleneck:
+ * `downsample = Sequential(AvgPool2d(stride), Conv2d 1x1, BatchNorm2d)`) -- so that no separate pooling pass re-reads y.
+ * Tiles are 4 x 8 pixel blocks: H % 4 == 0 and W % 8 == 0. */
+int ec_conv1x1_pair_pool_bf16(const void* a0, const void* w0, const float* b0, const void* res, void* y,
+                              void* y_pooled, const void* w2, const float* b2, void* z, int B, int H, int W, int K0,
+                              int N, int N2, ec_stream_t stream);
+
 /* Same, on the RAW uint8 HWC frame (thor_frames.py:33-34,96 writes uint8 frames): ToTensor (/255) and
  * Normalize(mean, std) of `clip_preprocess` (thor_image_features.py:108) are fused into the LDS staging.
  * h_mean3 / h_std3 are HOST pointers to 3 floats (CLIP_RGB_MEANS / CLIP_RGB_STDS). */

@@ -271,7 +271,8 @@ def test_rn50_fused_layer1_boundaries_match_unfused_plan(dev, monkeypatch):
     monkeypatch.setenv("EC_RN50_FUSE", "0")
     plain = RN50Trunk(sd, device=dev)
     monkeypatch.delenv("EC_RN50_FUSE")
-    assert fused.lib.ec_rn50_num_ops(fused.h) == plain.lib.ec_rn50_num_ops(plain.h) - 4   # 3 conv1 + 1 downsample launches gone
+    # 3 conv1 + 1 downsample + 1 avgpool (emitted by the layer-1 -> layer-2 boundary launch) launches gone
+    assert fused.lib.ec_rn50_num_ops(fused.h) == plain.lib.ec_rn50_num_ops(plain.h) - 5
     a, b = fused.forward(x).float().cpu(), plain.forward(x).float().cpu()
     assert _rel(a, b) < 1e-2, _rel(a, b)
     ref = ocr.clip_resnet_preprocessor(x.cpu(), sd)
@@ -297,3 +298,26 @@ def test_rn50x16_style_width96_trunk_and_preprocessor(dev):
     pooled = ClipResNetPreprocessor("rgb", "RN50x16", pool=True, state_dict=sd, device=dev)
     assert pooled.observation_space.shape == (3072,)
     assert _rel(pooled.process({"rgb": x}).cpu(), ref.mean(dim=(2, 3))) < 2e-2
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 4, 8), (2, 8, 16), (3, 12, 24), (2, 56, 56)])
+def test_conv1x1_pair_pool_matches_plain_pair_plus_avgpool(dev, B, H, W):
+    """The pooled-output variant of the layer-1 -> layer-2 boundary: y and z bit-identical to the plain fused pair
+    (same arithmetic, quad-ordered tiles), y_pooled == AvgPool2d(2) of the bf16 y (fp32 mean, one rounding)."""
+    from embodied_clip_amd.encoder import conv1x1_pair_bf16, conv1x1_pair_pool_bf16
+    g = torch.Generator().manual_seed(B * 100 + H)
+    bf = lambda t: t.to(torch.bfloat16).to(dev)  # noqa: E731
+    a0 = bf(torch.randn(B, H, W, 64, generator=g).relu())
+    r = bf(torch.randn(B, H, W, 256, generator=g).relu())
+    w0 = bf(torch.randn(256, 64, generator=g) * 0.15)
+    w2 = bf(torch.randn(128, 256, generator=g) * 0.08)
+    b0, b2 = torch.randn(256, generator=g).mul(0.3).to(dev), torch.randn(128, generator=g).mul(0.3).to(dev)
+    y, yp, z = conv1x1_pair_pool_bf16(a0, w0, b0, r, w2, b2)
+    M = B * H * W
+    if M % 32 == 0:
+        y2, z2 = conv1x1_pair_bf16(a0.reshape(M, 64), w0, b0, w2, b2, res=r.reshape(M, 256))
+        assert torch.equal(y.reshape(M, 256), y2) and torch.equal(z.reshape(M, 128), z2)
+    yf = (a0.float().reshape(M, 64) @ w0.float().t() + b0 + r.float().reshape(M, 256)).relu()
+    assert _rel(y.float().reshape(M, 256).cpu(), yf.cpu()) < 3e-3
+    ref_p = torch.nn.functional.avg_pool2d(y.float().permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1).to(torch.bfloat16)
+    assert torch.equal(yp, ref_p)

@@ -1,7 +1,7 @@
 """Join rocprofv3 PMC passes (counter_collection.csv) per dispatch of the LAST forward and print per-kernel rows."""
 import csv, sys, collections, os
 root = sys.argv[1]
-n_last = int(sys.argv[2]) if len(sys.argv) > 2 else 54
+n_last = int(sys.argv[2]) if len(sys.argv) > 2 else 53
 per = collections.OrderedDict()
 for p in sorted(os.listdir(root)):
     f = os.path.join(root, p, 'p_counter_collection.csv')
