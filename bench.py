@@ -36,7 +36,7 @@ POLICY_UPDATE_MAC = 150_775_808              # 4 x (fwd + bwd)
 MFMA_BF16_PEAK_TFLOPS = 2500.0               # MI355X_MICROARCH.md: dense bf16 MFMA
 # HBM bytes per ec_rn50_forward launch at N=256 from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction +
 # WRITE_SIZE, separate --pmc passes): profiles/r01_trunk_b256_hbm_traffic.txt.  Algorithmic: 45.7 MB/frame.
-TRUNK_HBM_BYTES_PER_LAUNCH_N256 = 1.32e10
+TRUNK_HBM_BYTES_PER_LAUNCH_N256 = 1.28e10
 
 
 def _usable_cpus() -> int:
