@@ -292,6 +292,157 @@ int launch_pair(const PairArgs& p, hipStream_t s) {
     return EC_OK;
 }
 
+
+// -----------------------------------------------------------------------------------------------------------------
+// Layer-2 boundary (a0 [M,128] . w0[512,128]^T + res -> y [M,512];  z = relu(y . w2[128,512]^T + b2) [M,128]).
+// The two weight matrices are 128 KB each -- they cannot both sit in LDS -- so here they live in REGISTERS: the four
+// waves of a workgroup split the OUTPUT CHANNELS (wave w owns y channels [128w, 128w+128) and z channels
+// [32w, 32w+32)), each holding its 32-KB slices of w0 and w2 as 2 x 128 VGPRs of ready-made MFMA fragments
+// (1 wave / SIMD, 512-register budget).  A workgroup walks 32-pixel tiles; the y tile (32 x 512 bf16) is exchanged
+// between the waves through a double-buffered LDS image (one barrier per tile), pixel operands and the residual
+// slice of the next tile are prefetched in registers.  Bytes per pixel: 256 + 1024 in, 1024 + 256 out -- y is never
+// re-read from HBM by the next block's conv1.
+// -----------------------------------------------------------------------------------------------------------------
+constexpr int K2 = 128, NY2 = 512, NZ2 = 128;
+constexpr int YP2 = NY2 * 2 + 16;           // y-tile row pitch: 260 dwords == 4 (mod 64): 16-lane read groups conflict-free
+constexpr int SP2 = 256 + 16;               // per-wave staging pitch (128-channel slice rows)
+
+struct Pair2Args {
+    const uint16_t *a0, *w0, *w2, *res;
+    const float *b0, *b2;
+    uint16_t *y, *z;
+    int ntiles;
+};
+
+__global__ __launch_bounds__(256, 1) void conv1x1_pair512_kernel(Pair2Args p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    unsigned char* ytile = sm;                                        // [2][32][YP2]
+    float* sBy = reinterpret_cast<float*>(sm + 2 * PX * YP2);         // [512]
+    float* sBz = sBy + NY2;                                           // [128]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned char* stg = sm + 2 * PX * YP2 + (NY2 + NZ2) * 4 + wave * (PX * SP2);
+    const int px = lane & 31, h = lane >> 5;
+
+    for (int i = tid; i < NY2; i += 256) sBy[i] = p.b0[i];
+    for (int i = tid; i < NZ2; i += 256) sBz[i] = p.b2[i];
+
+    // ---- this wave's weight slices as MFMA fragments, in registers for the lifetime of the workgroup ----
+    u32x4 w0f[4][8];      // y channels 128 w + 32 j + (lane & 31), K-step ks: k = 16 ks + 8 h ..
+    u32x4 w2f[32];        // z channel   32 w + (lane & 31),        K-step s : k = 16 s + 8 h ..
+    [&]<int... I>(std::integer_sequence<int, I...>) {
+        ((w0f[I >> 3][I & 7] = *reinterpret_cast<const u32x4*>(p.w0 + (long)(128 * wave + 32 * (I >> 3) + px) * K2 + 16 * (I & 7) + 8 * h)), ...);
+    }(std::make_integer_sequence<int, 32>{});
+    [&]<int... I>(std::integer_sequence<int, I...>) {
+        ((w2f[I] = *reinterpret_cast<const u32x4*>(p.w2 + (long)(32 * wave + px) * NY2 + 16 * I + 8 * h)), ...);
+    }(std::make_integer_sequence<int, 32>{});
+    __syncthreads();
+
+    int t = blockIdx.x;
+    if (t >= p.ntiles) return;      // (uniform per workgroup)
+    const int G = gridDim.x;
+
+    u32x4 an[8], rn[8];
+    auto prefetch = [&](int tile) {
+        const long m0 = (long)tile * PX;
+        [&]<int... I>(std::integer_sequence<int, I...>) {
+            ((an[I] = *reinterpret_cast<const u32x4*>(p.a0 + (m0 + px) * K2 + 16 * I + 8 * h)), ...);
+            ((rn[I] = *reinterpret_cast<const u32x4*>(p.res + (m0 + ((I * 64 + lane) >> 4)) * NY2 + 128 * wave + ((I * 64 + lane) & 15) * 8)), ...);
+        }(std::make_integer_sequence<int, 8>{});
+    };
+    prefetch(t);
+
+    for (int it = 0;; ++it) {
+        const long m0 = (long)t * PX;
+        unsigned char* yt = ytile + (it & 1) * (PX * YP2);
+        u32x4 ac[8], rc[8];
+        [&]<int... I>(std::integer_sequence<int, I...>) { ((ac[I] = an[I]), ...); ((rc[I] = rn[I]), ...); }(std::make_integer_sequence<int, 8>{});
+        const int tn = t + G;
+        const bool more = tn < p.ntiles;
+        if (more) prefetch(tn);
+
+        // ---- GEMM 1: this wave's 128 y channels of the 32 pixels ----
+        f32x16_t acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        [&]<int... I>(std::integer_sequence<int, I...>) {
+            ((acc[I >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, w0f[I >> 3][I & 7]),
+                                                                    __builtin_bit_cast(bf16x8_t, ac[I & 7]), acc[I >> 3], 0, 0, 0)), ...);
+        }(std::make_integer_sequence<int, 32>{});
+
+        // ---- epilogue 1: residual slice -> staging; bias + residual + ReLU -> bf16 -> staging AND shared y tile ----
+        [&]<int... I>(std::integer_sequence<int, I...>) {
+            ((*reinterpret_cast<u32x4*>(stg + ((I * 64 + lane) >> 4) * SP2 + ((I * 64 + lane) & 15) * 16) = rc[I]), ...);
+        }(std::make_integer_sequence<int, 8>{});
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int lc = 32 * j + 8 * g + 4 * h;                    // channel within the wave's slice
+                const float4 bv = *reinterpret_cast<const float4*>(sBy + 128 * wave + lc);
+                uint2* slot = reinterpret_cast<uint2*>(stg + px * SP2 + lc * 2);
+                const uint2 rr = *slot;
+                const float v0 = fmaxf(acc[j][4 * g + 0] + bv.x + ec_lo(rr.x), 0.f), v1 = fmaxf(acc[j][4 * g + 1] + bv.y + ec_hi(rr.x), 0.f);
+                const float v2 = fmaxf(acc[j][4 * g + 2] + bv.z + ec_lo(rr.y), 0.f), v3 = fmaxf(acc[j][4 * g + 3] + bv.w + ec_hi(rr.y), 0.f);
+                uint2 o;
+                o.x = ec_pack2(v0, v1);
+                o.y = ec_pack2(v2, v3);
+                *slot = o;
+                *reinterpret_cast<uint2*>(yt + px * YP2 + (128 * wave + lc) * 2) = o;
+            }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = i * 64 + lane;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(stg + (idx >> 4) * SP2 + (idx & 15) * 16);
+            __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p.y + (m0 + (idx >> 4)) * NY2 + 128 * wave + (idx & 15) * 8));
+        }
+        __syncthreads();            // the whole y tile is in LDS (and the other buffer's readers of tile it-1 are done)
+
+        // ---- GEMM 2: this wave's 32 z channels from the shared y tile ----
+        f32x16_t acc2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+        [&]<int... I>(std::integer_sequence<int, I...>) {
+            ((acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                  __builtin_bit_cast(bf16x8_t, w2f[I]),
+                  __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const s16x8_t*>(yt + px * YP2 + (16 * I + 8 * h) * 2)), acc2, 0, 0, 0)), ...);
+        }(std::make_integer_sequence<int, 32>{});
+        // ---- epilogue 2: 32 pixels x 32 channels -> 64-B row pieces ----
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int lc = 8 * g + 4 * h;
+            const float4 bv = *reinterpret_cast<const float4*>(sBz + 32 * wave + lc);
+            uint2 o;
+            o.x = ec_pack2(fmaxf(acc2[4 * g + 0] + bv.x, 0.f), fmaxf(acc2[4 * g + 1] + bv.y, 0.f));
+            o.y = ec_pack2(fmaxf(acc2[4 * g + 2] + bv.z, 0.f), fmaxf(acc2[4 * g + 3] + bv.w, 0.f));
+            *reinterpret_cast<uint2*>(stg + px * 80 + lc * 2) = o;          // 64-B rows, pitch 80
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = i * 64 + lane;                                    // 32 rows x 4 chunks
+            const u32x4 v = *reinterpret_cast<const u32x4*>(stg + (idx >> 2) * 80 + (idx & 3) * 16);
+            __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p.z + (m0 + (idx >> 2)) * NZ2 + 32 * wave + (idx & 3) * 8));
+        }
+        if (!more) break;
+        t = tn;
+    }
+}
+
+int launch_pair512(const Pair2Args& p, hipStream_t s) {
+    constexpr size_t lds = 2 * (size_t)PX * YP2 + (NY2 + NZ2) * 4 + 4 * (size_t)PX * SP2;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_pair512_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int wgs = p.ntiles < 256 ? p.ntiles : 256;
+    hipLaunchKernelGGL(conv1x1_pair512_kernel, dim3((unsigned)wgs), dim3(256), lds, s, p);
+    EC_CHECK_LAUNCH();
+    return EC_OK;
+}
+
 }  // namespace
 
 extern "C" int ec_conv1x1_pair_bf16(const void* a0, const void* w0, const float* b0, const void* a1, const void* w1,
@@ -299,7 +450,14 @@ extern "C" int ec_conv1x1_pair_bf16(const void* a0, const void* w0, const float*
                                     long M, int K0, int N, int N2, ec_stream_t stream) {
     if (!a0 || !w0 || !b0 || !y || !w2 || !b2 || !z) return EC_ERR_ARG;
     if ((a1 != nullptr) != (w1 != nullptr) || (a1 != nullptr) != (b1 != nullptr)) return EC_ERR_ARG;
-    if (K0 != KA || N != NY || (N2 != 64 && N2 != 128) || M <= 0 || (M % PX) != 0 || M / PX > 0x7fffffffL) return EC_ERR_SHAPE;
+    if (M <= 0 || (M % PX) != 0 || M / PX > 0x7fffffffL) return EC_ERR_SHAPE;
+    if (K0 == K2 && N == NY2 && N2 == NZ2) {            // layer-2 geometry: weights in registers (residual form only)
+        if (a1 || !res) return EC_ERR_SHAPE;
+        Pair2Args q{(const uint16_t*)a0, (const uint16_t*)w0, (const uint16_t*)w2, (const uint16_t*)res, b0, b2, (uint16_t*)y,
+                    (uint16_t*)z, (int)(M / PX)};
+        return launch_pair512(q, (hipStream_t)stream);
+    }
+    if (K0 != KA || N != NY || (N2 != 64 && N2 != 128)) return EC_ERR_SHAPE;
     PairArgs p{(const uint16_t*)a0, (const uint16_t*)a1, (const uint16_t*)w0, (const uint16_t*)w1, (const uint16_t*)w2,
                (const uint16_t*)res, b0, b1, b2, (uint16_t*)y, (uint16_t*)z, (int)(M / PX), nullptr, 0, 0};
     hipStream_t s = (hipStream_t)stream;

@@ -90,6 +90,7 @@ extern "C" int ec_rn50_create(ec_rn50_t** out, int width, const int* layers4, in
     const bool fuse_l1 = fuse_env && width == 64 && (R % 8) == 0;   // K = 64, N = 256; 32-pixel tiles divide R*R
     bool conv1_done = false;   // the previous boundary launch already produced this block's conv1 output in buffer 1
     int pooled_in = -1;        // ... and (layer-1 -> layer-2) the pooled block input for the downsample path, in this buffer
+    int c1_buf = 1;            // buffer holding that conv1 output
     int inplanes = width, x = 0;
     for (int li = 0; li < 4; ++li) {
         const int planes = width << li;
@@ -98,14 +99,16 @@ extern "C" int ec_rn50_create(ec_rn50_t** out, int width, const int* layers4, in
             const bool ds = stride > 1 || inplanes != planes * 4;
             const int y = (x == 0) ? 4 : 0;
             const int Ro = R / stride;
+            int c1 = 1;
             if (conv1_done) {   // weights are still laid out conv1, conv2, conv3, downsample: skip the slot
                 wo += (size_t)planes * inplanes;
                 bo += planes;
                 conv1_done = false;
+                c1 = c1_buf;
             } else {
                 conv(x, 1, -1, R, R, inplanes, planes, 1, 0, EC_ACT_RELU);
             }
-            conv(1, 2, -1, R, R, planes, planes, 3, stride > 1 ? 1 : 0, EC_ACT_RELU);
+            conv(c1, 2, -1, R, R, planes, planes, 3, stride > 1 ? 1 : 0, EC_ACT_RELU);
             int idt = x;
             // weights are laid out conv1, conv2, conv3, downsample; the downsample conv
             // has to run BEFORE conv3 (conv3 consumes its output as the residual), so
@@ -133,6 +136,7 @@ extern "C" int ec_rn50_create(ec_rn50_t** out, int width, const int* layers4, in
                 h->ops.push_back(o);
                 track(R, R, planes * 4);
                 conv1_done = true;
+                c1_buf = 1;
                 x = y;
                 inplanes = planes * 4;
                 continue;
@@ -152,7 +156,19 @@ extern "C" int ec_rn50_create(ec_rn50_t** out, int width, const int* layers4, in
                 conv(dsrc, ddst, -1, Ro, Ro, inplanes, planes * 4, 1, 0, EC_ACT_NONE);
                 idt = ddst;
             }
-            {
+            // Layer-2 block boundaries (28x28, 128 -> 512 -> 128): conv3 + identity + ReLU and the next block's conv1 in
+            // one launch with the weights in registers (conv_pair.hip, layer-2 geometry).  Frame counts whose row count
+            // is not a multiple of 32 run the two convs separately (see rn50_run).
+            if (fuse_l1 && li == 1 && planes == 128 && !last_of_layer) {
+                Op o{OP_PAIR, 2, y, idt, Ro, Ro, planes, planes * 4, 1, 0, EC_ACT_RELU, w_c3, b_c3};
+                o.dst2 = (idt == 1) ? 3 : 1;      // block 0 with a pooled input keeps its identity in buffer 1
+                o.N2 = planes;
+                o.w2_off = wo; o.b2_off = bo;     // == the next block's conv1 slot
+                h->ops.push_back(o);
+                track(Ro, Ro, planes * 4);
+                conv1_done = true;
+                c1_buf = o.dst2;
+            } else {
                 Op o{OP_CONV, 2, y, idt, Ro, Ro, planes, planes * 4, 1, 0, EC_ACT_RELU, w_c3, b_c3};
                 h->ops.push_back(o);
                 track(Ro, Ro, planes * 4);
@@ -248,6 +264,13 @@ int rn50_run(const ec_rn50_t* h, const void* rgb, bool u8, const float* mean3, c
                                               o.src1 >= 0 ? h->bias + o.b1_off : nullptr, o.res >= 0 ? buf(o.res) : nullptr,
                                               buf(o.dst), h->w + o.w2_off, h->bias + o.b2_off, buf(o.dst2),
                                               (long)nb * o.H * o.W, o.Cin, o.Cout, o.N2, stream);
+                    if (rc == EC_ERR_SHAPE && o.src1 < 0) {   // e.g. an odd number of 28x28 frames: the two convs separately
+                        rc = ec_conv_bf16(buf(o.src), h->w + o.w_off, h->bias + o.b_off, o.res >= 0 ? buf(o.res) : nullptr,
+                                          buf(o.dst), nb, o.H, o.W, o.Cin, o.Cout, 1, 0, EC_ACT_RELU, stream);
+                        if (rc == EC_OK)
+                            rc = ec_conv_bf16(buf(o.dst), h->w + o.w2_off, h->bias + o.b2_off, nullptr, buf(o.dst2), nb, o.H,
+                                              o.W, o.Cout, o.N2, 1, 0, EC_ACT_RELU, stream);
+                    }
                     break;
                 default:
                     rc = ec_conv_bf16(buf(o.src), h->w + o.w_off, h->bias + o.b_off, o.res >= 0 ? buf(o.res) : nullptr,

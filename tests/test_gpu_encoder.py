@@ -271,8 +271,9 @@ def test_rn50_fused_layer1_boundaries_match_unfused_plan(dev, monkeypatch):
     monkeypatch.setenv("EC_RN50_FUSE", "0")
     plain = RN50Trunk(sd, device=dev)
     monkeypatch.delenv("EC_RN50_FUSE")
-    # 3 conv1 + 1 downsample + 1 avgpool (emitted by the layer-1 -> layer-2 boundary launch) launches gone
-    assert fused.lib.ec_rn50_num_ops(fused.h) == plain.lib.ec_rn50_num_ops(plain.h) - 5
+    # layer 1: 3 conv1 + 1 downsample + 1 avgpool (emitted by the layer-1 -> layer-2 boundary launch) launches gone;
+    # layer 2: 3 conv1 launches gone
+    assert fused.lib.ec_rn50_num_ops(fused.h) == plain.lib.ec_rn50_num_ops(plain.h) - 8
     a, b = fused.forward(x).float().cpu(), plain.forward(x).float().cpu()
     assert _rel(a, b) < 1e-2, _rel(a, b)
     ref = ocr.clip_resnet_preprocessor(x.cpu(), sd)
@@ -321,3 +322,28 @@ def test_conv1x1_pair_pool_matches_plain_pair_plus_avgpool(dev, B, H, W):
     assert _rel(y.float().reshape(M, 256).cpu(), yf.cpu()) < 3e-3
     ref_p = torch.nn.functional.avg_pool2d(y.float().permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1).to(torch.bfloat16)
     assert torch.equal(yp, ref_p)
+
+
+@pytest.mark.parametrize("M", [32, 32 * 7, 32 * 1025, 256 * 784])
+def test_conv1x1_pair_layer2_geometry_matches_two_launches(dev, M):
+    """Layer-2 block boundary (128 -> 512 + residual + ReLU -> 128): weights in registers, y tile shared through LDS."""
+    from embodied_clip_amd.encoder import conv1x1_pair_bf16, gemm_bf16
+    g = torch.Generator().manual_seed(M % 9973)
+    bf = lambda t: t.to(torch.bfloat16).to(dev)  # noqa: E731
+    a0 = bf(torch.randn(M, 128, generator=g).relu())
+    r = bf(torch.randn(M, 512, generator=g).relu())
+    w0 = bf(torch.randn(512, 128, generator=g) * 0.1)
+    w2 = bf(torch.randn(128, 512, generator=g) * 0.06)
+    b0, b2 = torch.randn(512, generator=g).mul(0.3).to(dev), torch.randn(128, generator=g).mul(0.3).to(dev)
+    y, z = conv1x1_pair_bf16(a0, w0, b0, w2, b2, res=r)
+    y2 = gemm_bf16(a0, w0, b0, res=r, act=1)
+    z2 = gemm_bf16(y2, w2, b2, act=1)
+    torch.cuda.synchronize()
+    assert (y2 != y).float().mean().item() < 1e-3                      # same roundings up to rare 1-ulp flips
+    assert _rel(y.float().cpu(), y2.float().cpu()) < 1e-3
+    assert _rel(z.float().cpu(), z2.float().cpu()) < 2e-3
+    if M <= 32 * 1025:
+        yf = (a0.float() @ w0.float().t() + b0 + r.float()).relu()
+        assert _rel(y.float().cpu(), yf.cpu()) < 3e-3
+        zf = (y.float() @ w2.float().t() + b2).relu()
+        assert _rel(z.float().cpu(), zf.cpu()) < 3e-3

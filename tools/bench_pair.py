@@ -37,3 +37,14 @@ for N2 in (64, 128):
         t_two_u = timeit(unf_two)
         gb = M * (64 + 64 + 256 + N2) * 2 / 1e9
         print(f"N2={N2} downsample: fused {t_two_f:7.1f} us ({gb / t_two_f * 1e3:5.2f} TB/s)   unfused {t_two_u:7.1f} us")
+
+# layer-2 geometry (28x28): conv3 128->512 + residual, next conv1 512->128
+M2 = a.B * 28 * 28
+a2 = bf(torch.randn(M2, 128, generator=g)); r2 = bf(torch.randn(M2, 512, generator=g))
+w02 = bf(torch.randn(512, 128, generator=g) * 0.1); w22 = bf(torch.randn(128, 512, generator=g) * 0.05)
+b02 = torch.randn(512, generator=g).to(dev); b22 = torch.randn(128, generator=g).to(dev)
+def unf2():
+    y = enc.gemm_bf16(a2, w02, b02, res=r2, act=1); return enc.gemm_bf16(y, w22, b22, act=1)
+tf = timeit(lambda: enc.conv1x1_pair_bf16(a2, w02, b02, w22, b22, res=r2)); tu = timeit(unf2)
+gb = M2 * (128 + 512 + 512 + 128) * 2 / 1e9
+print(f"layer-2 boundary : fused {tf:7.1f} us ({gb / tf * 1e3:5.2f} TB/s)   unfused {tu:7.1f} us")
