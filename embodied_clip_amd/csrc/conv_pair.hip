@@ -321,6 +321,7 @@ __global__ __launch_bounds__(256, 1) void conv1x1_pair512_kernel(Pair2Args p) {
     float* sBz = sBy + NY2;                                           // [128]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     unsigned char* stg = sm + 2 * PX * YP2 + (NY2 + NZ2) * 4 + wave * (PX * SP2);
+    unsigned char* atile = sm + 2 * PX * YP2 + (NY2 + NZ2) * 4 + 4 * (PX * SP2);   // [2][32][SP2]: the pixel operand tile
     const int px = lane & 31, h = lane >> 5;
 
     for (int i = tid; i < NY2; i += 256) sBy[i] = p.b0[i];
@@ -341,21 +342,33 @@ __global__ __launch_bounds__(256, 1) void conv1x1_pair512_kernel(Pair2Args p) {
     if (t >= p.ntiles) return;      // (uniform per workgroup)
     const int G = gridDim.x;
 
-    u32x4 an[8], rn[8];
+    // The pixel operand tile (32 x 128 bf16 = 8 KB) is the same for all four waves: each wave fetches a quarter of it
+    // (2 coalesced loads per lane), the quarters meet in LDS behind the barrier of the PREVIOUS tile.
+    u32x4 an[2], rn[8];
     auto prefetch = [&](int tile) {
         const long m0 = (long)tile * PX;
         [&]<int... I>(std::integer_sequence<int, I...>) {
-            ((an[I] = *reinterpret_cast<const u32x4*>(p.a0 + (m0 + px) * K2 + 16 * I + 8 * h)), ...);
+            ((an[I] = *reinterpret_cast<const u32x4*>(p.a0 + (m0 + 8 * wave + 4 * I + (lane >> 4)) * K2 + (lane & 15) * 8)), ...);
+        }(std::make_integer_sequence<int, 2>{});
+        [&]<int... I>(std::integer_sequence<int, I...>) {
             ((rn[I] = *reinterpret_cast<const u32x4*>(p.res + (m0 + ((I * 64 + lane) >> 4)) * NY2 + 128 * wave + ((I * 64 + lane) & 15) * 8)), ...);
         }(std::make_integer_sequence<int, 8>{});
     };
+    auto publish_a = [&](int buf) {      // this wave's 8 rows of the prefetched operand tile -> LDS
+        [&]<int... I>(std::integer_sequence<int, I...>) {
+            ((*reinterpret_cast<u32x4*>(atile + buf * (PX * SP2) + (8 * wave + 4 * I + (lane >> 4)) * SP2 + (lane & 15) * 16) = an[I]), ...);
+        }(std::make_integer_sequence<int, 2>{});
+    };
     prefetch(t);
+    publish_a(0);
+    __syncthreads();
 
     for (int it = 0;; ++it) {
         const long m0 = (long)t * PX;
         unsigned char* yt = ytile + (it & 1) * (PX * YP2);
-        u32x4 ac[8], rc[8];
-        [&]<int... I>(std::integer_sequence<int, I...>) { ((ac[I] = an[I]), ...); ((rc[I] = rn[I]), ...); }(std::make_integer_sequence<int, 8>{});
+        u32x4 rc[8];
+        [&]<int... I>(std::integer_sequence<int, I...>) { ((rc[I] = rn[I]), ...); }(std::make_integer_sequence<int, 8>{});
+        const unsigned char* at = atile + (it & 1) * (PX * SP2);
         const int tn = t + G;
         const bool more = tn < p.ntiles;
         if (more) prefetch(tn);
@@ -368,7 +381,8 @@ __global__ __launch_bounds__(256, 1) void conv1x1_pair512_kernel(Pair2Args p) {
             for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
         [&]<int... I>(std::integer_sequence<int, I...>) {
             ((acc[I >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, w0f[I >> 3][I & 7]),
-                                                                    __builtin_bit_cast(bf16x8_t, ac[I & 7]), acc[I >> 3], 0, 0, 0)), ...);
+                                                                    __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const s16x8_t*>(at + px * SP2 + (16 * (I & 7) + 8 * h) * 2)),
+                                                                    acc[I >> 3], 0, 0, 0)), ...);
         }(std::make_integer_sequence<int, 32>{});
 
         // ---- epilogue 1: residual slice -> staging; bias + residual + ReLU -> bf16 -> staging AND shared y tile ----
@@ -397,6 +411,7 @@ __global__ __launch_bounds__(256, 1) void conv1x1_pair512_kernel(Pair2Args p) {
             const u32x4 v = *reinterpret_cast<const u32x4*>(stg + (idx >> 4) * SP2 + (idx & 15) * 16);
             __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p.y + (m0 + (idx >> 4)) * NY2 + 128 * wave + (idx & 15) * 8));
         }
+        if (more) publish_a((it + 1) & 1);   // next tile's operand quarter (its last readers were GEMM 1 of tile it-1)
         __syncthreads();            // the whole y tile is in LDS (and the other buffer's readers of tile it-1 are done)
 
         // ---- GEMM 2: this wave's 32 z channels from the shared y tile ----
@@ -430,7 +445,7 @@ __global__ __launch_bounds__(256, 1) void conv1x1_pair512_kernel(Pair2Args p) {
 }
 
 int launch_pair512(const Pair2Args& p, hipStream_t s) {
-    constexpr size_t lds = 2 * (size_t)PX * YP2 + (NY2 + NZ2) * 4 + 4 * (size_t)PX * SP2;
+    constexpr size_t lds = 2 * (size_t)PX * YP2 + (NY2 + NZ2) * 4 + 4 * (size_t)PX * SP2 + 2 * (size_t)PX * SP2;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
     if (!attr_set) {
