@@ -448,6 +448,10 @@ int dispatch_tile(const ConvArgs& a, hipStream_t s) {
 int ec_conv3x3_narrow(const void* in, const void* w, const float* bias, void* out, int B, int H, int W, int Cin, int Cout,
                       int pool, hipStream_t s);
 
+// conv_pair.hip: register-weight kernel for a few bandwidth-bound 1x1 shapes (EC_ERR_SHAPE = not handled)
+int ec_conv1x1_regw(const void* a, const void* w, const float* bias, const void* res, void* y, long M, int K, int N, int act,
+                    hipStream_t s);
+
 extern "C" int ec_conv_bf16(const void* in, const void* w, const float* bias, const void* res, void* out, int B,
                             int H, int W, int Cin, int Cout, int ksize, int pool, int act, ec_stream_t stream) {
     if (!in || !w || !out) return EC_ERR_ARG;
@@ -473,6 +477,7 @@ extern "C" int ec_conv_bf16(const void* in, const void* w, const float* bias, co
     a.in_bytes = (unsigned)((long)B * H * W * Cin * 2);
     a.w_bytes = (unsigned)((long)Cout * a.K * 2);
     hipStream_t s = (hipStream_t)stream;
+    if (ksize == 1 && !pool && ec_conv1x1_regw(in, w, bias, res, out, (long)B * H * W, Cin, Cout, act, s) == EC_OK) return EC_OK;
     if (ksize == 3 && !res && act == EC_ACT_RELU && Cin <= 64 && Cout <= 64 &&
         ec_conv3x3_narrow(in, w, bias, out, B, H, W, Cin, Cout, pool, s) == EC_OK)
         return EC_OK;

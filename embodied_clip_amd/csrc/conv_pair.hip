@@ -20,6 +20,8 @@
 //     ARE the k-slots a lane must supply for one K-step of the second GEMM -- y never leaves registers on its
 //     way into conv1; the matching K permutation is applied to w2 once, while it is staged into LDS;
 //   * y and z leave through a small per-wave LDS staging image so every global access is a 16-B row chunk.
+#include <stdlib.h>
+
 #include <type_traits>
 #include <utility>
 
@@ -458,6 +460,149 @@ int launch_pair512(const Pair2Args& p, hipStream_t s) {
     return EC_OK;
 }
 
+
+// -----------------------------------------------------------------------------------------------------------------
+// Single bandwidth-bound 1x1 convolution with the WEIGHTS IN REGISTERS (same scheme as the layer-2 boundary kernel,
+// without the second GEMM):  y = act(a . w^T + b (+ res)),  a [M, K], w [N, K], y [M, N].
+// The four waves of the persistent workgroup split the N output channels; each keeps its [N/4, K] weight slice as
+// MFMA fragments in <= 256 VGPRs, the 32-pixel operand tile is fetched once per workgroup (a quarter per wave) into a
+// double-buffered LDS image, one barrier per tile.  Used where K*N*2 B <= 256 KB and the tiled kernel is far from the
+// HBM roof: the layer-2 downsample conv (256 -> 512 @28x28), layer-2's last conv3 (128 -> 512 + residual) and
+// layer-3's first conv1 (512 -> 256 @28x28).
+// -----------------------------------------------------------------------------------------------------------------
+struct RegwArgs {
+    const uint16_t *a, *w, *res;
+    const float* b;
+    uint16_t* y;
+    int ntiles;
+};
+
+template <int K, int N, bool RES, bool RELU>
+__global__ __launch_bounds__(256, 1) void conv1x1_regw_kernel(RegwArgs p) {
+    constexpr int NPW = N / 4, FJ = NPW / 32, KS = K / 16;
+    constexpr int AP = K * 2 + 16;            // operand-tile row pitch (K*2 B is a multiple of 256 B: +16 staggers banks)
+    constexpr int OPW = NPW * 2 + 16;         // staging pitch of the wave's output slice
+    constexpr int CPR = K / 8;                // 16-B chunks per operand row
+    constexpr int AL = 8 * CPR / 64;          // operand loads per lane (8 rows per wave)
+    constexpr int OC = NPW / 8;               // 16-B chunks per output-slice row
+    constexpr int OL = PX * OC / 64;          // coalesced stores / residual loads per lane
+    static_assert(FJ >= 1 && FJ * KS * 4 <= 256, "weight slice must fit 256 VGPRs");
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    unsigned char* atile = sm;                                   // [2][32][AP]
+    float* sB = reinterpret_cast<float*>(sm + 2 * PX * AP);      // [N]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned char* stg = sm + 2 * PX * AP + N * 4 + wave * (PX * OPW);
+    const int px = lane & 31, h = lane >> 5;
+    for (int i = tid; i < N; i += 256) sB[i] = p.b ? p.b[i] : 0.f;
+
+    u32x4 wf[FJ][KS];
+    [&]<int... I>(std::integer_sequence<int, I...>) {
+        ((wf[I / KS][I % KS] = *reinterpret_cast<const u32x4*>(p.w + (long)(NPW * wave + 32 * (I / KS) + px) * K + 16 * (I % KS) + 8 * h)), ...);
+    }(std::make_integer_sequence<int, FJ * KS>{});
+
+    int t = blockIdx.x;
+    if (t >= p.ntiles) return;
+    const int G = gridDim.x;
+    u32x4 an[AL], rn[RES ? OL : 1];
+    auto prefetch = [&](int tile) {
+        const long m0 = (long)tile * PX;
+        [&]<int... I>(std::integer_sequence<int, I...>) {
+            ((an[I] = *reinterpret_cast<const u32x4*>(p.a + (m0 + 8 * wave + (I * 64 + lane) / CPR) * K + ((I * 64 + lane) % CPR) * 8)), ...);
+        }(std::make_integer_sequence<int, AL>{});
+        if constexpr (RES) {
+            [&]<int... I>(std::integer_sequence<int, I...>) {
+                ((rn[I] = *reinterpret_cast<const u32x4*>(p.res + (m0 + (I * 64 + lane) / OC) * N + NPW * wave + ((I * 64 + lane) % OC) * 8)), ...);
+            }(std::make_integer_sequence<int, OL>{});
+        }
+    };
+    auto publish_a = [&](int buf) {
+        [&]<int... I>(std::integer_sequence<int, I...>) {
+            ((*reinterpret_cast<u32x4*>(atile + buf * (PX * AP) + (8 * wave + (I * 64 + lane) / CPR) * AP + ((I * 64 + lane) % CPR) * 16) = an[I]), ...);
+        }(std::make_integer_sequence<int, AL>{});
+    };
+    prefetch(t);
+    publish_a(0);
+    __syncthreads();
+
+    for (int it = 0;; ++it) {
+        const long m0 = (long)t * PX;
+        const unsigned char* at = atile + (it & 1) * (PX * AP);
+        u32x4 rc[RES ? OL : 1];
+        if constexpr (RES) {
+            [&]<int... I>(std::integer_sequence<int, I...>) { ((rc[I] = rn[I]), ...); }(std::make_integer_sequence<int, OL>{});
+        }
+        const int tn = t + G;
+        const bool more = tn < p.ntiles;
+        if (more) prefetch(tn);
+
+        f32x16_t acc[FJ];
+#pragma unroll
+        for (int j = 0; j < FJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        [&]<int... I>(std::integer_sequence<int, I...>) {
+            (([&] {
+                 const bf16x8_t av = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const s16x8_t*>(at + px * AP + (16 * I + 8 * h) * 2));
+#pragma unroll
+                 for (int j = 0; j < FJ; ++j)
+                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf[j][I]), av, acc[j], 0, 0, 0);
+             }()),
+             ...);
+        }(std::make_integer_sequence<int, KS>{});
+
+        if constexpr (RES) {
+            [&]<int... I>(std::integer_sequence<int, I...>) {
+                ((*reinterpret_cast<u32x4*>(stg + ((I * 64 + lane) / OC) * OPW + ((I * 64 + lane) % OC) * 16) = rc[I]), ...);
+            }(std::make_integer_sequence<int, OL>{});
+        }
+#pragma unroll
+        for (int j = 0; j < FJ; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int lc = 32 * j + 8 * g + 4 * h;
+                const float4 bv = *reinterpret_cast<const float4*>(sB + NPW * wave + lc);
+                uint2* slot = reinterpret_cast<uint2*>(stg + px * OPW + lc * 2);
+                float v0 = acc[j][4 * g + 0] + bv.x, v1 = acc[j][4 * g + 1] + bv.y;
+                float v2 = acc[j][4 * g + 2] + bv.z, v3 = acc[j][4 * g + 3] + bv.w;
+                if constexpr (RES) {
+                    const uint2 rr = *slot;
+                    v0 += ec_lo(rr.x); v1 += ec_hi(rr.x); v2 += ec_lo(rr.y); v3 += ec_hi(rr.y);
+                }
+                if constexpr (RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                uint2 o;
+                o.x = ec_pack2(v0, v1);
+                o.y = ec_pack2(v2, v3);
+                *slot = o;
+            }
+#pragma unroll
+        for (int i = 0; i < OL; ++i) {
+            const int idx = i * 64 + lane;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(stg + (idx / OC) * OPW + (idx % OC) * 16);
+            *reinterpret_cast<u32x4*>(p.y + (m0 + idx / OC) * N + NPW * wave + (idx % OC) * 8) = v;
+        }
+        if (!more) break;
+        publish_a((it + 1) & 1);     // last readers of that buffer: the GEMM of tile it-1, before the previous barrier
+        __syncthreads();
+        t = tn;
+    }
+}
+
+template <int K, int N, bool RES, bool RELU>
+int launch_regw(const RegwArgs& p, hipStream_t s) {
+    constexpr size_t lds = 2 * (size_t)PX * (K * 2 + 16) + N * 4 + 4 * (size_t)PX * (N / 4 * 2 + 16);
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    auto kern = conv1x1_regw_kernel<K, N, RES, RELU>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int wgs = p.ntiles < 256 ? p.ntiles : 256;
+    hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(256), lds, s, p);
+    EC_CHECK_LAUNCH();
+    return EC_OK;
+}
+
 }  // namespace
 
 extern "C" int ec_conv1x1_pair_bf16(const void* a0, const void* w0, const float* b0, const void* a1, const void* w1,
@@ -498,4 +643,17 @@ extern "C" int ec_conv1x1_pair_pool_bf16(const void* a0, const void* w0, const f
     PairArgs p{(const uint16_t*)a0, nullptr, (const uint16_t*)w0, nullptr, (const uint16_t*)w2, (const uint16_t*)res, b0,
                nullptr, b2, (uint16_t*)y, (uint16_t*)z, (int)tiles, (uint16_t*)y_pooled, H, W};
     return launch_pair<false, true, 128, true>(p, (hipStream_t)stream);
+}
+
+// Register-weight 1x1 conv for the shapes listed at conv1x1_regw_kernel; EC_ERR_SHAPE = not handled (the caller then
+// uses conv_igemm).  Only worth it when the launch has enough 32-pixel tiles to keep 256 workgroups busy.
+int ec_conv1x1_regw(const void* a, const void* w, const float* bias, const void* res, void* y, long M, int K, int N, int act,
+                    hipStream_t s) {
+    static const bool on = [] { const char* e = getenv("EC_CONV_REGW"); return !e || atoi(e) != 0; }();
+    if (!on || (M % PX) != 0 || M / PX < 1024 || M / PX > 0x7fffffffL) return EC_ERR_SHAPE;
+    RegwArgs p{(const uint16_t*)a, (const uint16_t*)w, (const uint16_t*)res, bias, (uint16_t*)y, (int)(M / PX)};
+    if (K == 256 && N == 512 && !res && act == EC_ACT_NONE) return launch_regw<256, 512, false, false>(p, s);
+    if (K == 512 && N == 256 && !res && act == EC_ACT_RELU) return launch_regw<512, 256, false, true>(p, s);
+    if (K == 128 && N == 512 && res && act == EC_ACT_RELU) return launch_regw<128, 512, true, true>(p, s);
+    return EC_ERR_SHAPE;
 }
