@@ -212,7 +212,7 @@ def main():
                        "parallelism": f"dp{world} (actors sharded; one flat 13.9 MB grad all-reduce per optimiser step)",
                        "flop_per_frame": 2 * ((TRUNK_MAC_PER_FRAME + POLICY_ACT_MAC + POLICY_UPDATE_MAC)
                                              if a.encoder == "rn50" else VIT_MAC_PER_FRAME)},
-            "roofline": {"bound": "mfma", "kernel": ("ec_rn50_forward (conv_igemm / conv1x1_pair / conv3x3_narrow MFMA kernels, 53 launches per call)" if a.encoder == "rn50"
+            "roofline": {"bound": "mfma", "kernel": ("ec_rn50_forward (conv_igemm / conv1x1_pair / conv3x3_narrow MFMA kernels, 50 launches per call)" if a.encoder == "rn50"
                                     else "ec_vit_forward (conv_igemm GEMMs + mha/layernorm kernels)"),
                          "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),

@@ -1,7 +1,7 @@
 """Join rocprofv3 PMC passes (counter_collection.csv) per dispatch of the LAST forward and print per-kernel rows."""
 import csv, sys, collections, os
 root = sys.argv[1]
-n_last = int(sys.argv[2]) if len(sys.argv) > 2 else 53
+n_last = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 per = collections.OrderedDict()
 for p in sorted(os.listdir(root)):
     f = os.path.join(root, p, 'p_counter_collection.csv')
@@ -12,7 +12,7 @@ for p in sorted(os.listdir(root)):
         d = int(r['Dispatch_Id'])
         disp.setdefault(d, {'name': r['Kernel_Name'], 'grid': int(r['Grid_Size']) // max(1, int(r['Workgroup_Size']))})
         disp[d][r['Counter_Name']] = float(r['Counter_Value'])
-    ids = [d for d in disp if any(k in disp[d]['name'] for k in ('conv_igemm', 'stem', 'avgpool', 'conv1x1_pair', 'conv3x3_narrow', 'conv3x3_rows'))]
+    ids = [d for d in disp if any(k in disp[d]['name'] for k in ('conv_igemm', 'stem', 'avgpool', 'conv1x1_pair', 'conv1x1_regw', 'conv3x3_narrow', 'conv3x3_rows'))]
     ids = ids[-n_last:]
     for i, d in enumerate(ids):
         per.setdefault(i, {}).update(disp[d])
