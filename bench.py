@@ -36,7 +36,7 @@ POLICY_UPDATE_MAC = 150_775_808              # 4 x (fwd + bwd)
 MFMA_BF16_PEAK_TFLOPS = 2500.0               # MI355X_MICROARCH.md: dense bf16 MFMA
 # HBM bytes per ec_rn50_forward launch at N=256 from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction +
 # WRITE_SIZE, separate --pmc passes): profiles/r01_trunk_b256_hbm_traffic.txt.  Algorithmic: 45.7 MB/frame.
-TRUNK_HBM_BYTES_PER_LAUNCH_N256 = 1.28e10
+TRUNK_HBM_BYTES_PER_LAUNCH_N256 = 1.22e10
 
 
 def _usable_cpus() -> int:
@@ -212,7 +212,7 @@ def main():
                        "parallelism": f"dp{world} (actors sharded; one flat 13.9 MB grad all-reduce per optimiser step)",
                        "flop_per_frame": 2 * ((TRUNK_MAC_PER_FRAME + POLICY_ACT_MAC + POLICY_UPDATE_MAC)
                                              if a.encoder == "rn50" else VIT_MAC_PER_FRAME)},
-            "roofline": {"bound": "mfma", "kernel": ("ec_rn50_forward (conv_igemm / conv1x1_pair / conv3x3_narrow MFMA kernels, 50 launches per call)" if a.encoder == "rn50"
+            "roofline": {"bound": "mfma", "kernel": ("ec_rn50_forward (conv_igemm / conv_pair / conv3x3_narrow MFMA kernels, 50 launches per call)" if a.encoder == "rn50"
                                     else "ec_vit_forward (conv_igemm GEMMs + mha/layernorm kernels)"),
                          "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
