@@ -81,6 +81,7 @@ def _conv_case(dev, B, H, W, Cin, Cout, ks, pool, res, act, seed):
     (42, 28, 28, 256, 512, 1, False, False, 0),  # layer-2 downsample conv (no activation)
     (42, 28, 28, 512, 256, 1, False, False, 1),  # layer-3 first conv1
     (42, 28, 28, 128, 512, 1, False, True, 1),   # layer-2 last conv3 + residual
+    (96, 14, 14, 256, 1024, 1, False, True, 1),  # layer-3 conv3 + residual: two channel groups
     # 256 frames of 14x14: 512 padded (196-of-224-row) tiles -> the quantisation-friendly tile config of conv_igemm
     (256, 14, 14, 1024, 256, 1, False, False, 1),
     (256, 14, 14, 128, 256, 3, False, False, 1),
