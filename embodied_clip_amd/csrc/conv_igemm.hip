@@ -419,13 +419,16 @@ int dispatch_tile(const ConvArgs& a, hipStream_t s) {
         // tiles on 768 workgroups (16 tail tiles running alone).  Costs 12.5 % padding and runs 2 workgroups per CU, so
         // it only pays where quantisation hurts most: measured 3x3 256->256 @14x14 100.9 -> 79.3 us, 1x1 1024->256
         // 49.6 -> 39.2 us (B = 256); slower on short-K / residual convs and on 256-tile launches.
+        // In the two-stream engine (128-frame launches) the other stream's kernels already fill the tail, and there the
+        // padded tiles cost ~0.7 % (measured on the 28x28 3x3 convs, which also have 512 padded tiles at 128 frames):
+        // the rule is therefore limited to 14x14 maps, i.e. to single launches of 256 frames.
         // EC_CONV_T224: 0 off, 1 everywhere (tests/experiments), 2 (default) the rule below, 3 also 256-tile launches.
         static const int t224 = [] { const char* e = getenv("EC_CONV_T224"); return e ? atoi(e) : 2; }();
         if constexpr (!POOL) {
             const long t196 = (long)(a.M / 196) * (a.Cout / 128), t128 = (long)((a.M + 127) / 128) * (a.Cout / 128);
             if (a.M % 196 == 0 &&
                 (t224 == 1 || (t224 >= 2 && !a.res && a.K >= 1024 && (t196 == 256 || t196 == 512) && (t128 % 768) != 0 &&
-                               (t224 == 3 || t196 == 512))))
+                               (t224 == 3 || (t196 == 512 && (long)a.H * a.W == 196)))))
                 return launch<224, 128, 1, 4, KS, POOL, false, 196>(a, s);
         }
         // residual register prefetch only for the short-K, bandwidth-bound expanding 1x1 convs
