@@ -61,6 +61,7 @@ SIGNATURES = {
                                    c_void_p, c_void_p, c_void_p, c_void_p]),
     "ec_gae": (c_int, [c_void_p] * 7 + [c_int, c_int, c_float, c_float, c_float, c_void_p]),
     "ec_ppo_loss": (c_int, [c_void_p] * 8 + [C.c_long, c_int, c_float, c_float, c_float, c_float, c_void_p]),
+    "ec_ppo_loss_ex": (c_int, [c_void_p] * 8 + [C.c_long, c_int, c_float, c_float, c_float, c_float, c_float, c_void_p]),
     "ec_sample_actions": (c_int, [c_void_p] * 4 + [c_int, c_int, C.c_uint64, C.c_uint64, c_int, c_void_p]),
     "ec_vit_create": (c_int, [C.POINTER(c_void_p), c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p,
                               c_size_t]),
@@ -118,6 +119,33 @@ def ptr(t) -> int:
     return 0 if t is None else t.data_ptr()
 
 
-def stream_ptr() -> int:
+def stream_ptr(device=None) -> int:
+    """Raw ``hipStream_t`` of torch's current stream on ``device`` (default: the current device)."""
     import torch
-    return torch.cuda.current_stream().cuda_stream
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def on_device(fn):
+    """Method decorator: run ``fn`` with ``self.device`` as the current HIP device, so that the kernels behind the
+    C-ABI launch on the GPU that owns the handle's tensors (AllenAct places preprocessors on devices other than the
+    process default) and ``stream_ptr()`` resolves to that GPU's current stream."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *a, **kw):
+        import torch
+        dev = getattr(self, "device", None)
+        if dev is None or dev.type != "cuda" or dev.index is None or dev.index == torch.cuda.current_device():
+            return fn(self, *a, **kw)
+        with torch.cuda.device(dev):
+            return fn(self, *a, **kw)
+    return wrapped
+
+
+def tensor_guard(t):
+    """Context manager making ``t``'s GPU the current device (no-op on the current one)."""
+    import contextlib
+    import torch
+    if t is None or not t.is_cuda or t.device.index == torch.cuda.current_device():
+        return contextlib.nullcontext()
+    return torch.cuda.device(t.device)

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/ec_amd.h"
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
@@ -45,6 +47,17 @@ static inline int ec_ilog2(int v) {
     int l = 0;
     while ((1 << l) < v) ++l;
     return l;
+}
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is PER DEVICE: one flag bit per device ordinal, set the first time a
+// kernel is launched on that device (thread-safe; two racing threads both set the attribute, which is idempotent).
+static inline bool ec_attr_needed(std::atomic<uint64_t>& done) {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    const uint64_t bit = 1ull << (d & 63);
+    if (done.load(std::memory_order_relaxed) & bit) return false;
+    done.fetch_or(bit, std::memory_order_relaxed);
+    return true;
 }
 
 #define EC_CHECK_LAUNCH()                                   \

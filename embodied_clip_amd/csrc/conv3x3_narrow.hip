@@ -368,10 +368,9 @@ int launch_rows(const N3Args& p, hipStream_t s) {
     static_assert(lds <= 160 * 1024, "LDS budget");
     static_assert((NR * RPB + 4 * PITCH) % 16 == 0, "image alignment");
     auto kern = conv3x3_rows_kernel<CIN, COUT, POOL, NW>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<uint64_t> attr_done{0};
+    if (ec_attr_needed(attr_done)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
     }
     const int wgs = (p.ntiles + NW - 1) / NW < 256 ? (p.ntiles + NW - 1) / NW : 256;
     hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(NW * 64), lds, s, p);
@@ -384,10 +383,9 @@ int launch_n3(const N3Args& p, hipStream_t s) {
     constexpr size_t lds = (size_t)(9 * CIN / 16) * COUT * 32 + COUT * 4 + NW * (size_t)((POOL ? PX / 4 : PX) * (COUT * 2 + 16));
     static_assert(lds <= 160 * 1024, "LDS budget");
     auto kern = conv3x3_narrow_kernel<CIN, COUT, POOL, NW>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<uint64_t> attr_done{0};
+    if (ec_attr_needed(attr_done)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
     }
     const int wgs = (p.ntiles + NW - 1) / NW < 256 ? (p.ntiles + NW - 1) / NW : 256;
     hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(NW * 64), lds, s, p);

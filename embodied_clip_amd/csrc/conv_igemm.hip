@@ -394,11 +394,10 @@ int launch(const ConvArgs& a, hipStream_t s) {
     size_t lds = (size_t)p.nbuf * (BM + BN) * ROW_BYTES;   // (set after nbuf below)
     if (lds < epi) lds = epi;
     auto kern = conv_igemm_kernel<BM, BN, WM, WN, KS, POOL, PF, MV>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<uint64_t> attr_done{0};
+    if (ec_attr_needed(attr_done)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(lds_max > epi ? lds_max : epi));
-        attr_set = true;
     }
     // persistent: 3 workgroups per CU (<= 168 VGPRs, single 35-KB LDS stage), each walking several tiles
     static const int wg_cap = [] { const char* e = getenv("EC_CONV_WGS"); return e ? atoi(e) : 768; }();

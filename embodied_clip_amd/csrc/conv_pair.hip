@@ -283,10 +283,9 @@ int launch_pair(const PairArgs& p, hipStream_t s) {
                            (PL ? 4 * 8 * (NY * 2 + 16) : 0);
     static_assert(lds <= 160 * 1024, "LDS budget");
     auto kern = conv1x1_pair_kernel<TWO, RES, N2, PL>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<uint64_t> attr_done{0};
+    if (ec_attr_needed(attr_done)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
     }
     const int wgs = (p.ntiles + 3) / 4 < 256 ? (p.ntiles + 3) / 4 : 256;
     hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(256), lds, s, p);
@@ -449,10 +448,9 @@ __global__ __launch_bounds__(256, 1) void conv1x1_pair512_kernel(Pair2Args p) {
 int launch_pair512(const Pair2Args& p, hipStream_t s) {
     constexpr size_t lds = 2 * (size_t)PX * YP2 + (NY2 + NZ2) * 4 + 4 * (size_t)PX * SP2 + 2 * (size_t)PX * SP2;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<uint64_t> attr_done{0};
+    if (ec_attr_needed(attr_done)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_pair512_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
     }
     const int wgs = p.ntiles < 256 ? p.ntiles : 256;
     hipLaunchKernelGGL(conv1x1_pair512_kernel, dim3((unsigned)wgs), dim3(256), lds, s, p);
@@ -599,10 +597,9 @@ int launch_regw(const RegwArgs& p, hipStream_t s, int groups = 1) {
     constexpr size_t lds = 2 * (size_t)PX * (K * 2 + 16) + N * 4 + 4 * (size_t)PX * (N / 4 * 2 + 16);
     static_assert(lds <= 160 * 1024, "LDS budget");
     auto kern = conv1x1_regw_kernel<K, N, RES, RELU>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<uint64_t> attr_done{0};
+    if (ec_attr_needed(attr_done)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
     }
     int wgs = 256 / groups;
     if (wgs > p.ntiles) wgs = p.ntiles;

@@ -476,11 +476,10 @@ int launch_x3(GemmArgs& a, hipStream_t s) {
 #define EC_X3(ABF, BBF, AKC, BKC)                                                                            \
     do {                                                                                                     \
         auto kern = gemm_x3_kernel<BM, BN, WM, WN, ABF, BBF, AKC, BKC>;                                      \
-        static bool attr_set = false;                                                                        \
-        if (!attr_set) {                                                                                     \
+        static std::atomic<uint64_t> attr_done{0};                                                                        \
+        if (ec_attr_needed(attr_done)) {                                                                                     \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                   \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)((3 * BM + 3 * BN) * 64)); \
-            attr_set = true;                                                                                 \
         }                                                                                                    \
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);                                                \
     } while (0)
@@ -511,11 +510,10 @@ int launch_cfg(GemmArgs& a, hipStream_t s) {
 #define EC_GEMM_LAUNCH(ABF, BBF)                                                                            \
     do {                                                                                                    \
         auto kern = gemm_f32_kernel<BM, BN, WM, WN, ABF, BBF>;                                              \
-        static bool attr_set = false;                                                                       \
-        if (!attr_set) {                                                                                    \
+        static std::atomic<uint64_t> attr_done{0};                                                                       \
+        if (ec_attr_needed(attr_done)) {                                                                                    \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                  \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
-            attr_set = true;                                                                                \
         }                                                                                                   \
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);                                               \
     } while (0)
@@ -549,6 +547,9 @@ extern "C" int ec_gemm_f32(const void* A, const void* B, float* Cp, int M, int N
     a.splitk = splitk < 1 ? 1 : splitk;
     const int nk_total = (K + GBK - 1) / GBK;
     if (a.splitk > nk_total) a.splitk = nk_total;
+    // split-K partials are atomically ADDED into C: that is only a GEMM when C already holds the value to accumulate
+    // onto (ACCUMULATE) and no nonlinearity sits between the partial sums
+    if (a.splitk > 1 && (a.relu || !a.accumulate)) return EC_ERR_ARG;
     // vector loads need the contiguous axis to be unit stride, the other stride a multiple of 4
     // elements and a 16-byte (8-byte for bf16) aligned base
     auto vec_ok = [](const void* p, long s_contig, long s_other, int bf16) {

@@ -77,7 +77,7 @@ __global__ void ppo_loss_kernel(const float* __restrict__ hv, const long long* _
                                 const float* __restrict__ old_logp, const float* __restrict__ old_val,
                                 const float* __restrict__ returns, const float* __restrict__ nadv,
                                 float* __restrict__ dhv, double* __restrict__ sums, long B, int A, float clip,
-                                float vcoef, float ecoef, float grad_scale) {
+                                float vclip, float vcoef, float ecoef, float grad_scale) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     double acc[4] = {0, 0, 0, 0};
     if (i < B) {
@@ -116,10 +116,12 @@ __global__ void ppo_loss_kernel(const float* __restrict__ hv, const long long* _
         const float dla_dlp = dla_dratio * ratio;
         const float v = row[A], vo = old_val[i], R = returns[i];
         const float dv = v - vo;
-        const float vcl = vo + fminf(fmaxf(dv, -clip), clip);
+        // vclip < 0: use_clipped_value_loss=False -> 0.5 * (R - V)^2
+        const bool vc_on = vclip >= 0.f;
+        const float vcl = vc_on ? vo + fminf(fmaxf(dv, -vclip), vclip) : v;
         const float l1 = (v - R) * (v - R), l2 = (vcl - R) * (vcl - R);
         const float lv = 0.5f * fmaxf(l1, l2);
-        const bool v_in = (dv >= -clip) && (dv <= clip);
+        const bool v_in = !vc_on || ((dv >= -vclip) && (dv <= vclip));
         const float g1 = (v - R), g2 = v_in ? (vcl - R) : 0.f;
         const float dlv_dv = (l1 > l2) ? g1 : ((l2 > l1) ? g2 : 0.5f * (g1 + g2));   // torch.max splits ties evenly
         const float invB = grad_scale / (float)B;
@@ -133,6 +135,7 @@ __global__ void ppo_loss_kernel(const float* __restrict__ hv, const long long* _
             }
         drow[A] = invB * vcoef * dlv_dv;
         acc[0] = la; acc[1] = lv; acc[2] = -ent; acc[3] = ratio;
+        if (a < 0 || a >= A) acc[0] = (double)NAN;   // an out-of-range action id poisons the loss instead of passing silently
     }
     block_atomic_sum<4>(acc, sums);
 }
@@ -217,6 +220,14 @@ extern "C" int ec_gae(const float* rewards, const float* values, const float* ma
 extern "C" int ec_ppo_loss(const float* hv, const int64_t* actions, const float* old_logp, const float* old_values,
                            const float* returns, const float* norm_adv, float* dhv, double* sums4, long B, int A,
                            float clip, float vcoef, float ecoef, float grad_scale, ec_stream_t stream) {
+    return ec_ppo_loss_ex(hv, actions, old_logp, old_values, returns, norm_adv, dhv, sums4, B, A, clip, clip, vcoef, ecoef,
+                          grad_scale, stream);
+}
+
+extern "C" int ec_ppo_loss_ex(const float* hv, const int64_t* actions, const float* old_logp, const float* old_values,
+                              const float* returns, const float* norm_adv, float* dhv, double* sums4, long B, int A,
+                              float clip, float value_clip, float vcoef, float ecoef, float grad_scale,
+                              ec_stream_t stream) {
     if (!hv || !actions || !old_logp || !old_values || !returns || !norm_adv || !dhv || !sums4) return EC_ERR_ARG;
     if (B <= 0 || A <= 0 || A > 16) return EC_ERR_SHAPE;
     hipStream_t s = (hipStream_t)stream;
@@ -224,10 +235,10 @@ extern "C" int ec_ppo_loss(const float* hv, const int64_t* actions, const float*
     dim3 grid((unsigned)((B + 255) / 256));
     if (A <= 8)
         hipLaunchKernelGGL(ppo_loss_kernel<8>, grid, dim3(256), 0, s, hv, (const long long*)actions, old_logp, old_values,
-                           returns, norm_adv, dhv, sums4, B, A, clip, vcoef, ecoef, grad_scale);
+                           returns, norm_adv, dhv, sums4, B, A, clip, value_clip, vcoef, ecoef, grad_scale);
     else
         hipLaunchKernelGGL(ppo_loss_kernel<16>, grid, dim3(256), 0, s, hv, (const long long*)actions, old_logp, old_values,
-                           returns, norm_adv, dhv, sums4, B, A, clip, vcoef, ecoef, grad_scale);
+                           returns, norm_adv, dhv, sums4, B, A, clip, value_clip, vcoef, ecoef, grad_scale);
     EC_CHECK_LAUNCH();
     return EC_OK;
 }

@@ -438,12 +438,11 @@ int run_blocks(const uint16_t*& w, const float*& f, int layers, int heads, uint1
     const bool general = causal || L > 64;
     if (general) {
         if (L > MHA_GENERAL_MAX_TOKENS) return EC_ERR_SHAPE;
-        static bool attr_set = false;
-        if (!attr_set) {
+        static std::atomic<uint64_t> attr_done{0};
+        if (ec_attr_needed(attr_done)) {
             const int mx = (int)mha_general_lds(MHA_GENERAL_MAX_TOKENS);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mha_general_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mha_general_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
-            attr_set = true;
         }
     }
     for (int l = 0; l < layers; ++l) {

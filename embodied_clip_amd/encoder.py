@@ -131,6 +131,7 @@ class RN50Trunk:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
 
+    @_lib.on_device
     def forward(self, rgb: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """rgb: device fp32 [B, R, R, 3] contiguous (the RGB sensor's normalised frame).
         out: optional bf16 [B, S, S, C] destination (e.g. a slice of the rollout buffer)."""
@@ -147,6 +148,7 @@ class RN50Trunk:
                                             chunk, _lib.stream_ptr()), "ec_rn50_forward")
         return out
 
+    @_lib.on_device
     def forward_u8(self, rgb_u8: torch.Tensor, out: Optional[torch.Tensor] = None,
                    mean=(0.48145466, 0.4578275, 0.40821073), std=(0.26862954, 0.26130258, 0.27577711)) -> torch.Tensor:
         """rgb_u8: device uint8 [B, R, R, 3] raw frames; CLIP normalisation is fused into the stem kernel."""
@@ -163,6 +165,7 @@ class RN50Trunk:
                                                out.data_ptr(), chunk, _lib.stream_ptr()), "ec_rn50_forward_u8")
         return out
 
+    @_lib.on_device
     def to_nchw_f32(self, feat: torch.Tensor) -> torch.Tensor:
         B = feat.shape[0]
         S, Cc = self.out_spatial, self.out_channels
@@ -171,6 +174,7 @@ class RN50Trunk:
                    "ec_nhwc_bf16_to_nchw_f32")
         return o
 
+    @_lib.on_device
     def spatial_mean(self, feat: torch.Tensor) -> torch.Tensor:
         B = feat.shape[0]
         S, Cc = self.out_spatial, self.out_channels
@@ -201,6 +205,7 @@ class AttentionPool:
         self.heads = num_heads
         self._ws = None
 
+    @_lib.on_device
     def forward(self, feat: torch.Tensor) -> torch.Tensor:
         """feat bf16 [B,S,S,C] -> fp32 [B,out_dim]."""
         B = feat.shape[0]
@@ -266,6 +271,7 @@ class ViTEmbedder:
         except Exception:
             pass
 
+    @_lib.on_device
     def forward(self, rgb: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """rgb device fp32 [B,R,R,3] -> tokens bf16 [B,L,D]."""
         assert rgb.is_cuda and rgb.dtype == torch.float32 and rgb.is_contiguous()
@@ -279,6 +285,7 @@ class ViTEmbedder:
                                            out.data_ptr(), _lib.stream_ptr()), "ec_vit_forward")
         return out
 
+    @_lib.on_device
     def to_f32(self, tokens: torch.Tensor, class_emb_only: bool = False) -> torch.Tensor:
         B = tokens.shape[0]
         if class_emb_only:
@@ -294,6 +301,18 @@ class ViTEmbedder:
 
 # ---- thin op-level wrappers (used by the parity tests) -------------------------------------
 
+def _guard_first(fn):
+    """Run a free op wrapper on the GPU that owns its first tensor argument."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(x, *a, **kw):
+        with _lib.tensor_guard(x):
+            return fn(x, *a, **kw)
+    return wrapped
+
+
+@_guard_first
 def conv_bf16(x, w, bias, res=None, ksize=1, pool=False, act=1):
     """x bf16 [B,H,W,Cin]; w bf16 [Cout, k*k*Cin]; bias f32 [Cout] -> bf16 [B,H',W',Cout]."""
     lib = _lib.load()
@@ -306,6 +325,7 @@ def conv_bf16(x, w, bias, res=None, ksize=1, pool=False, act=1):
     return out
 
 
+@_guard_first
 def gemm_bf16(a, w, bias=None, res=None, act=0):
     """a bf16 [M,K]; w bf16 [N,K] -> bf16 [M,N] = act(a @ w.T + bias (+res))."""
     lib = _lib.load()
@@ -317,6 +337,7 @@ def gemm_bf16(a, w, bias=None, res=None, act=0):
     return out
 
 
+@_guard_first
 def conv1x1_pair_bf16(a0, w0, b0, w2, b2, a1=None, w1=None, b1=None, res=None):
     """y = relu(a0 @ w0.T + b0 [+ a1 @ w1.T + b1] [+ res]) bf16 [M,256];  z = relu(y @ w2.T + b2) bf16 [M,N2].
     a0/a1 bf16 [M,64], w0/w1 bf16 [256,64], res bf16 [M,256], w2 bf16 [N2,256] (layer-1 Bottleneck boundary)."""
@@ -383,6 +404,7 @@ class ClipTextEncoder:
         except Exception:
             pass
 
+    @_lib.on_device
     @torch.no_grad()
     def encode_text(self, tokens: torch.Tensor) -> torch.Tensor:
         assert tokens.dim() == 2 and tokens.shape[1] == self.cfg["context_length"], tokens.shape
@@ -402,6 +424,7 @@ class ClipTextEncoder:
         return e / e.norm(dim=-1, keepdim=True) if normalize else e
 
 
+@_guard_first
 def conv1x1_pair_pool_bf16(a0, w0, b0, res, w2, b2):
     """Layer-1 -> layer-2 boundary with the pooled copy: a0 bf16 [B,H,W,64], res bf16 [B,H,W,256] ->
     (y [B,H,W,256], AvgPool2d(2)(y) [B,H/2,W/2,256], z = relu(y @ w2.T + b2) [B,H,W,128])."""

@@ -79,7 +79,15 @@ class Worker:
                  tau: float = 0.95, encoder_sd=None, policy_sd=None, lr_total_steps: int = 300_000_000,
                  encoder_chunk: int = 0, encoder: str = "rn50", encoder_streams: int = 2, frames_u8: bool = False):
         self.lib = _lib.load()
-        self.dev = torch.device(device)
+        self.dev = self.device = torch.device(device)
+        if self.dev.index is None:
+            self.dev = self.device = torch.device("cuda", torch.cuda.current_device())
+        self._init(n_actors, T, seed, rank, world, update_repeats, lr, max_grad_norm, gamma, tau, encoder_sd, policy_sd,
+                   lr_total_steps, encoder_chunk, encoder, encoder_streams, frames_u8)
+
+    @_lib.on_device
+    def _init(self, n_actors, T, seed, rank, world, update_repeats, lr, max_grad_norm, gamma, tau, encoder_sd, policy_sd,
+              lr_total_steps, encoder_chunk, encoder, encoder_streams, frames_u8):
         self.N, self.T, self.rank, self.world = n_actors, T, rank, world
         self.update_repeats, self.gamma, self.tau = update_repeats, gamma, tau
         self.base_lr, self.lr_total_steps = lr, lr_total_steps
@@ -204,6 +212,7 @@ class Worker:
         else:   # bootstrap value of the last observation; memory is NOT advanced
             self.values[t][rs].copy_(self.hv_act[rs, self.A])
 
+    @_lib.on_device
     def collect_rollout(self):
         T = self.T
         self.h_start.copy_(self.h)
@@ -221,6 +230,7 @@ class Worker:
         if (T & 1) == 1:   # after an odd number of advancing steps the live memory sits in h_next
             self.h, self.h_next = self.h_next, self.h
 
+    @_lib.on_device
     def compute_returns(self):
         _lib.check(self.lib.ec_gae(self.env.rewards.data_ptr(), self.values.data_ptr(), self.env.masks.data_ptr(),
                                    self.returns.data_ptr(), self.adv.data_ptr(), self.nadv.data_ptr(),
@@ -238,6 +248,7 @@ class Worker:
             sl.actions, sl.logp, sl.old_v = c(self.actions), c(self.logp), c(self.values)
             sl.ret, sl.nadv = c(self.returns), c(self.nadv)
 
+    @_lib.on_device
     def update(self):
         T = self.T
         self._gather_slice_batches()
@@ -265,6 +276,7 @@ class Worker:
                 allreduce_flat(self.grads)                   # one flat 13.9 MB bucket over RCCL/xGMI
             self.opt.step(self.grads, lr=linear_decay_lr(self.base_lr, self.total_steps, self.lr_total_steps))
 
+    @_lib.on_device
     def after_update(self):
         for sl in self.slices:
             sl.feat[0].copy_(sl.feat[self.T])

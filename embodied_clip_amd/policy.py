@@ -146,6 +146,10 @@ class PolicyHandle:
         """feat: bf16 or fp32 NHWC rows [T*N, S*S, C]; returns (hv [T*N, A+1], h_final [N,H])."""
         assert feat.is_contiguous() and feat.dtype in (torch.bfloat16, torch.float32)
         dev = flat_params.device
+        with _lib.tensor_guard(flat_params):
+            return self._forward(flat_params, feat, goal, h0, masks, T, N, ws, hv, h_final, dev)
+
+    def _forward(self, flat_params, feat, goal, h0, masks, T, N, ws, hv, h_final, dev):
         if hv is None:
             hv = torch.empty((T * N, self.A + 1), dtype=torch.float32, device=dev)
         if h_final is None:
@@ -157,6 +161,10 @@ class PolicyHandle:
         return hv, h_final
 
     def backward(self, flat_params, feat, masks, T, N, ws, dhv, dh_final, flat_grads):
+        with _lib.tensor_guard(flat_params):
+            return self._backward(flat_params, feat, masks, T, N, ws, dhv, dh_final, flat_grads)
+
+    def _backward(self, flat_params, feat, masks, T, N, ws, dhv, dh_final, flat_grads):
         _lib.check(self.lib.ec_policy_backward(
             self.h, flat_params.data_ptr(), feat.data_ptr(), int(feat.dtype == torch.bfloat16), masks.data_ptr(), T, N,
             ws.data_ptr(), ws.numel() * ws.element_size(), dhv.data_ptr(), _lib.ptr(dh_final), flat_grads.data_ptr(),

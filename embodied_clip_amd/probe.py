@@ -118,6 +118,7 @@ class LinearEncoder:
                                           _lib.ptr(pred), _lib.ptr(dz), _lib.ptr(db), self._out5.data_ptr(),
                                           _lib.stream_ptr()), "ec_probe_head")
 
+    @_lib.on_device
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """Probabilities in the reference's layout: [B, C], or [B, 52, 9] for object_localization."""
         rows = self._rows(x)
@@ -143,6 +144,7 @@ class LinearEncoder:
             y = y.reshape(-1, self.C)                 # [B, 9, 52] -> rows (b, cell) == y.flatten(1) element order
         return y, idx
 
+    @_lib.on_device
     def compute_loss(self, batch, eval: bool = False, _backward: bool = False):
         """train.py:56-92.  Returns the mean loss as a 0-d device tensor (and the metrics dict when ``eval``)."""
         x, y = batch

@@ -5,11 +5,15 @@
 
 Extra flags (not in the reference): ``--synthetic-frames N`` first writes a synthetic feature cache into
 ``--data-dir`` by running N seeded frames through the HIP CLIP-RN50 encoder (there are no simulator frames or
-pretrained weights in this environment); ``--epochs`` bounds training (the reference trains with Lightning's default
-``max_epochs`` and early-stops on val_loss, train.py:139-156 -- trainer/callback machinery is control plane and not
-rebuilt); ``--batch-size`` (reference hard-codes 128, train.py:136; BASELINE config 1 quotes 32).
-Prints one JSON line with the final train/val/test loss and accuracy and writes the head's state_dict to
-``<log-dir>/<embedding>_<prediction>.pt``.
+pretrained weights in this environment); ``--epochs`` (default 250 == ``max_epochs=250``, train.py:158);
+``--batch-size`` (reference hard-codes 128, train.py:136; BASELINE config 1 quotes 32).
+
+Trainer semantics restated from train.py:153-174 (the Lightning machinery itself is control plane and not rebuilt):
+validation runs twice per epoch (``val_check_interval=0.5``, train.py:157), the head with the lowest ``val_loss`` so
+far is kept (``ModelCheckpoint(monitor="val_loss", mode="min")``, train.py:160-164) and the test metrics are computed
+on THAT head (``trainer.test(ckpt_path='best')``, train.py:170-174), not on the final weights.
+Prints one JSON line with the last train loss, the best val loss/acc and the test loss/acc of the best head, and
+writes the best head's state_dict to ``<log-dir>/<embedding>_<prediction>.pt``.
 """
 from __future__ import annotations
 
@@ -67,7 +71,7 @@ def main(argv=None):
                     help="Which task to evaluate", default="object_presence")
     ap.add_argument("--gpus", type=int, default=1, help="Number of GPUs to use (the probe is a single-GPU job)")
     ap.add_argument("--synthetic-frames", type=int, default=0)
-    ap.add_argument("--epochs", type=int, default=5)
+    ap.add_argument("--epochs", type=int, default=250, help="max_epochs (train.py:158)")
     ap.add_argument("--batch-size", type=int, default=128)
     a = ap.parse_args(argv)
     if not torch.cuda.is_available():
@@ -81,21 +85,36 @@ def main(argv=None):
     dm.setup()
     model = LinearEncoder(a.embedding_type, a.prediction_type, a.batch_size, lr, device=dev)
     train = dm.train_dataloader()
+    n_batches = len(train)
+    check_at = sorted({max(1, n_batches // 2), n_batches})            # val_check_interval=0.5 (train.py:157)
+    best = {"val_loss": float("inf"), "val_acc": 0.0, "epoch": -1, "sd": None}
+
+    def validate(epoch):
+        vl, va = evaluate(model, dm.val_dataloader(), "val")
+        if vl < best["val_loss"]:                                      # ModelCheckpoint(monitor="val_loss", mode="min")
+            best.update(val_loss=vl, val_acc=va, epoch=epoch,
+                        sd={k: v.detach().clone() for k, v in model.state_dict().items()})
+
     t0 = time.time()
     steps = 0
-    for _ in range(a.epochs):
+    for ep in range(a.epochs):
         for i, batch in enumerate(train):
             model.training_step(batch, i)
             steps += 1
+            if (i + 1) in check_at:
+                validate(ep)
     torch.cuda.synchronize()
     dt = time.time() - t0
-    val_loss, val_acc = evaluate(model, dm.val_dataloader(), "val")
+    if best["sd"] is None:
+        validate(-1)
+    model.load_state_dict(best["sd"])                                  # trainer.test(ckpt_path='best')
+    val_loss, val_acc = best["val_loss"], best["val_acc"]
     test_loss, test_acc = evaluate(model, dm.test_dataloader(), "test")
     os.makedirs(a.log_dir, exist_ok=True)
     torch.save({k: v.cpu() for k, v in model.state_dict().items()},
                os.path.join(a.log_dir, f"{a.embedding_type}_{a.prediction_type}.pt"))
     print(json.dumps({"embedding_type": a.embedding_type, "prediction_type": a.prediction_type,
-                      "train_frames": len(dm.train_dataset), "epochs": a.epochs, "batch_size": a.batch_size,
+                      "train_frames": len(dm.train_dataset), "epochs": a.epochs, "best_epoch": best["epoch"], "batch_size": a.batch_size,
                       "train_steps": steps, "train_steps_per_s": round(steps / max(dt, 1e-9), 1),
                       "train_loss": round(float(model.logged["train_loss"]), 6),
                       "val_loss": round(val_loss, 6), "val_acc": round(val_acc, 4),

@@ -225,6 +225,13 @@ int ec_gae(const float* rewards, const float* values, const float* masks, float*
 int ec_ppo_loss(const float* hv, const int64_t* actions, const float* old_logp, const float* old_values,
                 const float* returns, const float* norm_adv, float* dhv, double* sums4, long B, int A,
                 float clip, float vcoef, float ecoef, float grad_scale, ec_stream_t stream);
+/* As ec_ppo_loss with the value clip given separately: value_clip >= 0 is PPO(use_clipped_value_loss=True) with
+ * that clip (AllenAct uses the same, possibly decayed, clip_param for both); value_clip < 0 is
+ * use_clipped_value_loss=False, value loss = 0.5 (returns - values)^2.  An action id outside [0, A) makes
+ * sums4[0] NaN (the loss fails loudly instead of scoring log-prob 0). */
+int ec_ppo_loss_ex(const float* hv, const int64_t* actions, const float* old_logp, const float* old_values,
+                   const float* returns, const float* norm_adv, float* dhv, double* sums4, long B, int A,
+                   float clip, float value_clip, float vcoef, float ecoef, float grad_scale, ec_stream_t stream);
 /* actions ~ Categorical(logits = hv[:, :A]); logp = log_prob(actions); values = hv[:, A] (or NULL).
  * The counter-based uniform of row n is keyed by (seed, step, first_actor + n), so a batch may be sampled in
  * slices (e.g. one per HIP stream) with identical results. */

@@ -49,9 +49,11 @@ def normalized_advantages(returns: torch.Tensor, values: torch.Tensor, eps: floa
 def ppo_loss(logits: torch.Tensor, values: torch.Tensor, actions: torch.Tensor,
              old_log_probs: torch.Tensor, old_values: torch.Tensor, returns: torch.Tensor,
              norm_adv: torch.Tensor, clip_param: float = 0.1, value_loss_coef: float = 0.5,
-             entropy_coef: float = 0.01):
+             entropy_coef: float = 0.01, use_clipped_value_loss: bool = True):
     """``PPO.loss``.  logits [T,N,A]; values/old_values/returns/norm_adv [T,N,1];
-    actions [T,N] int64; old_log_probs [T,N,1].
+    actions [T,N] int64; old_log_probs [T,N,1].  ``clip_param`` is the already-decayed
+    ``clip_param * clip_decay(step_count)`` of upstream; ``use_clipped_value_loss=False`` is upstream's
+    ``0.5 * (returns - values).pow(2)`` branch.
     Returns (total scalar, info dict of python floats)."""
     logp = opolicy.categorical_log_prob(logits, actions).unsqueeze(-1)
     ent = opolicy.categorical_entropy(logits).unsqueeze(-1)
@@ -59,8 +61,11 @@ def ppo_loss(logits: torch.Tensor, values: torch.Tensor, actions: torch.Tensor,
     surr1 = ratio * norm_adv
     surr2 = torch.clamp(ratio, 1.0 - clip_param, 1.0 + clip_param) * norm_adv
     action_loss = -torch.where(surr2 < surr1, surr2, surr1)  # -min(surr1, surr2)
-    v_clipped = old_values + (values - old_values).clamp(-clip_param, clip_param)
-    value_loss = 0.5 * torch.max((values - returns).pow(2), (v_clipped - returns).pow(2))
+    if use_clipped_value_loss:
+        v_clipped = old_values + (values - old_values).clamp(-clip_param, clip_param)
+        value_loss = 0.5 * torch.max((values - returns).pow(2), (v_clipped - returns).pow(2))
+    else:
+        value_loss = 0.5 * (returns - values).pow(2)
     ent_loss = -ent
     la, lv, le = action_loss.mean(), value_loss.mean(), ent_loss.mean()
     total = la + value_loss_coef * lv + entropy_coef * le

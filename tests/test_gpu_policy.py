@@ -228,3 +228,50 @@ def test_actor_critic_module_autograd_surface(dev):
     for n, p in model.named_parameters():
         assert p.grad is not None and _rel(p.grad, leaves[n].grad) < 2e-4, n
     assert model.flat_grads.abs().sum() > 0          # grads landed in the single flat bucket
+
+
+def test_ppo_variants_unclipped_value_loss_clip_decay_and_bad_actions(dev):
+    """PPO options behind the reference's configs ([U] losses/ppo.py): use_clipped_value_loss=False,
+    clip_param * clip_decay(step_count), and loud failure on an out-of-range action id."""
+    from embodied_clip_amd import ppo
+    from embodied_clip_amd.policy import ActorCriticOutput, CategoricalDistr
+    T, N, A = 5, 8, 6
+    g = torch.Generator().manual_seed(4)
+    logits = torch.randn(T, N, A, generator=g, requires_grad=True)
+    values = torch.randn(T, N, 1, generator=g, requires_grad=True)
+    actions, old_lp, old_v, returns, nadv = _loss_inputs(T, N, 5)
+    with torch.no_grad():
+        old_lp = opol.categorical_log_prob(logits, actions).unsqueeze(-1) + 0.25 * torch.randn(T, N, 1, generator=g)
+        old_v = values + 0.2 * torch.randn(T, N, 1, generator=g)
+    hv = torch.cat([logits, values], -1).detach().reshape(T * N, A + 1).contiguous().to(dev)
+    f = lambda t: t.reshape(-1).contiguous().to(dev)
+    # (1) unclipped value loss, raw kernel: forward sums and gradient
+    total, info = oppo.ppo_loss(logits, values, actions, old_lp, old_v, returns, nadv, use_clipped_value_loss=False)
+    total.backward()
+    dhv, sums = ppo.ppo_loss_raw(hv, f(actions), f(old_lp), f(old_v), f(returns), f(nadv), A,
+                                 use_clipped_value_loss=False)
+    torch.cuda.synchronize()
+    s = (sums / (T * N)).cpu()
+    assert abs(s[1].item() - info["value"]) < 1e-5 and abs(s[0].item() - info["action"]) < 1e-5
+    assert _rel(dhv, torch.cat([logits.grad, values.grad], -1).reshape(T * N, A + 1)) < 1e-5
+    # (2) the shim applies clip_param * clip_decay(step_count) (a linear decay to 0 over 100 steps, step 40 -> 0.06)
+    decay = lambda step: max(0.0, 1.0 - step / 100.0)
+    lg = logits.detach().to(dev).requires_grad_(True)
+    vv = values.detach().to(dev).requires_grad_(True)
+    out = ActorCriticOutput(CategoricalDistr(lg), vv, {})
+    batch = dict(actions=actions.to(dev), old_action_log_probs=old_lp.to(dev), values=old_v.to(dev),
+                 returns=returns.to(dev), norm_adv_targ=nadv.to(dev), adv_targ=nadv.to(dev))
+    t40, _ = ppo.PPO(clip_param=0.1, clip_decay=decay).loss(40, batch, out)
+    l2, v2 = logits.detach().clone().requires_grad_(True), values.detach().clone().requires_grad_(True)
+    tref, _ = oppo.ppo_loss(l2, v2, actions, old_lp, old_v, returns, nadv, clip_param=0.1 * 0.6)
+    assert abs(float(t40) - float(tref)) < 1e-5
+    t0, _ = ppo.PPO(clip_param=0.1, clip_decay=decay).loss(0, batch, out)
+    tref0, _ = oppo.ppo_loss(l2, v2, actions, old_lp, old_v, returns, nadv, clip_param=0.1)
+    assert abs(float(t0) - float(tref0)) < 1e-5 and abs(float(t0) - float(t40)) > 1e-6
+    with pytest.raises(NotImplementedError):
+        ppo.PPO(entropy_method_name="conditional_entropy")
+    # (3) an action id outside [0, A) poisons the loss
+    bad = actions.clone(); bad[0, 0] = A
+    _, sums = ppo.ppo_loss_raw(hv, f(bad), f(old_lp), f(old_v), f(returns), f(nadv), A)
+    torch.cuda.synchronize()
+    assert torch.isnan(sums[0]).item()
