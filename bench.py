@@ -8,20 +8,25 @@ frames already resident in HBM:
          all-reduce + clip + Adam]
 value = (T * N_total * steps) / wall time, max over ranks, barrier+sync bracketed.
 
-    python bench.py                       # 1 GPU, 256 actors, K=2 W=1
+    python bench.py                            # 1 GPU, 256 actors, K=2 W=1
+    python bench.py --gpus 8                   # spawns its own 8 ranks (file-store rendezvous, RCCL)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
-        --master-port 29500 bench.py --gpus 8 --steps 2 --warmup 1
+        --master-port 29500 bench.py --gpus 8  # ... or is launched one rank per GPU by torchrun
 
-Scaling is WEAK: every GPU owns --actors (default 256) synthetic actors
-(DD-PPO: actors shard over GPUs; the only exchange is one SUM all-reduce of the
-13.9 MB flat policy-gradient bucket per optimiser step, RCCL over xGMI).
+Scaling: BASELINE.json's metric is "256 actors, 1/2/4/8 MI355X", i.e. the SAME 256 actors sharded over the GPUs
+(strong scaling: 256/N actors per GPU; `--actors-total 512` is config 4 = 64 per GPU at N=8).  For N > 1 the line
+also carries a `weak` object (256 actors PER GPU, the DD-PPO convention) measured in the same process.  Actors shard
+with no data-path collective; the only exchange is one SUM all-reduce of the 13.9 MB flat policy-gradient bucket
+per optimiser step (RCCL over xGMI), timed separately per rank (`allreduce_ms_per_rank`).
 """
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -31,12 +36,15 @@ import torch  # noqa: E402
 
 TRUNK_MAC_PER_FRAME = 5_367_226_368          # SURVEY.md §8d (RN50 trunk, 224x224)
 VIT_MAC_PER_FRAME = 4_050_683_904            # SURVEY.md §8d (ViT-B/32, 11 of 12 blocks)
+ATTNPOOL_MAC_PER_FRAME = 425_984_000 + 49 * 2048 * 2048   # CLS-only query + k/v projections
 POLICY_ACT_MAC = 16_846_336
 POLICY_UPDATE_MAC = 150_775_808              # 4 x (fwd + bwd)
 MFMA_BF16_PEAK_TFLOPS = 2500.0               # MI355X_MICROARCH.md: dense bf16 MFMA
-# HBM bytes per ec_rn50_forward launch at N=256 from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction +
-# WRITE_SIZE, separate --pmc passes): profiles/r01_trunk_b256_hbm_traffic.txt.  Algorithmic: 45.7 MB/frame.
-TRUNK_HBM_BYTES_PER_LAUNCH_N256 = 1.22e10
+POLICY_FLAT_PARAMS = 3_480_775
+# PMC-measured HBM bytes per encoder launch: written by tools/pmc_summary.py from separate rocprofv3 --pmc passes
+# (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), keyed by the library's launch-plan hash
+TRAFFIC_FILES = {"rn50": os.path.join(ROOT, "profiles", "trunk_b256_hbm_traffic.json"),
+                 "vit": os.path.join(ROOT, "profiles", "vit_b256_hbm_traffic.json")}
 
 
 def _usable_cpus() -> int:
@@ -100,85 +108,112 @@ def cpu_baseline(n_actors: int, T: int, update_repeats: int, budget_s: float = 3
             "cpu_model": cpu_model}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--actors", type=int, default=256, help="synthetic actors per GPU (weak) / in total (strong)")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="weak (default, DD-PPO convention): --actors per GPU; strong: --actors in total, sharded")
-    ap.add_argument("--rollout", type=int, default=128)
-    ap.add_argument("--update-repeats", type=int, default=4)
-    ap.add_argument("--encoder-chunk", type=int, default=0)
-    ap.add_argument("--encoder-streams", type=int, default=2, help="concurrent HIP streams for the RN50 encoder")
-    ap.add_argument("--frames-u8", action="store_true",
-                    help="raw uint8 frames in HBM (normalisation fused into the stem); default is the reference "
-                         "sensor's wire form, fp32 normalised HWC")
-    ap.add_argument("--encoder", choices=("rn50", "vit"), default="rn50",
-                    help="rn50 = BASELINE headline config; vit = config 3 (ViT-B/32, parity-unpinned fusion)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--phase-times", action="store_true", help="extra untimed iteration with per-phase sync timing")
-    ap.add_argument("--cpu-actors", type=int, default=32)
-    ap.add_argument("--cpu-rollout", type=int, default=8)
-    a = ap.parse_args()
+def measured_traffic(encoder: str, plan_hash, frames_per_launch: int):
+    """HBM bytes per encoder launch from the committed PMC summary (profiles/*.json), scaled to the launch size.
+    Fails LOUDLY when the summary was measured on a different launch plan / library version (stale evidence);
+    returns (None, note) when no summary exists for this encoder."""
+    path = TRAFFIC_FILES[encoder]
+    if not os.path.exists(path):
+        return None, f"no PMC summary at {os.path.relpath(path, ROOT)} (run tools/pmc_trunk.sh + tools/pmc_summary.py)"
+    rec = json.load(open(path))
+    if plan_hash is not None and rec.get("plan_hash") not in (None, plan_hash):
+        raise SystemExit(f"{os.path.relpath(path, ROOT)} is STALE: measured on launch plan {rec.get('plan_hash')}, the "
+                         f"library now runs plan {plan_hash}. Re-run tools/pmc_trunk.sh + tools/pmc_summary.py and commit "
+                         "the new summary (or pass --no-traffic).")
+    per_frame = rec["hbm_bytes_per_launch"] / rec["frames_per_launch"]
+    return per_frame * frames_per_launch, (
+        f"HBM bytes per launch = PMC-measured {rec['hbm_bytes_per_launch'] / 1e9:.2f} GB per {rec['frames_per_launch']}-frame "
+        f"launch ({os.path.relpath(path, ROOT)}: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc passes) "
+        f"scaled to {frames_per_launch} frames; algorithmic bytes {rec.get('algorithmic_mb_per_frame', 45.7)} MB/frame "
+        "layer by layer")
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus != world and world == 1 and a.gpus > 1:
-        raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nnodes=1 "
-                         f"--nproc-per-node {a.gpus} --master-addr 127.0.0.1 --master-port 29500 bench.py --gpus {a.gpus}")
+
+def _time_iterations(w, steps, warmup, barrier):
+    for _ in range(warmup):
+        w.iteration()
+    w.time_trunk = True
+    w.trunk_events = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        w.iteration()
+    barrier()
+    w.time_trunk = False
+    return time.perf_counter() - t0
+
+
+def run_rank(a, rank: int, local_rank: int, world: int, init_method=None):
+    dist = torch.distributed
+    if a.dry_run:   # launcher / rendezvous / bucket all-reduce only (CPU, gloo): what tests/test_bench_launch.py runs
+        if world > 1:
+            dist.init_process_group("gloo", init_method=init_method, rank=rank, world_size=world)
+        bucket = torch.full((POLICY_FLAT_PARAMS,), float(rank + 1))
+        if world > 1:
+            from embodied_clip_amd.dist import allreduce_flat
+            allreduce_flat(bucket)
+        ok = bool((bucket == world * (world + 1) / 2).all())
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+                              "bucket_elems": POLICY_FLAT_PARAMS, "allreduce_ok": ok}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return 0 if ok else 1
+
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback for the product path)"
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.distributed.init_process_group("nccl", rank=rank, world_size=world)   # RCCL over xGMI
+        dist.init_process_group("nccl", init_method=init_method, rank=rank, world_size=world,
+                                device_id=dev)   # RCCL over xGMI
 
     from embodied_clip_amd.engine import Worker
+    total = a.actors_total if a.actors_total else a.actors
     if a.scaling == "strong":          # the same global actor list sharded over the ranks (SURVEY.md 8e: N/G each)
-        if a.actors % world != 0:
-            raise SystemExit(f"--scaling strong needs --actors ({a.actors}) divisible by the world size ({world})")
-        a.actors //= world
-    w = Worker(a.actors, T=a.rollout, device=dev, seed=0, rank=rank, world=world, update_repeats=a.update_repeats,
+        if total % world != 0:
+            raise SystemExit(f"--scaling strong needs the actor total ({total}) divisible by the world size ({world})")
+        per_gpu = total // world
+    else:
+        per_gpu = total
+    wkw = dict(T=a.rollout, device=dev, seed=0, rank=rank, world=world, update_repeats=a.update_repeats,
                encoder_chunk=a.encoder_chunk, encoder=a.encoder, encoder_streams=a.encoder_streams,
                frames_u8=a.frames_u8)
+    if a.encoder == "zeroshot":
+        wkw.update(encoder="rn50", zeroshot=True)
+    w = Worker(per_gpu, frames_host=a.frames_host, **wkw)
 
     def barrier():
         if world > 1:
-            torch.distributed.barrier()
+            dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        w.iteration()
-    w.time_trunk = True
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        w.iteration()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tt.item())
+    def maxreduce(x: float) -> float:
+        if world == 1:
+            return x
+        tt = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    dt = maxreduce(_time_iterations(w, a.steps, a.warmup, barrier))
     # dominant kernel family: the RN50 trunk's MFMA implicit-GEMM convs, one ec_rn50_forward per env step
     trunk_ms = [e0.elapsed_time(e1) for e0, e1 in w.trunk_events]
     avg_trunk_ms = sum(trunk_ms) / max(1, len(trunk_ms))
     # The encoder launches of one env step run concurrently, one per HIP stream.  The chip-level rate is therefore
     # taken over the UNION of their [start, end] intervals (first start -> last end of the step's launches), which
     # stays correct whether the launches overlap fully, partly, or (under a serialising profiler) not at all.
-    n_conc_ev = max(1, a.actors // max(1, w.encode_frames))
+    n_conc = max(1, per_gpu // max(1, w.encode_frames))
     union_ms = []
     if w.trunk_events:
         ref = w.trunk_events[0][0]
-        for i in range(0, len(w.trunk_events) - n_conc_ev + 1, n_conc_ev):
-            grp = w.trunk_events[i:i + n_conc_ev]
+        for i in range(0, len(w.trunk_events) - n_conc + 1, n_conc):
+            grp = w.trunk_events[i:i + n_conc]
             union_ms.append(max(ref.elapsed_time(e1) for _, e1 in grp) - min(ref.elapsed_time(e0) for e0, _ in grp))
     avg_union_ms = sum(union_ms) / max(1, len(union_ms)) if union_ms else avg_trunk_ms
     info = w.loss_info()
+    plan_hash = w.slices[0].enc.plan_hash() if hasattr(w.slices[0].enc, "plan_hash") else None
+    enc_frames = w.encode_frames
 
     phases = None
     if a.phase_times:
@@ -188,55 +223,165 @@ def main():
         w.update(); w.after_update(); torch.cuda.synchronize(); p3 = time.perf_counter()
         phases = {"rollout_ms": round((p1 - p0) * 1e3, 1), "gae_ms": round((p2 - p1) * 1e3, 2),
                   "update_ms": round((p3 - p2) * 1e3, 1)}
+
+    # the single exchange step, timed alone on every rank (HIP events on the current stream, 20 calls)
+    ar_ms = None
+    if world > 1:
+        from embodied_clip_amd.dist import allreduce_flat
+        for _ in range(3):
+            allreduce_flat(w.grads)
+        barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            allreduce_flat(w.grads)
+        e1.record(); torch.cuda.synchronize()
+        mine = torch.tensor([e0.elapsed_time(e1) / 20], dtype=torch.float64, device=dev)
+        allv = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allv, mine)
+        ar_ms = [round(float(v.item()), 4) for v in allv]
+    rccl_ranks = dist.get_world_size() if world > 1 else 1
+
+    # secondary measurements (rank-synchronous, so every rank runs them)
+    h2d = None
+    if not a.no_h2d and not a.frames_host:
+        w = None             # free the first worker's ~11 GB before building the next
+        gc.collect(); torch.cuda.empty_cache()
+        wh = Worker(per_gpu, frames_host=True, **{**wkw, "frames_u8": True})
+        dth = maxreduce(_time_iterations(wh, 1, 1, barrier))
+        h2d = {"value": round(a.rollout * per_gpu * world / dth, 1), "unit": "env-frames/s", "steps": 1,
+               "frames": "uint8 HWC in PINNED HOST memory, copied per slice on its own copy stream (double-buffered) "
+                         "while the other slice computes; /255 + CLIP mean/std fused into the stem kernel",
+               "h2d_bytes_per_env_step": per_gpu * 224 * 224 * 3}
+        del wh
+        torch.cuda.empty_cache()
+    weak = None
+    if world > 1 and a.scaling == "strong" and not a.no_weak:
+        w = None
+        gc.collect(); torch.cuda.empty_cache()
+        ww = Worker(total, frames_host=a.frames_host, **wkw)
+        dtw = maxreduce(_time_iterations(ww, a.steps, a.warmup, barrier))
+        weak = {"value": round(a.rollout * total * world * a.steps / dtw, 1), "unit": "env-frames/s",
+                "actors_per_gpu": total, "global_actors": total * world, "ms_per_step": round(dtw / a.steps * 1e3, 2)}
+        del ww
+
     if rank == 0:
-        frames = a.rollout * a.actors * world * a.steps
+        frames = a.rollout * per_gpu * world * a.steps
         value = frames / dt
-        enc_mac = TRUNK_MAC_PER_FRAME if a.encoder == "rn50" else VIT_MAC_PER_FRAME
-        flops_call = 2.0 * enc_mac * w.encode_frames     # one timed launch = one (slice of the) encoder forward
-        # encoder launches run `n_conc` at a time (one per HIP stream): the chip-level rate is the aggregate
-        n_conc = max(1, a.actors // w.encode_frames)
+        enc_mac = {"rn50": TRUNK_MAC_PER_FRAME, "vit": VIT_MAC_PER_FRAME,
+                   "zeroshot": TRUNK_MAC_PER_FRAME + ATTNPOOL_MAC_PER_FRAME}[a.encoder]
+        trunk_mac = TRUNK_MAC_PER_FRAME if a.encoder != "vit" else VIT_MAC_PER_FRAME
+        flops_call = 2.0 * trunk_mac * enc_frames          # one timed launch = one (slice of the) encoder forward
         achieved_launch = flops_call / (avg_trunk_ms * 1e-3) / 1e12
         achieved = flops_call * n_conc / (avg_union_ms * 1e-3) / 1e12
+        traffic, tnote = (None, "--no-traffic") if a.no_traffic else measured_traffic(
+            "vit" if a.encoder == "vit" else "rn50", plan_hash, enc_frames)
+        workload = {"rn50": "RoboTHOR ObjectNav: frozen CLIP-RN50 encoder",
+                    "vit": "RoboTHOR ObjectNav: frozen CLIP ViT-B/32 encoder (11 blocks)",
+                    "zeroshot": "Zero-shot ObjectNav: frozen CLIP-RN50 trunk + AttentionPool2d image embedding, goal = "
+                                "CLIP text-tower embedding table"}[a.encoder]
         out = {
             "metric": "env-frames/sec (CLIP encode + policy fwd/bwd + PPO update)",
             "value": round(value, 1), "unit": "env-frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": a.scaling,
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": ("RoboTHOR ObjectNav: frozen CLIP-RN50 encoder" if a.encoder == "rn50" else
-                                    "RoboTHOR ObjectNav: frozen CLIP ViT-B/32 encoder (11 blocks)") +
-                                   " (bf16 MFMA, fp32 accumulate) + "
-                                   "1-layer GRU actor-critic PPO (fp32), synthetic 224x224 RGB + random goal ids",
-                       "actors_per_gpu": a.actors, "global_actors": a.actors * world, "rollout": a.rollout,
+            "config": {"workload": workload + " (bf16 MFMA, fp32 accumulate) + 1-layer GRU actor-critic PPO (fp32), "
+                                               "synthetic 224x224 RGB + random goal ids",
+                       "actors_per_gpu": per_gpu, "global_actors": per_gpu * world, "rollout": a.rollout,
                        "update_repeats": a.update_repeats, "num_mini_batch": 1, "encoder_streams": a.encoder_streams,
-                       "frames": "uint8 HWC (normalisation fused)" if a.frames_u8 else "fp32 normalised HWC",
+                       "frames": ("pinned host -> H2D per step, " if a.frames_host else "resident in HBM, ") +
+                                 ("uint8 HWC (normalisation fused)" if a.frames_u8 else "fp32 normalised HWC"),
                        "parallelism": f"dp{world} (actors sharded; one flat 13.9 MB grad all-reduce per optimiser step)",
-                       "flop_per_frame": 2 * ((TRUNK_MAC_PER_FRAME + POLICY_ACT_MAC + POLICY_UPDATE_MAC)
-                                             if a.encoder == "rn50" else VIT_MAC_PER_FRAME)},
-            "roofline": {"bound": "mfma", "kernel": ("ec_rn50_forward (conv_igemm / conv_pair / conv3x3_narrow MFMA kernels, 50 launches per call)" if a.encoder == "rn50"
-                                    else "ec_vit_forward (conv_igemm GEMMs + mha/layernorm kernels)"),
+                       "flop_per_frame": 2 * (enc_mac + POLICY_ACT_MAC + POLICY_UPDATE_MAC)},
+            "rccl_ranks": rccl_ranks, "allreduce_ms_per_rank": ar_ms,
+            "roofline": {"bound": "mfma",
+                         "kernel": ("ec_rn50_forward (conv_igemm / conv_pair / conv3x3_narrow MFMA kernels)"
+                                    if a.encoder != "vit" else "ec_vit_forward (conv_igemm GEMMs + mha/layernorm kernels)"),
                          "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
-                         "traffic": (TRUNK_HBM_BYTES_PER_LAUNCH_N256 * w.encode_frames / 256.0
-                                     if (a.actors == 256 and a.encoder == "rn50") else None),
-                         "traffic_note": "HBM bytes per launch, PMC-measured offline (profiles/r01_trunk_b256_hbm_traffic.txt); "
-                                         "algorithmic bytes 45.7 MB/frame x N (layer by layer; the fused layer-1 boundaries need less)",
+                         "traffic": traffic, "traffic_note": tnote, "plan_hash": plan_hash,
                          "avg_launch_ms": round(avg_trunk_ms, 3), "avg_step_union_ms": round(avg_union_ms, 3),
-                         "launches_timed": len(trunk_ms),
-                         "frames_per_launch": w.encode_frames, "concurrent_launches": n_conc,
-                         "achieved_per_launch": round(achieved_launch, 1),
+                         "launches_timed": len(trunk_ms), "frames_per_launch": enc_frames,
+                         "concurrent_launches": n_conc, "achieved_per_launch": round(achieved_launch, 1),
                          "algorithmic_flop_per_launch": flops_call,
-                         "encoder_share_of_step": round(sum(trunk_ms) / (dt * 1e3) * w.encode_frames / a.actors, 3)},
+                         "encoder_share_of_step": round(sum(trunk_ms) / (dt * 1e3) / max(1, n_conc), 3)},
             "loss": {k: round(v, 6) for k, v in info.items()},
             **({"phases": phases} if phases else {}),
+            **({"h2d_inclusive": h2d} if h2d else {}),
+            **({"weak": weak} if weak else {}),
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_actors, a.cpu_rollout, a.update_repeats)
             out["cpu_baseline"]["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
     if world > 1:
-        torch.distributed.barrier()
-        torch.distributed.destroy_process_group()
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--actors", type=int, default=256, help="synthetic actors in total (strong) / per GPU (weak)")
+    ap.add_argument("--actors-total", type=int, default=0,
+                    help="global actor count, overrides --actors (512 = BASELINE config 4: 64 per GPU at 8 GPUs)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
+                    help="strong (default; the metric's '256 actors, 1/2/4/8 GPUs'): the actor total is sharded over the "
+                         "ranks; weak: that many actors PER GPU")
+    ap.add_argument("--rollout", type=int, default=128)
+    ap.add_argument("--update-repeats", type=int, default=4)
+    ap.add_argument("--encoder-chunk", type=int, default=0)
+    ap.add_argument("--encoder-streams", type=int, default=2, help="concurrent HIP streams for the encoder")
+    ap.add_argument("--frames-u8", action="store_true",
+                    help="raw uint8 frames (normalisation fused into the stem); default is the reference sensor's wire "
+                         "form, fp32 normalised HWC")
+    ap.add_argument("--frames-host", action="store_true",
+                    help="frames live in pinned HOST memory and cross PCIe every env step (the plugin contract); the "
+                         "default keeps them resident in HBM (SURVEY.md 8d) and reports this as `h2d_inclusive`")
+    ap.add_argument("--encoder", "--config", dest="encoder", choices=("rn50", "vit", "zeroshot"), default="rn50",
+                    help="rn50 = BASELINE headline config; vit = config 3 (ViT-B/32); zeroshot = config 5 "
+                         "(RN50 + attnpool image embedding, CLIP-text goal table)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the secondary h2d_inclusive measurement")
+    ap.add_argument("--no-weak", action="store_true", help="skip the secondary weak-scaling measurement (N > 1)")
+    ap.add_argument("--no-traffic", action="store_true", help="do not read profiles/*_hbm_traffic.json")
+    ap.add_argument("--phase-times", action="store_true", help="extra untimed iteration with per-phase sync timing")
+    ap.add_argument("--cpu-actors", type=int, default=32)
+    ap.add_argument("--cpu-rollout", type=int, default=8)
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher check only: rendezvous + one flat-bucket all-reduce over gloo on CPU, no GPU work")
+    a = ap.parse_args(argv)
+    return a
+
+
+def main(argv=None):
+    a = parse_args(argv)
+    env_world = int(os.environ.get("WORLD_SIZE", "0") or 0)
+    if env_world >= 1 and "RANK" in os.environ:       # launched one process per GPU by torch.distributed.run
+        world, rank = env_world, int(os.environ["RANK"])
+        if a.gpus != world:
+            raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+        return run_rank(a, rank, int(os.environ.get("LOCAL_RANK", str(rank))), world, None)
+    if a.gpus > 1:                                      # self-launch: one spawned rank per GPU, file-store rendezvous
+        import torch.multiprocessing as mp
+        fd, store = tempfile.mkstemp(prefix="ec_bench_store_")
+        os.close(fd); os.unlink(store)
+        mp.spawn(_spawned_entry, args=(a, store), nprocs=a.gpus, join=True)
+        return 0
+    return run_rank(a, 0, 0, 1, None)
+
+
+def _spawned_entry(local_rank: int, a, store_path: str):
+    os.environ.update(RANK=str(local_rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(a.gpus),
+                      MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    rc = run_rank(a, local_rank, local_rank, a.gpus, f"file://{store_path}")
+    if rc:
+        raise SystemExit(rc)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

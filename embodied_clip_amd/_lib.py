@@ -33,6 +33,7 @@ SIGNATURES = {
     "ec_rn50_out_spatial": (c_int, [c_void_p]),
     "ec_rn50_forward": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p, c_int, c_void_p]),
     "ec_rn50_num_ops": (c_int, [c_void_p]),
+    "ec_rn50_plan_hash": (C.c_uint64, [c_void_p]),
     "ec_text_create": (c_int, [C.POINTER(c_void_p), c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p,
                                c_size_t]),
     "ec_text_destroy": (None, [c_void_p]),

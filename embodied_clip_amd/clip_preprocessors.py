@@ -22,6 +22,7 @@ import numpy as np
 import torch
 
 from . import spaces
+from .allenact_compat import Preprocessor
 
 
 def _load_visual_state_dict(clip_model_type: str, state_dict, weights_path):
@@ -46,16 +47,15 @@ def _load_visual_state_dict(clip_model_type: str, state_dict, weights_path):
             "or install openai/CLIP") from e
 
 
-class _PreprocessorBase:
-    """Duck-types ``allenact.base_abstractions.preprocessor.Preprocessor``."""
+class _PreprocessorBase(Preprocessor):
+    """An ``allenact.base_abstractions.preprocessor.Preprocessor`` (the real ABC when allenact is importable,
+    ``allenact_compat``'s restatement otherwise)."""
 
     CLIP_RGB_MEANS = (0.48145466, 0.4578275, 0.40821073)
     CLIP_RGB_STDS = (0.26862954, 0.26130258, 0.27577711)
 
     def __init__(self, input_uuids: List[str], output_uuid: str, observation_space):
-        self.input_uuids = input_uuids
-        self.uuid = output_uuid
-        self.observation_space = observation_space
+        super().__init__(input_uuids=input_uuids, output_uuid=output_uuid, observation_space=observation_space)
 
     def to(self, device: torch.device):
         self.device = torch.device(device)

@@ -192,6 +192,23 @@ extern "C" int ec_rn50_out_channels(const ec_rn50_t* h) { return h ? h->out_c : 
 extern "C" int ec_rn50_out_spatial(const ec_rn50_t* h) { return h ? h->out_sp : 0; }
 extern "C" int ec_rn50_num_ops(const ec_rn50_t* h) { return h ? (int)h->ops.size() : 0; }
 
+// FNV-1a over the launch plan (op kinds, shapes, buffer routing) and the library version: what a PMC traffic
+// summary under profiles/ was measured on.  bench.py refuses a summary whose hash differs (stale evidence).
+extern "C" uint64_t ec_rn50_plan_hash(const ec_rn50_t* h) {
+    if (!h) return 0;
+    uint64_t x = 1469598103934665603ull;
+    auto mix = [&](long v) {
+        for (int i = 0; i < 8; ++i) { x ^= (uint64_t)((v >> (8 * i)) & 0xff); x *= 1099511628211ull; }
+    };
+    mix(ec_version());
+    mix(h->width); mix(h->res);
+    for (const Op& o : h->ops) {
+        mix(o.kind); mix(o.src); mix(o.dst); mix(o.res); mix(o.H); mix(o.W); mix(o.Cin); mix(o.Cout); mix(o.ks);
+        mix(o.pool); mix(o.act); mix(o.src1); mix(o.dst2); mix(o.N2); mix(o.dst3);
+    }
+    return x;
+}
+
 extern "C" size_t ec_rn50_workspace_bytes(const ec_rn50_t* h, int batch) {
     if (!h || batch <= 0) return 0;
     return NBUF * align_up(h->max_elems_per_frame * 2 * (size_t)batch, 256);

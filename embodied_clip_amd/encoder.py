@@ -125,6 +125,10 @@ class RN50Trunk:
         except Exception:
             pass
 
+    def plan_hash(self) -> str:
+        """Hex hash of the launch plan + library version (keys the PMC summaries under profiles/)."""
+        return f"{self.lib.ec_rn50_plan_hash(self.h):016x}"
+
     def _workspace(self, n: int) -> torch.Tensor:
         need = self.lib.ec_rn50_workspace_bytes(self.h, n)
         if self._ws is None or self._ws.numel() < need:

@@ -39,8 +39,9 @@ class SyntheticEnv:
     random goal ids, episode resets w.p. 1/100, RoboTHOR-style rewards."""
 
     def __init__(self, n_actors: int, T: int, device, seed: int, pool_steps: int = 4, res: int = 224,
-                 frames_u8: bool = False):
+                 frames_u8: bool = False, host: bool = False):
         self.N, self.T = n_actors, T
+        self.host = host
         # frames_u8: raw uint8 frames (what the simulator renders); normalisation is then fused into the stem kernel
         base = (syn.synthetic_rgb_u8 if frames_u8 else syn.synthetic_rgb)(seed, min(n_actors, 32), res)
         reps = (n_actors + base.shape[0] - 1) // base.shape[0]
@@ -48,7 +49,10 @@ class SyntheticEnv:
         for s in range(pool_steps):   # distinct frame batches so consecutive steps differ
             f = base.roll(shifts=s + 1, dims=0).roll(shifts=7 * (s + 1), dims=2)
             frames.append(f.repeat(reps, 1, 1, 1)[:n_actors])
-        self.frames = torch.stack(frames).to(device).contiguous()      # [P, N, R, R, 3] fp32 | uint8
+        # host=True: the pool stays in PINNED HOST memory (what the simulators hand over through the plugin contract);
+        # the worker then streams each step's frames over PCIe on a copy stream (Worker._encode_slice)
+        self.frames = (torch.stack(frames).contiguous().pin_memory() if host
+                       else torch.stack(frames).to(device).contiguous())   # [P, N, R, R, 3] fp32 | uint8
         self.pool_steps = pool_steps
         masks = torch.cat([torch.ones(1, n_actors, 1), syn.synthetic_masks(seed + 1, T, n_actors)], 0)
         self.masks = masks.reshape(T + 1, n_actors).to(device).contiguous()
@@ -77,17 +81,18 @@ class Worker:
     def __init__(self, n_actors: int, T: int = 128, device="cuda:0", seed: int = 0, rank: int = 0, world: int = 1,
                  update_repeats: int = 4, lr: float = 3e-4, max_grad_norm: float = 0.5, gamma: float = 0.99,
                  tau: float = 0.95, encoder_sd=None, policy_sd=None, lr_total_steps: int = 300_000_000,
-                 encoder_chunk: int = 0, encoder: str = "rn50", encoder_streams: int = 2, frames_u8: bool = False):
+                 encoder_chunk: int = 0, encoder: str = "rn50", encoder_streams: int = 2, frames_u8: bool = False,
+                 frames_host: bool = False):
         self.lib = _lib.load()
         self.dev = self.device = torch.device(device)
         if self.dev.index is None:
             self.dev = self.device = torch.device("cuda", torch.cuda.current_device())
         self._init(n_actors, T, seed, rank, world, update_repeats, lr, max_grad_norm, gamma, tau, encoder_sd, policy_sd,
-                   lr_total_steps, encoder_chunk, encoder, encoder_streams, frames_u8)
+                   lr_total_steps, encoder_chunk, encoder, encoder_streams, frames_u8, frames_host)
 
     @_lib.on_device
     def _init(self, n_actors, T, seed, rank, world, update_repeats, lr, max_grad_norm, gamma, tau, encoder_sd, policy_sd,
-              lr_total_steps, encoder_chunk, encoder, encoder_streams, frames_u8):
+              lr_total_steps, encoder_chunk, encoder, encoder_streams, frames_u8, frames_host=False):
         self.N, self.T, self.rank, self.world = n_actors, T, rank, world
         self.update_repeats, self.gamma, self.tau = update_repeats, gamma, tau
         self.base_lr, self.lr_total_steps = lr, lr_total_steps
@@ -128,7 +133,7 @@ class Worker:
         self.hv_act = torch.empty((N, self.A + 1), dtype=torch.float32, device=d)
         self.stats = torch.zeros(2, dtype=torch.float64, device=d)
         self.sums = torch.zeros(4, dtype=torch.float64, device=d)
-        self.env = SyntheticEnv(N, T, d, seed=1000 + rank, frames_u8=frames_u8)
+        self.env = SyntheticEnv(N, T, d, seed=1000 + rank, frames_u8=frames_u8, host=frames_host)
         self.slices: List[_Slice] = []
         for i in range(ns):
             sl = _Slice()
@@ -143,6 +148,13 @@ class Worker:
             sl.grads = self.grads if ns == 1 else torch.zeros_like(self.params)
             sl.sums = torch.zeros(4, dtype=torch.float64, device=d)
             sl.goal = sl.masks = sl.actions = sl.logp = sl.old_v = sl.ret = sl.nadv = None
+            if frames_host:   # double-buffered device staging of the slice's frames + its own copy stream (SDMA)
+                fshape = (n,) + tuple(self.env.frames.shape[2:])
+                sl.stage = [torch.empty(fshape, dtype=self.env.frames.dtype, device=d) for _ in range(2)]
+                sl.copy_stream = torch.cuda.Stream(device=d)
+                sl.copied = [torch.cuda.Event() for _ in range(2)]
+                sl.consumed = [None, None]
+                sl.k = 0
             self.slices.append(sl)
         self.encode_frames = n                    # frames per timed encoder launch
         self.seed = seed + 7919 * rank
@@ -184,6 +196,19 @@ class Worker:
     # ---- HOT LOOP A ---------------------------------------------------------------------------
     def _encode_slice(self, sl, rgb: torch.Tensor, t: int):
         src = rgb[sl.o:sl.o + sl.n]
+        if self.env.host:
+            # H2D of this slice's frames on its copy stream, overlapping whatever the other slice is computing; the
+            # staging buffer is reused only after the encoder launch that read it two steps ago has finished
+            i = sl.k & 1
+            sl.k += 1
+            cur = torch.cuda.current_stream()
+            with torch.cuda.stream(sl.copy_stream):
+                if sl.consumed[i] is not None:
+                    sl.copy_stream.wait_event(sl.consumed[i])
+                sl.stage[i].copy_(src, non_blocking=True)
+                sl.copied[i].record(sl.copy_stream)
+            cur.wait_event(sl.copied[i])
+            src = sl.stage[i]
         timed = self.time_trunk
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -197,6 +222,10 @@ class Worker:
         if timed:
             e1.record(torch.cuda.current_stream())
             self.trunk_events.append((e0, e1))
+        if self.env.host:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            sl.consumed[i] = ev
 
     def _act_slice(self, sl, t: int, sample: bool = True):
         """Policy act step (T=1, no grad) for the slice's actors on the current stream."""

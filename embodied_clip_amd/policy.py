@@ -30,61 +30,8 @@ from . import _lib, spaces
 from .synthetic import POLICY_PARAM_ORDER, policy_param_shapes
 
 
-# ---- AllenAct duck types ---------------------------------------------------------------------
-
-class Memory(dict):
-    """Minimal ``allenact.base_abstractions.misc.Memory``: key -> (tensor, sampler_dim)."""
-
-    def check_append(self, key: str, tensor: torch.Tensor, sampler_dim: int) -> "Memory":
-        self[key] = (tensor, sampler_dim)
-        return self
-
-    def tensor(self, key: str) -> torch.Tensor:
-        return self[key][0]
-
-    def sampler_dim(self, key: str) -> int:
-        return self[key][1]
-
-    def set_tensor(self, key: str, tensor: torch.Tensor) -> "Memory":
-        self[key] = (tensor, self[key][1] if key in self else 1)
-        return self
-
-
-class CategoricalDistr:
-    """``allenact.base_abstractions.distributions.CategoricalDistr`` over logits [..., A]."""
-
-    def __init__(self, logits: torch.Tensor):
-        self.logits = logits
-
-    @property
-    def log_probs_tensor(self):
-        return torch.log_softmax(self.logits, dim=-1)
-
-    @property
-    def probs_tensor(self):
-        return torch.softmax(self.logits, dim=-1)
-
-    def log_prob(self, actions: torch.Tensor) -> torch.Tensor:
-        return self.log_probs_tensor.gather(-1, actions.unsqueeze(-1)).squeeze(-1)
-
-    def entropy(self) -> torch.Tensor:
-        lp = self.log_probs_tensor
-        return -(lp.exp() * lp).sum(-1)
-
-    def mode(self) -> torch.Tensor:
-        return self.logits.argmax(dim=-1)
-
-    def sample(self, sample_shape=torch.Size()) -> torch.Tensor:
-        p = self.probs_tensor
-        return torch.multinomial(p.reshape(-1, p.shape[-1]), 1).reshape(p.shape[:-1])
-
-
-class ActorCriticOutput:
-    def __init__(self, distributions, values, extras):
-        self.distributions, self.values, self.extras = distributions, values, extras
-
-    def __iter__(self):   # allow tuple-unpacking like the upstream NamedTuple
-        return iter((self.distributions, self.values, self.extras))
+# ---- AllenAct base abstractions (the real ones when allenact is importable) ----------------------
+from .allenact_compat import ActorCriticModel, ActorCriticOutput, CategoricalDistr, Memory  # noqa: E402,F401
 
 
 # ---- handle ----------------------------------------------------------------------------------
@@ -173,29 +120,51 @@ class PolicyHandle:
 
 
 class _PolicyFn(torch.autograd.Function):
-    """Autograd bridge: HIP forward, HIP backward."""
+    """Autograd bridge: HIP forward, HIP backward.  ``owner`` (the nn.Module, or None) lends a workspace pool and a
+    scratch gradient bucket so that the steady state of act -> learn -> backward allocates nothing."""
 
     @staticmethod
-    def forward(ctx, handle: PolicyHandle, flat, feat, goal, h0, masks, T, N, *params):
+    def forward(ctx, handle: PolicyHandle, owner, flat, feat, goal, h0, masks, T, N, *params):
         need_grad = any(ctx.needs_input_grad)   # (grad mode is always off inside Function.forward)
         nbytes = handle.workspace_bytes(T, N, need_grad)
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=flat.device)
+        pool = owner._ws_pool if owner is not None else None
+        ws = None
+        if pool is not None:
+            for i, t in enumerate(pool):
+                if t.numel() >= nbytes and t.device == flat.device:
+                    ws = pool.pop(i)
+                    break
+        if ws is None:
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=flat.device)
         hv, h_final = handle.forward(flat, feat, goal, h0, masks, T, N, ws)
         if need_grad:
-            ctx.handle, ctx.T, ctx.N = handle, T, N
+            ctx.handle, ctx.owner, ctx.T, ctx.N = handle, owner, T, N
             ctx.save_for_backward(flat, feat, masks, ws)
+        elif pool is not None:
+            pool.append(ws)         # stream-ordered reuse: the next launch on this stream runs after this one
         return hv, h_final
 
     @staticmethod
     def backward(ctx, dhv, dh_final):
         flat, feat, masks, ws = ctx.saved_tensors
         h: PolicyHandle = ctx.handle
-        g = torch.zeros_like(flat)
+        owner = ctx.owner
+        # the scratch bucket may only be lent when every .grad is already bound (autograd then accumulates INTO the
+        # bound views and never keeps a reference to what is returned here)
+        lend = owner is not None and all(p.grad is not None for p in owner.parameters())
+        if lend:
+            if owner._g_scratch is None or owner._g_scratch.device != flat.device:
+                owner._g_scratch = torch.empty_like(flat)
+            g = owner._g_scratch.zero_()
+        else:
+            g = torch.zeros_like(flat)
         dhv = dhv.contiguous() if dhv is not None else torch.zeros((ctx.T * ctx.N, h.A + 1), device=flat.device)
         dhf = dh_final.contiguous() if dh_final is not None else None
         h.backward(flat, feat, masks, ctx.T, ctx.N, ws, dhv, dhf, g)
+        if owner is not None and len(owner._ws_pool) < 4:
+            owner._ws_pool.append(ws)
         grads = tuple(g[o:o + k].view(h.shapes[n]) for n, (o, k) in h.offsets.items())
-        return (None, None, None, None, None, None, None, None) + grads
+        return (None,) * 9 + grads
 
 
 class _Holder(nn.Module):
@@ -212,24 +181,36 @@ def _set_nested(root: nn.Module, dotted: str, p: nn.Parameter):
     m.register_parameter(parts[-1], p)
 
 
-class ResnetTensorObjectNavActorCritic(nn.Module):
+class ResnetTensorObjectNavActorCritic(ActorCriticModel):
     """[U] ``ResnetTensorObjectNavActorCritic(action_space, observation_space, goal_sensor_uuid,
-    rgb_resnet_preprocessor_uuid, depth_resnet_preprocessor_uuid=None, hidden_size=512, goal_dims=32,
-    resnet_compressor_hidden_out_dims=(128, 32), combiner_hidden_out_dims=(128, 32))``."""
+    rgb_resnet_preprocessor_uuid=None, depth_resnet_preprocessor_uuid=None, hidden_size=512, goal_dims=32,
+    resnet_compressor_hidden_out_dims=(128, 32), combiner_hidden_out_dims=(128, 32))`` -- an
+    ``allenact...policy.ActorCriticModel`` (the real ABC when allenact is importable).
+
+    Exactly one of the two preprocessor uuids selects the single-tower ``ResnetTensorGoalEncoder`` (RGB for the CLIP
+    configs of the reference; a depth-only tower is the same arithmetic on the depth features).  Both at once is
+    upstream's ``ResnetDualTensorGoalEncoder`` (RGB-D), which none of the reference's CLIP configs use: not built.
+    """
 
     def __init__(self, action_space, observation_space, goal_sensor_uuid: str,
-                 rgb_resnet_preprocessor_uuid: Optional[str], depth_resnet_preprocessor_uuid: Optional[str] = None,
+                 rgb_resnet_preprocessor_uuid: Optional[str] = None, depth_resnet_preprocessor_uuid: Optional[str] = None,
                  hidden_size: int = 512, goal_dims: int = 32, resnet_compressor_hidden_out_dims=(128, 32),
                  combiner_hidden_out_dims=(128, 32), state_dict: Optional[Dict[str, torch.Tensor]] = None,
                  device="cuda"):
-        super().__init__()
-        if depth_resnet_preprocessor_uuid is not None:
-            raise NotImplementedError("RGB-only (the CLIP configs of the reference are RGB-only)")
-        self.action_space = action_space
-        self.observation_space = observation_space
+        super().__init__(action_space=action_space, observation_space=observation_space)
+        if rgb_resnet_preprocessor_uuid is not None and depth_resnet_preprocessor_uuid is not None:
+            raise NotImplementedError("RGB-D (ResnetDualTensorGoalEncoder) is not built: the reference's CLIP configs "
+                                      "are single-tower")
+        if rgb_resnet_preprocessor_uuid is None and depth_resnet_preprocessor_uuid is None:
+            raise ValueError("one of rgb_resnet_preprocessor_uuid / depth_resnet_preprocessor_uuid is required")
         self.goal_uuid = goal_sensor_uuid
-        self.resnet_uuid = rgb_resnet_preprocessor_uuid
+        self.resnet_uuid = (rgb_resnet_preprocessor_uuid if rgb_resnet_preprocessor_uuid is not None
+                            else depth_resnet_preprocessor_uuid)
         self._hidden_size = hidden_size
+        self._ws_pool: list = []
+        self._g_scratch: Optional[torch.Tensor] = None
+        if self.resnet_uuid not in observation_space.spaces:
+            raise NotImplementedError("blind agent (no visual tensor in the observation space) is not built")
         rs = observation_space.spaces[self.resnet_uuid].shape        # (C, S, S)
         num_goals = getattr(observation_space.spaces[self.goal_uuid], "n", 12)
         self.handle = PolicyHandle(in_channels=rs[0], spatial=rs[1], hidden=hidden_size, goal_dims=goal_dims,
@@ -253,7 +234,15 @@ class ResnetTensorObjectNavActorCritic(nn.Module):
         return [(n, d[n]) for n in POLICY_PARAM_ORDER]
 
     def _bind_grads(self):
+        """(Re)bind every ``p.grad`` to its view of the flat gradient bucket.  ``optimizer.zero_grad()`` of recent
+        torch sets grads to None: the view is then zeroed and bound again; a foreign grad tensor is copied in."""
         for (n, p), (_, g) in zip(self._named(), self.handle.views(self._flat_grad).items()):
+            if p.grad is None:
+                g.zero_()
+            elif p.grad.data_ptr() != g.data_ptr():
+                g.copy_(p.grad)
+            else:
+                continue
             p.grad = g
 
     def ensure_flat(self):
@@ -261,6 +250,7 @@ class ResnetTensorObjectNavActorCritic(nn.Module):
         ok = all(p.data_ptr() == self._flat.data_ptr() + 4 * off and p.device == self._flat.device
                  for (n, p), (off, _) in zip(self._named(), self.handle.offsets.values()))
         if ok:
+            self._bind_grads()
             return
         dev = self._named()[0][1].device
         self._flat = self.handle.flatten({n: p.data for n, p in self._named()}, dev)
@@ -288,6 +278,11 @@ class ResnetTensorObjectNavActorCritic(nn.Module):
     def num_recurrent_layers(self) -> int:
         return 1
 
+    @property
+    def is_blind(self) -> bool:
+        """True if the model has no visual input ([U] ``goal_visual_encoder.is_blind``); never, once constructed."""
+        return False
+
     def _recurrent_memory_specification(self):
         return dict(rnn=((("layer", self.num_recurrent_layers), ("sampler", None),
                           ("hidden", self.recurrent_hidden_state_size)), torch.float32))
@@ -312,8 +307,8 @@ class ResnetTensorObjectNavActorCritic(nn.Module):
         h0 = memory.tensor("rnn").reshape(N, self._hidden_size).to(torch.float32).contiguous()
         m = masks.reshape(T * N).to(torch.float32).contiguous()
         params = [p for _, p in self._named()]
-        hv, h_final = _PolicyFn.apply(self.handle, self._flat, rows, goal, h0, m, T, N, *params)
+        hv, h_final = _PolicyFn.apply(self.handle, self, self._flat, rows, goal, h0, m, T, N, *params)
         A = self.handle.A
         hv = hv.view(T, N, A + 1)
-        out = ActorCriticOutput(distributions=CategoricalDistr(hv[..., :A]), values=hv[..., A:], extras={})
+        out = ActorCriticOutput(distributions=CategoricalDistr(logits=hv[..., :A]), values=hv[..., A:], extras={})
         return out, memory.set_tensor("rnn", h_final.view(1, N, self._hidden_size))

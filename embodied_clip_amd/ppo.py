@@ -18,6 +18,7 @@ from typing import Dict, Optional, Tuple
 import torch
 
 from . import _lib
+from .allenact_compat import AbstractActorCriticLoss
 
 PPOConfig = dict(clip_param=0.1, value_loss_coef=0.5, entropy_coef=0.01)
 
@@ -59,11 +60,12 @@ class _PPOLossFn(torch.autograd.Function):
         return (dhv * gtotal,) + (None,) * 10
 
 
-class PPO:
-    """Drop-in for AllenAct's ``PPO`` loss (``AbstractActorCriticLoss``)."""
+class PPO(AbstractActorCriticLoss):
+    """Drop-in for AllenAct's ``PPO`` loss (an ``AbstractActorCriticLoss``; the real ABC when allenact is importable)."""
 
     def __init__(self, clip_param=0.1, value_loss_coef=0.5, entropy_coef=0.01, use_clipped_value_loss=True,
                  clip_decay=None, entropy_method_name="entropy", normalize_advantage=True, **kwargs):
+        super().__init__()
         if entropy_method_name != "entropy":
             # upstream calls getattr(distributions, entropy_method_name)(); only the categorical entropy is fused
             raise NotImplementedError(f"entropy_method_name={entropy_method_name!r}: only 'entropy' is implemented")

@@ -147,6 +147,9 @@ int ec_rn50_forward_u8(const ec_rn50_t* h, const uint8_t* rgb_u8_nhwc, const flo
 /* debugging / parity: copy of an intermediate stage of the LAST forward is not
  * kept; instead run only the first `n_ops` ops and return the op's output dims. */
 int ec_rn50_num_ops(const ec_rn50_t* h);
+/* 64-bit hash of the handle's launch plan (op kinds, shapes, buffer routing) and the library version: identifies
+ * what a profiler summary under profiles/ was measured on (bench.py rejects a stale one). */
+uint64_t ec_rn50_plan_hash(const ec_rn50_t* h);
 
 
 /* ------------------------------------------------------------------------

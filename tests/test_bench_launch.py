@@ -1,0 +1,46 @@
+"""CPU: `python bench.py --gpus N` launches its own N ranks.  `--dry-run` runs the launcher,
+the file-store rendezvous and ONE flat-bucket SUM all-reduce of the policy-gradient bucket (3,480,775 fp32) over
+gloo -- the path the driver's `--gpus 2/4/8` runs takes before any GPU work -- and the torchrun-style env launch."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _last_json(out: str):
+    return json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+
+
+@pytest.mark.timeout(300)
+def test_bench_self_launches_two_ranks():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"],
+                       capture_output=True, text=True, timeout=280, cwd=ROOT,
+                       env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = _last_json(r.stdout)
+    assert line == {"dry_run": True, "n_gpus": 2, "rccl_ranks": 2, "bucket_elems": 3480775, "allreduce_ok": True}
+
+
+@pytest.mark.timeout(300)
+def test_bench_single_rank_and_world_mismatch():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run"], capture_output=True, text=True,
+                       timeout=120, cwd=ROOT,
+                       env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+    assert r.returncode == 0 and _last_json(r.stdout)["n_gpus"] == 1, r.stdout + r.stderr
+    env = dict(os.environ, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-run"], capture_output=True,
+                       text=True, timeout=120, cwd=ROOT, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stdout + r.stderr)
+
+
+def test_bench_defaults_are_the_metric_configuration():
+    sys.path.insert(0, ROOT)
+    import bench
+    a = bench.parse_args([])
+    assert (a.gpus, a.actors, a.rollout, a.update_repeats, a.scaling, a.encoder) == (1, 256, 128, 4, "strong", "rn50")
+    a = bench.parse_args(["--gpus", "8", "--actors-total", "512"])
+    assert a.actors_total == 512 and a.scaling == "strong"       # config 4: 64 actors per GPU

@@ -210,10 +210,12 @@ def test_actor_critic_module_autograd_surface(dev):
                                              state_dict=sd, device=dev)
     assert [n for n, _ in model.named_parameters()] == list(syn.POLICY_PARAM_ORDER)
     assert model._recurrent_memory_specification()["rnn"][0] == (("layer", 1), ("sampler", None), ("hidden", 32))
+    assert model.recurrent_memory_specification["rnn"][1] == torch.float32 and not model.is_blind
     mem = Memory().check_append("rnn", h0.to(dev), 1)
     out, mem2 = model({"rgb_clip_resnet": feat.to(dev), "goal": goal.to(dev)}, mem, None, masks.to(dev))
     ref_logits, ref_values, ref_h = opol.actor_critic_forward(feat, goal, h0, masks, sd)
-    assert _rel(out.distributions.logits, ref_logits) < 2e-5 and _rel(out.values, ref_values) < 2e-5
+    # CategoricalDistr holds NORMALISED logits (torch.distributions.Categorical semantics, as upstream)
+    assert _rel(out.distributions.logits, torch.log_softmax(ref_logits, -1)) < 2e-5 and _rel(out.values, ref_values) < 2e-5
     assert _rel(mem2.tensor("rnn"), ref_h) < 2e-5
     actions, old_lp, old_v, returns, nadv = _loss_inputs(T, N, 12)
     batch = dict(actions=actions.to(dev), old_action_log_probs=old_lp.to(dev), values=old_v.to(dev),
@@ -258,7 +260,7 @@ def test_ppo_variants_unclipped_value_loss_clip_decay_and_bad_actions(dev):
     decay = lambda step: max(0.0, 1.0 - step / 100.0)
     lg = logits.detach().to(dev).requires_grad_(True)
     vv = values.detach().to(dev).requires_grad_(True)
-    out = ActorCriticOutput(CategoricalDistr(lg), vv, {})
+    out = ActorCriticOutput(CategoricalDistr(logits=lg), vv, {})
     batch = dict(actions=actions.to(dev), old_action_log_probs=old_lp.to(dev), values=old_v.to(dev),
                  returns=returns.to(dev), norm_adv_targ=nadv.to(dev), adv_targ=nadv.to(dev))
     t40, _ = ppo.PPO(clip_param=0.1, clip_decay=decay).loss(40, batch, out)
@@ -275,3 +277,69 @@ def test_ppo_variants_unclipped_value_loss_clip_decay_and_bad_actions(dev):
     _, sums = ppo.ppo_loss_raw(hv, f(bad), f(old_lp), f(old_v), f(returns), f(nadv), A)
     torch.cuda.synchronize()
     assert torch.isnan(sums[0]).item()
+
+
+def test_allenact_engine_call_sequence(dev):
+    """Replays what [U] AllenAct's OnPolicyTrainer does with the model: act steps (T=1, no_grad) that round-trip the
+    recurrent state through ``Memory`` (step_squeeze / sampler_select as ``RolloutStorage`` uses them), then a
+    ``recurrent_generator``-shaped batch -> ``PPO.loss`` -> ``backward()`` -> per-parameter ``.grad``, an
+    ``optimizer.zero_grad()`` (set_to_none) and a second update -- against the oracle at every stage."""
+    from embodied_clip_amd import spaces
+    from embodied_clip_amd.policy import Memory, ResnetTensorObjectNavActorCritic
+    from embodied_clip_amd.ppo import PPO
+    T, N = 5, 4
+    cfg, sd, feat, goal, h0, masks = _policy_case(T, N, C=64, S=3, H=32, seed=21)
+    obs_space = spaces.Dict({"rgb_clip_resnet": spaces.Box(-1e9, 1e9, (64, 3, 3)), "goal": spaces.Discrete(12)})
+    model = ResnetTensorObjectNavActorCritic(spaces.Discrete(6), obs_space, goal_sensor_uuid="goal",
+                                             rgb_resnet_preprocessor_uuid="rgb_clip_resnet", hidden_size=32,
+                                             state_dict=sd, device=dev)
+    spec = model.recurrent_memory_specification
+    (dims, dtype), = spec.values()
+    sampler_dim = [d[0] for d in dims].index("sampler")
+    # --- act: storage keeps memory as [step, layer, sampler, hidden]; the engine feeds step_squeeze(t) to the model
+    stored = torch.zeros(T + 1, 1, N, 32)
+    stored[0] = h0
+    actions, logps, vals = [], [], []
+    h_ref = h0.clone()
+    with torch.no_grad():
+        for t in range(T):
+            mem = Memory().check_append("rnn", stored[t:t + 1].to(dev), sampler_dim + 1).step_squeeze(0)
+            assert mem.sampler_dim("rnn") == sampler_dim and mem.tensor("rnn").shape == (1, N, 32)
+            obs = {"rgb_clip_resnet": feat[t:t + 1].to(dev), "goal": goal[t:t + 1].to(dev)}
+            out, mem2 = model(obs, mem, None, masks[t:t + 1].to(dev))
+            lg_ref, v_ref, h_ref = opol.actor_critic_forward(feat[t:t + 1], goal[t:t + 1], h_ref, masks[t:t + 1], sd)
+            assert _rel(out.distributions.probs_tensor, torch.softmax(lg_ref, -1)) < 2e-5
+            a = out.distributions.sample()
+            assert a.shape == (1, N)
+            actions.append(a.cpu()); logps.append(out.distributions.log_prob(a).cpu()); vals.append(out.values.cpu())
+            assert abs(float(logps[-1].sum()) - float(opol.categorical_log_prob(lg_ref, a.cpu()).sum())) < 1e-4
+            stored[t + 1] = mem2.tensor("rnn").cpu()
+            assert _rel(stored[t + 1], h_ref) < 2e-5
+            # a sampler paused / dropped: memory narrows along the sampler dim
+            assert mem2.sampler_select([0, 2]).tensor("rnn").shape == (1, 2, 32)
+    # --- learn: one recurrent minibatch (num_mini_batch=1 == all samplers), memory = the rollout's first step
+    actions = torch.cat(actions); old_lp = torch.cat(logps).unsqueeze(-1); old_v = torch.cat(vals)
+    returns = old_v + 0.3; nadv = torch.randn(T, N, 1, generator=torch.Generator().manual_seed(9))
+    batch = dict(actions=actions.to(dev), old_action_log_probs=old_lp.to(dev), values=old_v.to(dev),
+                 returns=returns.to(dev), norm_adv_targ=nadv.to(dev), adv_targ=nadv.to(dev))
+    opt = torch.optim.Adam(model.parameters(), lr=3e-4)
+    sd_ref = {k: v.clone() for k, v in sd.items()}
+    st = {}
+    ref_batch = dict(feat=feat, goal=goal, h0=h0, masks=masks, actions=actions, old_log_probs=old_lp, old_values=old_v,
+                     returns=returns, norm_adv=nadv)
+    for it in range(2):
+        mem = Memory().check_append("rnn", stored[0:1].to(dev), sampler_dim + 1).step_squeeze(0)
+        out, _ = model({"rgb_clip_resnet": feat.to(dev), "goal": goal.to(dev)}, mem, actions.to(dev), masks.to(dev))
+        total, info = PPO().loss(it, batch, out)
+        opt.zero_grad()                      # recent torch: grads -> None; the flat bucket must survive this
+        total.backward()
+        bucket = model.handle.views(model.flat_grads)      # (re)binds every .grad into the single flat bucket
+        for n, p in model.named_parameters():
+            assert p.grad is not None and p.grad.data_ptr() == bucket[n].data_ptr(), n
+        info_ref, _ = oppo.ppo_update_step(sd_ref, ref_batch, st, max_grad_norm=1e9)
+        assert abs(info["ppo_total"] - info_ref["ppo_total"]) < 1e-4 * max(1.0, abs(info_ref["ppo_total"]))
+        opt.step()
+        model.ensure_flat()
+    for n, p in model.named_parameters():
+        upd, upd_ref = p.detach().cpu() - sd[n], sd_ref[n] - sd[n]
+        assert (upd - upd_ref).abs().max() < 0.15 * 2 * 3e-4 + 1e-7, n
