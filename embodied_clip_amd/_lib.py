@@ -20,6 +20,7 @@ SIGNATURES = {
     "ec_version": (c_int, []),
     "ec_strerror": (C.c_char_p, [c_int]),
     "ec_conv_bf16": (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p]),
+    "ec_debug_stamps": (c_int, [c_void_p, c_int]),
     "ec_gemm_bf16": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
     "ec_stem_conv1": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
     "ec_avgpool2_bf16": (c_int, [c_void_p] * 2 + [c_int] * 4 + [c_void_p]),

@@ -388,7 +388,7 @@ int launch(const ConvArgs& a, hipStream_t s) {
     const size_t lds_max = 2 * (size_t)(BM + BN) * ROW_BYTES;
     const size_t epi = (size_t)(POOL ? BM / 4 : BM) * (BN * 2 + 16);
     static const int nbuf_force = [] { const char* e = getenv("EC_CONV_NBUF"); return e ? atoi(e) : 0; }();
-    p.nbuf = nbuf_force ? nbuf_force : 1;
+    p.nbuf = nbuf_force ? nbuf_force : ((BM * BN >= 256 * 256) ? 2 : 1);
     static const int ablate = [] { const char* e = getenv("EC_CONV_ABLATE"); return e ? atoi(e) : 0; }();
     p.ablate = ablate;
     size_t lds = (size_t)p.nbuf * (BM + BN) * ROW_BYTES;   // (set after nbuf below)
@@ -401,17 +401,385 @@ int launch(const ConvArgs& a, hipStream_t s) {
     }
     // persistent: 3 workgroups per CU (<= 168 VGPRs, single 35-KB LDS stage), each walking several tiles
     static const int wg_cap = [] { const char* e = getenv("EC_CONV_WGS"); return e ? atoi(e) : 768; }();
-    const int nwg = p.ntiles < wg_cap ? p.ntiles : wg_cap;
+    const int cap = (BM * BN >= 256 * 256) ? 256 : wg_cap;      // 8-wave 256x256 tiles: one workgroup per CU
+    const int nwg = p.ntiles < cap ? p.ntiles : cap;
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(WM * WN * 64), lds, s, p);
     EC_CHECK_LAUNCH();
     return EC_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// conv_igemm8: 8-wave "ping-pong" kernel for the compute-bound layers (round 2).
+//
+// Why: with 128x128 tiles the CU's vector-memory path (64 B/clk: one 1-KiB LDS-DMA piece per 16 clk) needs as long to
+// feed a K-tile (32 KB) as the four SIMDs need to multiply it (16 MFMAs x 32 clk), and because every wave of the
+// workgroup issues its pieces at the same point of the loop the two never overlap well (measured: MFMA 33 us + loads
+// 42 us ~ the sum).  This kernel halves the bytes per flop (256 x 256 x 64 tile, 64 KB per K-tile for 4x the MFMAs) and
+// makes the overlap structural:
+//   * 8 waves = 2 (M) x 4 (N), wave tile 128 x (BN/4), two waves per SIMD; one workgroup per CU, two 64-KB LDS stages;
+//   * the two waves of a SIMD belong to different GROUPS (waves 0-3 / 4-7) that run the same program shifted by one
+//     segment: while one group is in a MEMORY segment (LDS-DMA issue for the next K-tile + ds_read of the fragments of
+//     half a K-tile), the other is in a COMPUTE segment (16 back-to-back MFMAs at raised priority).  Segments are
+//     separated by raw s_barrier (no vmcnt drain); group 1 enters the loop through one extra barrier.
+//   * LDS-DMA pieces of K-tile t+1 are issued in the first two segments of K-tile t and waited for (s_waitcnt vmcnt(0),
+//     each wave for its own pieces) two segments later, just before the barrier that precedes the first read of t+1:
+//         s = 4t   : g0 MEM0(t)  [issue A pieces t+1 | read frags (t, k 0..31)]        g1 CMP1(t-1)
+//         s = 4t+1 : g0 CMP0(t)  [16 MFMA + issue B pieces t+1]                       g1 MEM0(t)
+//         s = 4t+2 : g0 MEM1(t)  [read frags (t, k 32..63)]                            g1 CMP0(t)
+//         s = 4t+3 : g0 CMP1(t)  [16 MFMA; vmcnt(0)]                                   g1 MEM1(t) [vmcnt(0)]
+//     WAR: the stage of K-tile t-1 is re-filled from s = 4t on; its last reader is g1's MEM1(t-1) at s = 4t-1, which
+//     ends with lgkmcnt(0) before the barrier.  RAW: every wave has waited for its pieces of t+1 before the barrier
+//     that ends s = 4t+3; the first reader is g0's MEM0(t+1) at s = 4t+4.
+// Operand fetch (implicit im2col, zero page for padding), LDS swizzle, swapped MFMA operands and the epilogue
+// (bias / residual / ReLU / fused 2x2 average pool through LDS, 16-byte coalesced stores) are those of conv_igemm_kernel.
+// Requires Cin % 64 == 0 (a K-tile never straddles a 3x3 tap) and Cout % BN == 0.
+__device__ unsigned long long ec_dbg_stamps[2 * 1024];   // profiling only (EC_CONV_ABLATE & 32): s_memtime stamps of block 0
+
+template <int BN, int KS, bool POOL, int ABL>
+__global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
+    constexpr int BM = 256, WN = 4;
+    constexpr int TM = 128, TN = BN / WN;
+    constexpr int FM = TM / 32, FN = TN / 32;
+    constexpr int NT = 512, LR = NT / 8;
+    constexpr int A_IT = BM / LR, B_IT = BN / LR;
+    constexpr int A_BYTES = BM * ROW_BYTES, B_BYTES = BN * ROW_BYTES, STAGE = A_BYTES + B_BYTES;
+    static_assert(FN >= 1 && B_IT >= 1, "BN must be 128 or 256");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int grp = wm;                                 // waves 0-3 / 4-7: the two waves of every SIMD
+
+    const int tile = (int)ec_xcd_remap(blockIdx.x, gridDim.x);
+    if (tile >= p.ntiles) return;
+    const int m0 = (tile / p.ntn) * BM;
+    const int n0 = (tile % p.ntn) * BN;
+
+    // ---- loader geometry (K-invariant) ----
+    const int chunk = (tid & 7) ^ ((tid >> 4) & 7);
+    const int lrow = tid >> 3;
+    unsigned a_off[A_IT], a_msk[A_IT], b_off[B_IT];
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int m = m0 + lrow + LR * i;
+        int pix, y = 0, x = 0;
+        if (POOL) {
+            const int q = m >> 2, s2 = m & 3;
+            const int Hp = p.H >> 1, Wp = p.W >> 1;
+            const int b = q / (Hp * Wp);
+            const int r2 = q - b * (Hp * Wp);
+            const int yp = r2 / Wp;
+            y = 2 * yp + (s2 >> 1);
+            x = 2 * (r2 - yp * Wp) + (s2 & 1);
+            pix = (b * p.H + y) * p.W + x;
+        } else if (KS == 1) {
+            pix = m;
+        } else {
+            const int b = m / (p.H * p.W);
+            const int r2 = m - b * (p.H * p.W);
+            y = r2 / p.W;
+            x = r2 - y * p.W;
+            pix = m;
+        }
+        unsigned msk = 1u;
+        if (KS == 3) {
+            const unsigned xm = (x > 0 ? 1u : 0u) | 2u | (x < p.W - 1 ? 4u : 0u);
+            msk = (y > 0 ? xm : 0u) | (xm << 3) | (y < p.H - 1 ? (xm << 6) : 0u);
+        }
+        a_msk[i] = (m < p.M) ? msk : 0u;
+        a_off[i] = (unsigned)pix * (unsigned)p.Cin * 2u + (unsigned)chunk * 16u;
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) b_off[i] = ((unsigned)(n0 + lrow + LR * i) * (unsigned)p.K + chunk * 8) * 2u;
+
+    const unsigned char* in_b = reinterpret_cast<const unsigned char*>(p.in);
+    const unsigned char* w_b = reinterpret_cast<const unsigned char*>(p.w);
+    const unsigned char* zp = reinterpret_cast<const unsigned char*>(ec_zero_page);
+    const int wave_lds = wave * 1024;
+    const int nk = p.K / BK;                            // Cin % 64 == 0: whole K-tiles, one tap per K-tile
+
+    // piece q of K-tile kt into stage buf: q < A_IT -> 8 pixel rows per wave, else 8 weight rows
+    int g_toff = 0; unsigned g_tapbit = 1u; int g_kt = 0;
+    unsigned char* g_sa = smem;
+    auto glds_begin = [&](int kt, int buf) {
+        g_sa = smem + buf * STAGE + wave_lds;
+        g_kt = kt;
+        g_toff = kt * (BK * 2);
+        g_tapbit = 1u;
+        if (KS == 3) {
+            const int k = kt * BK;
+            const int tap = k >> p.cin_log2, ci = k & (p.Cin - 1);
+            const int ky = (tap * 11) >> 5;
+            g_toff = (((ky - 1) * p.W + (tap - ky * 3 - 1)) * p.Cin + ci) * 2;
+            g_tapbit = 1u << tap;
+        }
+    };
+    auto glds_piece = [&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        if constexpr (q < A_IT) {
+            const unsigned char* src = (a_msk[q] & g_tapbit) ? in_b + (a_off[q] + (unsigned)g_toff) : zp;
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(g_sa + q * (LR * ROW_BYTES)), 16, 0, 0);
+        } else {
+            constexpr int i = q - A_IT;
+            const unsigned char* src = w_b + (b_off[i] + (unsigned)(g_kt * (BK * 2)));
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(g_sa + A_BYTES + i * (LR * ROW_BYTES)), 16, 0, 0);
+        }
+    };
+
+    f32x16_t acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int frow = lane & 31, fhalf = lane >> 5;
+    // fragment byte offsets inside a stage: row-dependent part (the swizzle XOR depends on (row>>1)&7 == (frow>>1)&7
+    // for rows that are multiples of 32 apart), k-step part added per read
+    int fa_base[FM], fb_base[FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) fa_base[i] = (wm * TM + i * 32 + frow) * ROW_BYTES;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) fb_base[j] = A_BYTES + (wn * TN + j * 32 + frow) * ROW_BYTES;
+    const int fsw = (frow >> 1) & 7;
+
+    s16x8_t fa[2][FM], fb[2][FN];
+    auto read_half = [&](int buf, auto hc) {            // fragments of k-steps 2h, 2h+1 of the K-tile in stage buf
+        constexpr int h = decltype(hc)::value;
+        const unsigned char* st = smem + buf * STAGE;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int c = ((h * 2 + u) * 2 + fhalf) ^ fsw;
+#pragma unroll
+            for (int i = 0; i < FM; ++i) fa[u][i] = *reinterpret_cast<const s16x8_t*>(st + fa_base[i] + (c << 4));
+#pragma unroll
+            for (int j = 0; j < FN; ++j) fb[u][j] = *reinterpret_cast<const s16x8_t*>(st + fb_base[j] + (c << 4));
+        }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+
+    // ---- prologue: K-tile 0 into stage 0 ----
+    glds_begin(0, 0);
+    [&]<int... Q>(std::integer_sequence<int, Q...>) { (glds_piece(std::integral_constant<int, Q>{}), ...); }
+    (std::make_integer_sequence<int, A_IT + B_IT>{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    auto issue_all = [&](int kt, int buf) {             // all of this wave's pieces of K-tile kt, back to back
+        glds_begin(kt, buf);
+        [&]<int... Q>(std::integer_sequence<int, Q...>) { (glds_piece(std::integral_constant<int, Q>{}), ...); }
+        (std::make_integer_sequence<int, A_IT + B_IT>{});
+    };
+    // 16 MFMAs (the two k-steps held in fa/fb); with PIECES the wave's LDS-DMA pieces of K-tile (pk -> stage pbuf) are
+    // issued in their shadow, one piece per 2 MFMAs
+    auto mfma16 = [&](bool issue, int pk, int pbuf) {   // `issue` is wave-uniform (scalar branch around each piece)
+        if (issue) glds_begin(pk, pbuf);
+        [&]<int... Q>(std::integer_sequence<int, Q...>) {
+            ([&] {
+                constexpr int u = Q / (FM * FN), r = Q % (FM * FN), i = r / FN, j = r % FN;
+                if constexpr (!(ABL & 2))
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        __builtin_bit_cast(bf16x8_t, fb[u][j]), __builtin_bit_cast(bf16x8_t, fa[u][i]), acc[i][j], 0, 0, 0);
+                constexpr int NP = A_IT + B_IT, EVERY = (2 * FM * FN) / NP;
+                if constexpr (Q % EVERY == EVERY - 1 && Q / EVERY < NP) {
+                    if (issue) glds_piece(std::integral_constant<int, Q / EVERY>{});
+                }
+            }(), ...);
+        }(std::make_integer_sequence<int, 2 * FM * FN>{});
+    };
+    if (grp) {                                          // stagger: group 1 runs one segment behind group 0 ...
+        if (nk > 1 && !(ABL & 1)) issue_all(1, 1);      // ... and uses the slot to fetch K-tile 1 (its "CMP1(-1)")
+        if constexpr (!(ABL & 16)) __builtin_amdgcn_s_barrier();
+    }
+
+    constexpr int abl = ABL;                            // profiling only: 1 no loads, 2 no MFMA, 4 no ds_read, 16 no barriers, 32 stamps
+    const bool dbg = (abl & 32) && blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0;
+    unsigned long long* dbg_lds = reinterpret_cast<unsigned long long*>(smem + 2 * STAGE) + grp * 256;
+    int dbg_i = 0;
+    auto stamp = [&]() { if constexpr ((abl & 32) != 0) if (dbg && dbg_i < 256) dbg_lds[dbg_i++] = __builtin_amdgcn_s_memtime(); };
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = (kt + 1) < nk && !(abl & 1);
+        // ---- MEM0 ----
+        if constexpr (!(abl & 4)) read_half(cur, I0{});
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        stamp();
+        if constexpr (!(abl & 16)) __builtin_amdgcn_s_barrier();
+        stamp();
+        // ---- CMP0: group 0 issues its pieces of K-tile kt+1 in the MFMA shadow (s = 4kt+1; waited for at s = 4kt+3) ----
+        __builtin_amdgcn_s_setprio(1);
+        mfma16(!grp && more, kt + 1, cur ^ 1);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        stamp();
+        if constexpr (!(abl & 16)) __builtin_amdgcn_s_barrier();
+        stamp();
+        // ---- MEM1 ----
+        if constexpr (!(abl & 4)) read_half(cur, I1{});
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (grp) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        stamp();
+        if constexpr (!(abl & 16)) __builtin_amdgcn_s_barrier();
+        stamp();
+        // ---- CMP1: group 1 issues its pieces of K-tile kt+2 (its CMP1(kt) is global segment 4(kt+1): the stage of
+        //      K-tile kt is free -- its last reader was this group's own MEM1(kt)); waited for at the end of its MEM1(kt+1)
+        __builtin_amdgcn_s_setprio(1);
+        mfma16(grp && (kt + 2) < nk && !(abl & 1), kt + 2, cur);
+        __builtin_amdgcn_s_setprio(0);
+        if (!grp) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        stamp();
+        if constexpr (!(abl & 16)) __builtin_amdgcn_s_barrier();
+        stamp();
+    }
+    if (!grp && !(ABL & 16)) __builtin_amdgcn_s_barrier();   // matches group 1's extra entry barrier
+    __syncthreads();                                    // every wave is done with the stages: LDS becomes the epilogue image
+    if constexpr ((abl & 32) != 0) if (dbg) {
+        for (int i = 0; i < 256; ++i) ec_dbg_stamps[grp * 1024 + i] = i < dbg_i ? dbg_lds[i] : 0ull;
+    }
+    if constexpr ((abl & 32) != 0) __syncthreads();
+
+    // ---- epilogue (as conv_igemm_kernel) ----
+    constexpr int CH = BN / 8;
+    constexpr int PITCH = BN * 2 + 16;
+    constexpr int RPP = NT / CH;
+    constexpr int OUT_ROWS = POOL ? BM / 4 : BM;
+    constexpr int NPASS = OUT_ROWS / RPP;
+    const int Mout = POOL ? (p.M >> 2) : p.M;
+    const int orow0 = POOL ? (m0 >> 2) : m0;
+    const int srow = tid / CH, schunk = tid % CH;
+    const bool has_res = !POOL && (p.res != nullptr);
+    if (has_res) {
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            const int row = i * RPP + srow;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (orow0 + row < Mout)
+                v = *reinterpret_cast<const uint4*>(p.res + (long)(orow0 + row) * p.Cout + n0 + schunk * 8);
+            *reinterpret_cast<uint4*>(smem + row * PITCH + schunk * 16) = v;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int lcol = wn * TN + j * 32 + 8 * g + 4 * fhalf;
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + n0 + lcol);
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int lrow_px = wm * TM + i * 32 + frow;
+                float v0 = acc[i][j][4 * g + 0] + bv.x, v1 = acc[i][j][4 * g + 1] + bv.y;
+                float v2 = acc[i][j][4 * g + 2] + bv.z, v3 = acc[i][j][4 * g + 3] + bv.w;
+                if (POOL) {
+                    v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+                    v0 += dpp_quad_xor1(v0); v1 += dpp_quad_xor1(v1); v2 += dpp_quad_xor1(v2); v3 += dpp_quad_xor1(v3);
+                    v0 += dpp_quad_xor2(v0); v1 += dpp_quad_xor2(v1); v2 += dpp_quad_xor2(v2); v3 += dpp_quad_xor2(v3);
+                    if ((lane & 3) == 0) {
+                        uint2 o;
+                        o.x = ec_pack2(0.25f * v0, 0.25f * v1);
+                        o.y = ec_pack2(0.25f * v2, 0.25f * v3);
+                        *reinterpret_cast<uint2*>(smem + (lrow_px >> 2) * PITCH + lcol * 2) = o;
+                    }
+                } else {
+                    uint2* slot = reinterpret_cast<uint2*>(smem + lrow_px * PITCH + lcol * 2);
+                    if (has_res) {
+                        const uint2 rr = *slot;
+                        v0 += ec_lo(rr.x); v1 += ec_hi(rr.x); v2 += ec_lo(rr.y); v3 += ec_hi(rr.y);
+                    }
+                    if (p.act == EC_ACT_RELU) {
+                        v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+                    } else if (p.act == EC_ACT_QUICKGELU) {
+                        v0 = v0 / (1.f + __expf(-1.702f * v0)); v1 = v1 / (1.f + __expf(-1.702f * v1));
+                        v2 = v2 / (1.f + __expf(-1.702f * v2)); v3 = v3 / (1.f + __expf(-1.702f * v3));
+                    }
+                    uint2 o;
+                    o.x = ec_pack2(v0, v1);
+                    o.y = ec_pack2(v2, v3);
+                    *slot = o;
+                }
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r0 = 0; r0 < OUT_ROWS; r0 += RPP) {
+        const int row = r0 + srow;
+        if (orow0 + row < Mout)
+            *reinterpret_cast<uint4*>(p.out + (long)(orow0 + row) * p.Cout + n0 + schunk * 8) =
+                *reinterpret_cast<const uint4*>(smem + row * PITCH + schunk * 16);
+    }
+}
+
+template <int BN, int KS, bool POOL>
+int launch8(const ConvArgs& a, hipStream_t s) {
+    ConvArgs p = a;
+    p.ntn = a.Cout / BN;
+    p.ntiles = ((a.M + 255) / 256) * p.ntn;
+    static const int ablate = [] { const char* e = getenv("EC_CONV_ABLATE"); return e ? atoi(e) : 0; }();
+    p.ablate = ablate;
+    const size_t stages = 2 * (size_t)(256 + BN) * ROW_BYTES;
+    const size_t epi = (size_t)(POOL ? 64 : 256) * (BN * 2 + 16);
+    const size_t lds = (stages > epi ? stages : epi) + 4096;   // + stamp area (profiling)
+    auto go = [&](auto kern) {
+        static std::atomic<uint64_t> attr_done{0};
+        if (ec_attr_needed(attr_done))
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3((unsigned)p.ntiles), dim3(512), lds, s, p);
+    };
+#ifdef EC_CONV8_PROFILE   // ablation / stamp instances (tools/ablate8.sh, tools/stamps8.py): build with -DEC_CONV8_PROFILE
+    if constexpr (BN == 256 && KS == 3 && !POOL) {
+        switch (ablate) {
+            case 1: go(conv_igemm8_kernel<BN, KS, POOL, 1>); break;
+            case 2: go(conv_igemm8_kernel<BN, KS, POOL, 2>); break;
+            case 3: go(conv_igemm8_kernel<BN, KS, POOL, 3>); break;
+            case 4: go(conv_igemm8_kernel<BN, KS, POOL, 4>); break;
+            case 5: go(conv_igemm8_kernel<BN, KS, POOL, 5>); break;
+            case 6: go(conv_igemm8_kernel<BN, KS, POOL, 6>); break;
+            case 7: go(conv_igemm8_kernel<BN, KS, POOL, 7>); break;
+            case 16: go(conv_igemm8_kernel<BN, KS, POOL, 16>); break;
+            case 32: go(conv_igemm8_kernel<BN, KS, POOL, 32>); break;
+            case 48: go(conv_igemm8_kernel<BN, KS, POOL, 48>); break;
+            default: go(conv_igemm8_kernel<BN, KS, POOL, 0>);
+        }
+        EC_CHECK_LAUNCH();
+        return EC_OK;
+    }
+#endif
+    go(conv_igemm8_kernel<BN, KS, POOL, 0>);
+    EC_CHECK_LAUNCH();
+    return EC_OK;
+}
+
 
 template <int KS, bool POOL>
 int dispatch_tile(const ConvArgs& a, hipStream_t s) {
     static const int force = [] { const char* e = getenv("EC_CONV_WAVES"); return e ? atoi(e) : 0; }();
     // Tile choice: 128x128 wherever Cout allows; 256-row tiles for the narrow early layers.
     // (Fatter 128x256 / 256x128 tiles were measured: no gain, and they spill once loads run two tiles ahead.)
+    // EC_CONV_BIG: 0 off; 1 (default) the 8-wave ping-pong kernel (conv_igemm8) where it was measured to win; 4 conv_igemm8
+    // wherever its preconditions hold (tests / A-B).  Measured and removed again: the plain
+    // double-buffered 256x256 configuration of conv_igemm_kernel (8 waves, one barrier per K-tile: 77.9 us where the
+    // ping-pong schedule takes 72-75) and a one-wave-per-SIMD 4-wave kernel with in-wave software pipelining (87.8 us:
+    // every LDS-DMA piece blocks its issuing wave for ~150 clk and there is no partner wave to keep the matrix pipe busy).
+    static const int big = [] { const char* e = getenv("EC_CONV_BIG"); return e ? atoi(e) : 1; }();
+    if (big == 1 && a.Cin % 64 == 0 && a.cin_log2 >= 0 && a.K >= 512 && a.M % (POOL ? 4 : 1) == 0) {
+        // measured (B = 256, tools/bench_big.sh): wins on the 3x3 convs with Cout % 256 == 0 once there are enough
+        // 256-row tiles to occupy most CUs; loses on N = 128, on the short launches of 7x7 maps and ties on 1x1
+        const long nt256 = (long)((a.M + 255) / 256) * (a.Cout / 256);
+        if (KS == 3 && a.Cout % 256 == 0 && nt256 >= 150) return launch8<256, KS, POOL>(a, s);
+    }
+    if (big == 4 && a.Cin % 64 == 0 && a.cin_log2 >= 0 && a.K >= 512 && a.M >= 256 * 32 && a.M % (POOL ? 4 : 1) == 0) {
+        if (a.Cout % 256 == 0) return launch8<256, KS, POOL>(a, s);     // (A/B: everywhere its preconditions hold)
+        if (a.Cout % 128 == 0) return launch8<128, KS, POOL>(a, s);
+    }
     if (a.Cout % 128 == 0) {
         // 196-of-224-row tiles: 196 = 14^2 divides every RN50 feature map (56^2, 28^2, 14^2, 4 x 7^2), so the tile count
         // becomes a multiple of the frame count -- e.g. layer 3 at 256 frames: 512 tiles = 2 per CU instead of 784
@@ -453,6 +821,11 @@ int ec_conv3x3_narrow(const void* in, const void* w, const float* bias, void* ou
 // conv_pair.hip: register-weight kernel for a few bandwidth-bound 1x1 shapes (EC_ERR_SHAPE = not handled)
 int ec_conv1x1_regw(const void* a, const void* w, const float* bias, const void* res, void* y, long M, int K, int N, int act,
                     hipStream_t s);
+
+extern "C" int ec_debug_stamps(unsigned long long* host_dst, int n) {   // profiling only
+    if (!host_dst || n <= 0 || n > 2048) return EC_ERR_ARG;
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(ec_dbg_stamps), (size_t)n * 8) == hipSuccess ? EC_OK : EC_ERR_LAUNCH;
+}
 
 extern "C" int ec_conv_bf16(const void* in, const void* w, const float* bias, const void* res, void* out, int B,
                             int H, int W, int Cin, int Cout, int ksize, int pool, int act, ec_stream_t stream) {

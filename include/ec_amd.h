@@ -68,6 +68,8 @@ int ec_conv_bf16(const void* in, const void* w, const float* bias, const void* r
 /* Plain GEMM view of the same kernel: out[M,N] = act(A[M,K] W[N,K]^T + bias (+res)).
  * Replaces nn.Linear / nn.MultiheadAttention projections of [U] clip/model.py
  * ResidualAttentionBlock and AttentionPool2d.  K multiple of 8, N multiple of 32. */
+/* profiling only: copies the s_memtime stamps the 8-wave conv kernel records under EC_CONV_ABLATE & 32 */
+int ec_debug_stamps(unsigned long long* host_dst, int n);
 int ec_gemm_bf16(const void* A, const void* W, const float* bias, const void* res, void* out,
                  int M, int N, int K, int act, ec_stream_t stream);
 

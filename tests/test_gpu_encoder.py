@@ -94,6 +94,48 @@ def test_conv_bf16_matches_oracle(dev, B, H, W, Cin, Cout, ks, pool, res, act):
     assert (got - ref).abs().max() <= 2e-2 * ref.abs().max() + 1e-3
 
 
+@pytest.mark.parametrize("big,B,H,W,Cin,Cout,ks,pool,res,act", [
+    # conv_igemm8 (8-wave ping-pong, 256 x 256 tiles) under its production rule (EC_CONV_BIG=1: 3x3, Cout % 256 == 0,
+    # >= 150 tiles): tiles straddle frames, every border is hit, the last tile is ragged (M % 256 != 0)
+    (1, 201, 14, 14, 64, 256, 3, False, False, 1),       # M = 39396 -> 154 tiles, K = 576 (9 K-tiles, one per tap)
+    (1, 51, 28, 28, 64, 256, 3, True, False, 1),         # fused AvgPool2d(2): quad-ordered rows, M = 39984
+    (1, 170, 7, 7, 128, 512, 3, False, False, 1),        # 7x7 maps, two N tiles, two K-tiles per tap
+    # every instantiation (EC_CONV_BIG=4: wherever the preconditions hold): 1x1 with a residual, BN = 128, short nk
+    (4, 45, 14, 14, 512, 256, 1, False, True, 1),
+    (4, 45, 14, 14, 512, 128, 1, False, False, 0),
+    (4, 43, 14, 14, 64, 128, 3, False, False, 1),
+    (4, 12, 28, 28, 64, 128, 3, True, False, 1),
+    (4, 9, 30, 30, 64, 256, 1, False, False, 2),         # K = 64 < 512: must fall back to the 4-wave kernel
+])
+def test_conv_igemm8_pingpong_matches_oracle(dev, monkeypatch, big, B, H, W, Cin, Cout, ks, pool, res, act):
+    """The 8-wave kernel's cross-wave LDS hand-offs (counted waits + raw barriers) are exercised on many tiles per
+    launch and repeated launches: a race shows up as rare wrong tiles, so every output element is compared, 3 times."""
+    import subprocess, sys, os, json
+    # EC_CONV_BIG is read once per process: run the case in a child process with the variable set
+    code = f"""
+import sys, torch
+sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
+sys.path.insert(0, {os.path.dirname(os.path.abspath(__file__))!r})
+import test_gpu_encoder as T
+dev = torch.device("cuda:0")
+worst = 0.0
+for rep in range(3):
+    got, ref = T._conv_case(dev, {B}, {H}, {W}, {Cin}, {Cout}, {ks}, {pool}, {res}, {act}, seed=7 + rep)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    err = (got - ref).abs()
+    tol = 2e-2 * ref.abs().clamp_min(1.0)
+    bad = int((err > tol).sum())
+    assert bad == 0, (rep, bad, float(err.max()))
+    worst = max(worst, T._rel(got, ref))
+print("REL", worst)
+"""
+    env = dict(os.environ, EC_CONV_BIG=str(big))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    rel = float(r.stdout.strip().split("REL")[-1])
+    assert rel < 4e-3, rel
+
+
 def test_gemm_bf16_tail_shapes(dev):
     from embodied_clip_amd import encoder as enc
     g = torch.Generator().manual_seed(7)
