@@ -39,6 +39,8 @@ VIT_MAC_PER_FRAME = 4_050_683_904            # SURVEY.md §8d (ViT-B/32, 11 of 1
 ATTNPOOL_MAC_PER_FRAME = 425_984_000 + 49 * 2048 * 2048   # CLS-only query + k/v projections
 POLICY_ACT_MAC = 16_846_336
 POLICY_UPDATE_MAC = 150_775_808              # 4 x (fwd + bwd)
+ZS_POLICY_ACT_MAC = 1536 * 1024 + 1536 * 512 + 7 * 512            # zero-shot policy: GRU (1024 -> 512) + heads
+ZS_POLICY_UPDATE_MAC = 4 * (ZS_POLICY_ACT_MAC + 1536 * 1024 + 2 * 1536 * 512 + 2 * 7 * 512)
 MFMA_BF16_PEAK_TFLOPS = 2500.0               # MI355X_MICROARCH.md: dense bf16 MFMA
 POLICY_FLAT_PARAMS = 3_480_775
 # PMC-measured HBM bytes per encoder launch: written by tools/pmc_summary.py from separate rocprofv3 --pmc passes
@@ -292,7 +294,8 @@ def run_rank(a, rank: int, local_rank: int, world: int, init_method=None):
                        "frames": ("pinned host -> H2D per step, " if a.frames_host else "resident in HBM, ") +
                                  ("uint8 HWC (normalisation fused)" if a.frames_u8 else "fp32 normalised HWC"),
                        "parallelism": f"dp{world} (actors sharded; one flat 13.9 MB grad all-reduce per optimiser step)",
-                       "flop_per_frame": 2 * (enc_mac + POLICY_ACT_MAC + POLICY_UPDATE_MAC)},
+                       "flop_per_frame": 2 * (enc_mac + (ZS_POLICY_ACT_MAC + ZS_POLICY_UPDATE_MAC if a.encoder == "zeroshot"
+                                                         else POLICY_ACT_MAC + POLICY_UPDATE_MAC))},
             "rccl_ranks": rccl_ranks, "allreduce_ms_per_rank": ar_ms,
             "roofline": {"bound": "mfma",
                          "kernel": ("ec_rn50_forward (conv_igemm / conv_pair / conv3x3_narrow MFMA kernels)"

@@ -132,6 +132,31 @@ __global__ void group_sum_scatter_kernel(const float* __restrict__ dm1, const in
     }
 }
 
+// zero-shot fusion: x[b, :] = feat[b, :] / |feat[b, :]| * table[goal[b], :]   (one wave per row; fp32 statistics)
+template <bool BF16>
+__global__ __launch_bounds__(256) void fuse_goal_kernel(const void* __restrict__ feat, const float* __restrict__ table,
+                                                       const int* __restrict__ goal, float* __restrict__ x, long B, int E,
+                                                       int num_goals) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= B) return;
+    float ss = 0.f;
+    for (int k = lane; k < E; k += 64) {
+        const float v = BF16 ? ec_bf2f(((const uint16_t*)feat)[row * E + k]) : ((const float*)feat)[row * E + k];
+        ss += v * v;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+    int g = goal[row];
+    g = g < 0 ? 0 : (g >= num_goals ? num_goals - 1 : g);
+    const float* t = table + (long)g * E;
+    for (int k = lane; k < E; k += 64) {
+        const float v = BF16 ? ec_bf2f(((const uint16_t*)feat)[row * E + k]) : ((const float*)feat)[row * E + k];
+        x[row * E + k] = v * inv * t[k];
+    }
+}
+
 inline size_t al(size_t v) { return (v + 255) / 256 * 256; }
 
 enum { P_EMB, P_W1, P_B1, P_W2, P_B2, P_W3, P_B3, P_W4, P_B4, P_WIH, P_WHH, P_BIH, P_BHH, P_WA, P_BA, P_WC, P_BC, P_COUNT };
@@ -141,6 +166,7 @@ enum { P_EMB, P_W1, P_B1, P_W2, P_B2, P_W3, P_B3, P_W4, P_B4, P_WIH, P_WHH, P_BI
 struct ec_policy {
     ec_policy_cfg c;
     size_t off[P_COUNT], num[P_COUNT], total;
+    const float* goal_table = nullptr;   // fusion == 1: borrowed f32 [num_goals, in_channels]
 };
 
 namespace {
@@ -152,8 +178,8 @@ struct Ws {   // float offsets into the workspace
 
 Ws layout(const ec_policy* h, int T, int N, bool bwd) {
     const ec_policy_cfg& c = h->c;
-    const size_t B = (size_t)T * N, S = (size_t)c.spatial * c.spatial, M49 = B * S, H = c.hidden;
-    const size_t flat = (size_t)c.comb_out * S;
+    const size_t B = (size_t)T * N, S = (size_t)c.spatial * c.spatial, M49 = c.fusion ? 0 : B * S, H = c.hidden;
+    const size_t flat = c.fusion ? (size_t)c.in_channels : (size_t)c.comb_out * S;
     Ws w; size_t o = 0;
     auto take = [&](size_t n) { size_t r = o; o += al(n * 4) / 4; return r; };
     w.E1 = take((size_t)c.num_goals * c.comb_hid);
@@ -248,23 +274,31 @@ int step_splitk(long M, long N, long K) {
 extern "C" int ec_policy_create(ec_policy_t** out, const ec_policy_cfg* cfg) {
     if (!out || !cfg) return EC_ERR_ARG;
     const ec_policy_cfg& c = *cfg;
-    if (c.in_channels <= 0 || c.spatial <= 0 || c.hidden <= 0 || c.goal_dims <= 0 || c.num_goals <= 0 ||
-        c.num_actions <= 0 || c.compress_hid <= 0 || c.compress_out <= 0 || c.comb_hid <= 0 || c.comb_out <= 0)
-        return EC_ERR_SHAPE;
-    if ((c.in_channels & 3) || (c.hidden & 3) || (c.compress_hid & 3) || (c.compress_out & 3) || (c.comb_hid & 3) ||
-        (c.comb_out & 3) || (c.goal_dims & 3))
-        return EC_ERR_SHAPE;
+    if (c.fusion != 0 && c.fusion != 1) return EC_ERR_ARG;
+    if (c.in_channels <= 0 || c.spatial <= 0 || c.hidden <= 0 || c.num_goals <= 0 || c.num_actions <= 0) return EC_ERR_SHAPE;
+    if ((c.in_channels & 3) || (c.hidden & 3)) return EC_ERR_SHAPE;
+    if (c.fusion) {
+        if (c.spatial != 1) return EC_ERR_SHAPE;
+    } else {
+        if (c.goal_dims <= 0 || c.compress_hid <= 0 || c.compress_out <= 0 || c.comb_hid <= 0 || c.comb_out <= 0)
+            return EC_ERR_SHAPE;
+        if ((c.compress_hid & 3) || (c.compress_out & 3) || (c.comb_hid & 3) || (c.comb_out & 3) || (c.goal_dims & 3))
+            return EC_ERR_SHAPE;
+    }
     ec_policy* h = new (std::nothrow) ec_policy();
     if (!h) return EC_ERR_ALLOC;
     h->c = c;
-    const size_t S = (size_t)c.spatial * c.spatial, flat = c.comb_out * S, H = c.hidden;
-    const size_t n[P_COUNT] = {(size_t)c.num_goals * c.goal_dims,
+    const size_t S = (size_t)c.spatial * c.spatial, H = c.hidden;
+    const size_t flat = c.fusion ? (size_t)c.in_channels : (size_t)c.comb_out * S;
+    size_t n[P_COUNT] = {(size_t)c.num_goals * c.goal_dims,
                                (size_t)c.compress_hid * c.in_channels, (size_t)c.compress_hid,
                                (size_t)c.compress_out * c.compress_hid, (size_t)c.compress_out,
                                (size_t)c.comb_hid * (c.compress_out + c.goal_dims), (size_t)c.comb_hid,
                                (size_t)c.comb_out * c.comb_hid, (size_t)c.comb_out,
                                3 * H * flat, 3 * H * H, 3 * H, 3 * H,
                                (size_t)c.num_actions * H, (size_t)c.num_actions, H, 1};
+    if (c.fusion)
+        for (int i = P_EMB; i <= P_B4; ++i) n[i] = 0;      // no goal embedding / compressor / combiner: GRU + heads only
     size_t o = 0;
     for (int i = 0; i < P_COUNT; ++i) { h->off[i] = o; h->num[i] = n[i]; o += (n[i] + 3) / 4 * 4; }   // 16-B aligned
     h->total = o;
@@ -272,6 +306,11 @@ extern "C" int ec_policy_create(ec_policy_t** out, const ec_policy_cfg* cfg) {
     return EC_OK;
 }
 extern "C" void ec_policy_destroy(ec_policy_t* h) { delete h; }
+extern "C" int ec_policy_set_goal_table(ec_policy_t* h, const float* table) {
+    if (!h || !table || !h->c.fusion) return EC_ERR_ARG;
+    h->goal_table = table;
+    return EC_OK;
+}
 extern "C" int ec_policy_num_param_tensors(const ec_policy_t*) { return P_COUNT; }
 extern "C" size_t ec_policy_flat_size(const ec_policy_t* h) { return h ? h->total : 0; }
 extern "C" int ec_policy_param_offset(const ec_policy_t* h, int idx, size_t* off, size_t* numel) {
@@ -295,11 +334,21 @@ extern "C" int ec_policy_forward(const ec_policy_t* h, const float* params, cons
     float* ws = (float*)workspace;
     hipStream_t s = (hipStream_t)stream;
     const int B = T * N, S = c.spatial * c.spatial, H = c.hidden, A1 = c.num_actions + 1;
-    const int M49 = B * S, C = c.in_channels, cat = c.compress_out + c.goal_dims, flat = c.comb_out * S;
+    const int M49 = B * S, C = c.in_channels, cat = c.compress_out + c.goal_dims;
+    const int flat = c.fusion ? c.in_channels : c.comb_out * S;
     const float* P = params;
     auto W = [&](int i) { return P + h->off[i]; };
     int* goal32 = (int*)(ws + w.goal32);
     hipLaunchKernelGGL(goal_to_i32_kernel, dim3((B + 255) / 256), dim3(256), 0, s, (const long long*)goal, goal32, B);
+    if (c.fusion) {
+        if (!h->goal_table) return EC_ERR_ARG;
+        if (feat_bf16)
+            hipLaunchKernelGGL(fuse_goal_kernel<true>, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s, feat, h->goal_table,
+                               goal32, ws + w.x, (long)B, flat, c.num_goals);
+        else
+            hipLaunchKernelGGL(fuse_goal_kernel<false>, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s, feat, h->goal_table,
+                               goal32, ws + w.x, (long)B, flat, c.num_goals);
+    } else {
     // E1 = embed_class @ W3[:, co:]^T + b3
     RC(ec_gemm_f32(W(P_EMB), W(P_W3) + c.compress_out, ws + w.E1, c.num_goals, c.comb_hid, c.goal_dims, c.goal_dims, 1,
                    1, cat, c.comb_hid, 0, W(P_B3), nullptr, nullptr, 0, nullptr, nullptr, 1, stream));
@@ -320,6 +369,7 @@ extern "C" int ec_policy_forward(const ec_policy_t* h, const float* params, cons
         hipLaunchKernelGGL(to_cmajor_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ws + w.x4, ws + w.x,
                            S, c.comb_out, total);
     }
+    }   // !fusion
     // GRU: input projection for all T at once, then the sequential recurrence
     // (no split-K here: the act step stays free of float atomics, so rollouts are bit-reproducible)
     RC(ec_gemm_f32(ws + w.x, W(P_WIH), ws + w.gi, B, 3 * H, flat, flat, 1, 1, flat, 3 * H, 0, W(P_BIH), nullptr,
@@ -360,7 +410,8 @@ extern "C" int ec_policy_backward(const ec_policy_t* h, const float* params, con
     float* ws = (float*)workspace;
     hipStream_t s = (hipStream_t)stream;
     const int B = T * N, S = c.spatial * c.spatial, H = c.hidden, A = c.num_actions, A1 = A + 1;
-    const int M49 = B * S, C = c.in_channels, cat = c.compress_out + c.goal_dims, flat = c.comb_out * S;
+    const int M49 = B * S, C = c.in_channels, cat = c.compress_out + c.goal_dims;
+    const int flat = c.fusion ? c.in_channels : c.comb_out * S;
     auto W = [&](int i) { return params + h->off[i]; };
     auto G = [&](int i) { return grads + h->off[i]; };
     const int* goal32 = (const int*)(ws + w.goal32);
@@ -404,6 +455,10 @@ extern "C" int ec_policy_backward(const ec_policy_t* h, const float* params, con
     colsum(ws + w.dghb, G(P_BHH), B, 3 * H, 3 * H);
     RC(tn(ws + w.dgi, 3 * H, ws + w.x, flat, 0, G(P_WIH), 3 * H, flat, B, flat));
     colsum(ws + w.dgi, G(P_BIH), B, 3 * H, 3 * H);
+    if (c.fusion) {   // the image embedding and the goal table are frozen: nothing trainable upstream of the GRU
+        EC_CHECK_LAUNCH();
+        return EC_OK;
+    }
     // dx = dgi @ W_ih
     RC(ec_gemm_f32(ws + w.dgi, W(P_WIH), ws + w.dx, B, flat, 3 * H, 3 * H, 1, flat, 1, flat, 0, nullptr, nullptr, nullptr,
                    0, nullptr, nullptr, 1, stream));

@@ -210,14 +210,16 @@ class AttentionPool:
         self._ws = None
 
     @_lib.on_device
-    def forward(self, feat: torch.Tensor) -> torch.Tensor:
-        """feat bf16 [B,S,S,C] -> fp32 [B,out_dim]."""
+    def forward(self, feat: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """feat bf16 [B,S,S,C] -> fp32 [B,out_dim] (written into ``out`` when given, e.g. a rollout-buffer slice)."""
         B = feat.shape[0]
         HW = feat.numel() // (B * self.C)
         need = self.lib.ec_attnpool_workspace_bytes(B, HW, self.C)
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        out = torch.empty((B, self.out_dim), dtype=torch.float32, device=self.device)
+        if out is None:
+            out = torch.empty((B, self.out_dim), dtype=torch.float32, device=self.device)
+        assert out.is_contiguous() and out.dtype == torch.float32 and out.numel() == B * self.out_dim
         _lib.check(self.lib.ec_attnpool_forward(feat.data_ptr(), B, HW, self.C, self.heads, self.out_dim,
                                                 self.pos.data_ptr(), self.wq.data_ptr(), self.bq.data_ptr(),
                                                 self.wkv.data_ptr(), self.bkv.data_ptr(), self.wc.data_ptr(),

@@ -29,7 +29,7 @@ import torch
 from . import _lib
 from . import synthetic as syn
 from .dist import allreduce_flat
-from .encoder import RN50Trunk, ViTEmbedder
+from .encoder import AttentionPool, ClipTextEncoder, RN50Trunk, ViTEmbedder
 from .policy import PolicyHandle
 from .ppo import FlatAdam, linear_decay_lr, ppo_loss_raw
 
@@ -82,8 +82,12 @@ class Worker:
                  update_repeats: int = 4, lr: float = 3e-4, max_grad_norm: float = 0.5, gamma: float = 0.99,
                  tau: float = 0.95, encoder_sd=None, policy_sd=None, lr_total_steps: int = 300_000_000,
                  encoder_chunk: int = 0, encoder: str = "rn50", encoder_streams: int = 2, frames_u8: bool = False,
-                 frames_host: bool = False):
+                 frames_host: bool = False, zeroshot: bool = False, text_sd=None, goal_tokens=None):
+        """``zeroshot=True`` (BASELINE config 5, readme_files/zeroshot_objectnav.md): the observation is the CLIP image
+        EMBEDDING (RN50 trunk + AttentionPool2d, 1024-d), the goal is the frozen CLIP text embedding of its prompt
+        (text tower run once -> [12, 1024] table) and the policy is the fusion=1 variant (GRU + heads trainable)."""
         self.lib = _lib.load()
+        self.zeroshot, self._text_sd, self._goal_tokens = zeroshot, text_sd, goal_tokens
         self.dev = self.device = torch.device(device)
         if self.dev.index is None:
             self.dev = self.device = torch.device("cuda", torch.cuda.current_device())
@@ -101,10 +105,15 @@ class Worker:
         self.ns = ns
         n = n_actors // ns
         d = self.dev
+        pools = [None] * ns
         if encoder == "rn50":
             sd = encoder_sd if encoder_sd is not None else syn.rn50_visual_state_dict(0)
             encs = [RN50Trunk(sd, device=d, chunk=encoder_chunk) for _ in range(ns)]
             self.S, self.C = encs[0].out_spatial, encs[0].out_channels
+            if self.zeroshot:
+                pools = [AttentionPool(sd, device=d) for _ in range(ns)]
+                self.trunk_S, self.trunk_C = self.S, self.C
+                self.S, self.C = 1, pools[0].out_dim
         elif encoder == "vit":
             # BASELINE config 3 (builder-defined fusion, SURVEY.md §8d note): ClipViTEmbedder tokens, CLS dropped,
             # the 49 patch tokens are the 7x7 channels-last "feature map" [n,49,768] of the goal encoder
@@ -114,7 +123,17 @@ class Worker:
         else:
             raise ValueError(encoder)
         pkw = dict(in_channels=self.C, spatial=self.S)
+        if self.zeroshot:
+            assert encoder == "rn50", "the zero-shot variant uses the CLIP-RN50 image embedding"
+            pkw["fusion"] = 1
         self.policy = PolicyHandle(**pkw)
+        if self.zeroshot:
+            # goal table: the CLIP text tower over the 12 goal prompts, once, L2-normalised; frozen
+            tsd = self._text_sd if self._text_sd is not None else syn.text_state_dict(0)
+            tok = self._goal_tokens if self._goal_tokens is not None else syn.synthetic_tokens(
+                7, 12, context_length=tsd["positional_embedding"].shape[0], vocab_size=tsd["token_embedding.weight"].shape[0])
+            self.goal_table = ClipTextEncoder(tsd, device=d).goal_table(tok).contiguous()
+            self.policy.set_goal_table(self.goal_table)
         self.H, self.A = self.policy.H, self.policy.A
         self.params = self.policy.flatten(policy_sd if policy_sd is not None else syn.policy_state_dict(0, **pkw), d)
         self.grads = torch.zeros_like(self.params)
@@ -137,9 +156,12 @@ class Worker:
         self.slices: List[_Slice] = []
         for i in range(ns):
             sl = _Slice()
-            sl.o, sl.n, sl.enc = i * n, n, encs[i]
+            sl.o, sl.n, sl.enc, sl.pool = i * n, n, encs[i], pools[i]
             sl.stream = torch.cuda.Stream(device=d) if ns > 1 else None
-            sl.feat = torch.empty((T + 1, n, S2, self.C), dtype=torch.bfloat16, device=d)
+            # zero-shot: the rollout buffer holds fp32 image embeddings [T+1, n, 1, 1024]; else bf16 feature maps
+            sl.feat = torch.empty((T + 1, n, S2, self.C), dtype=torch.float32 if self.zeroshot else torch.bfloat16, device=d)
+            sl.trunk_out = (torch.empty((n, self.trunk_S, self.trunk_S, self.trunk_C), dtype=torch.bfloat16, device=d)
+                            if self.zeroshot else None)
             sl.tok = (torch.empty((n, encs[i].L, encs[i].D), dtype=torch.bfloat16, device=d) if encoder == "vit" else None)
             sl.ws_act = torch.empty(self.policy.workspace_bytes(1, n, False), dtype=torch.uint8, device=d)
             sl.ws_learn = torch.empty(self.policy.workspace_bytes(T, n, True), dtype=torch.uint8, device=d)
@@ -213,7 +235,10 @@ class Worker:
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream())
-        if self.encoder == "rn50":
+        if self.zeroshot:
+            (sl.enc.forward_u8 if src.dtype == torch.uint8 else sl.enc.forward)(src, sl.trunk_out)
+            sl.pool.forward(sl.trunk_out, sl.feat[t].view(sl.n, self.C))     # AttentionPool2d -> rollout slice
+        elif self.encoder == "rn50":
             # the last conv writes straight into the rollout slice
             (sl.enc.forward_u8 if src.dtype == torch.uint8 else sl.enc.forward)(src, sl.feat[t])
         else:

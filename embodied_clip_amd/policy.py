@@ -42,7 +42,7 @@ class PolicyHandle:
     def __init__(self, **cfg: int):
         self.lib = _lib.load()
         self.cfg = dict(in_channels=2048, spatial=7, hidden=512, goal_dims=32, num_goals=12, num_actions=6,
-                        compress_hid=128, compress_out=32, comb_hid=128, comb_out=32)
+                        compress_hid=128, compress_out=32, comb_hid=128, comb_out=32, fusion=0)
         self.cfg.update(cfg)
         c = _lib.PolicyCfg(**self.cfg)
         h = C.c_void_p()
@@ -68,6 +68,13 @@ class PolicyHandle:
                 self.h = None
         except Exception:
             pass
+
+    def set_goal_table(self, table: torch.Tensor) -> None:
+        """``fusion=1``: frozen goal table f32 [num_goals, in_channels] (CLIP text embeddings of the goal prompts)."""
+        assert table.dtype == torch.float32 and table.is_contiguous()
+        assert tuple(table.shape) == (self.cfg["num_goals"], self.cfg["in_channels"]), table.shape
+        self._goal_table = table          # the handle borrows the pointer: keep the tensor alive
+        _lib.check(self.lib.ec_policy_set_goal_table(self.h, table.data_ptr()), "ec_policy_set_goal_table")
 
     @property
     def A(self):

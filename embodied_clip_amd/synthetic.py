@@ -254,8 +254,22 @@ POLICY_PARAM_ORDER: Tuple[str, ...] = (
 
 def policy_param_shapes(in_channels: int = 2048, spatial: int = 7, hidden: int = 512, goal_dims: int = 32,
                         num_goals: int = 12, num_actions: int = 6, compress_hid: int = 128,
-                        compress_out: int = 32, comb_hid: int = 128, comb_out: int = 32):
+                        compress_out: int = 32, comb_hid: int = 128, comb_out: int = 32, fusion: int = 0):
+    """``fusion=1`` (zero-shot dual-encoder policy): the goal-embedding / compressor / combiner tensors have zero
+    elements and the GRU reads the ``in_channels``-wide fused embedding."""
     flat = comb_out * spatial * spatial
+    if fusion:
+        z = (0,)
+        return OrderedDict([(k, z) for k in POLICY_PARAM_ORDER[:9]] + [
+            ("state_encoder.rnn.weight_ih_l0", (3 * hidden, in_channels)),
+            ("state_encoder.rnn.weight_hh_l0", (3 * hidden, hidden)),
+            ("state_encoder.rnn.bias_ih_l0", (3 * hidden,)),
+            ("state_encoder.rnn.bias_hh_l0", (3 * hidden,)),
+            ("actor.linear.weight", (num_actions, hidden)),
+            ("actor.linear.bias", (num_actions,)),
+            ("critic.fc.weight", (1, hidden)),
+            ("critic.fc.bias", (1,)),
+        ])
     return OrderedDict([
         ("goal_visual_encoder.embed_class.weight", (num_goals, goal_dims)),
         ("goal_visual_encoder.resnet_compressor.0.weight", (compress_hid, in_channels, 1, 1)),
@@ -282,7 +296,9 @@ def policy_state_dict(seed: int = 0, **kw) -> "OrderedDict[str, torch.Tensor]":
     shapes = policy_param_shapes(**kw)
     sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
     for k, shp in shapes.items():
-        if k.endswith("bias") or "bias_" in k:
+        if int(np.prod(shp)) == 0:
+            sd[k] = torch.zeros(shp)
+        elif k.endswith("bias") or "bias_" in k:
             sd[k] = _normal(seed, k, shp, 0.02)
         elif "embed_class" in k:
             sd[k] = _normal(seed, k, shp, 1.0)

@@ -193,10 +193,19 @@ typedef struct {
     int compress_out;  /* 32   */
     int comb_hid;      /* 128  */
     int comb_out;      /* 32   */
+    int fusion;        /* 0: ResnetTensorGoalEncoder (goal-embedding fusion of the RoboTHOR/Habitat configs);
+                        * 1: zero-shot dual-encoder fusion (readme_files/zeroshot_objectnav.md:3-8; builder-defined,
+                        *    parity-unpinned): x = feat/|feat| (*) goal_table[goal], feat = [T*N, 1, in_channels] CLIP
+                        *    image embeddings, goal_table = frozen CLIP text embeddings (ec_policy_set_goal_table);
+                        *    spatial must be 1, the compressor/combiner fields are ignored and those nine parameter
+                        *    tensors have zero elements (the trainable part is GRU + heads) */
 } ec_policy_cfg;
 typedef struct ec_policy ec_policy_t;
 
 int ec_policy_create(ec_policy_t** out, const ec_policy_cfg* cfg);
+/* fusion == 1 only: borrow the device goal table f32 [num_goals, in_channels] (e.g. ec_text_forward over the goal
+ * prompts, L2-normalised); frozen -- it receives no gradient. */
+int ec_policy_set_goal_table(ec_policy_t* h, const float* table);
 void ec_policy_destroy(ec_policy_t* h);
 int ec_policy_num_param_tensors(const ec_policy_t* h);
 size_t ec_policy_flat_size(const ec_policy_t* h);                      /* floats, incl. alignment padding */

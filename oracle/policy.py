@@ -83,6 +83,23 @@ def actor_critic_forward(feat: torch.Tensor, goal: torch.Tensor, h0: torch.Tenso
     return logits, values, h
 
 
+def zeroshot_actor_critic_forward(img_emb: torch.Tensor, goal: torch.Tensor, h0: torch.Tensor, masks: torch.Tensor,
+                                  sd: Dict[str, torch.Tensor], goal_table: torch.Tensor):
+    """Zero-shot ObjectNav policy (BASELINE config 5; ``readme_files/zeroshot_objectnav.md:3-8``: "CLIP text encoder
+    for goal embedding").  The model code lives on the unmounted ``zeroshot-objectnav`` branch, so the FUSION OP IS
+    BUILDER-DEFINED AND PARITY-UNPINNED: the L2-normalised CLIP image embedding (AttentionPool2d output, 1024-d)
+    is multiplied element-wise with the goal's frozen, L2-normalised CLIP text embedding (the per-dimension
+    terms of CLIP's own image-text cosine score) and fed to the same 1-layer GRU + linear actor/critic heads
+    as the RoboTHOR policy; there is no trainable goal embedding, compressor or combiner.
+    img_emb: [T, N, E] fp32; goal: [T, N] int64; goal_table: [num_goals, E]; h0: [1, N, hidden]; masks: [T, N, 1].
+    Returns (logits [T,N,A], values [T,N,1], h [1,N,hidden])."""
+    x = F.normalize(img_emb, dim=-1, eps=1e-12) * goal_table[goal]
+    out, h = rnn_state_encoder(x, h0, masks, sd)
+    logits = F.linear(out, sd["actor.linear.weight"], sd["actor.linear.bias"])
+    values = F.linear(out, sd["critic.fc.weight"], sd["critic.fc.bias"])
+    return logits, values, h
+
+
 def categorical_log_prob(logits: torch.Tensor, actions: torch.Tensor) -> torch.Tensor:
     """``CategoricalDistr.log_prob``: log_softmax(logits)[a].  [T,N,A],[T,N] -> [T,N]."""
     return torch.log_softmax(logits, dim=-1).gather(-1, actions.unsqueeze(-1)).squeeze(-1)

@@ -38,6 +38,36 @@ def text_case():
     return sd, syn.synthetic_tokens(22, 12, 77, 1000)
 
 
+def zeroshot_case(T=6, N=5, E=1024, H=512, seed=61):
+    """Zero-shot dual-encoder policy (fusion=1): seeded image embeddings, goal table, GRU + heads, loss inputs."""
+    sd = syn.policy_state_dict(seed, in_channels=E, spatial=1, hidden=H, fusion=1)
+    f = lambda s, n: torch.from_numpy(syn.hash_normal(seed + s, n).astype("float32"))
+    emb = f(1, T * N * E).reshape(T, N, E) * 0.7
+    table = torch.nn.functional.normalize(f(2, 12 * E).reshape(12, E), dim=-1)
+    goal = syn.synthetic_goals(seed + 3, (T, N))
+    h0 = f(4, N * H).reshape(1, N, H) * 0.5
+    masks = syn.synthetic_masks(seed + 5, T, N, p_reset=0.2)
+    actions = syn.synthetic_goals(seed + 6, (T, N), num_goals=6)
+    u = lambda s: f(s, T * N).reshape(T, N, 1)
+    return sd, emb, table, goal, h0, masks, actions, u(7), u(8), u(9), u(10)
+
+
+def zeroshot_golden():
+    sd, emb, table, goal, h0, masks, actions, a, b, c, d = zeroshot_case()
+    with torch.no_grad():
+        lg, vv, hT = opol.zeroshot_actor_critic_forward(emb, goal, h0, masks, sd, table)
+        old_lp = opol.categorical_log_prob(lg, actions).unsqueeze(-1) + 0.2 * a
+        old_v = vv + 0.2 * b
+    names = [k for k, v in sd.items() if v.numel()]
+    leaves = {k: (v.clone().requires_grad_(True) if v.numel() else v) for k, v in sd.items()}
+    lg2, vv2, _ = opol.zeroshot_actor_critic_forward(emb, goal, h0, masks, leaves, table)
+    total, info = oppo.ppo_loss(lg2, vv2, actions, old_lp, old_v, c, d)
+    total.backward()
+    return {"seed": 61, "logits": lg.clone(), "values": vv.clone(), "h": hT.clone(), "loss": info,
+            "grad_norms": {k: float(leaves[k].grad.norm()) for k in names},
+            "grad_slices": {k: leaves[k].grad.reshape(-1)[:4096:7].clone() for k in names}}
+
+
 def probe_cases():
     """Seeded (x, y, weight, bias) for the four probe tasks (clip_avgpool / clip_conv embeddings)."""
     cases = {}
@@ -101,5 +131,14 @@ def main():
     print("wrote", os.path.join(OUT, "oracle_golden.pt"), os.path.getsize(os.path.join(OUT, "oracle_golden.pt")), "bytes")
 
 
+def main_zeroshot():
+    path = os.path.join(OUT, "zeroshot_golden.pt")
+    torch.save(zeroshot_golden(), path)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "zeroshot":      # added in round 2; oracle_golden.pt is left untouched
+        main_zeroshot()
+    else:
+        main()

@@ -75,3 +75,19 @@ def test_oracle_text_reproduces_golden():
     sd, tok = mg.text_case()
     assert tok.shape == (12, 77) and int(tok.max()) == 999          # <EOT> = vocab-1 is the arg-max
     assert torch.allclose(otxt.encode_text(tok, sd, heads=8), gold, atol=1e-5)
+
+
+def test_oracle_zeroshot_policy_reproduces_golden():
+    """Zero-shot dual-encoder policy (BASELINE config 5; builder-defined fusion, parity-unpinned)."""
+    gz = torch.load(os.path.join(os.path.dirname(__file__), "golden", "zeroshot_golden.pt"))
+    sd, emb, table, goal, h0, masks, actions, a, b, c, d = mg.zeroshot_case()
+    assert sum(v.numel() for v in sd.values()) == 3 * 512 * 1024 + 3 * 512 * 512 + 6 * 512 + 6 * 512 + 7 + 512
+    with torch.no_grad():
+        lg, vv, hT = opol.zeroshot_actor_critic_forward(emb, goal, h0, masks, sd, table)
+    assert torch.allclose(lg, gz["logits"], rtol=1e-4, atol=1e-5)
+    assert torch.allclose(vv, gz["values"], rtol=1e-4, atol=1e-5)
+    assert torch.allclose(hT, gz["h"], rtol=1e-4, atol=1e-5)
+    # the fusion is the per-dimension cosine term: summing the fused vector gives CLIP's image-text cosine score
+    x = torch.nn.functional.normalize(emb, dim=-1) * table[goal]
+    cos = torch.nn.functional.cosine_similarity(emb, table[goal], dim=-1)
+    assert torch.allclose(x.sum(-1), cos, atol=1e-5)
