@@ -25,18 +25,34 @@ from . import spaces
 from .allenact_compat import Preprocessor
 
 
+def load_checkpoint_state_dict(path: str) -> Dict[str, torch.Tensor]:
+    """Read a CLIP checkpoint the way ``clip.load`` does ([U] openai/CLIP clip/clip.py): the published files
+    (``RN50.pt``, ``ViT-B-32.pt``) are TorchScript archives -> ``torch.jit.load(...).state_dict()``; anything else
+    is tried as a plain ``state_dict`` file (``torch.load``, tensors only)."""
+    try:
+        return dict(torch.jit.load(path, map_location="cpu").eval().state_dict())
+    except RuntimeError:
+        obj = torch.load(path, map_location="cpu")          # weights_only: a dict of tensors
+        return dict(obj.state_dict() if hasattr(obj, "state_dict") else obj)
+
+
+def visual_state_dict(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """The visual tower's entries of a whole-CLIP ``state_dict`` with the ``visual.`` prefix removed (a dict that
+    already is a visual tower is returned unchanged).  Weights may be fp16 (CLIP's published checkpoints are):
+    the packers fold / round from fp32 copies."""
+    if any(k.startswith("visual.") for k in sd):
+        return {k[len("visual."):]: v for k, v in sd.items() if k.startswith("visual.")}
+    return sd
+
+
 def _load_visual_state_dict(clip_model_type: str, state_dict, weights_path):
     if state_dict is not None:
-        return state_dict
+        return visual_state_dict(state_dict)
     cand = weights_path
     if cand is None and os.environ.get("EC_CLIP_WEIGHTS_DIR"):
         cand = os.path.join(os.environ["EC_CLIP_WEIGHTS_DIR"], clip_model_type.replace("/", "-") + ".pt")
     if cand is not None and os.path.exists(cand):
-        obj = torch.load(cand, map_location="cpu")
-        sd = obj.state_dict() if hasattr(obj, "state_dict") else obj
-        if any(k.startswith("visual.") for k in sd):
-            sd = {k[len("visual."):]: v for k, v in sd.items() if k.startswith("visual.")}
-        return sd
+        return visual_state_dict(load_checkpoint_state_dict(cand))
     try:  # exactly what the reference does (thor_image_features.py:57,59)
         import clip  # type: ignore
         model, _ = clip.load(clip_model_type, device="cpu")

@@ -394,3 +394,41 @@ def test_conv1x1_pair_layer2_geometry_matches_two_launches(dev, M):
         assert _rel(y.float().cpu(), yf.cpu()) < 3e-3
         zf = (y.float() @ w2.float().t() + b2).relu()
         assert _rel(z.float().cpu(), zf.cpu()) < 3e-3
+
+
+def test_preprocessor_loads_fp16_checkpoint_from_weights_dir(dev, tmp_path, monkeypatch):
+    """a2: `ClipResNetPreprocessor('rgb', 'RN50', ...)` with no state_dict finds `$EC_CLIP_WEIGHTS_DIR/RN50.pt`, a
+    whole-CLIP fp16 state_dict with `visual.`-prefixed keys (what `clip.load(...).state_dict()` holds), and matches the
+    oracle run on the same fp16-rounded weights."""
+    from embodied_clip_amd.clip_preprocessors import ClipResNetPreprocessor
+    sd = syn.rn50_visual_state_dict(5)
+    full = {"visual." + k: v.half() for k, v in sd.items()}
+    full["logit_scale"] = torch.tensor(4.6).half()
+    torch.save(full, tmp_path / "RN50.pt")
+    monkeypatch.setenv("EC_CLIP_WEIGHTS_DIR", str(tmp_path))
+    pre = ClipResNetPreprocessor("rgb", "RN50", pool=False, device=dev)
+    rgb = syn.synthetic_rgb(11, 2)
+    out = pre.process({"rgb": rgb})
+    assert out.shape == (2, 2048, 7, 7) and out.dtype == torch.float32 and out.device.type == "cuda"
+    ref = ocr.clip_resnet_preprocessor(rgb, {k: v.half().float() for k, v in sd.items()})
+    assert _rel(out.cpu(), ref) < 2e-2
+
+
+def test_real_clip_rn50_checkpoint_if_present(dev):
+    """With a REAL OpenAI `RN50.pt` in $EC_CLIP_WEIGHTS_DIR (none ships with this repo: no network in the build image)
+    the HIP embedding is compared with the fp32 oracle on the real weights; skipped otherwise."""
+    import os
+    d = os.environ.get("EC_CLIP_WEIGHTS_DIR", "")
+    path = os.path.join(d, "RN50.pt")
+    if not d or not os.path.exists(path) or os.path.getsize(path) < 100_000_000:
+        pytest.skip("no real RN50.pt in $EC_CLIP_WEIGHTS_DIR")
+    from embodied_clip_amd.clip_preprocessors import ClipResNetPreprocessor, _load_visual_state_dict
+    sd = {k: v.float() for k, v in _load_visual_state_dict("RN50", None, path).items()}
+    assert ocr.param_count(sd) == 38_316_896
+    pre = ClipResNetPreprocessor("rgb", "RN50", pool=True, device=dev, weights_path=path)
+    rgb = syn.synthetic_rgb(12, 4)
+    out = pre.process({"rgb": rgb}).cpu()
+    ref = ocr.clip_resnet_preprocessor(rgb, sd, pool=True)
+    cos = F.cosine_similarity(out, ref, dim=1)
+    print("real RN50.pt: cosine vs fp32 oracle", cos.tolist())
+    assert cos.min() > 0.999 and _rel(out, ref) < 2e-2
