@@ -20,6 +20,9 @@ SIGNATURES = {
     "ec_version": (c_int, []),
     "ec_strerror": (C.c_char_p, [c_int]),
     "ec_conv_bf16": (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p]),
+    "ec_clip_resize_table_ints": (c_size_t, [c_int, c_int, c_int]),
+    "ec_clip_resize_table": (c_int, [c_int, c_int, c_int, c_void_p, c_size_t]),
+    "ec_clip_resize_crop_u8": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "ec_debug_stamps": (c_int, [c_void_p, c_int]),
     "ec_gemm_bf16": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
     "ec_stem_conv1": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),

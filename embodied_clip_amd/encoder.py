@@ -90,6 +90,42 @@ def pack_rn50(sd: Dict[str, torch.Tensor]):
     return (width, layers), stem_w, torch.cat(ws), torch.cat(bs)
 
 
+class ClipResizeCrop:
+    """``Resize(n_px, BICUBIC)`` + ``CenterCrop(n_px)`` of CLIP's ``_transform`` on raw uint8 frames, bit-exact with
+    Pillow (``clip_preprocess``: primitive_probing/generate_data/thor_image_features.py:108).  The coefficient tables
+    are built on the host once per frame geometry (``ec_clip_resize_table``) and cached on the device."""
+
+    def __init__(self, device="cuda", n_px: int = 224):
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        self.n_px = n_px
+        self._tables: Dict[Tuple[int, int], Tuple[torch.Tensor, int]] = {}
+
+    def table(self, H: int, W: int) -> Tuple[torch.Tensor, int]:
+        """(host int32 table, LDS rows) for H x W frames -- pure host arithmetic, no GPU call."""
+        n = self.lib.ec_clip_resize_table_ints(H, W, self.n_px)
+        if n == 0:
+            raise _lib.EcError(f"unsupported frame geometry {H}x{W} -> {self.n_px}")
+        t = torch.empty(n, dtype=torch.int32)
+        _lib.check(self.lib.ec_clip_resize_table(H, W, self.n_px, t.data_ptr(), n), "ec_clip_resize_table")
+        return t, int(t[6])
+
+    @_lib.on_device
+    def __call__(self, frames_u8: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """frames_u8: device uint8 [B, H, W, 3] -> uint8 [B, n_px, n_px, 3]."""
+        assert frames_u8.is_cuda and frames_u8.dtype == torch.uint8 and frames_u8.is_contiguous() and frames_u8.shape[3] == 3
+        B, H, W, _ = frames_u8.shape
+        if (H, W) not in self._tables:
+            t, rows = self.table(H, W)
+            self._tables[(H, W)] = (t.to(self.device), rows)
+        tab, rows = self._tables[(H, W)]
+        if out is None:
+            out = torch.empty((B, self.n_px, self.n_px, 3), dtype=torch.uint8, device=self.device)
+        _lib.check(self.lib.ec_clip_resize_crop_u8(frames_u8.data_ptr(), tab.data_ptr(), rows, out.data_ptr(), B, H, W,
+                                                   self.n_px, _lib.stream_ptr()), "ec_clip_resize_crop_u8")
+        return out
+
+
 class RN50Trunk:
     """Frozen CLIP ModifiedResNet trunk on one MI355X.
 
@@ -116,6 +152,7 @@ class RN50Trunk:
         self.out_channels = self.lib.ec_rn50_out_channels(h)
         self.out_spatial = self.lib.ec_rn50_out_spatial(h)
         self._ws: Optional[torch.Tensor] = None
+        self._resize: Optional[ClipResizeCrop] = None
 
     def __del__(self):
         try:
@@ -155,10 +192,14 @@ class RN50Trunk:
     @_lib.on_device
     def forward_u8(self, rgb_u8: torch.Tensor, out: Optional[torch.Tensor] = None,
                    mean=(0.48145466, 0.4578275, 0.40821073), std=(0.26862954, 0.26130258, 0.27577711)) -> torch.Tensor:
-        """rgb_u8: device uint8 [B, R, R, 3] raw frames; CLIP normalisation is fused into the stem kernel."""
-        assert rgb_u8.is_cuda and rgb_u8.dtype == torch.uint8 and rgb_u8.is_contiguous()
+        """rgb_u8: device uint8 [B, H, W, 3] raw frames.  Frames that are not already R x R first go through CLIP's
+        Resize(R, BICUBIC) + CenterCrop(R) (bit-exact with Pillow); /255 and the CLIP mean/std are fused into the stem."""
+        assert rgb_u8.is_cuda and rgb_u8.dtype == torch.uint8 and rgb_u8.is_contiguous() and rgb_u8.shape[3] == 3
+        if rgb_u8.shape[1] != self.input_resolution or rgb_u8.shape[2] != self.input_resolution:
+            if self._resize is None:
+                self._resize = ClipResizeCrop(self.device, self.input_resolution)
+            rgb_u8 = self._resize(rgb_u8)
         B, R = rgb_u8.shape[0], rgb_u8.shape[1]
-        assert R == self.input_resolution and rgb_u8.shape[3] == 3
         S, Cc = self.out_spatial, self.out_channels
         if out is None:
             out = torch.empty((B, S, S, Cc), dtype=torch.bfloat16, device=self.device)

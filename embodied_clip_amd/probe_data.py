@@ -39,7 +39,9 @@ PREDICTION_TYPES = ("object_presence", "object_localization", "reachability", "f
 # writer
 # ------------------------------------------------------------------------------------------------
 class ClipFeatureExtractor:
-    """frames uint8 [n,224,224,3] -> the three CLIP embeddings the cache stores (all fp32, on the host)."""
+    """frames uint8 [n,H,W,3] -> the three CLIP embeddings the cache stores (all fp32, on the host).  Frames that are
+    not 224x224 (the reference renders 300x300: thor_frames.py:33-34) go through CLIP's Resize(224, BICUBIC) +
+    CenterCrop(224) on the GPU, bit-exact with the Pillow path of ``clip_preprocess`` (thor_image_features.py:108)."""
 
     def __init__(self, visual_state_dict, device="cuda:0", batch: int = 64):
         from .encoder import AttentionPool, RN50Trunk

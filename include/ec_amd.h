@@ -68,6 +68,22 @@ int ec_conv_bf16(const void* in, const void* w, const float* bias, const void* r
 /* Plain GEMM view of the same kernel: out[M,N] = act(A[M,K] W[N,K]^T + bias (+res)).
  * Replaces nn.Linear / nn.MultiheadAttention projections of [U] clip/model.py
  * ResidualAttentionBlock and AttentionPool2d.  K multiple of 8, N multiple of 32. */
+/* ------------------------------------------------------------------------
+ * CLIP image preprocessing on raw uint8 frames: Resize(n_px, BICUBIC) + CenterCrop(n_px), bit-exact with Pillow.
+ * Replaces the PIL/torchvision half of `clip_preprocess(frame)` (primitive_probing/generate_data/
+ * thor_image_features.py:108, :36-44; frames are 300x300: thor_frames.py:33-34).  ToTensor + Normalize are fused into
+ * the stem (ec_rn50_forward_u8).
+ *   ec_clip_resize_table_ints / ec_clip_resize_table: HOST ONLY -- torchvision's resize / center-crop geometry and
+ *     Pillow's two 22-bit fixed-point coefficient tables (libImaging/Resample.c precompute_coeffs +
+ *     normalize_coeffs_8bpc) for H x W frames; table[6] = the LDS rows the kernel needs (pass as table_max_rows).
+ *     The caller copies the table to the device once per frame geometry.
+ *   ec_clip_resize_crop_u8: frames uint8 [B, H, W, 3] -> uint8 [B, n_px, n_px, 3].
+ * ---------------------------------------------------------------------- */
+size_t ec_clip_resize_table_ints(int H, int W, int n_px);
+int ec_clip_resize_table(int H, int W, int n_px, int* host_table, size_t n_ints);
+int ec_clip_resize_crop_u8(const uint8_t* frames_u8, const int* table_dev, int table_max_rows, uint8_t* out_u8, int B,
+                           int H, int W, int n_px, ec_stream_t stream);
+
 /* profiling only: copies the s_memtime stamps the 8-wave conv kernel records under EC_CONV_ABLATE & 32 */
 int ec_debug_stamps(unsigned long long* host_dst, int n);
 int ec_gemm_bf16(const void* A, const void* W, const float* bias, const void* res, void* out,
