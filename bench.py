@@ -116,11 +116,11 @@ def measured_traffic(encoder: str, plan_hash, frames_per_launch: int):
     returns (None, note) when no summary exists for this encoder."""
     path = TRAFFIC_FILES[encoder]
     if not os.path.exists(path):
-        return None, f"no PMC summary at {os.path.relpath(path, ROOT)} (run tools/pmc_trunk.sh + tools/pmc_summary.py)"
+        return None, f"no PMC summary at {os.path.relpath(path, ROOT)} (run tools/pmc_collect.sh + tools/pmc_summary.py)"
     rec = json.load(open(path))
     if plan_hash is not None and rec.get("plan_hash") not in (None, plan_hash):
         raise SystemExit(f"{os.path.relpath(path, ROOT)} is STALE: measured on launch plan {rec.get('plan_hash')}, the "
-                         f"library now runs plan {plan_hash}. Re-run tools/pmc_trunk.sh + tools/pmc_summary.py and commit "
+                         f"library now runs plan {plan_hash}. Re-run tools/pmc_collect.sh + tools/pmc_summary.py and commit "
                          "the new summary (or pass --no-traffic).")
     per_frame = rec["hbm_bytes_per_launch"] / rec["frames_per_launch"]
     return per_frame * frames_per_launch, (

@@ -1,30 +1,90 @@
-"""Join rocprofv3 PMC passes (counter_collection.csv) per dispatch of the LAST forward and print per-kernel rows."""
-import csv, sys, collections, os
-root = sys.argv[1]
-n_last = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+"""Join the rocprofv3 passes of tools/pmc_collect.sh per dispatch of the LAST encoder forward and write
+  <out>_per_kernel.txt   per-launch table: duration, MFMA-busy %, VALU/LDS mix, HBM bytes
+  <out>_hbm_traffic.json the record bench.py reads for roofline.traffic (keyed by the library's launch-plan hash)
+
+usage: python tools/pmc_summary.py gpurun_out/pmc_<name> <launches per forward> <frames per forward> <out prefix> [plan_hash] [alg MB/frame]
+
+HBM bytes = FETCH_SIZE x 2 (gfx950: FETCH_SIZE tallies 128-B requests at 64 B -- MI355X_MICROARCH.md "HBM") + WRITE_SIZE,
+both reported by rocprofv3 in KB.  MFMA busy % = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES): the share of
+SIMD-cycles of busy CUs in which the matrix pipe is executing; next to it the same numerator over ALL 1024 SIMDs for the
+kernel's wall time (GRBM_GUI_ACTIVE), which also charges idle CUs (tile quantisation) to the kernel.
+"""
+import collections
+import csv
+import json
+import os
+import sys
+
+root, n_last, frames, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+plan_hash = sys.argv[5] if len(sys.argv) > 5 else None
+alg_mb = float(sys.argv[6]) if len(sys.argv) > 6 else 45.7
+KEYS = ('conv_igemm', 'stem', 'avgpool', 'conv1x1_pair', 'conv1x1_regw', 'conv3x3_narrow', 'conv3x3_rows', 'layernorm',
+        'mha_', 'patchify', 'assemble', 'attn', 'resize')
+
+
+def find_csv(d, suffix):
+    for base, _, files in os.walk(d):
+        for f in files:
+            if f.endswith(suffix):
+                return os.path.join(base, f)
+    return None
+
+
 per = collections.OrderedDict()
 for p in sorted(os.listdir(root)):
-    f = os.path.join(root, p, 'p_counter_collection.csv')
-    if not os.path.exists(f): continue
-    rows = list(csv.DictReader(open(f)))
+    f = find_csv(os.path.join(root, p), 'counter_collection.csv')
+    if not f:
+        continue
     disp = collections.OrderedDict()
-    for r in rows:
+    for r in csv.DictReader(open(f)):
         d = int(r['Dispatch_Id'])
         disp.setdefault(d, {'name': r['Kernel_Name'], 'grid': int(r['Grid_Size']) // max(1, int(r['Workgroup_Size']))})
-        disp[d][r['Counter_Name']] = float(r['Counter_Value'])
-    ids = [d for d in disp if any(k in disp[d]['name'] for k in ('conv_igemm', 'stem', 'avgpool', 'conv1x1_pair', 'conv1x1_regw', 'conv3x3_narrow', 'conv3x3_rows'))]
-    ids = ids[-n_last:]
+        disp[d][r['Counter_Name']] = disp[d].get(r['Counter_Name'], 0.0) + float(r['Counter_Value'])
+    ids = [d for d in disp if any(k in disp[d]['name'] for k in KEYS)][-n_last:]
     for i, d in enumerate(ids):
         per.setdefault(i, {}).update(disp[d])
-cols = ['SQ_WAVE_CYCLES','SQ_BUSY_CYCLES','SQ_WAIT_ANY','SQ_WAIT_INST_ANY','SQ_ACTIVE_INST_ANY','SQ_ACTIVE_INST_VALU','SQ_VALU_MFMA_BUSY_CYCLES','SQ_WAIT_INST_LDS','SQ_LDS_BANK_CONFLICT','SQ_LDS_IDX_ACTIVE','SQ_ACTIVE_INST_LDS','SQ_ACTIVE_INST_VMEM','SQ_INSTS_VALU','SQ_INSTS_MFMA','SQ_INSTS_LDS','SQ_INSTS_VMEM_RD','FETCH_SIZE','WRITE_SIZE','GRBM_GUI_ACTIVE']
-print('idx kernel grid | wait_any% wait_inst% active% valu% mfma_busy%(of busy*4simd) lds_wait% | bankconf/lds_active  valu/mfma insts | fetchMB(x2) writeMB | gui_active')
-for i, r in per.items():
-    wc = r.get('SQ_WAVE_CYCLES', 1) or 1
-    nm = r['name'].replace('void ', '').replace('(anonymous namespace)::', '')
-    nm = nm.split('conv_igemm_kernel')[-1][:26] if 'conv_igemm' in nm else nm[:26]
-    busy = r.get('SQ_BUSY_CYCLES', 1) or 1
-    print(f"{i:2d} {nm:28s} {r['grid']:6d} | {100*r.get('SQ_WAIT_ANY',0)/wc:5.1f} {100*r.get('SQ_WAIT_INST_ANY',0)/wc:5.1f} {100*r.get('SQ_ACTIVE_INST_ANY',0)/wc:5.1f} {100*r.get('SQ_ACTIVE_INST_VALU',0)/wc:5.1f}  mfma_busy={r.get('SQ_VALU_MFMA_BUSY_CYCLES',0):.3g} busy={busy:.3g} ldsw {100*r.get('SQ_WAIT_INST_LDS',0)/wc:5.1f} | {r.get('SQ_LDS_BANK_CONFLICT',0)/max(1,r.get('SQ_LDS_IDX_ACTIVE',1)):5.2f} {r.get('SQ_INSTS_VALU',0)/max(1,r.get('SQ_INSTS_MFMA',1)):6.1f} lds/mfma {r.get('SQ_INSTS_LDS',0)/max(1,r.get('SQ_INSTS_MFMA',1)):5.1f} | {2*r.get('FETCH_SIZE',0)/1024:8.1f} {r.get('WRITE_SIZE',0)/1024:8.1f} | {r.get('GRBM_GUI_ACTIVE',0):.3g}")
+# durations from the plain kernel trace
+kt = find_csv(os.path.join(root, 'kt'), 'kernel_trace.csv')
+if kt:
+    rows = [r for r in csv.DictReader(open(kt)) if any(k in r['Kernel_Name'] for k in KEYS)][-n_last:]
+    for i, r in enumerate(rows):
+        per.setdefault(i, {})['dur_us'] = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+        per[i].setdefault('name', r['Kernel_Name'])
 
-tot_f = sum(2 * r.get('FETCH_SIZE', 0) for r in per.values()) / 1024 / 1024
-tot_w = sum(r.get('WRITE_SIZE', 0) for r in per.values()) / 1024 / 1024
-print(f"TOTAL per forward: fetch {tot_f:.2f} GB (FETCH_SIZE x2 gfx950 correction)  write {tot_w:.2f} GB  sum {tot_f + tot_w:.2f} GB")
+lines = ['idx kernel                               grid |  dur_us | mfma_busy%%(busy CUs) mfma%%(all SIMDs,wall) | wait_any%% active%% valu%% | valu/mfma lds/mfma bankconf | fetchMB(x2) writeMB']
+tot_f = tot_w = tot_us = 0.0
+agg = collections.OrderedDict()
+for i, r in per.items():
+    wc = r.get('SQ_WAVE_CYCLES', 0) or 1
+    nm = r.get('name', '?').replace('void ', '').replace('(anonymous namespace)::', '')
+    nm = nm.split('(')[0][:36]
+    mb = r.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0)
+    busy_cu = r.get('SQ_BUSY_CU_CYCLES', 0.0)
+    gui = r.get('GRBM_GUI_ACTIVE', 0.0)
+    u1 = 100 * mb / (4 * busy_cu) if busy_cu else float('nan')
+    u2 = 100 * mb / (1024 * gui) if gui else float('nan')
+    fmb, wmb = 2 * r.get('FETCH_SIZE', 0) / 1024, r.get('WRITE_SIZE', 0) / 1024
+    tot_f += fmb; tot_w += wmb; tot_us += r.get('dur_us', 0)
+    a = agg.setdefault(nm, [0, 0.0, 0.0, 0.0, 0.0, 0.0])
+    a[0] += 1; a[1] += r.get('dur_us', 0); a[2] += mb; a[3] += busy_cu; a[4] += fmb; a[5] += wmb
+    lines.append(f"{i:3d} {nm:36s} {r.get('grid', 0):5d} | {r.get('dur_us', 0):7.1f} | {u1:8.1f} {u2:8.1f} | "
+                 f"{100 * r.get('SQ_WAIT_ANY', 0) / wc:5.1f} {100 * r.get('SQ_ACTIVE_INST_ANY', 0) / wc:5.1f} "
+                 f"{100 * r.get('SQ_ACTIVE_INST_VALU', 0) / wc:5.1f} | {r.get('SQ_INSTS_VALU', 0) / max(1, r.get('SQ_INSTS_MFMA', 1)):6.1f} "
+                 f"{r.get('SQ_INSTS_LDS', 0) / max(1, r.get('SQ_INSTS_MFMA', 1)):5.1f} "
+                 f"{r.get('SQ_LDS_BANK_CONFLICT', 0) / max(1, r.get('SQ_LDS_IDX_ACTIVE', 1)):5.2f} | {fmb:8.1f} {wmb:8.1f}")
+lines.append('')
+lines.append('per kernel (this forward): calls total_us  mfma_busy%(busy CUs)  fetchMB writeMB')
+for nm, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+    lines.append(f"  {nm:36s} {a[0]:3d} {a[1]:8.1f}  {100 * a[2] / (4 * a[3]) if a[3] else float('nan'):6.1f}   {a[4]:8.1f} {a[5]:8.1f}")
+mb_all = sum(a[2] for a in agg.values()); cu_all = sum(a[3] for a in agg.values())
+lines.append(f"TOTAL per forward ({frames} frames, {len(per)} launches): {tot_us:.1f} us kernel time; HBM fetch {tot_f / 1024:.2f} GB "
+             f"(FETCH_SIZE x2) + write {tot_w / 1024:.2f} GB = {(tot_f + tot_w) / 1024:.2f} GB; "
+             f"MFMA busy {100 * mb_all / (4 * cu_all) if cu_all else float('nan'):.1f} % of the SIMD-cycles of busy CUs")
+open(out + '_per_kernel.txt', 'w').write('\n'.join(lines) + '\n')
+rec = {"plan_hash": plan_hash, "frames_per_launch": frames, "launches": len(per),
+       "hbm_bytes_per_launch": (tot_f + tot_w) * 1024 * 1024, "fetch_bytes_x2": tot_f * 1024 * 1024,
+       "write_bytes": tot_w * 1024 * 1024, "kernel_time_us": tot_us, "algorithmic_mb_per_frame": alg_mb,
+       "mfma_busy_frac_of_busy_cus": (mb_all / (4 * cu_all)) if cu_all else None,
+       "source": "tools/pmc_collect.sh + tools/pmc_summary.py (rocprofv3 --pmc passes, counters only)"}
+json.dump(rec, open(out + '_hbm_traffic.json', 'w'), indent=1)
+print('\n'.join(lines[-(len(agg) + 3):]))
