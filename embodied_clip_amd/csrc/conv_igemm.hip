@@ -438,8 +438,10 @@ __device__ unsigned long long ec_dbg_stamps[2 * 1024];   // profiling only (EC_C
 
 template <int BN, int KS, bool POOL, int ABL>
 __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
-    constexpr int BM = 256, WN = 4;
-    constexpr int TM = 128, TN = BN / WN;
+    // wave grid: 2 (M) x 4 (N) for 256-wide tiles (wave tile 128 x 64); 4 x 2 for 128-wide tiles (wave tile 64 x 64:
+    // 4 fragment reads per 4 MFMAs instead of the 5 a 128 x 32 wave tile needs)
+    constexpr int BM = 256, WN = (BN >= 256) ? 4 : 2, WMW = 8 / WN;
+    constexpr int TM = BM / WMW, TN = BN / WN;
     constexpr int FM = TM / 32, FN = TN / 32;
     constexpr int NT = 512, LR = NT / 8;
     constexpr int A_IT = BM / LR, B_IT = BN / LR;
@@ -451,7 +453,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    const int grp = wm;                                 // waves 0-3 / 4-7: the two waves of every SIMD
+    const int grp = wave >> 2;                          // waves 0-3 / 4-7: the two waves of every SIMD
 
     const int tile = (int)ec_xcd_remap(blockIdx.x, gridDim.x);
     if (tile >= p.ntiles) return;
