@@ -249,12 +249,14 @@ def run_rank(a, rank: int, local_rank: int, world: int, init_method=None):
     if not a.no_h2d and not a.frames_host:
         w = None             # free the first worker's ~11 GB before building the next
         gc.collect(); torch.cuda.empty_cache()
-        wh = Worker(per_gpu, frames_host=True, **{**wkw, "frames_u8": True})
+        u8 = a.encoder != "vit"          # (the ViT patch-embed kernel takes the sensor's fp32 frames only)
+        wh = Worker(per_gpu, frames_host=True, **{**wkw, "frames_u8": u8})
         dth = maxreduce(_time_iterations(wh, 1, 1, barrier))
         h2d = {"value": round(a.rollout * per_gpu * world / dth, 1), "unit": "env-frames/s", "steps": 1,
-               "frames": "uint8 HWC in PINNED HOST memory, copied per slice on its own copy stream (double-buffered) "
-                         "while the other slice computes; /255 + CLIP mean/std fused into the stem kernel",
-               "h2d_bytes_per_env_step": per_gpu * 224 * 224 * 3}
+               "frames": ("uint8 HWC" if u8 else "fp32 normalised HWC") + " in PINNED HOST memory, copied per slice on its "
+                         "own copy stream (double-buffered) while the other slice computes" +
+                         ("; /255 + CLIP mean/std fused into the stem kernel" if u8 else ""),
+               "h2d_bytes_per_env_step": per_gpu * 224 * 224 * 3 * (1 if u8 else 4)}
         del wh
         torch.cuda.empty_cache()
     weak = None

@@ -776,13 +776,14 @@ int dispatch_tile(const ConvArgs& a, hipStream_t s) {
         // measured (B = 256, tools/bench_big.sh): wins on the 3x3 convs with Cout % 256 == 0 once there are enough
         // 256-row tiles to occupy most CUs; loses on N = 128, on the short launches of 7x7 maps and ties on 1x1
         const long nt256 = (long)((a.M + 255) / 256) * (a.Cout / 256), nt128 = (long)((a.M + 255) / 256) * (a.Cout / 128);
-        if (KS == 3 && a.Cout % 256 == 0 && nt256 >= 150) return launch8<256, KS, POOL>(a, s);
+        static const long mint = [] { const char* e = getenv("EC_CONV8_MIN_TILES"); return e ? atol(e) : 150L; }();
+        if (KS == 3 && a.Cout % 256 == 0 && nt256 >= mint) return launch8<256, KS, POOL>(a, s);
         // long-K 1x1 convs (tools/bench_l4.sh, B = 256): 1024->2048 @7x7 83.7 -> 70.5 us, 1024->512 @14x14 82.9 -> 70.5,
         // 1024->256 @14x14 40.6 -> 37.0 with 256-wide tiles; 2048->512 @7x7 46.4 -> 40.1 with 128-wide tiles (196 of them);
         // K = 512 and residual launches stay on the 4-wave kernel (slower here)
         if (KS == 1 && !POOL && !a.res && a.K >= 1024) {
-            if (a.Cout % 256 == 0 && nt256 >= 150) return launch8<256, KS, POOL>(a, s);
-            if (a.Cout % 128 == 0 && nt256 < 150 && nt128 >= 150) return launch8<128, KS, POOL>(a, s);
+            if (a.Cout % 256 == 0 && nt256 >= mint) return launch8<256, KS, POOL>(a, s);
+            if (a.Cout % 128 == 0 && nt256 < mint && nt128 >= mint) return launch8<128, KS, POOL>(a, s);
         }
     }
     if (big == 4 && a.Cin % 64 == 0 && a.cin_log2 >= 0 && a.K >= 512 && a.M >= 256 * 32 && a.M % (POOL ? 4 : 1) == 0) {

@@ -51,7 +51,7 @@ if kt:
         per.setdefault(i, {})['dur_us'] = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
         per[i].setdefault('name', r['Kernel_Name'])
 
-lines = ['idx kernel                               grid |  dur_us | mfma_busy%%(busy CUs) mfma%%(all SIMDs,wall) | wait_any%% active%% valu%% | valu/mfma lds/mfma bankconf | fetchMB(x2) writeMB']
+lines = ['idx kernel                               grid |  dur_us | mfma_busy%%(busy CUs) mfma%%(all SIMDs,wall) | wait_any%% active%% valu%% | valu/mfma lds/mfma bankconf | fetchMiB(x2) writeMiB']
 tot_f = tot_w = tot_us = 0.0
 agg = collections.OrderedDict()
 for i, r in per.items():
@@ -77,8 +77,9 @@ lines.append('per kernel (this forward): calls total_us  mfma_busy%(busy CUs)  f
 for nm, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     lines.append(f"  {nm:36s} {a[0]:3d} {a[1]:8.1f}  {100 * a[2] / (4 * a[3]) if a[3] else float('nan'):6.1f}   {a[4]:8.1f} {a[5]:8.1f}")
 mb_all = sum(a[2] for a in agg.values()); cu_all = sum(a[3] for a in agg.values())
-lines.append(f"TOTAL per forward ({frames} frames, {len(per)} launches): {tot_us:.1f} us kernel time; HBM fetch {tot_f / 1024:.2f} GB "
-             f"(FETCH_SIZE x2) + write {tot_w / 1024:.2f} GB = {(tot_f + tot_w) / 1024:.2f} GB; "
+GB = 1024 * 1024 / 1e9      # table columns are MiB (rocprofv3 reports KiB); totals in GB = 1e9 bytes
+lines.append(f"TOTAL per forward ({frames} frames, {len(per)} launches): {tot_us:.1f} us kernel time; HBM fetch {tot_f * GB:.2f} GB "
+             f"(FETCH_SIZE x2) + write {tot_w * GB:.2f} GB = {(tot_f + tot_w) * GB:.2f} GB; "
              f"MFMA busy {100 * mb_all / (4 * cu_all) if cu_all else float('nan'):.1f} % of the SIMD-cycles of busy CUs")
 open(out + '_per_kernel.txt', 'w').write('\n'.join(lines) + '\n')
 rec = {"plan_hash": plan_hash, "frames_per_launch": frames, "launches": len(per),
