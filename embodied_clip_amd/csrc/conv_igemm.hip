@@ -809,6 +809,14 @@ int dispatch_tile(const ConvArgs& a, hipStream_t s) {
                                (t224 == 3 || (t196 == 512 && (long)a.H * a.W == 196)))))
                 return launch<224, 128, 1, 4, KS, POOL, false, 196>(a, s);
         }
+        // Small launches (strong scaling: 32-64 frames per GPU): with fewer 128x128 tiles than CUs every workgroup is one
+        // long serial K chain and most of the chip idles -> 64x64 tiles give 4x the workgroups for the long-K layers
+        // (batch 32: layer-4 3x3 52 tiles x 72 K-tiles = 76 us).  EC_CONV_T64: tile-count threshold (0 = off).
+        static const int t64 = [] { const char* e = getenv("EC_CONV_T64"); return e ? atoi(e) : 150; }();
+        if constexpr (!POOL) {
+            const long t128 = (long)((a.M + 127) / 128) * (a.Cout / 128);
+            if (t128 < t64 && a.K >= 512 && a.Cout % 64 == 0) return launch<64, 64, 2, 2, KS, POOL>(a, s);
+        }
         // residual register prefetch only for the short-K, bandwidth-bound expanding 1x1 convs
         if (force != 8) {
             if (KS == 1 && !POOL && a.res && a.K <= 256) return launch<128, 128, 2, 2, KS, POOL, (KS == 1 && !POOL)>(a, s);
