@@ -772,7 +772,7 @@ int dispatch_tile(const ConvArgs& a, hipStream_t s) {
     // ping-pong schedule takes 72-75) and a one-wave-per-SIMD 4-wave kernel with in-wave software pipelining (87.8 us:
     // every LDS-DMA piece blocks its issuing wave for ~150 clk and there is no partner wave to keep the matrix pipe busy).
     static const int big = [] { const char* e = getenv("EC_CONV_BIG"); return e ? atoi(e) : 1; }();
-    if (big == 1 && a.Cin % 64 == 0 && a.cin_log2 >= 0 && a.K >= 512 && a.M % (POOL ? 4 : 1) == 0) {
+    if (big == 1 && a.Cin % 64 == 0 && (KS == 1 || a.cin_log2 >= 0) && a.K >= 512 && a.M % (POOL ? 4 : 1) == 0) {
         // measured (B = 256, tools/bench_big.sh): wins on the 3x3 convs with Cout % 256 == 0 once there are enough
         // 256-row tiles to occupy most CUs; loses on N = 128, on the short launches of 7x7 maps and ties on 1x1
         const long nt256 = (long)((a.M + 255) / 256) * (a.Cout / 256), nt128 = (long)((a.M + 255) / 256) * (a.Cout / 128);
@@ -781,12 +781,15 @@ int dispatch_tile(const ConvArgs& a, hipStream_t s) {
         // long-K 1x1 convs (tools/bench_l4.sh, B = 256): 1024->2048 @7x7 83.7 -> 70.5 us, 1024->512 @14x14 82.9 -> 70.5,
         // 1024->256 @14x14 40.6 -> 37.0 with 256-wide tiles; 2048->512 @7x7 46.4 -> 40.1 with 128-wide tiles (196 of them);
         // K = 512 and residual launches stay on the 4-wave kernel (slower here)
-        if (KS == 1 && !POOL && !a.res && a.K >= 1024) {
+        // K = 512 and short-K residual launches stay on the 4-wave kernel (slower here).  ViT-B/32 GEMMs (tools/bench_vitgemm.sh,
+        // 12800 tokens): in_proj 768->2304 78.6 -> 57.6 us, c_fc 768->3072 105 -> 82, c_proj 3072->768 + residual 91.7 -> 85.1;
+        // out_proj 768->768 + residual is slower (31 -> 35) and keeps the 4-wave kernel
+        if (KS == 1 && !POOL && ((!a.res && a.K >= 768) || (a.res && a.K >= 2048))) {
             if (a.Cout % 256 == 0 && nt256 >= mint) return launch8<256, KS, POOL>(a, s);
-            if (a.Cout % 128 == 0 && nt256 < mint && nt128 >= mint) return launch8<128, KS, POOL>(a, s);
+            if (!a.res && a.K >= 1024 && a.Cout % 128 == 0 && nt256 < mint && nt128 >= mint) return launch8<128, KS, POOL>(a, s);
         }
     }
-    if (big == 4 && a.Cin % 64 == 0 && a.cin_log2 >= 0 && a.K >= 512 && a.M >= 256 * 32 && a.M % (POOL ? 4 : 1) == 0) {
+    if (big == 4 && a.Cin % 64 == 0 && (KS == 1 || a.cin_log2 >= 0) && a.K >= 512 && a.M >= 256 * 32 && a.M % (POOL ? 4 : 1) == 0) {
         static const int bn128 = [] { const char* e = getenv("EC_CONV8_BN128"); return e ? atoi(e) : 0; }();
         if (a.Cout % 256 == 0 && !bn128) return launch8<256, KS, POOL>(a, s);     // (A/B: everywhere its preconditions hold)
         if (a.Cout % 128 == 0) return launch8<128, KS, POOL>(a, s);

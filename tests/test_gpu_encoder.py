@@ -106,6 +106,8 @@ def test_conv_bf16_matches_oracle(dev, B, H, W, Cin, Cout, ks, pool, res, act):
     (4, 43, 14, 14, 64, 128, 3, False, False, 1),
     (4, 12, 28, 28, 64, 128, 3, True, False, 1),
     (4, 9, 30, 30, 64, 256, 1, False, False, 2),         # K = 64 < 512: must fall back to the 4-wave kernel
+    (1, 50, 14, 14, 768, 1024, 1, False, False, 2),      # ViT c_fc-like: Cin = 768 (not a power of two), QuickGELU, production rule
+    (1, 200, 7, 7, 2048, 256, 1, False, True, 1),        # long-K 1x1 with a residual (ViT c_proj-like), production rule
 ])
 def test_conv_igemm8_pingpong_matches_oracle(dev, monkeypatch, big, B, H, W, Cin, Cout, ks, pool, res, act):
     """The 8-wave kernel's cross-wave LDS hand-offs (counted waits + raw barriers) are exercised on many tiles per
