@@ -14,6 +14,8 @@
 //   grads  one flat fp32 buffer, same offsets (one all-reduce bucket)
 // The goal embedding is folded into a [num_goals, 128] row-group bias table
 // E1 = embed_class @ W3[:, 32:]^T + b3, so the 64-channel concat is never built.
+#include <stdlib.h>
+
 #include <new>
 
 #include "common.h"
@@ -77,6 +79,121 @@ __global__ void gru_gates_fwd_kernel(const float* __restrict__ gi, const float* 
         g[j] = r; g[H + j] = z; g[2 * H + j] = nn;
         hn_s[i] = hn;
         hp_s[i] = hp;
+    }
+}
+
+// Fused GRU forward step (round 2): recurrent projection + gate math in ONE launch per time step, replacing the
+// [N x 3H x H] GEMM launch + gru_gates_fwd_kernel pair (17 + 7 us per step at N = 128, 128 steps per direction).
+// Workgroup (blockIdx.x, blockIdx.y) owns hidden units j0..j0+7 (24 gate columns of W_hh) of actors n0..n0+31:
+//   * hp = m * h_prev tile [32 x H] and the 24 W_hh rows [24 x H] are staged in LDS (row pitch H + 4 floats: the
+//     16-lane groups of a ds_read_b128 hit 16 different 16-byte slots);
+//   * wave w contracts its quarter of K with the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32 == an fmaf chain, so the
+//     result stays within fp32 rounding of the reference GRU): lane (i = l & 31, hh = l >> 5) feeds k = kb + 4 hh + q
+//     to the q-th MFMA of a k-block of 8, one ds_read_b128 per operand per 4 MFMAs;
+//   * the four partial 32 x 32 tiles are summed through LDS in a fixed order (actor-local, batch-invariant: act steps
+//     stay bit-reproducible whatever the slicing), then thread (a, u) applies the gate math of unit j0 + u of actor a.
+__global__ __launch_bounds__(256) void gru_step_fwd_kernel(const float* __restrict__ gi, const float* __restrict__ Whh,
+                                                          const float* __restrict__ bhh, const float* __restrict__ hprev,
+                                                          const float* __restrict__ mask, float* __restrict__ hout,
+                                                          float* __restrict__ gates, float* __restrict__ hn_s,
+                                                          float* __restrict__ hp_s, int N, int H) {
+    extern __shared__ __attribute__((aligned(16))) float gsm[];
+    const int P = H + 4;
+    float* sA = gsm;
+    float* sB = gsm + 32 * P;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j0 = blockIdx.x * 8, n0 = blockIdx.y * 32;
+    // the episode mask is applied to the contraction result (m (h W^T) == (m h) W^T exactly for m in {0, 1})
+    if ((H & 255) == 0) {
+        // LDS-DMA staging: a 1-KiB piece is 256 consecutive floats of one row; 56 rows x H/256 pieces, round-robin over waves
+        typedef __attribute__((address_space(3))) void lds_v;
+        typedef const __attribute__((address_space(1))) void gbl_v;
+        const int ppr = H >> 8;
+        const int uwave = __builtin_amdgcn_readfirstlane(wave);
+        for (int pc = uwave; pc < 56 * ppr; pc += 4) {
+            const int r = pc / ppr, seg = pc - r * ppr;
+            const float* src;
+            float* dst;
+            if (r < 32) {
+                const int n = min(n0 + r, N - 1);                       // rows past N are never read back
+                src = hprev + (long)n * H + seg * 256 + lane * 4;
+                dst = sA + r * P + seg * 256;
+            } else {
+                const int c = r - 32;
+                src = Whh + ((long)(c >> 3) * H + j0 + (c & 7)) * H + seg * 256 + lane * 4;
+                dst = sB + c * P + seg * 256;
+            }
+            __builtin_amdgcn_global_load_lds((gbl_v*)src, (lds_v*)dst, 16, 0, 0);
+        }
+        if (tid < 8 * (H >> 2)) {                                       // W rows 24..31 of the B tile: zeros
+            const int r = 24 + tid / (H >> 2), c4 = tid % (H >> 2);
+            *reinterpret_cast<float4*>(sB + r * P + c4 * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        for (int idx = tid + 256; idx < 8 * (H >> 2); idx += 256) {
+            const int r = 24 + idx / (H >> 2), c4 = idx % (H >> 2);
+            *reinterpret_cast<float4*>(sB + r * P + c4 * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        const int q4 = H >> 2;
+        for (int idx = tid; idx < 32 * q4; idx += 256) {
+            const int r = idx / q4, c4 = idx - r * q4;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+            const int n = n0 + r;
+            if (n < N) a = *reinterpret_cast<const float4*>(hprev + (long)n * H + c4 * 4);
+            if (r < 24) b = *reinterpret_cast<const float4*>(Whh + ((long)(r >> 3) * H + j0 + (r & 7)) * H + c4 * 4);
+            *reinterpret_cast<float4*>(sA + r * P + c4 * 4) = a;
+            *reinterpret_cast<float4*>(sB + r * P + c4 * 4) = b;
+        }
+    }
+    __syncthreads();
+    f32x16_t acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int i = lane & 31, hh = lane >> 5;
+    const int kq = H >> 2;
+    const float* pa = sA + i * P + wave * kq + 4 * hh;
+    const float* pb = sB + i * P + wave * kq + 4 * hh;
+    for (int kb = 0; kb < kq; kb += 8) {
+        const float4 a = *reinterpret_cast<const float4*>(pa + kb);
+        const float4 b = *reinterpret_cast<const float4*>(pb + kb);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+    }
+    __syncthreads();                       // the operand tiles are dead: LDS becomes the 4 partial [32 x 32] tiles
+    float* part = gsm;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;     // actor (C/D layout of the 32x32 MFMA), column = lane & 31
+        part[(wave * 32 + row) * 32 + i] = acc[r];
+    }
+    __syncthreads();
+    const int a_ = tid >> 3, u = tid & 7;
+    const int n = n0 + a_, j = j0 + u;
+    if (n >= N) return;
+    float gh[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        const int c = g * 8 + u;
+        gh[g] = ((part[(0 * 32 + a_) * 32 + c] + part[(1 * 32 + a_) * 32 + c]) + part[(2 * 32 + a_) * 32 + c]) +
+                part[(3 * 32 + a_) * 32 + c];
+    }
+    const float* gir = gi + (long)n * 3 * H;
+    const float m = mask[n];
+    const float hp = m * hprev[(long)n * H + j];
+    const float r = sigmoidf_(gir[j] + m * gh[0] + bhh[j]);
+    const float z = sigmoidf_(gir[H + j] + m * gh[1] + bhh[H + j]);
+    const float hn = m * gh[2] + bhh[2 * H + j];
+    const float nn = tanhf(gir[2 * H + j] + r * hn);
+    const long o = (long)n * H + j;
+    hout[o] = (1.f - z) * nn + z * hp;
+    if (gates) {
+        float* gp = gates + (long)n * 3 * H;
+        gp[j] = r; gp[H + j] = z; gp[2 * H + j] = nn;
+        hn_s[o] = hn;
+        hp_s[o] = hp;
     }
 }
 
@@ -374,11 +491,28 @@ extern "C" int ec_policy_forward(const ec_policy_t* h, const float* params, cons
     // (no split-K here: the act step stays free of float atomics, so rollouts are bit-reproducible)
     RC(ec_gemm_f32(ws + w.x, W(P_WIH), ws + w.gi, B, 3 * H, flat, flat, 1, 1, flat, 3 * H, 0, W(P_BIH), nullptr,
                    nullptr, 0, nullptr, nullptr, 1, stream));
+    // EC_GRU_FUSED (default 1): one fused launch per step where the geometry allows (H % 32 == 0, tiles fit the LDS)
+    static const int gru_fused = [] { const char* e = getenv("EC_GRU_FUSED"); return e ? atoi(e) : 1; }();
+    size_t gru_lds = (size_t)2 * 32 * (H + 4) * sizeof(float);      // operand tiles ...
+    if (gru_lds < 4 * 32 * 32 * sizeof(float)) gru_lds = 4 * 32 * 32 * sizeof(float);   // ... reused for the 4 partial tiles
+    const bool fused_step = gru_fused && (H % 32) == 0 && gru_lds <= 160 * 1024;
+    if (fused_step) {
+        static std::atomic<uint64_t> attr_done{0};
+        if (ec_attr_needed(attr_done))
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gru_step_fwd_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
     for (int t = 0; t < T; ++t) {
         const float* hprev = (t == 0) ? h0 : ws + w.hs + (size_t)(t - 1) * N * H;
+        const size_t o3 = (size_t)t * N * 3 * H, o1 = (size_t)t * N * H;
+        if (fused_step) {
+            hipLaunchKernelGGL(gru_step_fwd_kernel, dim3((unsigned)(H / 8), (unsigned)((N + 31) / 32)), dim3(256), gru_lds, s,
+                               ws + w.gi + o3, W(P_WHH), W(P_BHH), hprev, masks + (size_t)t * N, ws + w.hs + o1,
+                               ws + w.gates + o3, ws + w.hn + o1, ws + w.hp + o1, N, H);
+            continue;
+        }
         RC(ec_gemm_f32(hprev, W(P_WHH), ws + w.gh, N, 3 * H, H, H, 1, 1, H, 3 * H, 0, nullptr, nullptr, nullptr, 0,
                        nullptr, nullptr, 1, stream));
-        const size_t o3 = (size_t)t * N * 3 * H, o1 = (size_t)t * N * H;
         hipLaunchKernelGGL(gru_gates_fwd_kernel, dim3((N * H + 255) / 256), dim3(256), 0, s, ws + w.gi + o3, ws + w.gh,
                            W(P_BHH), hprev, masks + (size_t)t * N, ws + w.hs + o1, ws + w.gates + o3, ws + w.hn + o1,
                            ws + w.hp + o1, N, H);
