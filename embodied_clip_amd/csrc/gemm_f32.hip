@@ -565,6 +565,9 @@ extern "C" int ec_gemm_f32(const void* A, const void* B, float* Cp, int M, int N
     const bool b_ok = a.b_vec && ((sbk == 1) ? (K % 4 == 0) : (N % 4 == 0 && sbn == 1));
     if (!x3_off && a_ok && b_ok && M >= 32 && N >= 32 && K >= 32 && !(a.a_bf16 && sak != 1) && !(a.b_bf16 && sbk == 1)) {
         const long blocks128 = (long)((M + 127) / 128) * ((N + 127) / 128) * a.splitk;
+        // N <= 32 (the compressor / combiner 128 -> 32 convs over T*N*49 rows and their input gradients): a 128-wide
+        // tile would spend 3/4 of its MFMAs on padding columns
+        if (N <= 32 && (long)((M + 255) / 256) * a.splitk >= 512) return launch_x3<256, 32, 4, 1>(a, s);
         if (blocks128 < 512) return launch_x3<64, 64, 2, 2>(a, s);
         return launch_x3<128, 128, 2, 2>(a, s);
     }
