@@ -98,69 +98,71 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(const float* __restri
                                                           float* __restrict__ gates, float* __restrict__ hn_s,
                                                           float* __restrict__ hp_s, int N, int H) {
     extern __shared__ __attribute__((aligned(16))) float gsm[];
-    const int P = H + 4;
+    // K is walked in chunks of KC = 256 (whole K when H is not a multiple of 256): the two tiles then take 66.5 KB, so two
+    // workgroups fit a CU and the recurrences of the two actor slices (two HIP streams) overlap instead of queueing
+    const int KC = ((H & 255) == 0) ? 256 : H;
+    const int P = KC + 4;
     float* sA = gsm;
     float* sB = gsm + 32 * P;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j0 = blockIdx.x * 8, n0 = blockIdx.y * 32;
-    // the episode mask is applied to the contraction result (m (h W^T) == (m h) W^T exactly for m in {0, 1})
-    if ((H & 255) == 0) {
-        // LDS-DMA staging: a 1-KiB piece is 256 consecutive floats of one row; 56 rows x H/256 pieces, round-robin over waves
-        typedef __attribute__((address_space(3))) void lds_v;
-        typedef const __attribute__((address_space(1))) void gbl_v;
-        const int ppr = H >> 8;
-        const int uwave = __builtin_amdgcn_readfirstlane(wave);
-        for (int pc = uwave; pc < 56 * ppr; pc += 4) {
-            const int r = pc / ppr, seg = pc - r * ppr;
-            const float* src;
-            float* dst;
-            if (r < 32) {
-                const int n = min(n0 + r, N - 1);                       // rows past N are never read back
-                src = hprev + (long)n * H + seg * 256 + lane * 4;
-                dst = sA + r * P + seg * 256;
-            } else {
-                const int c = r - 32;
-                src = Whh + ((long)(c >> 3) * H + j0 + (c & 7)) * H + seg * 256 + lane * 4;
-                dst = sB + c * P + seg * 256;
-            }
-            __builtin_amdgcn_global_load_lds((gbl_v*)src, (lds_v*)dst, 16, 0, 0);
-        }
-        if (tid < 8 * (H >> 2)) {                                       // W rows 24..31 of the B tile: zeros
-            const int r = 24 + tid / (H >> 2), c4 = tid % (H >> 2);
-            *reinterpret_cast<float4*>(sB + r * P + c4 * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        for (int idx = tid + 256; idx < 8 * (H >> 2); idx += 256) {
-            const int r = 24 + idx / (H >> 2), c4 = idx % (H >> 2);
-            *reinterpret_cast<float4*>(sB + r * P + c4 * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-        const int q4 = H >> 2;
-        for (int idx = tid; idx < 32 * q4; idx += 256) {
-            const int r = idx / q4, c4 = idx - r * q4;
-            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-            const int n = n0 + r;
-            if (n < N) a = *reinterpret_cast<const float4*>(hprev + (long)n * H + c4 * 4);
-            if (r < 24) b = *reinterpret_cast<const float4*>(Whh + ((long)(r >> 3) * H + j0 + (r & 7)) * H + c4 * 4);
-            *reinterpret_cast<float4*>(sA + r * P + c4 * 4) = a;
-            *reinterpret_cast<float4*>(sB + r * P + c4 * 4) = b;
-        }
-    }
-    __syncthreads();
+    const int i = lane & 31, hh = lane >> 5;
     f32x16_t acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const int i = lane & 31, hh = lane >> 5;
-    const int kq = H >> 2;
-    const float* pa = sA + i * P + wave * kq + 4 * hh;
-    const float* pb = sB + i * P + wave * kq + 4 * hh;
-    for (int kb = 0; kb < kq; kb += 8) {
-        const float4 a = *reinterpret_cast<const float4*>(pa + kb);
-        const float4 b = *reinterpret_cast<const float4*>(pb + kb);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+    if (KC == 256) {                                                    // W rows 24..31 of the B tile: zeros, once
+        for (int idx = tid; idx < 8 * 64; idx += 256) {
+            const int r = 24 + (idx >> 6), c4 = idx & 63;
+            *reinterpret_cast<float4*>(sB + r * P + c4 * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    // the episode mask is applied to the contraction result (m (h W^T) == (m h) W^T exactly for m in {0, 1})
+    for (int k0 = 0; k0 < H; k0 += KC) {
+        if (k0) __syncthreads();                                        // every wave is done reading the previous chunk
+        if (KC == 256) {
+            // LDS-DMA staging: one 1-KiB piece per tile row (256 floats); 56 rows round-robin over the 4 waves
+            typedef __attribute__((address_space(3))) void lds_v;
+            typedef const __attribute__((address_space(1))) void gbl_v;
+            const int uwave = __builtin_amdgcn_readfirstlane(wave);
+            for (int r = uwave; r < 56; r += 4) {
+                const float* src;
+                float* dst;
+                if (r < 32) {
+                    const int n = min(n0 + r, N - 1);                   // rows past N are never read back
+                    src = hprev + (long)n * H + k0 + lane * 4;
+                    dst = sA + r * P;
+                } else {
+                    const int c = r - 32;
+                    src = Whh + ((long)(c >> 3) * H + j0 + (c & 7)) * H + k0 + lane * 4;
+                    dst = sB + c * P;
+                }
+                __builtin_amdgcn_global_load_lds((gbl_v*)src, (lds_v*)dst, 16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            const int q4 = H >> 2;
+            for (int idx = tid; idx < 32 * q4; idx += 256) {
+                const int r = idx / q4, c4 = idx - r * q4;
+                float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+                const int n = n0 + r;
+                if (n < N) a = *reinterpret_cast<const float4*>(hprev + (long)n * H + c4 * 4);
+                if (r < 24) b = *reinterpret_cast<const float4*>(Whh + ((long)(r >> 3) * H + j0 + (r & 7)) * H + c4 * 4);
+                *reinterpret_cast<float4*>(sA + r * P + c4 * 4) = a;
+                *reinterpret_cast<float4*>(sB + r * P + c4 * 4) = b;
+            }
+        }
+        __syncthreads();
+        const int kq = KC >> 2;
+        const float* pa = sA + i * P + wave * kq + 4 * hh;
+        const float* pb = sB + i * P + wave * kq + 4 * hh;
+        for (int kb = 0; kb < kq; kb += 8) {
+            const float4 a = *reinterpret_cast<const float4*>(pa + kb);
+            const float4 b = *reinterpret_cast<const float4*>(pb + kb);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+        }
     }
     __syncthreads();                       // the operand tiles are dead: LDS becomes the 4 partial [32 x 32] tiles
     float* part = gsm;
@@ -271,6 +273,169 @@ __global__ __launch_bounds__(256) void fuse_goal_kernel(const void* __restrict__
     for (int k = lane; k < E; k += 64) {
         const float v = BF16 ? ec_bf2f(((const uint16_t*)feat)[row * E + k]) : ((const float*)feat)[row * E + k];
         x[row * E + k] = v * inv * t[k];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Fused forward "tail" of ResnetTensorGoalEncoder (round 2): for every feature-map pixel (row)
+//     c2 = relu(W2 c1 + b2)            128 -> 32    (resnet_compressor.2)
+//     m1 = relu(W3[:, :32] c2 + E1[goal])  32 -> 128   (target_obs_combiner.0; the goal half is the row-group bias E1)
+//     x4 = W4 m1 + b4                  128 -> 32    (target_obs_combiner.2)
+// in ONE pass over c1 instead of three GEMM launches that each stream a [T*N*49, 128] fp32 tensor through HBM with
+// 32- or 128-long contractions (0.5-0.9 ms each per slice and epoch against ~0.2 ms of traffic for all three together).
+// A wave owns 32-row tiles: the c1 tile is staged in a wave-private LDS image, each stage runs on the exact-fp32 MFMA
+// (v_mfma_f32_32x32x2_f32, an fmaf chain) with the weights resident in LDS as B operands, and a stage's output tile goes
+// back to the wave's LDS image (bias + ReLU applied) as the next stage's A operand -- and to HBM, because the backward
+// needs c2 and m1.  No workgroup barrier after the weights are staged.  Geometry fixed to the reference's
+// (128, 32, 128, 32); other widths keep the GEMM path.
+constexpr int TL_P128 = 132, TL_P32 = 36;     // LDS row pitches (floats): 16-byte slots of 16 consecutive rows differ
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void tail_fwd_kernel(const float* __restrict__ c1, const float* __restrict__ W2,
+                                                         const float* __restrict__ b2, const float* __restrict__ W3,
+                                                         int w3_ld, const float* __restrict__ E1,
+                                                         const int* __restrict__ goal, int S, int num_goals,
+                                                         const float* __restrict__ W4, const float* __restrict__ b4,
+                                                         float* __restrict__ c2, float* __restrict__ m1,
+                                                         float* __restrict__ x4, long M) {
+    extern __shared__ __attribute__((aligned(16))) float tsm[];
+    float* sW2 = tsm;                            // [32][132]
+    float* sW3 = sW2 + 32 * TL_P128;             // [128][36]
+    float* sW4 = sW3 + 128 * TL_P32;             // [32][132]
+    float* sE1 = sW4 + 32 * TL_P128;             // [num_goals][128]
+    float* sB = sE1 + num_goals * 128;           // b2[32], b4[32]
+    float* wave_base = sB + 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* T1 = wave_base + wave * (32 * TL_P128 + 32 * TL_P32);   // c1 tile, later the m1 tile
+    float* T2 = T1 + 32 * TL_P128;                                 // c2 tile
+    for (int idx = tid; idx < 32 * 32; idx += 256) {               // W2, W4: [32][128]
+        const int r = idx >> 5, c4 = idx & 31;
+        *reinterpret_cast<float4*>(sW2 + r * TL_P128 + c4 * 4) = *reinterpret_cast<const float4*>(W2 + r * 128 + c4 * 4);
+        *reinterpret_cast<float4*>(sW4 + r * TL_P128 + c4 * 4) = *reinterpret_cast<const float4*>(W4 + r * 128 + c4 * 4);
+    }
+    for (int idx = tid; idx < 128 * 8; idx += 256) {               // W3[:, :32]: [128][32] out of rows of w3_ld floats
+        const int r = idx >> 3, c4 = idx & 7;
+        *reinterpret_cast<float4*>(sW3 + r * TL_P32 + c4 * 4) = *reinterpret_cast<const float4*>(W3 + (long)r * w3_ld + c4 * 4);
+    }
+    for (int idx = tid; idx < num_goals * 32; idx += 256)
+        *reinterpret_cast<float4*>(sE1 + idx * 4) = *reinterpret_cast<const float4*>(E1 + idx * 4);
+    if (tid < 32) { sB[tid] = b2[tid]; sB[32 + tid] = b4[tid]; }
+    __syncthreads();
+
+    const int i = lane & 31, hh = lane >> 5;
+    const long ntiles = (M + 31) / 32;
+    const long tstep = (long)gridDim.x * 4;
+    // c1 tiles are fetched one tile ahead into registers (16 float4 per lane: rows past M clamp to the last row)
+    // (plain unrolled loops, no lambda: an array captured by a lambda lands in scratch memory)
+    f32x4_t st[16];                                                // native vector type: HIP's float4 struct would be memcpy'd through scratch
+    long tile = (long)blockIdx.x * 4 + wave;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {                                 // (unconditional, clamped: keeps st[] in registers)
+        const int idx = lane + 64 * q, r = idx >> 5, c4 = idx & 31;
+        st[q] = *reinterpret_cast<const f32x4_t*>(c1 + min(tile * 32 + r, M - 1) * 128 + c4 * 4);
+    }
+    for (; tile < ntiles; tile += tstep) {
+        const long m0 = tile * 32;
+        const long grp_base = m0 / S;                               // wave-uniform
+        const int grp_rem = (int)(m0 - grp_base * S);
+        const int last_row = (int)min((long)31, M - 1 - m0);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int idx = lane + 64 * q, r = idx >> 5, c4 = idx & 31;
+            *reinterpret_cast<f32x4_t*>(T1 + r * TL_P128 + c4 * 4) = st[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {                             // next tile: in flight under this tile's three contractions
+            const int idx = lane + 64 * q, r = idx >> 5, c4 = idx & 31;
+            st[q] = *reinterpret_cast<const f32x4_t*>(c1 + min((tile + tstep) * 32 + r, M - 1) * 128 + c4 * 4);
+        }
+        // ---- c2 = relu(c1 W2^T + b2) ----
+        f32x16_t acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int kb = 0; kb < 128; kb += 8) {
+            const float4 a = *reinterpret_cast<const float4*>(T1 + i * TL_P128 + kb + 4 * hh);
+            const float4 b = *reinterpret_cast<const float4*>(sW2 + i * TL_P128 + kb + 4 * hh);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+        }
+        {
+            const float bj = sB[i];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;     // C/D layout: column = lane & 31
+                T2[row * TL_P32 + i] = fmaxf(acc[r] + bj, 0.f);
+            }
+        }
+        // the tile leaves through the wave's LDS image as 16-byte row chunks (a lane of the C/D layout holds single floats)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = lane + 64 * q, r = idx >> 3, c4 = idx & 7;
+            if (m0 + r < M)
+                *reinterpret_cast<float4*>(c2 + (m0 + r) * 32 + c4 * 4) = *reinterpret_cast<const float4*>(T2 + r * TL_P32 + c4 * 4);
+        }
+        // ---- m1 = relu(c2 W3a^T + E1[goal]) : four 32-column tiles, K = 32 ----
+        f32x16_t am[4];
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) am[jt][r] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 32; kb += 8) {
+            const float4 a = *reinterpret_cast<const float4*>(T2 + i * TL_P32 + kb + 4 * hh);
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) {
+                const float4 b = *reinterpret_cast<const float4*>(sW3 + (jt * 32 + i) * TL_P32 + kb + 4 * hh);
+                am[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, am[jt], 0, 0, 0);
+                am[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, am[jt], 0, 0, 0);
+                am[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, am[jt], 0, 0, 0);
+                am[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, am[jt], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+            // row group (actor-step) of this row in 32-bit arithmetic: a 64-bit division per element would cost more than the MFMAs
+            const unsigned trow = min((unsigned)(grp_rem + row), (unsigned)(grp_rem + last_row));
+            int g = goal[grp_base + (long)(trow / (unsigned)S)];
+            g = g < 0 ? 0 : (g >= num_goals ? num_goals - 1 : g);
+            const float* e = sE1 + g * 128 + i;
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+                T1[row * TL_P128 + jt * 32 + i] = fmaxf(am[jt][r] + e[jt * 32], 0.f);   // (the c1 tile is dead by now)
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int idx = lane + 64 * q, r = idx >> 5, c4 = idx & 31;
+            if (m0 + r < M)
+                *reinterpret_cast<float4*>(m1 + (m0 + r) * 128 + c4 * 4) = *reinterpret_cast<const float4*>(T1 + r * TL_P128 + c4 * 4);
+        }
+        // ---- x4 = m1 W4^T + b4 ----
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int kb = 0; kb < 128; kb += 8) {
+            const float4 a = *reinterpret_cast<const float4*>(T1 + i * TL_P128 + kb + 4 * hh);
+            const float4 b = *reinterpret_cast<const float4*>(sW4 + i * TL_P128 + kb + 4 * hh);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+        }
+        {
+            const float bj = sB[32 + i];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                T2[row * TL_P32 + i] = acc[r] + bj;                   // (the c2 tile is dead: m1's MFMAs have read it)
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = lane + 64 * q, r = idx >> 3, c4 = idx & 7;
+            if (m0 + r < M)
+                *reinterpret_cast<float4*>(x4 + (m0 + r) * 32 + c4 * 4) = *reinterpret_cast<const float4*>(T2 + r * TL_P32 + c4 * 4);
+        }
     }
 }
 
@@ -473,6 +638,22 @@ extern "C" int ec_policy_forward(const ec_policy_t* h, const float* params, cons
     RC(ec_gemm_f32(feat, W(P_W1), ws + w.c1, M49, c.compress_hid, C, C, 1, 1, C, c.compress_hid,
                    EC_GEMM_RELU | (feat_bf16 ? EC_GEMM_A_BF16 : 0), W(P_B1), nullptr, nullptr, 0, nullptr, nullptr, 1,
                    stream));
+    // EC_TAIL_FUSED (default 1): c2 / m1 / x4 in one pass over c1 for the reference's widths
+    static const int tail_fused = [] { const char* e = getenv("EC_TAIL_FUSED"); return e ? atoi(e) : 1; }();
+    const size_t tail_lds = ((size_t)2 * 32 * TL_P128 + 128 * TL_P32 + (size_t)c.num_goals * 128 + 64 +
+                             4 * (size_t)(32 * TL_P128 + 32 * TL_P32)) * sizeof(float);
+    if (tail_fused && c.compress_hid == 128 && c.compress_out == 32 && c.comb_hid == 128 && c.comb_out == 32 &&
+        tail_lds <= 160 * 1024) {
+        static std::atomic<uint64_t> attr_done{0};
+        if (ec_attr_needed(attr_done))
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tail_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      160 * 1024);
+        const long ntiles = ((long)M49 + 31) / 32;
+        long nwg = (ntiles + 3) / 4;
+        if (nwg > 512) nwg = 512;
+        hipLaunchKernelGGL(tail_fwd_kernel, dim3((unsigned)nwg), dim3(256), tail_lds, s, ws + w.c1, W(P_W2), W(P_B2), W(P_W3), cat,
+                           ws + w.E1, goal32, S, c.num_goals, W(P_W4), W(P_B4), ws + w.c2, ws + w.m1, ws + w.x4, (long)M49);
+    } else {
     RC(ec_gemm_f32(ws + w.c1, W(P_W2), ws + w.c2, M49, c.compress_out, c.compress_hid, c.compress_hid, 1, 1,
                    c.compress_hid, c.compress_out, EC_GEMM_RELU, W(P_B2), nullptr, nullptr, 0, nullptr, nullptr, 1,
                    stream));
@@ -481,6 +662,7 @@ extern "C" int ec_policy_forward(const ec_policy_t* h, const float* params, cons
                    c.comb_hid, EC_GEMM_RELU, nullptr, ws + w.E1, goal32, S, nullptr, nullptr, 1, stream));
     RC(ec_gemm_f32(ws + w.m1, W(P_W4), ws + w.x4, M49, c.comb_out, c.comb_hid, c.comb_hid, 1, 1, c.comb_hid,
                    c.comb_out, 0, W(P_B4), nullptr, nullptr, 0, nullptr, nullptr, 1, stream));
+    }
     {
         const long total = (long)B * flat;
         hipLaunchKernelGGL(to_cmajor_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ws + w.x4, ws + w.x,
@@ -493,7 +675,7 @@ extern "C" int ec_policy_forward(const ec_policy_t* h, const float* params, cons
                    nullptr, 0, nullptr, nullptr, 1, stream));
     // EC_GRU_FUSED (default 1): one fused launch per step where the geometry allows (H % 32 == 0, tiles fit the LDS)
     static const int gru_fused = [] { const char* e = getenv("EC_GRU_FUSED"); return e ? atoi(e) : 1; }();
-    size_t gru_lds = (size_t)2 * 32 * (H + 4) * sizeof(float);      // operand tiles ...
+    size_t gru_lds = (size_t)2 * 32 * (((H & 255) == 0 ? 256 : H) + 4) * sizeof(float);      // operand tiles (K chunk) ...
     if (gru_lds < 4 * 32 * 32 * sizeof(float)) gru_lds = 4 * 32 * 32 * sizeof(float);   // ... reused for the 4 partial tiles
     const bool fused_step = gru_fused && (H % 32) == 0 && gru_lds <= 160 * 1024;
     if (fused_step) {
