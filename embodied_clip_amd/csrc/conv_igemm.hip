@@ -449,6 +449,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
     static_assert(FN >= 1 && B_IT >= 1, "BN must be 128 or 256");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
+    const unsigned long long t_entry = (ABL & 32) ? __builtin_amdgcn_s_memtime() : 0ull;   // profiling only
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -642,8 +643,11 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
     }
     if (!grp && !(ABL & 16)) __builtin_amdgcn_s_barrier();   // matches group 1's extra entry barrier
     __syncthreads();                                    // every wave is done with the stages: LDS becomes the epilogue image
+    const unsigned long long t_loop_end = (ABL & 32) ? __builtin_amdgcn_s_memtime() : 0ull;
     if constexpr ((abl & 32) != 0) if (dbg) {
         for (int i = 0; i < 256; ++i) ec_dbg_stamps[grp * 1024 + i] = i < dbg_i ? dbg_lds[i] : 0ull;
+        ec_dbg_stamps[grp * 1024 + 300] = t_entry;
+        ec_dbg_stamps[grp * 1024 + 301] = t_loop_end;
     }
     if constexpr ((abl & 32) != 0) __syncthreads();
 
@@ -718,6 +722,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
             *reinterpret_cast<uint4*>(p.out + (long)(orow0 + row) * p.Cout + n0 + schunk * 8) =
                 *reinterpret_cast<const uint4*>(smem + row * PITCH + schunk * 16);
     }
+    if constexpr ((ABL & 32) != 0) if (blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0) ec_dbg_stamps[grp * 1024 + 302] = __builtin_amdgcn_s_memtime();
 }
 
 template <int BN, int KS, bool POOL>

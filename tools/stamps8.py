@@ -30,3 +30,5 @@ for grp in (0, 1):
             row.append(f"{work:5d}+{wait:4d}")
         print("   kt", kt, "  ".join(row))
     print("   mean cycles per K-tile:", (st[-1] - st[0]) / (len(st) / 8))
+    t_entry, t_loop_end, t_end = (buf[grp * 1024 + k] for k in (300, 301, 302))
+    print(f"   phases (clk): entry -> first loop barrier {st[0] - t_entry}, K loop {t_loop_end - st[0]}, epilogue {t_end - t_loop_end}, total {t_end - t_entry}")
