@@ -498,9 +498,10 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) b_off[i] = ((unsigned)(n0 + lrow + LR * i) * (unsigned)p.K + chunk * 8) * 2u;
 
-    const unsigned char* in_b = reinterpret_cast<const unsigned char*>(p.in);
-    const unsigned char* w_b = reinterpret_cast<const unsigned char*>(p.w);
-    const unsigned char* zp = reinterpret_cast<const unsigned char*>(ec_zero_page);
+#if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the kernel's stub; the buffer builtins are device-only
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+#endif
     const int wave_lds = wave * 1024;
     const int nk = p.K / BK;                            // Cin % 64 == 0: whole K-tiles, one tap per K-tile
 
@@ -522,14 +523,18 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
     };
     auto glds_piece = [&](auto qc) {
         constexpr int q = decltype(qc)::value;
+        // buffer_load ... lds through a descriptor: a 32-bit per-lane offset (no 64-bit pointer arithmetic), and a padding tap
+        // is an out-of-range offset, which the hardware answers with zeros (no zero page, no pointer select)
+#if defined(__HIP_DEVICE_COMPILE__)
         if constexpr (q < A_IT) {
-            const unsigned char* src = (a_msk[q] & g_tapbit) ? in_b + (a_off[q] + (unsigned)g_toff) : zp;
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(g_sa + q * (LR * ROW_BYTES)), 16, 0, 0);
+            const unsigned off = (a_msk[q] & g_tapbit) ? a_off[q] + (unsigned)g_toff : 0xFFFFFFF0u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void_t*)(g_sa + q * (LR * ROW_BYTES)), 16, off, 0, 0, 0);
         } else {
             constexpr int i = q - A_IT;
-            const unsigned char* src = w_b + (b_off[i] + (unsigned)(g_kt * (BK * 2)));
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(g_sa + A_BYTES + i * (LR * ROW_BYTES)), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_t*)(g_sa + A_BYTES + i * (LR * ROW_BYTES)), 16,
+                                                     b_off[i] + (unsigned)(g_kt * (BK * 2)), 0, 0, 0);
         }
+#endif
     };
 
     f32x16_t acc[FM][FN];
