@@ -439,6 +439,280 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Fused backward "tail" (round 2): the reverse of tail_fwd_kernel in ONE pass, for every 32-row tile
+//     dm1 = (dx4 W4) * [m1 > 0]        32 -> 128      dW4 += dx4^T m1      db4 += colsum dx4     dE1[goal] += rowgroup-sum dm1
+//     dc2 = (dm1 W3a) * [c2 > 0]       128 -> 32      dW3a += dm1^T c2
+//     dc1 = (dc2 W2) * [c1 > 0]        32 -> 128      dW2 += dc2^T c1      db2 += colsum dc2     db1 += colsum dc1
+// The GEMM path did this with three NN GEMMs, three TN GEMMs, three column sums and a row-group scatter, each streaming
+// [T*N*49, 128|32] fp32 tensors through HBM (~9 ms per slice and epoch); this kernel reads dx4, m1, c2, c1 once and writes
+// dc1 once (~1.4 GB, the floor).  A wave owns 32-row tiles; everything runs on the exact-fp32 MFMA (32x32x2): the data
+// GEMMs read A rows as float4 from the wave's LDS image and B from transposed weight copies in LDS; the weight-gradient
+// GEMMs contract over the tile's ROWS, so their operands are single floats of the same LDS images (lane = channel,
+// k = row: the fp32 MFMA takes one element per lane, no transposed copy needed).  The weight gradients stay in the wave's
+// accumulators for all of its tiles and leave as one partial set per wave; tail_bwd_reduce_kernel folds the sets into the
+// gradient tensors.  dE1 is accumulated in an LDS table per workgroup (a 32-row tile touches at most two row groups: S >= 32).
+constexpr int TB_MAX_WG = 256;
+constexpr int TB_W = 3 * 4096;                    // dW4 [32][128], dW3a [128][32], dW2 [32][128]
+constexpr int TB_PART = TB_W + 64 + 64 + 256;     // + db4, db2 (two lane halves each), db1 (two halves)
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void tail_bwd_kernel(
+    const float* __restrict__ dx4, const float* __restrict__ m1, const float* __restrict__ c2, const float* __restrict__ c1,
+    const float* __restrict__ W2, const float* __restrict__ W3, int w3_ld, const float* __restrict__ W4,
+    const int* __restrict__ goal, int S, int num_goals, float* __restrict__ dc1, float* __restrict__ part,
+    float* __restrict__ partE, long M) {
+    extern __shared__ __attribute__((aligned(16))) float tsm[];
+    float* sW4T = tsm;                            // [128 n][36]:  sW4T[n][k] = W4[k][n]
+    float* sW3T = sW4T + 128 * TL_P32;            // [32 n][132]:  sW3T[n][k] = W3[k][n], n < 32
+    float* sW2T = sW3T + 32 * TL_P128;            // [128 n][36]:  sW2T[n][k] = W2[k][n]
+    float* sE = sW2T + 128 * TL_P32;              // [num_goals][128]
+    float* wave_base = sE + num_goals * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* Tm = wave_base + wave * (32 * TL_P128 + 32 * TL_P32);   // m1 tile -> dm1 -> c1 tile -> dc1
+    float* Tx = Tm + 32 * TL_P128;                                 // dx4 tile -> c2 tile -> dc2
+    for (int idx = tid; idx < 4096; idx += 256) {
+        const int k = idx >> 7, n = idx & 127;
+        sW4T[n * TL_P32 + k] = W4[idx];
+        sW2T[n * TL_P32 + k] = W2[idx];
+        const int k3 = idx >> 5, n3 = idx & 31;
+        sW3T[n3 * TL_P128 + k3] = W3[(long)k3 * w3_ld + n3];
+    }
+    for (int idx = tid; idx < num_goals * 128; idx += 256) sE[idx] = 0.f;
+    __syncthreads();
+
+    const int i = lane & 31, hh = lane >> 5;
+    const long ntiles = (M + 31) / 32;
+    const long tstep = (long)gridDim.x * 4;
+    const long ngroups = (M + S - 1) / S;
+    f32x16_t gW4[4], gW3[4], gW2[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { gW4[t][r] = 0.f; gW3[t][r] = 0.f; gW2[t][r] = 0.f; }
+    float db4p = 0.f, db2p = 0.f, db1p[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x4_t sm[16], sx[4];                          // register prefetch (native vectors; see tail_fwd_kernel)
+    long tile = (long)blockIdx.x * 4 + wave;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int idx = lane + 64 * q, r = idx >> 3, c4 = idx & 7;
+        sx[q] = *reinterpret_cast<const f32x4_t*>(dx4 + min(tile * 32 + r, M - 1) * 32 + c4 * 4);
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int idx = lane + 64 * q, r = idx >> 5, c4 = idx & 31;
+        sm[q] = *reinterpret_cast<const f32x4_t*>(m1 + min(tile * 32 + r, M - 1) * 128 + c4 * 4);
+    }
+    for (; tile < ntiles; tile += tstep) {
+        const long m0 = tile * 32;
+        const long grp_base = m0 / S;                                // wave-uniform
+        const int nb = (int)((grp_base + 1) * S - m0);               // rows [0, nb) belong to group grp_base, the rest to the next
+        // ---- stage dx4 (rows past M as zeros: they then contribute nothing anywhere) and m1 ----
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = lane + 64 * q, r = idx >> 3, c4 = idx & 7;
+            f32x4_t v = sx[q];
+            if (m0 + r >= M) v = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4_t*>(Tx + r * TL_P32 + c4 * 4) = v;
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int idx = lane + 64 * q, r = idx >> 5, c4 = idx & 31;
+            *reinterpret_cast<f32x4_t*>(Tm + r * TL_P128 + c4 * 4) = sm[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                                // c2 and c1 of this tile: in flight under dW4 / dm1
+            const int idx = lane + 64 * q, r = idx >> 3, c4 = idx & 7;
+            sx[q] = *reinterpret_cast<const f32x4_t*>(c2 + min(m0 + r, M - 1) * 32 + c4 * 4);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int idx = lane + 64 * q, r = idx >> 5, c4 = idx & 31;
+            sm[q] = *reinterpret_cast<const f32x4_t*>(c1 + min(m0 + r, M - 1) * 128 + c4 * 4);
+        }
+        // ---- dW4[k][n] += sum_rows dx4[row][k] m1[row][n];  db4 ----
+#pragma unroll 1
+        for (int st = 0; st < 16; ++st) {
+            const int row = 2 * st + hh;
+            const float a = Tx[row * TL_P32 + i];
+            db4p += a;
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+                gW4[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Tm[row * TL_P128 + jt * 32 + i], gW4[jt], 0, 0, 0);
+        }
+        // ---- dm1 = (dx4 W4) * [m1 > 0] -> Tm;  dE1 row-group sums (one 32-column tile at a time: 16 live accumulators) ----
+        {
+            int g0 = goal[min(grp_base, ngroups - 1)], g1 = goal[min(grp_base + 1, ngroups - 1)];
+            g0 = g0 < 0 ? 0 : (g0 >= num_goals ? num_goals - 1 : g0);
+            g1 = g1 < 0 ? 0 : (g1 >= num_goals ? num_goals - 1 : g1);
+#pragma unroll 1
+            for (int jt = 0; jt < 4; ++jt) {
+                f32x16_t acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                for (int kb = 0; kb < 32; kb += 8) {
+                    const float4 a = *reinterpret_cast<const float4*>(Tx + i * TL_P32 + kb + 4 * hh);
+                    const float4 b = *reinterpret_cast<const float4*>(sW4T + (jt * 32 + i) * TL_P32 + kb + 4 * hh);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+                }
+                float e0 = 0.f, e1 = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;     // C/D layout: column = lane & 31
+                    float* pm = Tm + row * TL_P128 + jt * 32 + i;
+                    const float v = (*pm > 0.f) ? acc[r] : 0.f;
+                    *pm = v;
+                    if (row < nb) e0 += v; else e1 += v;
+                }
+                atomicAdd(sE + g0 * 128 + jt * 32 + i, e0);
+                if (nb < 32) atomicAdd(sE + g1 * 128 + jt * 32 + i, e1);
+            }
+        }
+        // ---- stage c2 (dx4 is dead); fetch the next tile's dx4 ----
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = lane + 64 * q, r = idx >> 3, c4 = idx & 7;
+            *reinterpret_cast<f32x4_t*>(Tx + r * TL_P32 + c4 * 4) = sx[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = lane + 64 * q, r = idx >> 3, c4 = idx & 7;
+            sx[q] = *reinterpret_cast<const f32x4_t*>(dx4 + min((tile + tstep) * 32 + r, M - 1) * 32 + c4 * 4);
+        }
+        // ---- dW3a[m][c] += sum_rows dm1[row][m] c2[row][c] ----
+#pragma unroll 1
+        for (int st = 0; st < 16; ++st) {
+            const int row = 2 * st + hh;
+            const float b = Tx[row * TL_P32 + i];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+                gW3[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Tm[row * TL_P128 + mt * 32 + i], b, gW3[mt], 0, 0, 0);
+        }
+        // ---- dc2 = (dm1 W3a) * [c2 > 0] -> Tx;  db2 ----
+        {
+            f32x16_t acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            for (int kb = 0; kb < 128; kb += 8) {
+                const float4 a = *reinterpret_cast<const float4*>(Tm + i * TL_P128 + kb + 4 * hh);
+                const float4 b = *reinterpret_cast<const float4*>(sW3T + i * TL_P128 + kb + 4 * hh);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                float* px = Tx + row * TL_P32 + i;
+                const float v = (*px > 0.f) ? acc[r] : 0.f;
+                *px = v;
+                db2p += v;
+            }
+        }
+        // ---- stage c1 (dm1 is dead); fetch the next tile's m1 ----
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int idx = lane + 64 * q, r = idx >> 5, c4 = idx & 31;
+            *reinterpret_cast<f32x4_t*>(Tm + r * TL_P128 + c4 * 4) = sm[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int idx = lane + 64 * q, r = idx >> 5, c4 = idx & 31;
+            sm[q] = *reinterpret_cast<const f32x4_t*>(m1 + min((tile + tstep) * 32 + r, M - 1) * 128 + c4 * 4);
+        }
+        // ---- dW2[k][n] += sum_rows dc2[row][k] c1[row][n] ----
+#pragma unroll 1
+        for (int st = 0; st < 16; ++st) {
+            const int row = 2 * st + hh;
+            const float a = Tx[row * TL_P32 + i];
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+                gW2[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Tm[row * TL_P128 + jt * 32 + i], gW2[jt], 0, 0, 0);
+        }
+        // ---- dc1 = (dc2 W2) * [c1 > 0] -> Tm -> HBM;  db1 ----
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            f32x16_t acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 32; kb += 8) {
+                const float4 a = *reinterpret_cast<const float4*>(Tx + i * TL_P32 + kb + 4 * hh);
+                const float4 b = *reinterpret_cast<const float4*>(sW2T + (jt * 32 + i) * TL_P32 + kb + 4 * hh);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+            }
+            float d = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                float* pm = Tm + row * TL_P128 + jt * 32 + i;
+                const float v = (*pm > 0.f) ? acc[r] : 0.f;
+                *pm = v;
+                d += v;
+            }
+            db1p[jt] += d;
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int idx = lane + 64 * q, r = idx >> 5, c4 = idx & 31;
+            if (m0 + r < M)
+                *reinterpret_cast<float4*>(dc1 + (m0 + r) * 128 + c4 * 4) = *reinterpret_cast<const float4*>(Tm + r * TL_P128 + c4 * 4);
+        }
+    }
+    // ---- one partial set per wave; the dE1 table per workgroup ----
+    float* pp = part + ((long)blockIdx.x * 4 + wave) * TB_PART;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+            pp[row * 128 + t * 32 + i] = gW4[t][r];                  // dW4[k = row][n = t*32 + i]
+            pp[4096 + (t * 32 + row) * 32 + i] = gW3[t][r];          // dW3a[m = t*32 + row][c = i]
+            pp[8192 + row * 128 + t * 32 + i] = gW2[t][r];           // dW2[k = row][n = t*32 + i]
+        }
+    pp[TB_W + hh * 32 + i] = db4p;
+    pp[TB_W + 64 + hh * 32 + i] = db2p;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) pp[TB_W + 128 + hh * 128 + jt * 32 + i] = db1p[jt];
+    __syncthreads();
+    for (int idx = tid; idx < num_goals * 128; idx += 256) partE[(long)blockIdx.x * num_goals * 128 + idx] = sE[idx];
+}
+
+// folds the per-wave partial sets of tail_bwd_kernel into the gradient tensors (grads +=, dE1 +=)
+__global__ __launch_bounds__(256) void tail_bwd_reduce_kernel(const float* __restrict__ part, int nsets,
+                                                               const float* __restrict__ partE, int nwg, int num_goals,
+                                                               float* __restrict__ gW4, float* __restrict__ gW3, int w3_ld,
+                                                               float* __restrict__ gW2, float* __restrict__ gb4,
+                                                               float* __restrict__ gb2, float* __restrict__ gb1,
+                                                               float* __restrict__ dE1) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    const int ne = TB_PART + num_goals * 128;
+    if (e >= ne) return;
+    float s = 0.f;
+    if (e < TB_PART) {
+        for (int p = blockIdx.y; p < nsets; p += gridDim.y) s += part[(long)p * TB_PART + e];
+    } else {
+        const int q = e - TB_PART;
+        for (int p = blockIdx.y; p < nwg; p += gridDim.y) s += partE[(long)p * num_goals * 128 + q];
+    }
+    float* dst;
+    if (e < 4096) dst = gW4 + e;
+    else if (e < 8192) { const int q = e - 4096; dst = gW3 + (long)(q >> 5) * w3_ld + (q & 31); }
+    else if (e < TB_W) dst = gW2 + (e - 8192);
+    else if (e < TB_W + 64) dst = gb4 + ((e - TB_W) & 31);
+    else if (e < TB_W + 128) dst = gb2 + ((e - TB_W - 64) & 31);
+    else if (e < TB_PART) dst = gb1 + ((e - TB_W - 128) & 127);
+    else dst = dE1 + (e - TB_PART);
+    atomicAdd(dst, s);
+}
+
 inline size_t al(size_t v) { return (v + 255) / 256 * 256; }
 
 enum { P_EMB, P_W1, P_B1, P_W2, P_B2, P_W3, P_B3, P_W4, P_B4, P_WIH, P_WHH, P_BIH, P_BHH, P_WA, P_BA, P_WC, P_BC, P_COUNT };
@@ -455,7 +729,7 @@ namespace {
 
 struct Ws {   // float offsets into the workspace
     size_t E1, c1, c2, m1, x4, x, gi, gh, gates, hn, hp, hs, goal32;
-    size_t dhs, dhc, dgi, dghb, dx, dx4, dm1, dc2, dc1, dE1, end;
+    size_t dhs, dhc, dgi, dghb, dx, dx4, dm1, dc2, dc1, dE1, tpart, tpartE, end;
 };
 
 Ws layout(const ec_policy* h, int T, int N, bool bwd) {
@@ -477,7 +751,7 @@ Ws layout(const ec_policy* h, int T, int N, bool bwd) {
     w.hp = take(B * H);
     w.hs = take(B * H);
     w.goal32 = take(B);
-    w.dhs = w.dhc = w.dgi = w.dghb = w.dx = w.dx4 = w.dm1 = w.dc2 = w.dc1 = w.dE1 = o;
+    w.dhs = w.dhc = w.dgi = w.dghb = w.dx = w.dx4 = w.dm1 = w.dc2 = w.dc1 = w.dE1 = w.tpart = w.tpartE = o;
     if (bwd) {
         w.dhs = take(B * H);
         w.dhc = take((size_t)N * H);
@@ -489,6 +763,8 @@ Ws layout(const ec_policy* h, int T, int N, bool bwd) {
         w.dc2 = take(M49 * c.compress_out);
         w.dc1 = take(M49 * c.compress_hid);
         w.dE1 = take((size_t)c.num_goals * c.comb_hid);
+        w.tpart = take(c.fusion ? 0 : (size_t)TB_MAX_WG * 4 * TB_PART);              // tail_bwd_kernel's partial sets
+        w.tpartE = take(c.fusion ? 0 : (size_t)TB_MAX_WG * c.num_goals * 128);
     }
     w.end = o;
     return w;
@@ -783,20 +1059,37 @@ extern "C" int ec_policy_backward(const ec_policy_t* h, const float* params, con
         hipLaunchKernelGGL(from_cmajor_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ws + w.dx,
                            ws + w.dx4, S, c.comb_out, total);
     }
+    static const int tail_fused = [] { const char* e = getenv("EC_TAIL_FUSED"); return e ? atoi(e) : 1; }();
+    const size_t tb_lds = ((size_t)2 * 128 * TL_P32 + 32 * TL_P128 + (size_t)c.num_goals * 128 +
+                           4 * (size_t)(32 * TL_P128 + 32 * TL_P32)) * sizeof(float);
+    const bool fused_bwd = tail_fused && c.compress_hid == 128 && c.compress_out == 32 && c.comb_hid == 128 &&
+                           c.comb_out == 32 && S >= 32 && tb_lds <= 160 * 1024;
+    (void)hipMemsetAsync(ws + w.dE1, 0, (size_t)c.num_goals * c.comb_hid * 4, s);
+    if (fused_bwd) {
+        // EC_TAIL_FUSED (default 1): dm1 / dc2 / dc1 and all small weight gradients of the tail in one pass
+        static std::atomic<uint64_t> attr_done{0};
+        if (ec_attr_needed(attr_done))
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tail_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      160 * 1024);
+        const long ntiles = ((long)M49 + 31) / 32;
+        long nwg = (ntiles + 3) / 4;
+        if (nwg > TB_MAX_WG) nwg = TB_MAX_WG;
+        hipLaunchKernelGGL(tail_bwd_kernel, dim3((unsigned)nwg), dim3(256), tb_lds, s, ws + w.dx4, ws + w.m1, ws + w.c2, ws + w.c1,
+                           W(P_W2), W(P_W3), cat, W(P_W4), goal32, S, c.num_goals, ws + w.dc1, ws + w.tpart, ws + w.tpartE,
+                           (long)M49);
+        const int ne = TB_PART + c.num_goals * 128;
+        hipLaunchKernelGGL(tail_bwd_reduce_kernel, dim3((unsigned)((ne + 255) / 256), 8), dim3(256), 0, s, ws + w.tpart,
+                           (int)nwg * 4, ws + w.tpartE, (int)nwg, c.num_goals, G(P_W4), G(P_W3), cat, G(P_W2), G(P_B4), G(P_B2),
+                           G(P_B1), ws + w.dE1);
+    } else {
     // ---- target_obs_combiner ----
     RC(tn(ws + w.dx4, c.comb_out, ws + w.m1, c.comb_hid, 0, G(P_W4), c.comb_out, c.comb_hid, M49, c.comb_hid));
     colsum(ws + w.dx4, G(P_B4), M49, c.comb_out, c.comb_out);
     RC(ec_gemm_f32(ws + w.dx4, W(P_W4), ws + w.dm1, M49, c.comb_hid, c.comb_out, c.comb_out, 1, c.comb_hid, 1, c.comb_hid,
                    0, nullptr, nullptr, nullptr, 0, ws + w.m1, nullptr, 1, stream));
     RC(tn(ws + w.dm1, c.comb_hid, ws + w.c2, c.compress_out, 0, G(P_W3), c.comb_hid, c.compress_out, M49, cat));
-    (void)hipMemsetAsync(ws + w.dE1, 0, (size_t)c.num_goals * c.comb_hid * 4, s);
     hipLaunchKernelGGL(group_sum_scatter_kernel, dim3((unsigned)B), dim3(128), 0, s, ws + w.dm1, goal32, ws + w.dE1, S,
                        c.comb_hid, (long)B);
-    colsum(ws + w.dE1, G(P_B3), c.num_goals, c.comb_hid, c.comb_hid);
-    RC(tn(ws + w.dE1, c.comb_hid, W(P_EMB), c.goal_dims, 0, G(P_W3) + c.compress_out, c.comb_hid, c.goal_dims,
-          c.num_goals, cat));
-    RC(ec_gemm_f32(ws + w.dE1, W(P_W3) + c.compress_out, G(P_EMB), c.num_goals, c.goal_dims, c.comb_hid, c.comb_hid, 1,
-                   cat, 1, c.goal_dims, EC_GEMM_ACCUMULATE, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 1, stream));
     // ---- resnet_compressor ----
     RC(ec_gemm_f32(ws + w.dm1, W(P_W3), ws + w.dc2, M49, c.compress_out, c.comb_hid, c.comb_hid, 1, cat, 1,
                    c.compress_out, 0, nullptr, nullptr, nullptr, 0, ws + w.c2, nullptr, 1, stream));
@@ -805,8 +1098,15 @@ extern "C" int ec_policy_backward(const ec_policy_t* h, const float* params, con
     colsum(ws + w.dc2, G(P_B2), M49, c.compress_out, c.compress_out);
     RC(ec_gemm_f32(ws + w.dc2, W(P_W2), ws + w.dc1, M49, c.compress_hid, c.compress_out, c.compress_out, 1,
                    c.compress_hid, 1, c.compress_hid, 0, nullptr, nullptr, nullptr, 0, ws + w.c1, nullptr, 1, stream));
-    RC(tn(ws + w.dc1, c.compress_hid, feat, C, feat_bf16, G(P_W1), c.compress_hid, C, M49, C));
     colsum(ws + w.dc1, G(P_B1), M49, c.compress_hid, c.compress_hid);
+    }
+    // goal half of target_obs_combiner.0 (dE1 = row-group sums of dm1 scattered by goal id)
+    colsum(ws + w.dE1, G(P_B3), c.num_goals, c.comb_hid, c.comb_hid);
+    RC(tn(ws + w.dE1, c.comb_hid, W(P_EMB), c.goal_dims, 0, G(P_W3) + c.compress_out, c.comb_hid, c.goal_dims,
+          c.num_goals, cat));
+    RC(ec_gemm_f32(ws + w.dE1, W(P_W3) + c.compress_out, G(P_EMB), c.num_goals, c.goal_dims, c.comb_hid, c.comb_hid, 1,
+                   cat, 1, c.goal_dims, EC_GEMM_ACCUMULATE, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 1, stream));
+    RC(tn(ws + w.dc1, c.compress_hid, feat, C, feat_bf16, G(P_W1), c.compress_hid, C, M49, C));
     EC_CHECK_LAUNCH();
     return EC_OK;
 }

@@ -88,10 +88,10 @@ def _policy_case(T, N, C=64, S=3, H=32, seed=0, bf16=False):
     return cfg, sd, feat, goal, h0, masks
 
 
-@pytest.mark.parametrize("T,N,bf16", [(1, 5, False), (6, 4, False), (5, 3, True)])
-def test_policy_forward_matches_oracle(dev, T, N, bf16):
+@pytest.mark.parametrize("T,N,bf16,S", [(1, 5, False, 3), (6, 4, False, 3), (5, 3, True, 3), (3, 5, False, 7), (4, 37, True, 7)])
+def test_policy_forward_matches_oracle(dev, T, N, bf16, S):
     from embodied_clip_amd.policy import PolicyHandle
-    cfg, sd, feat, goal, h0, masks = _policy_case(T, N, bf16=bf16)
+    cfg, sd, feat, goal, h0, masks = _policy_case(T, N, S=S, bf16=bf16)
     ref_logits, ref_values, ref_h = opol.actor_critic_forward(feat, goal, h0, masks, sd)
     h = PolicyHandle(**cfg)
     flat = h.flatten(sd, dev)
@@ -154,12 +154,14 @@ def test_gae_matches_oracle(dev):
     assert _rel(r2, R) < 1e-6 and _rel(a2, adv) < 1e-5 and _rel(n2, nadv) < 1e-5
 
 
-@pytest.mark.parametrize("T,N,bf16", [(6, 4, False), (8, 4, True)])
-def test_policy_backward_and_update_step_match_oracle(dev, T, N, bf16):
-    """One full optimiser step of HOT LOOP B: forward, PPO loss, backward, clip, Adam."""
+@pytest.mark.parametrize("T,N,bf16,S", [(6, 4, False, 3), (8, 4, True, 3), (3, 5, False, 7), (4, 37, True, 7)])
+def test_policy_backward_and_update_step_match_oracle(dev, T, N, bf16, S):
+    """One full optimiser step of HOT LOOP B: forward, PPO loss, backward, clip, Adam.
+    S = 7 is the reference's 7x7 feature map: the fused tail kernels (tail_fwd_kernel / tail_bwd_kernel) run there, with
+    ragged last tiles (T*N*49 not a multiple of 32) and row groups straddling tiles; S = 3 keeps the GEMM path covered."""
     from embodied_clip_amd import ppo
     from embodied_clip_amd.policy import PolicyHandle
-    cfg, sd, feat, goal, h0, masks = _policy_case(T, N, seed=7, bf16=bf16)
+    cfg, sd, feat, goal, h0, masks = _policy_case(T, N, S=S, seed=7, bf16=bf16)
     actions, old_lp, old_v, returns, nadv = _loss_inputs(T, N, 8)
     with torch.no_grad():
         lg, vv, _ = opol.actor_critic_forward(feat, goal, h0, masks, sd)
@@ -194,8 +196,12 @@ def test_policy_backward_and_update_step_match_oracle(dev, T, N, bf16):
     pv = h.views(flat)
     for name, pref in sd_ref.items():
         # Adam's first step moves every weight by ~lr regardless of gradient scale: compare the UPDATE
+        # (an element whose gradient is within ~100x of Adam's eps = 1e-8 is ill-conditioned -- its step is
+        # lr * g / (|g| + eps) -- so those are only bounded by the step size)
         upd, upd_ref = pv[name].cpu() - sd[name], pref - sd[name]
-        assert (upd - upd_ref).abs().max() < 0.05 * 3e-4 + 1e-7, name
+        well = ref_grads[name].abs() > 1e-6
+        assert ((upd - upd_ref).abs() * well).max() < 0.05 * 3e-4 + 1e-7, name
+        assert upd.abs().max() <= 3e-4 * 1.001 + 1e-7, name
 
 
 def test_actor_critic_module_autograd_surface(dev):
