@@ -436,7 +436,11 @@ int launch(const ConvArgs& a, hipStream_t s) {
 // Requires Cin % 64 == 0 (a K-tile never straddles a 3x3 tap) and Cout % BN == 0.
 __device__ unsigned long long ec_dbg_stamps[2 * 1024];   // profiling only (EC_CONV_ABLATE & 32): s_memtime stamps of block 0
 
-template <int BN, int KS, bool POOL, int ABL>
+// X3 (policy compressor, ec_gemm_bf16a_x3): the weight operand is an fp32 matrix split into three bf16 planes
+// ([Cout][3][K], lowest plane first in the K walk); a K-tile of A is walked three times, once against each plane, into
+// the same accumulators, and the epilogue writes fp32 (bias / ReLU) -- the bf16x3 "exact fp32" product of gemm_f32.hip on
+// this kernel's schedule.
+template <int BN, int KS, bool POOL, int ABL, bool X3 = false>
 __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
     // wave grid: 2 (M) x 4 (N) for 256-wide tiles (wave tile 128 x 64); 4 x 2 for 128-wide tiles (wave tile 64 x 64:
     // 4 fragment reads per 4 MFMAs instead of the 5 a 128 x 32 wave tile needs)
@@ -496,23 +500,28 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
         a_off[i] = (unsigned)pix * (unsigned)p.Cin * 2u + (unsigned)chunk * 16u;
     }
 #pragma unroll
-    for (int i = 0; i < B_IT; ++i) b_off[i] = ((unsigned)(n0 + lrow + LR * i) * (unsigned)p.K + chunk * 8) * 2u;
+    for (int i = 0; i < B_IT; ++i) b_off[i] = ((unsigned)(n0 + lrow + LR * i) * (unsigned)(X3 ? 3 * p.K : p.K) + chunk * 8) * 2u;
 
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the kernel's stub; the buffer builtins are device-only
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
 #endif
     const int wave_lds = wave * 1024;
-    const int nk = p.K / BK;                            // Cin % 64 == 0: whole K-tiles, one tap per K-tile
+    const int nk = (X3 ? 3 : 1) * (p.K / BK);           // Cin % 64 == 0: whole K-tiles, one tap per K-tile
 
     // piece q of K-tile kt into stage buf: q < A_IT -> 8 pixel rows per wave, else 8 weight rows
-    int g_toff = 0; unsigned g_tapbit = 1u; int g_kt = 0;
+    int g_toff = 0; unsigned g_tapbit = 1u; int g_kb = 0;
     unsigned char* g_sa = smem;
     auto glds_begin = [&](int kt, int buf) {
         g_sa = smem + buf * STAGE + wave_lds;
-        g_kt = kt;
+        g_kb = kt * (BK * 2);
         g_toff = kt * (BK * 2);
         g_tapbit = 1u;
+        if (X3) {                                       // K-tile kt = (A chunk kt / 3) x (weight plane 2 - kt % 3)
+            const int ch = kt / 3, pl = 2 - (kt - 3 * ch);
+            g_toff = ch * (BK * 2);
+            g_kb = (pl * p.K + ch * BK) * 2;
+        }
         if (KS == 3) {
             const int k = kt * BK;
             const int tap = k >> p.cin_log2, ci = k & (p.Cin - 1);
@@ -532,7 +541,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
         } else {
             constexpr int i = q - A_IT;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_t*)(g_sa + A_BYTES + i * (LR * ROW_BYTES)), 16,
-                                                     b_off[i] + (unsigned)(g_kt * (BK * 2)), 0, 0, 0);
+                                                     b_off[i] + (unsigned)g_kb, 0, 0, 0);
         }
 #endif
     };
@@ -656,6 +665,45 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
     }
     if constexpr ((abl & 32) != 0) __syncthreads();
 
+    if constexpr (X3) {                                 // fp32 rows through LDS, 128 tile rows per pass
+        static_assert(!X3 || (BN == 128 && !POOL && KS == 1), "X3: 128-wide 1x1 tiles");
+        constexpr int PITCHF = BN * 4 + 16;
+        float* outf = reinterpret_cast<float*>(p.out);
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            if ((wm >> 1) == pass) {
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int lcol = wn * TN + j * 32 + 8 * g + 4 * fhalf;
+                        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + n0 + lcol);
+#pragma unroll
+                        for (int i = 0; i < FM; ++i) {
+                            const int lr = (wm & 1) * TM + i * 32 + frow;
+                            float4 v = make_float4(acc[i][j][4 * g + 0] + bv.x, acc[i][j][4 * g + 1] + bv.y,
+                                                   acc[i][j][4 * g + 2] + bv.z, acc[i][j][4 * g + 3] + bv.w);
+                            if (p.act == EC_ACT_RELU) {
+                                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                            }
+                            *reinterpret_cast<float4*>(smem + lr * PITCHF + lcol * 4) = v;
+                        }
+                    }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r0 = 0; r0 < 128; r0 += NT / 32) {
+                const int row = r0 + (tid >> 5), ch = tid & 31;
+                const long grow = (long)m0 + pass * 128 + row;
+                if (grow < p.M)
+                    *reinterpret_cast<float4*>(outf + grow * p.Cout + n0 + ch * 4) =
+                        *reinterpret_cast<const float4*>(smem + row * PITCHF + ch * 16);
+            }
+            __syncthreads();
+        }
+        return;
+    }
     // ---- epilogue (as conv_igemm_kernel) ----
     constexpr int CH = BN / 8;
     constexpr int PITCH = BN * 2 + 16;
@@ -730,7 +778,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
     if constexpr ((ABL & 32) != 0) if (blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0) ec_dbg_stamps[grp * 1024 + 302] = __builtin_amdgcn_s_memtime();
 }
 
-template <int BN, int KS, bool POOL>
+template <int BN, int KS, bool POOL, bool X3 = false>
 int launch8(const ConvArgs& a, hipStream_t s) {
     ConvArgs p = a;
     p.ntn = a.Cout / BN;
@@ -738,7 +786,7 @@ int launch8(const ConvArgs& a, hipStream_t s) {
     static const int ablate = [] { const char* e = getenv("EC_CONV_ABLATE"); return e ? atoi(e) : 0; }();
     p.ablate = ablate;
     const size_t stages = 2 * (size_t)(256 + BN) * ROW_BYTES;
-    const size_t epi = (size_t)(POOL ? 64 : 256) * (BN * 2 + 16);
+    const size_t epi = X3 ? (size_t)128 * (BN * 4 + 16) : (size_t)(POOL ? 64 : 256) * (BN * 2 + 16);
     const size_t lds = (stages > epi ? stages : epi) + 4096;   // + stamp area (profiling)
     auto go = [&](auto kern) {
         static std::atomic<uint64_t> attr_done{0};
@@ -747,7 +795,7 @@ int launch8(const ConvArgs& a, hipStream_t s) {
         hipLaunchKernelGGL(kern, dim3((unsigned)p.ntiles), dim3(512), lds, s, p);
     };
 #ifdef EC_CONV8_PROFILE   // ablation / stamp instances (tools/ablate8.sh, tools/stamps8.py): build with -DEC_CONV8_PROFILE
-    if constexpr (BN == 256 && KS == 3 && !POOL) {
+    if constexpr (BN == 256 && KS == 3 && !POOL && !X3) {
         switch (ablate) {
             case 1: go(conv_igemm8_kernel<BN, KS, POOL, 1>); break;
             case 2: go(conv_igemm8_kernel<BN, KS, POOL, 2>); break;
@@ -765,7 +813,7 @@ int launch8(const ConvArgs& a, hipStream_t s) {
         return EC_OK;
     }
 #endif
-    go(conv_igemm8_kernel<BN, KS, POOL, 0>);
+    go(conv_igemm8_kernel<BN, KS, POOL, 0, X3>);
     EC_CHECK_LAUNCH();
     return EC_OK;
 }
@@ -890,6 +938,38 @@ extern "C" int ec_conv_bf16(const void* in, const void* w, const float* bias, co
         return EC_OK;
     if (ksize == 3) return pool ? dispatch_tile<3, true>(a, s) : dispatch_tile<3, false>(a, s);
     return pool ? dispatch_tile<1, true>(a, s) : dispatch_tile<1, false>(a, s);
+}
+
+// out[M, N] (fp32) = act(A[M, K] (bf16) @ W^T + bias) with W given as three bf16 planes [N][3][K] (ec_split3_bf16):
+// the exact-fp32 product of a bf16 activation matrix with an fp32 weight matrix, on the 8-wave ping-pong kernel.
+// Replaces the resnet_compressor's first 1x1 conv over the stored features
+// (allenact_plugins/.../resnet_tensor... ResnetTensorGoalEncoder.resnet_compressor[0], SURVEY.md section 8 row a).
+extern "C" int ec_gemm_bf16a_x3(const void* A, const void* Wplanes, const float* bias, float* out, long M, int N, int K,
+                                int act, ec_stream_t stream) {
+    if (!A || !Wplanes || !out) return EC_ERR_ARG;
+    if (M <= 0 || N % 128 != 0 || K % 64 != 0 || K < 64) return EC_ERR_SHAPE;
+    if ((long)N * 3 * K * 2 >= (1L << 31)) return EC_ERR_SHAPE;
+    // 32-bit byte offsets inside a launch: rows are processed in slabs of < 4 GiB of A
+    const long slab = (((1L << 32) - 1) / ((long)K * 2)) / 256 * 256;
+    for (long r0 = 0; r0 < M; r0 += slab) {
+        const long rows = (M - r0 < slab) ? M - r0 : slab;
+        ConvArgs a;
+        a.in = (const uint16_t*)A + r0 * K;
+        a.w = (const uint16_t*)Wplanes;
+        a.bias = bias;
+        a.res = nullptr;
+        a.out = reinterpret_cast<uint16_t*>(out + r0 * N);
+        a.H = 1; a.W = (int)rows; a.Cin = K; a.Cout = N;
+        a.K = K; a.M = (int)rows;
+        a.cin_log2 = 0;
+        a.act = act;
+        a.ntn = 0;
+        a.in_bytes = (unsigned)(rows * K * 2);
+        a.w_bytes = (unsigned)((long)N * 3 * K * 2);
+        int rc = launch8<128, 1, false, true>(a, (hipStream_t)stream);
+        if (rc != EC_OK) return rc;
+    }
+    return EC_OK;
 }
 
 extern "C" int ec_gemm_bf16(const void* A, const void* Wt, const float* bias, const void* res, void* out, int M, int N,

@@ -264,6 +264,23 @@ __device__ __forceinline__ void split3x4(const float (&x)[4], uint2& p0, uint2& 
     p2.x = ec_pack2(r0 - ec_lo(p1.x), r1 - ec_hi(p1.x)); p2.y = ec_pack2(r2 - ec_lo(p1.y), r3 - ec_hi(p1.y));
 }
 
+// fp32 [rows][K] -> three bf16 planes [rows][3][K] (plane 0 = leading bits), the same split the x3 kernels do on the fly
+__global__ __launch_bounds__(256) void split3_planes_kernel(const float* __restrict__ W, uint16_t* __restrict__ P, long rows, int K) {
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;      // one float4 of W
+    const long n4 = rows * (K / 4);
+    if (q >= n4) return;
+    const long r = q / (K / 4);
+    const int k = (int)(q - r * (K / 4)) * 4;
+    const float4 w = *reinterpret_cast<const float4*>(W + r * K + k);
+    const float x[4] = {w.x, w.y, w.z, w.w};
+    uint2 p0, p1, p2;
+    split3x4(x, p0, p1, p2);
+    uint16_t* d = P + r * 3 * K + k;
+    *reinterpret_cast<uint2*>(d) = p0;
+    *reinterpret_cast<uint2*>(d + K) = p1;
+    *reinterpret_cast<uint2*>(d + 2 * (long)K) = p2;
+}
+
 // One operand tile (R rows x 32 k): global -> registers.  KC: k-contiguous source (4 consecutive k per lane),
 // else row-contiguous (a 4x4 (k x row) block per lane, transposed in registers on the way to LDS).
 template <int R, bool BF16, bool KC>
@@ -578,4 +595,15 @@ extern "C" int ec_gemm_f32(const void* A, const void* B, float* Cp, int M, int N
     const long blocks128 = (long)((M + 127) / 128) * ((N + 127) / 128) * a.splitk;
     if (blocks128 < 512) return launch_cfg<64, 64, 2, 2>(a, s);
     return launch_cfg<128, 128, 2, 2>(a, s);
+}
+
+// W fp32 [rows][K] -> bf16 planes [rows][3][K] for ec_gemm_bf16a_x3 (K % 4 == 0)
+extern "C" int ec_split3_bf16(const float* W, void* planes, long rows, int K, ec_stream_t stream) {
+    if (!W || !planes) return EC_ERR_ARG;
+    if (rows <= 0 || K <= 0 || K % 4 != 0) return EC_ERR_SHAPE;
+    const long n4 = rows * (K / 4);
+    hipLaunchKernelGGL(split3_planes_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W,
+                       (uint16_t*)planes, rows, K);
+    EC_CHECK_LAUNCH();
+    return EC_OK;
 }

@@ -20,6 +20,9 @@
 
 #include "common.h"
 
+extern "C" int ec_split3_bf16(const float* W, void* planes, long rows, int K, ec_stream_t stream);
+extern "C" int ec_gemm_bf16a_x3(const void* A, const void* Wplanes, const float* bias, float* out, long M, int N, int K,
+                                int act, ec_stream_t stream);
 extern "C" int ec_gemm_f32(const void* A, const void* B, float* Cp, int M, int N, int K, long sam, long sak, long sbk,
                            long sbn, int ldc, int flags, const float* bias, const float* gbias, const int* gidx,
                            int group, const float* dmask, const float* rowscale, int splitk, ec_stream_t stream);
@@ -728,7 +731,7 @@ struct ec_policy {
 namespace {
 
 struct Ws {   // float offsets into the workspace
-    size_t E1, c1, c2, m1, x4, x, gi, gh, gates, hn, hp, hs, goal32;
+    size_t E1, c1, c2, m1, x4, x, gi, gh, gates, hn, hp, hs, goal32, w1p;
     size_t dhs, dhc, dgi, dghb, dx, dx4, dm1, dc2, dc1, dE1, tpart, tpartE, end;
 };
 
@@ -751,6 +754,7 @@ Ws layout(const ec_policy* h, int T, int N, bool bwd) {
     w.hp = take(B * H);
     w.hs = take(B * H);
     w.goal32 = take(B);
+    w.w1p = take(c.fusion ? 0 : ((size_t)c.compress_hid * 3 * c.in_channels + 1) / 2);   // W1 as three bf16 planes
     w.dhs = w.dhc = w.dgi = w.dghb = w.dx = w.dx4 = w.dm1 = w.dc2 = w.dc1 = w.dE1 = w.tpart = w.tpartE = o;
     if (bwd) {
         w.dhs = take(B * H);
@@ -911,6 +915,13 @@ extern "C" int ec_policy_forward(const ec_policy_t* h, const float* params, cons
     RC(ec_gemm_f32(W(P_EMB), W(P_W3) + c.compress_out, ws + w.E1, c.num_goals, c.comb_hid, c.goal_dims, c.goal_dims, 1,
                    1, cat, c.comb_hid, 0, W(P_B3), nullptr, nullptr, 0, nullptr, nullptr, 1, stream));
     // resnet_compressor
+    // EC_C1_PINGPONG (default 1): bf16 features x fp32 W1 as three bf16 planes on the 8-wave ping-pong kernel
+    // (conv_igemm8, X3 mode) once there are enough 256-row tiles to fill the chip; else the generic x3 GEMM
+    static const int c1_pp = [] { const char* e = getenv("EC_C1_PINGPONG"); return e ? atoi(e) : 1; }();
+    if (c1_pp && feat_bf16 && c.compress_hid % 128 == 0 && C % 64 == 0 && M49 >= 256 * 128) {
+        RC(ec_split3_bf16(W(P_W1), ws + w.w1p, c.compress_hid, C, stream));
+        RC(ec_gemm_bf16a_x3(feat, ws + w.w1p, W(P_B1), ws + w.c1, M49, c.compress_hid, C, 1 /* EC_ACT_RELU */, stream));
+    } else
     RC(ec_gemm_f32(feat, W(P_W1), ws + w.c1, M49, c.compress_hid, C, C, 1, 1, C, c.compress_hid,
                    EC_GEMM_RELU | (feat_bf16 ? EC_GEMM_A_BF16 : 0), W(P_B1), nullptr, nullptr, 0, nullptr, nullptr, 1,
                    stream));

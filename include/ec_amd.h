@@ -89,6 +89,14 @@ int ec_debug_stamps(unsigned long long* host_dst, int n);
 int ec_gemm_bf16(const void* A, const void* W, const float* bias, const void* res, void* out,
                  int M, int N, int K, int act, ec_stream_t stream);
 
+/* out[M, N] (fp32) = act(A[M, K] (bf16) @ W^T + bias), W an fp32 [N, K] matrix handed over as the three bf16 planes
+ * ec_split3_bf16 writes ([N][3][K]): the exact-fp32 product of stored bf16 features with fp32 weights -- the first
+ * 1x1 conv of ResnetTensorGoalEncoder.resnet_compressor (allenact_plugins/robothor_plugin/.../resnet_tensor encoders;
+ * SURVEY.md section 8 row a) -- on the 8-wave ping-pong kernel.  N % 128 == 0, K % 64 == 0. */
+int ec_split3_bf16(const float* W, void* planes, long rows, int K, ec_stream_t stream);
+int ec_gemm_bf16a_x3(const void* A_bf16, const void* W_planes, const float* bias, float* out, long M, int N, int K,
+                     int act, ec_stream_t stream);
+
 /* Stem conv1: 3x3 stride 2 pad 1 on the fp32 NHWC frame the RGB sensor hands
  * over ([U] ClipResNetPreprocessor.process: obs[rgb].permute(0,3,1,2)), folded
  * BN + ReLU, LDS-staged image tiles.  w f32 [3*3*3][Cout] (ky,kx,ci major),

@@ -75,6 +75,31 @@ def test_gemm_f32_bf16_operands_nn_tn_epilogues(dev):
     assert _rel(o, ref) < 2e-5
 
 
+@pytest.mark.parametrize("M,N,K,relu", [(1000, 128, 256, True), (256 * 3 + 17, 256, 2048, False), (40000, 128, 2048, True)])
+def test_gemm_bf16a_x3_pingpong_matches_fp64(dev, M, N, K, relu):
+    """bf16 activations x fp32 weights (three bf16 planes) on the 8-wave ping-pong kernel: exact-fp32 grade product
+    (the compressor's first 1x1 conv over stored features); ragged last tile, two N tiles, bias / ReLU."""
+    from embodied_clip_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M + K)
+    a = torch.randn(M, K, generator=g).abs().to(torch.bfloat16)
+    w = torch.randn(N, K, generator=g) * K ** -0.5
+    b = torch.randn(N, generator=g)
+    ref = a.double() @ w.double().t() + b.double()
+    ref = torch.relu(ref) if relu else ref
+    ad, wd, bd = a.to(dev), w.to(dev), b.to(dev)
+    planes = torch.empty(N, 3, K, dtype=torch.bfloat16, device=dev)
+    out = torch.full((M, N), float("nan"), device=dev)
+    _lib.check(lib.ec_split3_bf16(wd.data_ptr(), planes.data_ptr(), N, K, 0))
+    _lib.check(lib.ec_gemm_bf16a_x3(ad.data_ptr(), planes.data_ptr(), bd.data_ptr(), out.data_ptr(), M, N, K, 1 if relu else 0, 0))
+    torch.cuda.synchronize()
+    # the planes reconstruct W to ~2^-24 relative
+    rec = planes.float().sum(1)
+    assert (rec.cpu() - w).abs().max() <= 2 ** -22 * w.abs().max()
+    assert _rel(out, ref.float()) < 2e-6
+    assert (out.cpu().double() - ref).abs().max() < 2e-5 * max(1.0, ref.abs().max().item())
+
+
 def _policy_case(T, N, C=64, S=3, H=32, seed=0, bf16=False):
     cfg = dict(in_channels=C, spatial=S, hidden=H)
     sd = syn.policy_state_dict(seed, **cfg)
