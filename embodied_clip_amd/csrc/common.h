@@ -32,6 +32,14 @@ __device__ __forceinline__ uint32_t ec_pack2(float lo, float hi) {
 __device__ __forceinline__ float ec_lo(uint32_t p) { return __uint_as_float(p << 16); }
 __device__ __forceinline__ float ec_hi(uint32_t p) { return __uint_as_float(p & 0xffff0000u); }
 
+// fp32 -> three bf16 planes (leading bits, then two residuals): x == p0 + p1 + p2 to ~2^-24; four values at a time
+__device__ __forceinline__ void ec_split3x4(const float (&x)[4], uint2& p0, uint2& p1, uint2& p2) {
+    p0.x = ec_pack2(x[0], x[1]); p0.y = ec_pack2(x[2], x[3]);
+    const float r0 = x[0] - ec_lo(p0.x), r1 = x[1] - ec_hi(p0.x), r2 = x[2] - ec_lo(p0.y), r3 = x[3] - ec_hi(p0.y);
+    p1.x = ec_pack2(r0, r1); p1.y = ec_pack2(r2, r3);
+    p2.x = ec_pack2(r0 - ec_lo(p1.x), r1 - ec_hi(p1.x)); p2.y = ec_pack2(r2 - ec_lo(p1.y), r3 - ec_hi(p1.y));
+}
+
 // Bijective XCD-aware remap of a linear block id (cdna guide T1): the
 // dispatcher places block b on XCD b % 8; give each XCD a contiguous chunk of
 // the logical tile space so neighbouring tiles share an L2.

@@ -257,12 +257,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int xoff(int row, int c) { return row * 64 + ((c ^ ((row >> 2) & 3)) << 4); }
 
-__device__ __forceinline__ void split3x4(const float (&x)[4], uint2& p0, uint2& p1, uint2& p2) {
-    p0.x = ec_pack2(x[0], x[1]); p0.y = ec_pack2(x[2], x[3]);
-    const float r0 = x[0] - ec_lo(p0.x), r1 = x[1] - ec_hi(p0.x), r2 = x[2] - ec_lo(p0.y), r3 = x[3] - ec_hi(p0.y);
-    p1.x = ec_pack2(r0, r1); p1.y = ec_pack2(r2, r3);
-    p2.x = ec_pack2(r0 - ec_lo(p1.x), r1 - ec_hi(p1.x)); p2.y = ec_pack2(r2 - ec_lo(p1.y), r3 - ec_hi(p1.y));
-}
+using ::ec_split3x4;
+__device__ __forceinline__ void split3x4(const float (&x)[4], uint2& p0, uint2& p1, uint2& p2) { ec_split3x4(x, p0, p1, p2); }
 
 // fp32 [rows][K] -> three bf16 planes [rows][3][K] (plane 0 = leading bits), the same split the x3 kernels do on the fly
 __global__ __launch_bounds__(256) void split3_planes_kernel(const float* __restrict__ W, uint16_t* __restrict__ P, long rows, int K) {

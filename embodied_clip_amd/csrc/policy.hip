@@ -20,6 +20,8 @@
 
 #include "common.h"
 
+extern "C" int ec_dw_tn_x3_splits(long M, int NX);
+extern "C" int ec_dw_tn_x3(const void* dYplanes, const void* X, float* part, float* dW, long M, int NX, ec_stream_t stream);
 extern "C" int ec_split3_bf16(const float* W, void* planes, long rows, int K, ec_stream_t stream);
 extern "C" int ec_gemm_bf16a_x3(const void* A, const void* Wplanes, const float* bias, float* out, long M, int N, int K,
                                 int act, ec_stream_t stream);
@@ -462,8 +464,8 @@ constexpr int TB_PART = TB_W + 64 + 64 + 256;     // + db4, db2 (two lane halves
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void tail_bwd_kernel(
     const float* __restrict__ dx4, const float* __restrict__ m1, const float* __restrict__ c2, const float* __restrict__ c1,
     const float* __restrict__ W2, const float* __restrict__ W3, int w3_ld, const float* __restrict__ W4,
-    const int* __restrict__ goal, int S, int num_goals, float* __restrict__ dc1, float* __restrict__ part,
-    float* __restrict__ partE, long M) {
+    const int* __restrict__ goal, int S, int num_goals, float* __restrict__ dc1, uint16_t* __restrict__ dc1p,
+    float* __restrict__ part, float* __restrict__ partE, long M) {
     extern __shared__ __attribute__((aligned(16))) float tsm[];
     float* sW4T = tsm;                            // [128 n][36]:  sW4T[n][k] = W4[k][n]
     float* sW3T = sW4T + 128 * TL_P32;            // [32 n][132]:  sW3T[n][k] = W3[k][n], n < 32
@@ -662,11 +664,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
             db1p[jt] += d;
         }
+        if (dc1p) {                                       // dc1 leaves as three bf16 planes [row][3][128]: the operand of ec_dw_tn_x3
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int idx = lane + 64 * q, r = idx >> 5, c4 = idx & 31;
+                const float4 v = *reinterpret_cast<const float4*>(Tm + r * TL_P128 + c4 * 4);
+                const float x[4] = {v.x, v.y, v.z, v.w};
+                uint2 p0, p1, p2;
+                ec_split3x4(x, p0, p1, p2);
+                if (m0 + r < M) {
+                    uint16_t* d = dc1p + (m0 + r) * 384 + c4 * 4;
+                    *reinterpret_cast<uint2*>(d) = p0;
+                    *reinterpret_cast<uint2*>(d + 128) = p1;
+                    *reinterpret_cast<uint2*>(d + 256) = p2;
+                }
+            }
+        } else {
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int idx = lane + 64 * q, r = idx >> 5, c4 = idx & 31;
             if (m0 + r < M)
                 *reinterpret_cast<float4*>(dc1 + (m0 + r) * 128 + c4 * 4) = *reinterpret_cast<const float4*>(Tm + r * TL_P128 + c4 * 4);
+        }
         }
     }
     // ---- one partial set per wave; the dE1 table per workgroup ----
@@ -765,7 +784,7 @@ Ws layout(const ec_policy* h, int T, int N, bool bwd) {
         w.dx4 = take(M49 * c.comb_out);
         w.dm1 = take(M49 * c.comb_hid);
         w.dc2 = take(M49 * c.compress_out);
-        w.dc1 = take(M49 * c.compress_hid);
+        w.dc1 = take(M49 * c.compress_hid * 3 / 2 + 4);   // fp32 [M49][hid], or its three bf16 planes [M49][3][hid]
         w.dE1 = take((size_t)c.num_goals * c.comb_hid);
         w.tpart = take(c.fusion ? 0 : (size_t)TB_MAX_WG * 4 * TB_PART);              // tail_bwd_kernel's partial sets
         w.tpartE = take(c.fusion ? 0 : (size_t)TB_MAX_WG * c.num_goals * 128);
@@ -1075,6 +1094,10 @@ extern "C" int ec_policy_backward(const ec_policy_t* h, const float* params, con
                            4 * (size_t)(32 * TL_P128 + 32 * TL_P32)) * sizeof(float);
     const bool fused_bwd = tail_fused && c.compress_hid == 128 && c.compress_out == 32 && c.comb_hid == 128 &&
                            c.comb_out == 32 && S >= 32 && tb_lds <= 160 * 1024;
+    // EC_DW1_TR (default 1): dW1 through the transpose-read kernel (dw_tn.hip); dc1 then only exists as bf16 planes
+    static const int dw1_tr = [] { const char* e = getenv("EC_DW1_TR"); return e ? atoi(e) : 1; }();
+    const bool dw1_planes = fused_bwd && dw1_tr && feat_bf16 && C % 256 == 0 && M49 >= 2048 &&
+                            (size_t)ec_dw_tn_x3_splits(M49, C) * 128 * C <= (size_t)TB_MAX_WG * 4 * TB_PART;
     (void)hipMemsetAsync(ws + w.dE1, 0, (size_t)c.num_goals * c.comb_hid * 4, s);
     if (fused_bwd) {
         // EC_TAIL_FUSED (default 1): dm1 / dc2 / dc1 and all small weight gradients of the tail in one pass
@@ -1086,7 +1109,8 @@ extern "C" int ec_policy_backward(const ec_policy_t* h, const float* params, con
         long nwg = (ntiles + 3) / 4;
         if (nwg > TB_MAX_WG) nwg = TB_MAX_WG;
         hipLaunchKernelGGL(tail_bwd_kernel, dim3((unsigned)nwg), dim3(256), tb_lds, s, ws + w.dx4, ws + w.m1, ws + w.c2, ws + w.c1,
-                           W(P_W2), W(P_W3), cat, W(P_W4), goal32, S, c.num_goals, ws + w.dc1, ws + w.tpart, ws + w.tpartE,
+                           W(P_W2), W(P_W3), cat, W(P_W4), goal32, S, c.num_goals, ws + w.dc1,
+                           dw1_planes ? (uint16_t*)(ws + w.dc1) : nullptr, ws + w.tpart, ws + w.tpartE,
                            (long)M49);
         const int ne = TB_PART + c.num_goals * 128;
         hipLaunchKernelGGL(tail_bwd_reduce_kernel, dim3((unsigned)((ne + 255) / 256), 8), dim3(256), 0, s, ws + w.tpart,
@@ -1117,7 +1141,8 @@ extern "C" int ec_policy_backward(const ec_policy_t* h, const float* params, con
           c.num_goals, cat));
     RC(ec_gemm_f32(ws + w.dE1, W(P_W3) + c.compress_out, G(P_EMB), c.num_goals, c.goal_dims, c.comb_hid, c.comb_hid, 1,
                    cat, 1, c.goal_dims, EC_GEMM_ACCUMULATE, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 1, stream));
-    RC(tn(ws + w.dc1, c.compress_hid, feat, C, feat_bf16, G(P_W1), c.compress_hid, C, M49, C));
+    if (dw1_planes) RC(ec_dw_tn_x3(ws + w.dc1, feat, ws + w.tpart, G(P_W1), M49, C, stream));   // (tpart: free again after the reducer)
+    else RC(tn(ws + w.dc1, c.compress_hid, feat, C, feat_bf16, G(P_W1), c.compress_hid, C, M49, C));
     EC_CHECK_LAUNCH();
     return EC_OK;
 }

@@ -97,6 +97,12 @@ int ec_split3_bf16(const float* W, void* planes, long rows, int K, ec_stream_t s
 int ec_gemm_bf16a_x3(const void* A_bf16, const void* W_planes, const float* bias, float* out, long M, int N, int K,
                      int act, ec_stream_t stream);
 
+/* dW[128, NX] += dY^T X over M token rows: dY as three bf16 planes [M][3][128] (ec_split3_bf16 layout), X bf16 [M][NX]
+ * (NX % 256 == 0) -- the weight gradient of the compressor's first 1x1 conv over the stored features.  `part` is scratch
+ * of ec_dw_tn_x3_splits(M, NX) * 128 * NX floats (per-split partial tiles, folded deterministically). */
+int ec_dw_tn_x3_splits(long M, int NX);
+int ec_dw_tn_x3(const void* dY_planes, const void* X_bf16, float* part, float* dW, long M, int NX, ec_stream_t stream);
+
 /* Stem conv1: 3x3 stride 2 pad 1 on the fp32 NHWC frame the RGB sensor hands
  * over ([U] ClipResNetPreprocessor.process: obs[rgb].permute(0,3,1,2)), folded
  * BN + ReLU, LDS-staged image tiles.  w f32 [3*3*3][Cout] (ky,kx,ci major),

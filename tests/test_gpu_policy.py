@@ -100,6 +100,30 @@ def test_gemm_bf16a_x3_pingpong_matches_fp64(dev, M, N, K, relu):
     assert (out.cpu().double() - ref).abs().max() < 2e-5 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("M,NX", [(64, 256), (1000, 512), (49 * 37 * 4, 2048), (70001, 256)])
+def test_dw_tn_x3_transpose_read_matches_fp64(dev, M, NX):
+    """dW[128, NX] += dY^T X with both operands token-major (LDS transpose reads), dY as three bf16 planes: ragged
+    last K-tile, empty trailing splits, accumulation into a non-zero dW; the operands are asymmetric and random so
+    a transposed or permuted fragment cannot pass."""
+    from embodied_clip_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M + NX)
+    dy = torch.randn(M, 128, generator=g) * torch.rand(1, 128, generator=g)
+    x = torch.randn(M, NX, generator=g).abs().to(torch.bfloat16)
+    w0 = torch.randn(128, NX, generator=g)
+    ref = w0.double() + dy.double().t() @ x.double()
+    dyd, xd, wd = dy.to(dev), x.to(dev), w0.to(dev)
+    planes = torch.empty(M, 3, 128, dtype=torch.bfloat16, device=dev)
+    _lib.check(lib.ec_split3_bf16(dyd.data_ptr(), planes.data_ptr(), M, 128, 0))
+    ns = lib.ec_dw_tn_x3_splits(M, NX)
+    assert ns >= 1
+    part = torch.full((ns, 128, NX), float("nan"), device=dev)
+    _lib.check(lib.ec_dw_tn_x3(planes.data_ptr(), xd.data_ptr(), part.data_ptr(), wd.data_ptr(), M, NX, 0))
+    torch.cuda.synchronize()
+    err = (wd.cpu().double() - ref).abs().max().item()
+    assert err < 3e-6 * max(1.0, ref.abs().max().item()) * max(1.0, (M / 1000) ** 0.5), err
+
+
 def _policy_case(T, N, C=64, S=3, H=32, seed=0, bf16=False):
     cfg = dict(in_channels=C, spatial=S, hidden=H)
     sd = syn.policy_state_dict(seed, **cfg)
@@ -179,14 +203,16 @@ def test_gae_matches_oracle(dev):
     assert _rel(r2, R) < 1e-6 and _rel(a2, adv) < 1e-5 and _rel(n2, nadv) < 1e-5
 
 
-@pytest.mark.parametrize("T,N,bf16,S", [(6, 4, False, 3), (8, 4, True, 3), (3, 5, False, 7), (4, 37, True, 7)])
-def test_policy_backward_and_update_step_match_oracle(dev, T, N, bf16, S):
+@pytest.mark.parametrize("T,N,bf16,S,C", [(6, 4, False, 3, 64), (8, 4, True, 3, 64), (3, 5, False, 7, 64), (4, 37, True, 7, 64),
+                                          (3, 19, True, 7, 256)])
+def test_policy_backward_and_update_step_match_oracle(dev, T, N, bf16, S, C):
     """One full optimiser step of HOT LOOP B: forward, PPO loss, backward, clip, Adam.
     S = 7 is the reference's 7x7 feature map: the fused tail kernels (tail_fwd_kernel / tail_bwd_kernel) run there, with
-    ragged last tiles (T*N*49 not a multiple of 32) and row groups straddling tiles; S = 3 keeps the GEMM path covered."""
+    ragged last tiles (T*N*49 not a multiple of 32) and row groups straddling tiles; S = 3 keeps the GEMM path covered.
+    C = 256 with bf16 features additionally takes dW1 through the transpose-read kernel (dc1 as bf16 planes)."""
     from embodied_clip_amd import ppo
     from embodied_clip_amd.policy import PolicyHandle
-    cfg, sd, feat, goal, h0, masks = _policy_case(T, N, S=S, seed=7, bf16=bf16)
+    cfg, sd, feat, goal, h0, masks = _policy_case(T, N, C=C, S=S, seed=7, bf16=bf16)
     actions, old_lp, old_v, returns, nadv = _loss_inputs(T, N, 8)
     with torch.no_grad():
         lg, vv, _ = opol.actor_critic_forward(feat, goal, h0, masks, sd)
