@@ -202,8 +202,6 @@ class Worker:
     def enc_streams(self):
         return [sl.stream for sl in self.slices if sl.stream is not None]
 
-    slice_offset_cycles = int(os.environ.get("EC_SLICE_OFFSET_CYCLES", "0"))
-
     def _on(self, sl):
         return torch.cuda.stream(sl.stream) if sl.stream is not None else _NullCtx()
 
@@ -275,11 +273,6 @@ class Worker:
         T = self.T
         self.h_start.copy_(self.h)
         self._fork()
-        if self.slice_offset_cycles > 0 and self.ns > 1:
-            # experiment (EC_SLICE_OFFSET_CYCLES): start the second slice's chain late, so that its bandwidth-bound
-            # front layers meet the first slice's MFMA-bound back layers instead of its own kind
-            with self._on(self.slices[1]):
-                torch.cuda._sleep(self.slice_offset_cycles)
         for t in range(T):
             rgb = self.env.observe()      # env.step(actions[t]) happens here in the real system (fp32 NHWC frames)
             for sl in self.slices:
