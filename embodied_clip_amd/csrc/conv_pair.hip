@@ -215,11 +215,13 @@ __global__ __launch_bounds__(256, 1) void conv1x1_pair_kernel(PairArgs p) {
                 P[j][0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
                 P[j][1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
             }
+            if (!PL || p.y) {   // (layer-1 -> layer-2 boundary: nobody reads the full-resolution y -- its consumers are z and y_pooled)
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int idx = i * 64 + lane;
                 const uint4 v = *reinterpret_cast<const uint4*>(stg + (idx >> 4) * SP + (idx & 15) * 16);
                 __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(p.y + (m0 + rrow[i]) * NY + hf * 128 + (idx & 15) * 8));
+            }
             }
         };
         half_epilogue(std::integral_constant<int, 0>{});
@@ -641,7 +643,7 @@ extern "C" int ec_conv1x1_pair_bf16(const void* a0, const void* w0, const float*
 extern "C" int ec_conv1x1_pair_pool_bf16(const void* a0, const void* w0, const float* b0, const void* res, void* y,
                                          void* y_pooled, const void* w2, const float* b2, void* z, int B, int H, int W,
                                          int K0, int N, int N2, ec_stream_t stream) {
-    if (!a0 || !w0 || !b0 || !res || !y || !y_pooled || !w2 || !b2 || !z) return EC_ERR_ARG;
+    if (!a0 || !w0 || !b0 || !res || !y_pooled || !w2 || !b2 || !z) return EC_ERR_ARG;   // y may be NULL: not stored
     if (K0 != KA || N != NY || N2 != 128 || B <= 0 || H <= 0 || W <= 0 || (H % 4) != 0 || (W % 8) != 0) return EC_ERR_SHAPE;
     const long tiles = (long)B * (H / 4) * (W / 8);
     if (tiles > 0x7fffffffL) return EC_ERR_SHAPE;

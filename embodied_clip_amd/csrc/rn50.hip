@@ -271,7 +271,8 @@ int rn50_run(const ec_rn50_t* h, const void* rgb, bool u8, const float* mean3, c
                     break;
                 case OP_PAIR:
                     if (o.dst3 >= 0) {
-                        rc = ec_conv1x1_pair_pool_bf16(buf(o.src), h->w + o.w_off, h->bias + o.b_off, buf(o.res), buf(o.dst),
+                        // (the full-resolution block output is dead here: the next block reads dst2 and dst3 only)
+                        rc = ec_conv1x1_pair_pool_bf16(buf(o.src), h->w + o.w_off, h->bias + o.b_off, buf(o.res), nullptr,
                                                        buf(o.dst3), h->w + o.w2_off, h->bias + o.b2_off, buf(o.dst2), nb, o.H,
                                                        o.W, o.Cin, o.Cout, o.N2, stream);
                         break;

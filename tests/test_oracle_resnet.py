@@ -119,3 +119,42 @@ def test_emulated_bf16_close_to_fp32():
     b = ocr.rn50_trunk(x, sd, emulate_bf16=True)
     cos = torch.nn.functional.cosine_similarity(a.flatten(1), b.flatten(1)).min()
     assert cos > 0.999
+
+
+def test_bottleneck_matches_hf_resnet_bottleneck_layer():
+    """Independent pin for the bottleneck arithmetic (row a5): HuggingFace transformers' ResNetBottleNeckLayer is a
+    third-party implementation of conv1x1-BN-ReLU -> conv3x3-BN-ReLU -> conv1x1-BN (+ 1x1-conv/BN shortcut) -> add ->
+    ReLU with eval-mode BatchNorm.  For stride 1 that is exactly CLIP's Bottleneck (whose AvgPool2d(stride) is the
+    identity at stride 1), with and without the projection shortcut; the oracle's folded and unfolded forms must both
+    reproduce it.  (The anti-aliased stride-2 blocks and the 3-conv stem have no third-party counterpart installed.)"""
+    pytest = __import__("pytest")
+    m = pytest.importorskip("transformers.models.resnet.modeling_resnet")
+    import torch
+    from oracle import clip_resnet as R
+    g = torch.Generator().manual_seed(5)
+    for cin, cout in ((64, 64), (32, 64)):
+        layer = m.ResNetBottleNeckLayer(cin, cout, stride=1).eval()
+        with torch.no_grad():
+            for mod in layer.modules():
+                if isinstance(mod, torch.nn.BatchNorm2d):
+                    mod.weight.copy_(torch.rand(mod.weight.shape, generator=g) + 0.5)
+                    mod.bias.copy_(torch.randn(mod.bias.shape, generator=g) * 0.1)
+                    mod.running_mean.copy_(torch.randn(mod.running_mean.shape, generator=g) * 0.2)
+                    mod.running_var.copy_(torch.rand(mod.running_var.shape, generator=g) + 0.5)
+                elif isinstance(mod, torch.nn.Conv2d):
+                    mod.weight.copy_(torch.randn(mod.weight.shape, generator=g) * (mod.weight[0].numel() ** -0.5))
+        sd = {}
+        for i, name in enumerate(("1", "2", "3")):
+            sd[f"blk.conv{name}.weight"] = layer.layer[i].convolution.weight.detach()
+            for k in ("weight", "bias", "running_mean", "running_var"):
+                sd[f"blk.bn{name}.{k}"] = getattr(layer.layer[i].normalization, k).detach()
+        if cin != cout:
+            sd["blk.downsample.0.weight"] = layer.shortcut.convolution.weight.detach()
+            for k in ("weight", "bias", "running_mean", "running_var"):
+                sd[f"blk.downsample.1.{k}"] = getattr(layer.shortcut.normalization, k).detach()
+        x = torch.randn(2, cin, 9, 11, generator=g)
+        with torch.no_grad():
+            ref = layer(x.clone())
+        for fold in (True, False):
+            out = R.bottleneck(x, sd, "blk", 1, emulate=False, fold=fold)
+            assert (out - ref).abs().max() < 2e-5, (cin, cout, fold, float((out - ref).abs().max()))
