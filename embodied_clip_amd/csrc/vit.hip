@@ -266,8 +266,10 @@ __global__ __launch_bounds__(256) void attnpool_tokens_kernel(const uint16_t* __
     }
 }
 
-// CLS-only query attention (AttentionPool2d returns token 0): one wave per (frame, head), head dim 64.
+// CLS-only query attention (AttentionPool2d returns token 0): one wave per (frame, head), head dim 64, up to
+// ATTNPOOL_MAX_L tokens (RN50: 7x7 + 1 = 50; RN50x16 at 384 px: 12x12 + 1 = 145, 48 heads; RN50x64 at 448 px: 197).
 // q bf16 [B, C]; kv bf16 [B*L, 2C] (k | v); out bf16 [B, C]
+constexpr int ATTNPOOL_MAX_L = 1024;
 __global__ __launch_bounds__(64) void attnpool_core_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ kv,
                                                           uint16_t* __restrict__ out, int L, int C, int heads,
                                                           float scale) {
@@ -275,18 +277,23 @@ __global__ __launch_bounds__(64) void attnpool_core_kernel(const uint16_t* __res
     const int b = blockIdx.x / heads, h = blockIdx.x % heads;
     const float qd = ec_bf2f(q[(long)b * C + h * 64 + lane]) * scale;   // q is scaled before the dot product
     const uint16_t* kb = kv + (long)b * L * 2 * C + h * 64;
-    __shared__ float sc[64];
+    __shared__ float sc[ATTNPOOL_MAX_L];
     for (int t = 0; t < L; ++t) {
         const float s = wave_sum_f(qd * ec_bf2f(kb[(long)t * 2 * C + lane]));
         if (lane == 0) sc[t] = s;
     }
     __syncthreads();
-    const float mine = (lane < L) ? sc[lane] : -INFINITY;
-    const float mx = wave_max_f(mine);
-    const float e = (lane < L) ? __expf(mine - mx) : 0.f;
-    const float inv = 1.f / wave_sum_f(e);
-    __syncthreads();
-    sc[lane] = e * inv;
+    float mx = -INFINITY;
+    for (int t = lane; t < L; t += 64) mx = fmaxf(mx, sc[t]);
+    mx = wave_max_f(mx);
+    float sum = 0.f;
+    for (int t = lane; t < L; t += 64) {
+        const float e = __expf(sc[t] - mx);
+        sc[t] = e;
+        sum += e;
+    }
+    const float inv = 1.f / wave_sum_f(sum);
+    for (int t = lane; t < L; t += 64) sc[t] *= inv;
     __syncthreads();
     float o = 0.f;
     for (int t = 0; t < L; ++t) o += sc[t] * ec_bf2f(kb[(long)t * 2 * C + C + lane]);
@@ -628,7 +635,7 @@ extern "C" int ec_attnpool_forward(const void* feat, int batch, int HW, int C, i
                                    const void* wq, const float* bq, const void* wkv, const float* bkv, const void* wc,
                                    const float* bc, void* workspace, size_t ws_bytes, float* out, ec_stream_t stream) {
     if (!feat || !pos || !wq || !bq || !wkv || !bkv || !wc || !bc || !workspace || !out) return EC_ERR_ARG;
-    if (batch <= 0 || HW + 1 > 64 || C / heads != 64 || C % 64 != 0 || out_dim % 32 != 0 || out_dim > C) return EC_ERR_SHAPE;
+    if (batch <= 0 || HW + 1 > ATTNPOOL_MAX_L || C / heads != 64 || C % 64 != 0 || out_dim % 32 != 0 || out_dim > C) return EC_ERR_SHAPE;
     if (ws_bytes < ec_attnpool_workspace_bytes(batch, HW, C)) return EC_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     const size_t B = batch, L = HW + 1;

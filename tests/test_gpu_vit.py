@@ -80,6 +80,26 @@ def test_attnpool_matches_oracle_and_golden(dev):
     assert _rel(out, G["rn50"]["attnpool"]) < 3e-2, _rel(out, G["rn50"]["attnpool"])
 
 
+def test_attnpool_rn50x16_geometry_145_tokens(dev):
+    """AttentionPool2d of RN50x16 (384 px: 12x12 + 1 = 145 tokens, 64-wide heads; `imagenet_vs_objectnav.md:11`) and of a
+    197-token map: the CLS-query core walks any token count.  Reduced width (192 channels, 3 heads) keeps the oracle quick."""
+    from embodied_clip_amd.encoder import AttentionPool
+    for (S, C, out_dim) in ((12, 192, 64), (14, 128, 32)):
+        n = lambda seed, *shape: torch.from_numpy(syn.hash_normal(seed, int(torch.tensor(shape).prod()))).float().reshape(*shape)
+        sd = {"attnpool.positional_embedding": n(1, S * S + 1, C) * C ** -0.5}
+        for i, name in enumerate(("q_proj", "k_proj", "v_proj")):
+            sd[f"attnpool.{name}.weight"] = n(10 + i, C, C) * C ** -0.5
+            sd[f"attnpool.{name}.bias"] = n(20 + i, C) * 0.1
+        sd["attnpool.c_proj.weight"] = n(30, out_dim, C) * C ** -0.5
+        sd["attnpool.c_proj.bias"] = n(31, out_dim) * 0.1
+        feat = (n(40, 3, S, S, C).abs() * 0.7).to(torch.bfloat16)             # NHWC trunk features (post-ReLU)
+        pool = AttentionPool(sd, device=dev, num_heads=C // 64)
+        out = pool.forward(feat.to(dev)).cpu()
+        ref = ocr.attnpool(feat.float().permute(0, 3, 1, 2).contiguous(), sd, num_heads=C // 64)
+        assert out.shape == ref.shape == (3, out_dim)
+        assert _rel(out, ref) < 1.5e-2, (S, _rel(out, ref))
+
+
 def test_vit_b16_style_197_tokens_general_attention(dev):
     """ClipViTPreprocessor('ViT-B/16'): 14x14+1 = 197 tokens run the general LDS attention core (L > 64)."""
     from embodied_clip_amd.clip_preprocessors import ClipViTPreprocessor
