@@ -181,7 +181,7 @@ def run_rank(a, rank: int, local_rank: int, world: int, init_method=None):
         per_gpu = total
     wkw = dict(T=a.rollout, device=dev, seed=0, rank=rank, world=world, update_repeats=a.update_repeats,
                encoder_chunk=a.encoder_chunk, encoder=a.encoder, encoder_streams=a.encoder_streams,
-               frames_u8=a.frames_u8)
+               frames_u8=a.frames_u8, num_mini_batch=a.num_mini_batch)
     if a.encoder == "zeroshot":
         wkw.update(encoder="rn50", zeroshot=True)
     w = Worker(per_gpu, frames_host=a.frames_host, **wkw)
@@ -292,7 +292,7 @@ def run_rank(a, rank: int, local_rank: int, world: int, init_method=None):
             "config": {"workload": workload + " (bf16 MFMA, fp32 accumulate) + 1-layer GRU actor-critic PPO (fp32), "
                                                "synthetic 224x224 RGB + random goal ids",
                        "actors_per_gpu": per_gpu, "global_actors": per_gpu * world, "rollout": a.rollout,
-                       "update_repeats": a.update_repeats, "num_mini_batch": 1, "encoder_streams": a.encoder_streams,
+                       "update_repeats": a.update_repeats, "num_mini_batch": a.num_mini_batch, "encoder_streams": a.encoder_streams,
                        "frames": ("pinned host -> H2D per step, " if a.frames_host else "resident in HBM, ") +
                                  ("uint8 HWC (normalisation fused)" if a.frames_u8 else "fp32 normalised HWC"),
                        "parallelism": f"dp{world} (actors sharded; one flat 13.9 MB grad all-reduce per optimiser step)",
@@ -338,6 +338,7 @@ def parse_args(argv=None):
                          "ranks; weak: that many actors PER GPU")
     ap.add_argument("--rollout", type=int, default=128)
     ap.add_argument("--update-repeats", type=int, default=4)
+    ap.add_argument("--num-mini-batch", type=int, default=1, help="PPO minibatches per epoch (contiguous actor ranges)")
     ap.add_argument("--encoder-chunk", type=int, default=0)
     ap.add_argument("--encoder-streams", type=int, default=2, help="concurrent HIP streams for the encoder")
     ap.add_argument("--frames-u8", action="store_true",

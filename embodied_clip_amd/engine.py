@@ -25,6 +25,7 @@ from __future__ import annotations
 from typing import Dict, List, Optional
 
 import os
+import random
 
 import torch
 
@@ -84,12 +85,17 @@ class Worker:
                  update_repeats: int = 4, lr: float = 3e-4, max_grad_norm: float = 0.5, gamma: float = 0.99,
                  tau: float = 0.95, encoder_sd=None, policy_sd=None, lr_total_steps: int = 300_000_000,
                  encoder_chunk: int = 0, encoder: str = "rn50", encoder_streams: int = 2, frames_u8: bool = False,
-                 frames_host: bool = False, zeroshot: bool = False, text_sd=None, goal_tokens=None):
+                 frames_host: bool = False, zeroshot: bool = False, text_sd=None, goal_tokens=None,
+                 num_mini_batch: int = 1):
         """``zeroshot=True`` (BASELINE config 5, readme_files/zeroshot_objectnav.md): the observation is the CLIP image
         EMBEDDING (RN50 trunk + AttentionPool2d, 1024-d), the goal is the frozen CLIP text embedding of its prompt
         (text tower run once -> [12, 1024] table) and the policy is the fusion=1 variant (GRU + heads trainable)."""
         self.lib = _lib.load()
         self.zeroshot, self._text_sd, self._goal_tokens = zeroshot, text_sd, goal_tokens
+        # [U] allenact RolloutStorage.recurrent_generator(num_mini_batch): contiguous sampler ranges, shuffled order
+        assert 1 <= num_mini_batch <= n_actors, "num_mini_batch must not exceed the number of samplers"
+        self.num_mini_batch = num_mini_batch
+        self._mb_rng = random.Random(seed + 104729 * rank)
         self.dev = self.device = torch.device(device)
         if self.dev.index is None:
             self.dev = self.device = torch.device("cuda", torch.cuda.current_device())
@@ -304,33 +310,72 @@ class Worker:
             sl.actions, sl.logp, sl.old_v = c(self.actions), c(self.logp), c(self.values)
             sl.ret, sl.nadv = c(self.returns), c(self.nadv)
 
+    def minibatch_ranges(self):
+        """[U] allenact ``RolloutStorage.recurrent_generator``: the samplers (actors) are cut at
+        ``round(linspace(0, N, num_mini_batch + 1))`` into contiguous ranges which are visited in a shuffled order;
+        every range keeps its full T-step sequences (the GRU needs them)."""
+        N, M = self.N, self.num_mini_batch
+        inds = [int(round(i * N / M)) for i in range(M + 1)]      # == np.round(np.linspace(0, N, M + 1))
+        pairs = list(zip(inds[:-1], inds[1:]))
+        self._mb_rng.shuffle(pairs)
+        return pairs
+
+    def _gather_part(self, sl, a: int, b: int):
+        """Contiguous [T * (b - a)] batch of actors [a, b) of slice ``sl`` (slice-local indices) in the slice's staging
+        buffers; the whole slice is used in place."""
+        T = self.T
+        if a == 0 and b == sl.n:
+            return (sl.feat[:T].view(T * sl.n, self.S * self.S, self.C), sl.goal, sl.masks, sl.actions, sl.logp, sl.old_v,
+                    sl.ret, sl.nadv)
+        m = b - a
+        if getattr(sl, "feat_mb", None) is None:                   # staging for partial-slice minibatches (allocated on first use)
+            sl.feat_mb = torch.empty((T, sl.n, self.S * self.S, self.C), dtype=sl.feat.dtype, device=self.dev)
+        fm = sl.feat_mb.view(-1)[:T * m * self.S * self.S * self.C].view(T, m, self.S * self.S, self.C)
+        fm.copy_(sl.feat[:T, a:b])
+        c = lambda x: x.view(T, sl.n)[:, a:b].reshape(-1).contiguous()
+        return (fm.view(T * m, self.S * self.S, self.C), c(sl.goal), c(sl.masks), c(sl.actions), c(sl.logp), c(sl.old_v),
+                c(sl.ret), c(sl.nadv))
+
     @_lib.on_device
     def update(self):
         T = self.T
         self._gather_slice_batches()
-        # d(total)/d(hv) carries 1/B_slice inside the loss kernel: rescale to the mean over the WHOLE local batch,
-        # then local_bsize / global_bsize for the SUM all-reduce (global mean gradient)
-        grad_scale = (1.0 / self.ns) * (1.0 / self.world)
         for _ in range(self.update_repeats):
-            self._fork()
-            for sl in self.slices:
-                with self._on(sl):
-                    n = sl.n
-                    self.policy.forward(self.params, sl.feat[:T].view(T * n, self.S * self.S, self.C), sl.goal,
-                                        self.h_start[sl.o:sl.o + n], sl.masks, T, n, sl.ws_learn, hv=sl.hv)
-                    ppo_loss_raw(sl.hv, sl.actions, sl.logp, sl.old_v, sl.ret, sl.nadv, self.A, grad_scale=grad_scale,
-                                 dhv=sl.dhv, sums=sl.sums)
-                    sl.grads.zero_()
-                    self.policy.backward(self.params, sl.feat[:T].view(T * n, self.S * self.S, self.C), sl.masks, T, n,
-                                         sl.ws_learn, sl.dhv, None, sl.grads)
-            self._join()
-            if self.ns > 1:
-                torch.add(self.slices[0].grads, self.slices[1].grads, out=self.grads)
-                for sl in self.slices[2:]:
-                    self.grads.add_(sl.grads)
-            if self.world > 1:
-                allreduce_flat(self.grads)                   # one flat 13.9 MB bucket over RCCL/xGMI
-            self.opt.step(self.grads, lr=linear_decay_lr(self.base_lr, self.total_steps, self.lr_total_steps))
+            for (s0, s1) in self.minibatch_ranges():
+                # the minibatch's actors, slice by slice (each part on its slice's stream)
+                parts = []
+                for sl in self.slices:
+                    a, b = max(s0, sl.o) - sl.o, min(s1, sl.o + sl.n) - sl.o
+                    if b > a:
+                        parts.append((sl, a, b))
+                nmb = s1 - s0
+                self._fork()
+                for (sl, a, b) in parts:
+                    with self._on(sl):
+                        m = b - a
+                        feat, goal, masks, actions, logp, old_v, ret, nadv = self._gather_part(sl, a, b)
+                        hv, dhv = sl.hv[:T * m], sl.dhv[:T * m]
+                        # d(total)/d(hv) carries 1/B_part inside the loss kernel: rescale to the mean over the WHOLE
+                        # local minibatch, then local_bsize / global_bsize for the SUM all-reduce (global mean gradient)
+                        grad_scale = (m / nmb) * (1.0 / self.world)
+                        self.policy.forward(self.params, feat, goal, self.h_start[sl.o + a:sl.o + b], masks, T, m,
+                                            sl.ws_learn, hv=hv)
+                        ppo_loss_raw(hv, actions, logp, old_v, ret, nadv, self.A, grad_scale=grad_scale, dhv=dhv,
+                                     sums=sl.sums)
+                        sl.grads.zero_()
+                        self.policy.backward(self.params, feat, masks, T, m, sl.ws_learn, dhv, None, sl.grads)
+                self._join()
+                self._loss_parts = [(sl, b - a) for (sl, a, b) in parts]
+                if self.ns > 1:
+                    if len(parts) == 1:
+                        self.grads.copy_(parts[0][0].grads)
+                    else:
+                        torch.add(parts[0][0].grads, parts[1][0].grads, out=self.grads)
+                        for (sl, _, _) in parts[2:]:
+                            self.grads.add_(sl.grads)
+                if self.world > 1:
+                    allreduce_flat(self.grads)                   # one flat 13.9 MB bucket over RCCL/xGMI
+                self.opt.step(self.grads, lr=linear_decay_lr(self.base_lr, self.total_steps, self.lr_total_steps))
 
     @_lib.on_device
     def after_update(self):
@@ -346,8 +391,9 @@ class Worker:
         self.after_update()
 
     def loss_info(self) -> Dict[str, float]:
-        tot = sum(sl.sums for sl in self.slices)
-        s = (tot / (self.T * self.N)).tolist()
+        parts = getattr(self, "_loss_parts", None) or [(sl, sl.n) for sl in self.slices]   # the last minibatch
+        tot = sum(sl.sums for sl, _ in parts)
+        s = (tot / (self.T * sum(m for _, m in parts))).tolist()
         return {"action": s[0], "value": s[1], "entropy": s[2], "ratio": s[3],
                 "ppo_total": s[0] + 0.5 * s[1] + 0.01 * s[2], "grad_norm": self.opt.grad_norm()}
 

@@ -21,7 +21,7 @@ from . import ppo as oppo
 
 def run_iteration(enc_sd, pol_sd, frames: torch.Tensor, goals: torch.Tensor, masks: torch.Tensor,
                   rewards: torch.Tensor, T: int, N: int, update_repeats: int = 4, seed: int = 0,
-                  opt_state=None) -> Dict[str, float]:
+                  opt_state=None, num_mini_batch: int = 1, mb_rng=None) -> Dict[str, float]:
     """frames: fp32 NHWC [P, N, R, R, 3] pool (cycled); goals [T+1,N]; masks [T+1,N,1]; rewards [T,N,1].
     pol_sd is updated in place.  Returns timing + loss info."""
     g = torch.Generator().manual_seed(seed)
@@ -49,8 +49,15 @@ def run_iteration(enc_sd, pol_sd, frames: torch.Tensor, goals: torch.Tensor, mas
                  old_values=values[:T], returns=returns[:T], norm_adv=nadv)
     opt_state = {} if opt_state is None else opt_state
     info = {}
+    if num_mini_batch > 1 and mb_rng is None:
+        import random
+        mb_rng = random.Random(seed)
     for _ in range(update_repeats):
-        info, _ = oppo.ppo_update_step(pol_sd, batch, opt_state)
+        if num_mini_batch == 1:
+            info, _ = oppo.ppo_update_step(pol_sd, batch, opt_state)
+        else:
+            for (s0, s1) in oppo.recurrent_minibatch_ranges(N, num_mini_batch, mb_rng):
+                info, _ = oppo.ppo_update_step(pol_sd, oppo.slice_batch(batch, s0, s1), opt_state)
     dt = time.perf_counter() - t0
     info.update(seconds=dt, seconds_rollout=t_rollout, frames=T * N, frames_per_s=T * N / dt)
     return info

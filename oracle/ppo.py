@@ -121,3 +121,22 @@ def ppo_update_step(sd: Dict[str, torch.Tensor], batch: Dict[str, torch.Tensor],
     with torch.no_grad():
         adam_step([sd[k] for k in names], grads, opt_state["m"], opt_state["v"], opt_state["step"], lr=lr)
     return info, dict(zip(names, raw))
+
+
+def recurrent_minibatch_ranges(num_samplers: int, num_mini_batch: int, rng) -> list:
+    """[U] allenact/algorithms/onpolicy_sync/storage.py ``RolloutStorage.recurrent_generator``: samplers are split at
+    ``np.round(np.linspace(0, num_samplers, num_mini_batch + 1))`` into contiguous ranges, ``random.shuffle``d;
+    every minibatch keeps whole T-step sequences.  ``rng``: a ``random.Random``."""
+    assert num_samplers >= num_mini_batch
+    inds = [int(round(i * num_samplers / num_mini_batch)) for i in range(num_mini_batch + 1)]
+    pairs = list(zip(inds[:-1], inds[1:]))
+    rng.shuffle(pairs)
+    return pairs
+
+
+def slice_batch(batch: Dict[str, torch.Tensor], s0: int, s1: int) -> Dict[str, torch.Tensor]:
+    """The columns (samplers) [s0, s1) of a [T, N, ...] rollout batch; ``h0`` is [1, N, H]."""
+    out = {}
+    for k, v in batch.items():
+        out[k] = v[:, s0:s1].contiguous()
+    return out

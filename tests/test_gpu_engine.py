@@ -15,6 +15,43 @@ def _rel(a, b):
     return ((a - b).norm() / b.norm().clamp_min(1e-20)).item()
 
 
+def test_worker_num_mini_batch_matches_oracle():
+    """[U] allenact recurrent_generator(num_mini_batch=M): contiguous sampler ranges in shuffled order, one optimiser
+    step per minibatch (update_repeats x M steps per rollout).  N = 5, M = 2 -> ranges [0,2) and [2,5): both are
+    partial slices, i.e. the staging-copy path; the oracle replays the same shuffle stream."""
+    import random
+    from embodied_clip_amd.engine import Worker
+    T, N, R, M = 3, 5, 2, 2
+    enc_sd, pol_sd = syn.rn50_visual_state_dict(0), syn.policy_state_dict(0)
+    w = Worker(N, T=T, device="cuda:0", seed=3, update_repeats=R, encoder_sd=enc_sd, policy_sd=pol_sd, num_mini_batch=M)
+    w.collect_rollout()
+    w.compute_returns()
+    torch.cuda.synchronize()
+    S, C = w.S, w.C
+    feat_gpu = w.feat.float().cpu().view(T + 1, N, S, S, C).permute(0, 1, 4, 2, 3).contiguous()
+    masks = w.env.masks.cpu().unsqueeze(-1)
+    batch = dict(feat=feat_gpu[:T], goal=w.env.goals.cpu()[:T], h0=torch.zeros(1, N, w.H), masks=masks[:T],
+                 actions=w.actions.cpu(), old_log_probs=w.logp.cpu().unsqueeze(-1),
+                 old_values=w.values[:T].cpu().unsqueeze(-1), returns=w.returns[:T].cpu().unsqueeze(-1),
+                 norm_adv=w.nadv.cpu().unsqueeze(-1))
+    sd_ref = {k: v.clone() for k, v in pol_sd.items()}
+    st, rng, seen = {}, random.Random(3), []
+    for _ in range(R):
+        for (s0, s1) in oppo.recurrent_minibatch_ranges(N, M, rng):
+            seen.append((s0, s1))
+            info, _ = oppo.ppo_update_step(sd_ref, oppo.slice_batch(batch, s0, s1), st)
+    assert sorted(seen[:M]) == [(0, 2), (2, 5)] and st["step"] == R * M
+    w.update()
+    torch.cuda.synchronize()
+    got = w.loss_info()
+    assert abs(got["ppo_total"] - info["ppo_total"]) < 5e-4 * max(1.0, abs(info["ppo_total"]))
+    pv = w.policy.views(w.params)
+    for name, pref in sd_ref.items():
+        upd, upd_ref = pv[name].cpu() - pol_sd[name], pref - pol_sd[name]
+        assert (upd - upd_ref).abs().max() < 0.15 * R * M * 3e-4 + 1e-7, (name, (upd - upd_ref).abs().max())
+    assert w.opt.step_count == R * M
+
+
 def test_worker_iteration_matches_oracle():
     from embodied_clip_amd.engine import Worker
     assert torch.cuda.is_available()

@@ -76,3 +76,17 @@ def test_ppo_loss_at_ratio_one():
     assert abs(info["action"] - float(-adv.mean())) < 1e-6
     assert abs(info["value"] - float(0.5 * ((values - returns) ** 2).mean())) < 1e-6
     assert abs(info["ratio_mean"] - 1.0) < 1e-6
+
+
+def test_recurrent_minibatch_ranges_restates_allenact_generator():
+    """[U] RolloutStorage.recurrent_generator: np.round(np.linspace(0, N, M + 1)) cuts, random.shuffle order."""
+    import random
+    import numpy as np
+    from oracle import ppo as oppo
+    for N, M in ((5, 2), (60, 1), (60, 7), (256, 2), (9, 9)):
+        inds = np.round(np.linspace(0, N, M + 1, endpoint=True)).astype(np.int32)
+        want = list(zip(inds[:-1].tolist(), inds[1:].tolist()))
+        random.Random(11).shuffle(want)
+        got = oppo.recurrent_minibatch_ranges(N, M, random.Random(11))
+        assert got == want
+        assert sorted(got)[0][0] == 0 and sorted(got)[-1][1] == N and sum(b - a for a, b in got) == N
