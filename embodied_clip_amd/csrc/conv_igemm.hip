@@ -160,9 +160,10 @@ __global__ __launch_bounds__(WM * WN * 64, (BM > 192) ? 2 : ((WM * WN == 8) ? 4 
     decode();
 
     // direct global -> LDS (LDS-DMA): no staging registers, no ds_write pass
-    const unsigned char* in_b = reinterpret_cast<const unsigned char*>(p.in);
-    const unsigned char* w_b = reinterpret_cast<const unsigned char*>(p.w);
-    const unsigned char* zp = reinterpret_cast<const unsigned char*>(ec_zero_page);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+#endif
     const int wave_lds = wave * 1024;                       // 64 lanes x 16 B
     // per-K-tile addressing state shared by the pieces of one tile
     int g_toff = 0; unsigned g_tapbit = 0; bool g_kin = false; int g_kt = 0;
@@ -192,14 +193,16 @@ __global__ __launch_bounds__(WM * WN * 64, (BM > 192) ? 2 : ((WM * WN == 8) ? 4 
     // piece q of the tile begun last: q < A_IT -> A rows, else B rows (each piece = one 1-KiB wave LDS-DMA)
     auto glds_piece = [&](auto qc) {
         constexpr int q = decltype(qc)::value;
+#if defined(__HIP_DEVICE_COMPILE__)   // buffer descriptors: 32-bit offsets, out-of-range = zeros (as in conv_igemm8)
         if constexpr (q < A_IT) {
-            const unsigned char* src = (a_msk[q] & g_tapbit) ? in_b + (a_off[q] + (unsigned)g_toff) : zp;
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(g_sa + q * (LR * ROW_BYTES)), 16, 0, 0);
+            const unsigned off = (a_msk[q] & g_tapbit) ? a_off[q] + (unsigned)g_toff : 0xFFFFFFF0u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void_t*)(g_sa + q * (LR * ROW_BYTES)), 16, off, 0, 0, 0);
         } else {
             constexpr int i = q - A_IT;
-            const unsigned char* src = g_kin ? w_b + (b_off[i] + (unsigned)(g_kt * (BK * 2))) : zp;
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(g_sb + i * (LR * ROW_BYTES)), 16, 0, 0);
+            const unsigned off = g_kin ? b_off[i] + (unsigned)(g_kt * (BK * 2)) : 0xFFFFFFF0u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_t*)(g_sb + i * (LR * ROW_BYTES)), 16, off, 0, 0, 0);
         }
+#endif
     };
     auto glds_tile = [&](int kt, int buf) {
         glds_begin(kt, buf);
