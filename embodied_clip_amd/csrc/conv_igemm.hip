@@ -22,7 +22,7 @@
 //     ds_write pass.  The LDS image has 128-byte rows; LDS-DMA writes are lane-linear, so the XOR swizzle
 //     ((row>>1)&7 on the 16-byte chunk index) is applied to the SOURCE chunk each lane fetches and again
 //     on the fragment ds_read_b128 (conflict-free for the 16-lane groups {0-3,12-15,20-27},...).
-//     Padding / ragged-K chunks read a zero page, selected per row from a 9-bit tap-validity mask that is
+//     Padding / ragged-K chunks are out-of-range buffer offsets (the hardware returns zeros), selected per row from a 9-bit tap-validity mask that is
 //     computed once per tile -- the 3x3 halo costs one v_cndmask per chunk, no branches.
 //   * SWAPPED MFMA operands (D[n][m]): a lane owns ONE pixel and, per 4 accumulator registers, 4
 //     consecutive channels -> bias/residual/activation/bf16-rounding work on packed 8-byte LDS slots
@@ -72,8 +72,6 @@ struct ConvArgs {
 
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void_t;
-typedef const __attribute__((address_space(1))) void gbl_void_t;
-__device__ uint4 ec_zero_page[8];   // source for padded / out-of-range 16-byte chunks of LDS-DMA loads
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {
     return row * ROW_BYTES + ((chunk ^ ((row >> 1) & 7)) << 4);
@@ -192,7 +190,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM > 192) ? 2 : ((WM * WN == 8) ? 4 
     };
     // piece q of the tile begun last: q < A_IT -> A rows, else B rows (each piece = one 1-KiB wave LDS-DMA)
     auto glds_piece = [&](auto qc) {
-        constexpr int q = decltype(qc)::value;
+        [[maybe_unused]] constexpr int q = decltype(qc)::value;
 #if defined(__HIP_DEVICE_COMPILE__)   // buffer descriptors: 32-bit offsets, out-of-range = zeros (as in conv_igemm8)
         if constexpr (q < A_IT) {
             const unsigned off = (a_msk[q] & g_tapbit) ? a_off[q] + (unsigned)g_toff : 0xFFFFFFF0u;
@@ -434,7 +432,7 @@ int launch(const ConvArgs& a, hipStream_t s) {
 //     WAR: the stage of K-tile t-1 is re-filled from s = 4t on; its last reader is g1's MEM1(t-1) at s = 4t-1, which
 //     ends with lgkmcnt(0) before the barrier.  RAW: every wave has waited for its pieces of t+1 before the barrier
 //     that ends s = 4t+3; the first reader is g0's MEM0(t+1) at s = 4t+4.
-// Operand fetch (implicit im2col, zero page for padding), LDS swizzle, swapped MFMA operands and the epilogue
+// Operand fetch (implicit im2col, out-of-range buffer offsets for padding), LDS swizzle, swapped MFMA operands and the epilogue
 // (bias / residual / ReLU / fused 2x2 average pool through LDS, 16-byte coalesced stores) are those of conv_igemm_kernel.
 // Requires Cin % 64 == 0 (a K-tile never straddles a 3x3 tap) and Cout % BN == 0.
 __device__ unsigned long long ec_dbg_stamps[2 * 1024];   // profiling only (EC_CONV_ABLATE & 32): s_memtime stamps of block 0
@@ -534,7 +532,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
         }
     };
     auto glds_piece = [&](auto qc) {
-        constexpr int q = decltype(qc)::value;
+        [[maybe_unused]] constexpr int q = decltype(qc)::value;
         // buffer_load ... lds through a descriptor: a 32-bit per-lane offset (no 64-bit pointer arithmetic), and a padding tap
         // is an out-of-range offset, which the hardware answers with zeros (no zero page, no pointer select)
 #if defined(__HIP_DEVICE_COMPILE__)
