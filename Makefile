@@ -6,7 +6,7 @@ CSRC  := embodied_clip_amd/csrc
 OUT   := embodied_clip_amd/lib/libec_amd.so
 SRCS  := $(wildcard $(CSRC)/*.hip)
 OBJS  := $(patsubst $(CSRC)/%.hip,build/%.o,$(SRCS))
-FLAGS := --offload-arch=$(ARCH) -O3 -std=c++20 -fPIC -Wall -Wno-unused-function -ffp-contract=fast $(EXTRA)
+FLAGS := --offload-arch=$(ARCH) -O3 -std=c++20 -fPIC -Wall -Wno-unused-function -Wno-unused-but-set-variable -ffp-contract=fast $(EXTRA)
 
 all: $(OUT)
 
