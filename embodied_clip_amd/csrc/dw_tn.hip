@@ -16,7 +16,7 @@
 // Workgroup: 8 waves, output tile 128 (dc1 channels) x 256 (feature channels), wave tile 64 x 64 (4 accumulator tiles);
 // per K-tile and wave 32 transpose reads feed 24 MFMAs (2 k-steps x 2 x 2 tiles x 3 planes, smallest plane first).
 // Three LDS stages, K-tile t+2 in flight while t is consumed, one barrier per K-tile.  The token range is split
-// over gridDim.y workgroups (8 column tiles x 32 splits = 256 workgroups); each writes its partial tile, and
+// over token splits (8 column tiles x 32 splits = 256 workgroups, the column tiles of a split on one XCD); each writes its partial tile, and
 // dw_reduce_kernel folds the splits into the gradient (deterministic: no atomics).
 #include "common.h"
 
@@ -44,6 +44,7 @@ struct DwArgs {
     long M;
     int NX;
     long tok_per_split;   // multiple of KT
+    int ntile, nsplit;    // column tiles (NX / 256), token splits
 };
 
 __global__ __launch_bounds__(512) void dw_tn_x3_kernel(DwArgs p) {
@@ -51,8 +52,14 @@ __global__ __launch_bounds__(512) void dw_tn_x3_kernel(DwArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
-    const int n0 = blockIdx.x * NXT;
-    const long tok0 = (long)blockIdx.y * p.tok_per_split;
+    // XCD-aware work assignment: consecutive workgroup ids go to different XCDs (id % 8), each with its own L2.  The
+    // column tiles of one token split read the SAME dY rows, so they are placed on one XCD (ids id, id + 8, ...):
+    // dY then crosses HBM once per split instead of once per column tile (measured: 8.2 -> 2.3 GB per call).
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int col = slot % p.ntile, split = xcd + 8 * (slot / p.ntile);
+    if (split >= p.nsplit) return;
+    const int n0 = col * NXT;
+    const long tok0 = (long)split * p.tok_per_split;
     long ntok = p.M - tok0;
     if (ntok > p.tok_per_split) ntok = p.tok_per_split;
     if (ntok <= 0) ntok = 0;
@@ -181,8 +188,8 @@ __global__ __launch_bounds__(512) void dw_tn_x3_kernel(DwArgs p) {
 #undef WAIT0
 #undef MFMA4
     // ---- partial tile out: C/D layout, column = lane & 31 (feature channel), rows = dY channels ----
-    float* out = p.part + (long)blockIdx.y * NYT * p.NX;
-    const int col = lane & 31, hh = lane >> 5;
+    float* out = p.part + (long)split * NYT * p.NX;
+    const int ocol = lane & 31, hh = lane >> 5;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -190,7 +197,7 @@ __global__ __launch_bounds__(512) void dw_tn_x3_kernel(DwArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                out[(long)m * p.NX + n0 + wn * 64 + j * 32 + col] = acc[i][j][r];
+                out[(long)m * p.NX + n0 + wn * 64 + j * 32 + ocol] = acc[i][j][r];
             }
 }
 
@@ -236,7 +243,9 @@ extern "C" int ec_dw_tn_x3(const void* dYplanes, const void* X, float* part, flo
     static std::atomic<uint64_t> attr_done{0};
     if (ec_attr_needed(attr_done))
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dw_tn_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(dw_tn_x3_kernel, dim3((unsigned)(NX / NXT), (unsigned)ns), dim3(512), lds, (hipStream_t)stream, a);
+    a.ntile = NX / NXT;
+    a.nsplit = ns;
+    hipLaunchKernelGGL(dw_tn_x3_kernel, dim3((unsigned)(8 * a.ntile * ((ns + 7) / 8))), dim3(512), lds, (hipStream_t)stream, a);
     const long n4 = (long)NYT * NX / 4;
     hipLaunchKernelGGL(dw_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, part, ns, n4, dW);
     EC_CHECK_LAUNCH();
