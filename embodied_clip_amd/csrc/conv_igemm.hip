@@ -512,16 +512,22 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
 
     // piece q of K-tile kt into stage buf: q < A_IT -> 8 pixel rows per wave, else 8 weight rows
     int g_toff = 0; unsigned g_tapbit = 1u; int g_kb = 0;
-    unsigned char* g_sa = smem;
+    unsigned char* g_sa = smem; unsigned char* g_sb = smem; bool g_issue_a = true;
     auto glds_begin = [&](int kt, int buf) {
         g_sa = smem + buf * STAGE + wave_lds;
+        g_sb = g_sa + A_BYTES;
         g_kb = kt * (BK * 2);
         g_toff = kt * (BK * 2);
         g_tapbit = 1u;
         if (X3) {                                       // K-tile kt = (A chunk kt / 3) x (weight plane 2 - kt % 3)
+            // LDS: [A chunk 0][A chunk 1][B 0][B 1] -- the A chunk is fetched ONCE (with the K-tile of its first plane)
+            // and read by the three K-tiles of the chunk; only the 16-KB plane tiles alternate per K-tile
             const int ch = kt / 3, pl = 2 - (kt - 3 * ch);
             g_toff = ch * (BK * 2);
             g_kb = (pl * p.K + ch * BK) * 2;
+            g_sa = smem + (ch & 1) * A_BYTES + wave_lds;
+            g_sb = smem + 2 * A_BYTES + (kt & 1) * B_BYTES + wave_lds;
+            g_issue_a = (kt == 3 * ch);
         }
         if (KS == 3) {
             const int k = kt * BK;
@@ -537,11 +543,13 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
         // is an out-of-range offset, which the hardware answers with zeros (no zero page, no pointer select)
 #if defined(__HIP_DEVICE_COMPILE__)
         if constexpr (q < A_IT) {
-            const unsigned off = (a_msk[q] & g_tapbit) ? a_off[q] + (unsigned)g_toff : 0xFFFFFFF0u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void_t*)(g_sa + q * (LR * ROW_BYTES)), 16, off, 0, 0, 0);
+            if (!X3 || g_issue_a) {
+                const unsigned off = (a_msk[q] & g_tapbit) ? a_off[q] + (unsigned)g_toff : 0xFFFFFFF0u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void_t*)(g_sa + q * (LR * ROW_BYTES)), 16, off, 0, 0, 0);
+            }
         } else {
             constexpr int i = q - A_IT;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_t*)(g_sa + A_BYTES + i * (LR * ROW_BYTES)), 16,
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_t*)(g_sb + i * (LR * ROW_BYTES)), 16,
                                                      b_off[i] + (unsigned)g_kb, 0, 0, 0);
         }
 #endif
@@ -566,16 +574,21 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
     const int fsw = (frow >> 1) & 7;
 
     s16x8_t fa[2][FM], fb[2][FN];
-    auto read_half = [&](int buf, auto hc) {            // fragments of k-steps 2h, 2h+1 of the K-tile in stage buf
+    auto read_half = [&](int kt, auto hc) {             // fragments of k-steps 2h, 2h+1 of K-tile kt
         constexpr int h = decltype(hc)::value;
-        const unsigned char* st = smem + buf * STAGE;
+        const unsigned char* sta = smem + (kt & 1) * STAGE;
+        const unsigned char* stb = sta;
+        if (X3) {                                       // (fb_base carries + A_BYTES: see the LDS map in glds_begin)
+            sta = smem + ((kt / 3) & 1) * A_BYTES;
+            stb = smem + A_BYTES + (kt & 1) * B_BYTES;
+        }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int c = ((h * 2 + u) * 2 + fhalf) ^ fsw;
 #pragma unroll
-            for (int i = 0; i < FM; ++i) fa[u][i] = *reinterpret_cast<const s16x8_t*>(st + fa_base[i] + (c << 4));
+            for (int i = 0; i < FM; ++i) fa[u][i] = *reinterpret_cast<const s16x8_t*>(sta + fa_base[i] + (c << 4));
 #pragma unroll
-            for (int j = 0; j < FN; ++j) fb[u][j] = *reinterpret_cast<const s16x8_t*>(st + fb_base[j] + (c << 4));
+            for (int j = 0; j < FN; ++j) fb[u][j] = *reinterpret_cast<const s16x8_t*>(stb + fb_base[j] + (c << 4));
         }
     };
     using I0 = std::integral_constant<int, 0>;
@@ -623,7 +636,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
         const int cur = kt & 1;
         const bool more = (kt + 1) < nk && !(abl & 1);
         // ---- MEM0 ----
-        if constexpr (!(abl & 4)) read_half(cur, I0{});
+        if constexpr (!(abl & 4)) read_half(kt, I0{});
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         stamp();
@@ -638,7 +651,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
         if constexpr (!(abl & 16)) __builtin_amdgcn_s_barrier();
         stamp();
         // ---- MEM1 ----
-        if constexpr (!(abl & 4)) read_half(cur, I1{});
+        if constexpr (!(abl & 4)) read_half(kt, I1{});
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (grp) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
