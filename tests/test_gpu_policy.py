@@ -75,7 +75,8 @@ def test_gemm_f32_bf16_operands_nn_tn_epilogues(dev):
     assert _rel(o, ref) < 2e-5
 
 
-@pytest.mark.parametrize("M,N,K,relu", [(1000, 128, 256, True), (256 * 3 + 17, 256, 2048, False), (40000, 128, 2048, True)])
+@pytest.mark.parametrize("M,N,K,relu", [(1000, 128, 256, True), (256 * 3 + 17, 256, 2048, False), (40000, 128, 2048, True),
+                                           (5000, 128, 768, True)])
 def test_gemm_bf16a_x3_pingpong_matches_fp64(dev, M, N, K, relu):
     """bf16 activations x fp32 weights (three bf16 planes) on the 8-wave ping-pong kernel: exact-fp32 grade product
     (the compressor's first 1x1 conv over stored features); ragged last tile, two N tiles, bias / ReLU."""
@@ -100,7 +101,7 @@ def test_gemm_bf16a_x3_pingpong_matches_fp64(dev, M, N, K, relu):
     assert (out.cpu().double() - ref).abs().max() < 2e-5 * max(1.0, ref.abs().max().item())
 
 
-@pytest.mark.parametrize("M,NX", [(64, 256), (1000, 512), (49 * 37 * 4, 2048), (70001, 256)])
+@pytest.mark.parametrize("M,NX", [(64, 256), (1000, 512), (49 * 37 * 4, 2048), (70001, 256), (4001, 768)])
 def test_dw_tn_x3_transpose_read_matches_fp64(dev, M, NX):
     """dW[128, NX] += dY^T X with both operands token-major (LDS transpose reads), dY as three bf16 planes: ragged
     last K-tile, empty trailing splits, accumulation into a non-zero dW; the operands are asymmetric and random so

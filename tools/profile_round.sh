@@ -16,6 +16,9 @@ print(len(rows)//2)
 PY
 )
 python tools/pmc_summary.py gpurun_out/pmc_vit_$R $NV 256 $O/vit_b256 "" 0 > $O/vit_summary_tail.txt 2>&1
+bash tools/pmc_collect.sh upd_$R tools/bench_update.py --iters 1 > $O/pmc_upd.log 2>&1
+python tools/pmc_by_name.py gpurun_out/pmc_upd_$R 2.0 > $O/update_pmc_by_kernel.txt 2>&1
+rm -rf gpurun_out/pmc_trunk_$R gpurun_out/pmc_vit_$R gpurun_out/pmc_upd_$R    # raw counter CSVs: ~80 MB, summaries are kept
 cp $O/trunk_b256_hbm_traffic.json profiles/trunk_b256_hbm_traffic.json
 cp $O/vit_b256_hbm_traffic.json profiles/vit_b256_hbm_traffic.json
 python bench.py --steps 2 --warmup 1 > $O/bench_line.json 2> $O/bench.err
@@ -27,4 +30,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof
 cd $GRAFT_REPO_ROOT
 find $O/prof_bench -name "*kernel_stats.csv" -exec cp {} $O/bench_kernel_stats.csv \;
 rm -rf $O/prof_bench
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_upd -o u -- python $GRAFT_REPO_ROOT/tools/bench_update.py --iters 3 > $GRAFT_REPO_ROOT/$O/update_under_rocprof.log 2>&1
+cd $GRAFT_REPO_ROOT
+(echo "# rocprofv3 --kernel-trace --stats of tools/bench_update.py --iters 3 (4 updates of 4 epochs incl. warm-up + one 128-step rollout): non-encoder kernels, total ms / calls / avg us / min us"; python tools/stats_noconv.py $(find $O/prof_upd -name "*kernel_stats.csv" | head -1) 0.5; grep "conv_igemm8.*true>" $(find $O/prof_upd -name "*kernel_stats.csv" | head -1) | cut -c1-160; tail -1 $O/update_under_rocprof.log) > $O/update_kernel_stats.txt
+rm -rf $O/prof_upd
+python tools/bench_update.py --iters 3 | tail -1 > $O/update_ms.txt
 tail -c 600 $O/bench_line.json; echo; tail -3 $O/trunk_summary_tail.txt; tail -2 $O/vit_summary_tail.txt
