@@ -62,7 +62,6 @@ __device__ __forceinline__ int pw_off(int row, int chunk) {   // 128-B rows, XOR
 template <bool TWO, bool RES, int N2, bool PL>
 __global__ __launch_bounds__(256, 1) void conv1x1_pair_kernel(PairArgs p) {
     static_assert(!PL || N2 == 128, "pooled variant: the layer-1 -> layer-2 boundary");
-    constexpr int PP = NY * 2 + 16;            // pooled staging pitch
     constexpr int W0_BYTES = (TWO ? 2 : 1) * NY * 128;
     constexpr int W2_BYTES = 4 * N2 * 128;
     constexpr int FN2 = N2 / 32;
@@ -73,7 +72,6 @@ __global__ __launch_bounds__(256, 1) void conv1x1_pair_kernel(PairArgs p) {
     float* sBz = sBy + NY;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     unsigned char* stg = sm + W0_BYTES + W2_BYTES + (NY + N2) * 4 + wave * STG;
-    unsigned char* pstg = sm + W0_BYTES + W2_BYTES + (NY + N2) * 4 + 4 * STG + wave * (8 * PP);   // PL only
     const int px = lane & 31, h = lane >> 5;
     // tile row r -> pixel offset from the tile's first pixel
     auto roff = [&](int r) -> int {
@@ -172,6 +170,13 @@ __global__ __launch_bounds__(256, 1) void conv1x1_pair_kernel(PairArgs p) {
 
         // ---- epilogue 1 (two 128-channel halves) + the packed operand of GEMM 2 ----
         uint4 P[8][2];
+        long pool_base = 0;                       // PL: first pooled pixel of the tile (8 pooled pixels = a 2 x 4 block)
+        if constexpr (PL) {
+            const int tt = __builtin_amdgcn_readfirstlane(t);
+            const int tpr = p.W / 8, tpi = (p.H / 4) * tpr;
+            const int b = tt / tpi, rem = tt - b * tpi, ty = rem / tpr, tx = rem - ty * tpr;
+            pool_base = ((long)b * (p.H / 2) + 2 * ty) * (p.W / 2) + 4 * tx;
+        }
         auto half_epilogue = [&](auto hfc) {
             constexpr int hf = decltype(hfc)::value;   // compile-time: keeps rc[] / acc[] / P[] in registers
             if constexpr (RES) {
@@ -200,20 +205,32 @@ __global__ __launch_bounds__(256, 1) void conv1x1_pair_kernel(PairArgs p) {
                     o.y = ec_pack2(v2, v3);
                     *slot = o;
                     pk[2 * g] = o.x; pk[2 * g + 1] = o.y;
-                    if constexpr (PL) {   // mean of the ROUNDED bf16 values of the window, as avgpool2 on y would compute
-                        float q0 = ec_lo(o.x), q1 = ec_hi(o.x), q2 = ec_lo(o.y), q3 = ec_hi(o.y);
-                        q0 += pq_xor1(q0); q1 += pq_xor1(q1); q2 += pq_xor1(q2); q3 += pq_xor1(q3);
-                        q0 += pq_xor2(q0); q1 += pq_xor2(q1); q2 += pq_xor2(q2); q3 += pq_xor2(q3);
-                        if ((lane & 3) == 0) {
-                            uint2 po;
-                            po.x = ec_pack2(0.25f * q0, 0.25f * q1);
-                            po.y = ec_pack2(0.25f * q2, 0.25f * q3);
-                            *reinterpret_cast<uint2*>(pstg + (px >> 2) * PP + (hf * 128 + lc) * 2) = po;
-                        }
-                    }
                 }
                 P[j][0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
                 P[j][1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+            }
+            if constexpr (PL) {
+                // AvgPool2d(2)(y) from the staged half: window w = tile rows 4w..4w+3 (quad order); a lane takes two
+                // (window, 8-channel chunk) items: mean of the ROUNDED bf16 values, summed as (r0 + r1) + (r2 + r3) like
+                // avgpool2_kernel, straight to global memory (was: two DPP adds per value in the epilogue loop + a
+                // staging pass -- ~4x the VALU work of this)
+#pragma unroll
+                for (int it2 = 0; it2 < 2; ++it2) {
+                    const int item = it2 * 64 + lane, w = item >> 4, c = item & 15;
+                    const uint4 r0 = *reinterpret_cast<const uint4*>(stg + (4 * w + 0) * SP + c * 16);
+                    const uint4 r1 = *reinterpret_cast<const uint4*>(stg + (4 * w + 1) * SP + c * 16);
+                    const uint4 r2 = *reinterpret_cast<const uint4*>(stg + (4 * w + 2) * SP + c * 16);
+                    const uint4 r3 = *reinterpret_cast<const uint4*>(stg + (4 * w + 3) * SP + c * 16);
+                    auto avg2 = [](unsigned a, unsigned b, unsigned cc, unsigned d) {
+                        const float lo = 0.25f * ((ec_lo(a) + ec_lo(b)) + (ec_lo(cc) + ec_lo(d)));
+                        const float hi = 0.25f * ((ec_hi(a) + ec_hi(b)) + (ec_hi(cc) + ec_hi(d)));
+                        return ec_pack2(lo, hi);
+                    };
+                    u32x4 po;
+                    po[0] = avg2(r0.x, r1.x, r2.x, r3.x); po[1] = avg2(r0.y, r1.y, r2.y, r3.y);
+                    po[2] = avg2(r0.z, r1.z, r2.z, r3.z); po[3] = avg2(r0.w, r1.w, r2.w, r3.w);
+                    *reinterpret_cast<u32x4*>(p.yp + (pool_base + (w >> 2) * (p.W / 2) + (w & 3)) * NY + hf * 128 + c * 8) = po;
+                }
             }
             if (!PL || p.y) {   // (layer-1 -> layer-2 boundary: nobody reads the full-resolution y -- its consumers are z and y_pooled)
 #pragma unroll
@@ -226,18 +243,6 @@ __global__ __launch_bounds__(256, 1) void conv1x1_pair_kernel(PairArgs p) {
         };
         half_epilogue(std::integral_constant<int, 0>{});
         half_epilogue(std::integral_constant<int, 1>{});
-        if constexpr (PL) {   // 8 pooled pixels x 256 channels leave as 16-B row chunks
-            const int tt = __builtin_amdgcn_readfirstlane(t);
-            const int tpr = p.W / 8, tpi = (p.H / 4) * tpr;
-            const int b = tt / tpi, rem = tt - b * tpi, ty = rem / tpr, tx = rem - ty * tpr;
-            const long pb = ((long)b * (p.H / 2) + 2 * ty) * (p.W / 2) + 4 * tx;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int idx = i * 64 + lane, prow = idx >> 5, c = idx & 31;
-                const u32x4 v = *reinterpret_cast<const u32x4*>(pstg + prow * PP + c * 16);
-                *reinterpret_cast<u32x4*>(p.yp + (pb + (prow >> 2) * (p.W / 2) + (prow & 3)) * NY + c * 8) = v;
-            }
-        }
 
         // ---- GEMM 2, pixel operand straight from registers: z[n][pixel] ----
         f32x16_t acc2[FN2];
@@ -281,8 +286,7 @@ __global__ __launch_bounds__(256, 1) void conv1x1_pair_kernel(PairArgs p) {
 
 template <bool TWO, bool RES, int N2, bool PL = false>
 int launch_pair(const PairArgs& p, hipStream_t s) {
-    constexpr size_t lds = (size_t)(TWO ? 2 : 1) * NY * 128 + 4 * N2 * 128 + (NY + N2) * 4 + 4 * STG +
-                           (PL ? 4 * 8 * (NY * 2 + 16) : 0);
+    constexpr size_t lds = (size_t)(TWO ? 2 : 1) * NY * 128 + 4 * N2 * 128 + (NY + N2) * 4 + 4 * STG;
     static_assert(lds <= 160 * 1024, "LDS budget");
     auto kern = conv1x1_pair_kernel<TWO, RES, N2, PL>;
     static std::atomic<uint64_t> attr_done{0};
