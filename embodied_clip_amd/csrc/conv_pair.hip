@@ -56,6 +56,41 @@ __device__ __forceinline__ int pw_off(int row, int chunk) {   // 128-B rows, XOR
     return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
 
+// Software-pipelined LDS fragment stream for kernels that run ONE wave per SIMD: left to the compiler every MFMA gets its
+// own `ds_read_b128 -> s_waitcnt lgkmcnt(0)` in front (it sinks operand reads to their use), i.e. the full LDS latency per
+// MFMA with nothing to hide it.  Here the reads are inline asm, LEAD steps ahead of the MFMA that consumes them, and the
+// waits carry the fragment register so the MFMA cannot be scheduled above its wait (LDS returns data in order:
+// "lgkmcnt(n)" = all but the newest n have arrived; compiler-generated LDS traffic in between only makes the waits
+// conservative).  addr(i): LDS byte address (VGPR) and immediate offset of step i; mma(i, frag) consumes it.
+template <int I, int LEAD, class AddrFn>
+__device__ __forceinline__ void lsm_issue(u32x4 (&ring)[LEAD], AddrFn& addr) {
+    const auto a = addr(std::integral_constant<int, I>{});
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[I % LEAD]) : "v"(a.first), "n"(decltype(a.second)::value));
+}
+template <int I, int NSTEP, int LEAD, class AddrFn, class MmaFn>
+__device__ __forceinline__ void lsm_step(u32x4 (&ring)[LEAD], AddrFn& addr, MmaFn& mma) {
+    if constexpr (I < NSTEP) {
+        constexpr int after = (LEAD - 1 < NSTEP - 1 - I) ? LEAD - 1 : NSTEP - 1 - I;   // reads issued after read I
+        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(ring[I % LEAD]) : "n"(after));
+        mma(std::integral_constant<int, I>{}, ring[I % LEAD]);
+        if constexpr (I + LEAD < NSTEP) lsm_issue<I + LEAD, LEAD>(ring, addr);
+        lsm_step<I + 1, NSTEP, LEAD>(ring, addr, mma);
+    }
+}
+template <int I, int N, int LEAD, class AddrFn>
+__device__ __forceinline__ void lsm_prologue(u32x4 (&ring)[LEAD], AddrFn& addr) {
+    if constexpr (I < N) {
+        lsm_issue<I, LEAD>(ring, addr);
+        lsm_prologue<I + 1, N, LEAD>(ring, addr);
+    }
+}
+template <int NSTEP, int LEAD, class AddrFn, class MmaFn>
+__device__ __forceinline__ void lds_stream_mfma(AddrFn addr, MmaFn mma) {
+    u32x4 ring[LEAD];
+    lsm_prologue<0, (LEAD < NSTEP ? LEAD : NSTEP), LEAD>(ring, addr);
+    lsm_step<0, NSTEP, LEAD>(ring, addr, mma);
+}
+
 // PL: the tile is a 4 x 8 block of pixels in quad order (row r of the tile = window (r >> 2), corner r & 3), so a 2 x 2
 // pooling window is one lane quad and the kernel also emits AvgPool2d(2)(y) -- the input of the next layer's
 // downsample path -- instead of a separate pooling pass over y.
@@ -73,6 +108,12 @@ __global__ __launch_bounds__(256, 1) void conv1x1_pair_kernel(PairArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     unsigned char* stg = sm + W0_BYTES + W2_BYTES + (NY + N2) * 4 + wave * STG;
     const int px = lane & 31, h = lane >> 5;
+    // LDS byte address of the weight images and this lane's per-K-step fragment offsets (pw_off(32 j + px, 2 ks + h) minus
+    // the 32 j rows, which go into the instruction's immediate offset: the swizzle term only depends on px)
+    const unsigned w_lds = (unsigned)(unsigned long)(__attribute__((address_space(3))) unsigned char*)sW0;
+    unsigned wk_off[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) wk_off[ks] = (unsigned)pw_off(px, 2 * ks + h);
     // tile row r -> pixel offset from the tile's first pixel
     auto roff = [&](int r) -> int {
         if (!PL) return r;
@@ -150,22 +191,19 @@ __global__ __launch_bounds__(256, 1) void conv1x1_pair_kernel(PairArgs p) {
         for (int j = 0; j < 8; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const s16x8_t wf = *reinterpret_cast<const s16x8_t*>(sW0 + pw_off(32 * j + px, 2 * ks + h));
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf),
-                                                                 __builtin_bit_cast(bf16x8_t, a0c[ks]), acc[j], 0, 0, 0);
-            }
-            if (TWO) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const s16x8_t wf = *reinterpret_cast<const s16x8_t*>(sW0 + NY * 128 + pw_off(32 * j + px, 2 * ks + h));
+        {   // step i = (ks, operand 0 | 1, j): weight fragment W[32 j + px][16 ks + 8 h ..] of sW0 (+ the second matrix)
+            constexpr int PER_KS = (TWO ? 16 : 8);
+            lds_stream_mfma<4 * PER_KS, 8>(
+                [&](auto ic) {
+                    constexpr int i = decltype(ic)::value, ks = i / PER_KS, r = i % PER_KS, j = r & 7, second = r >> 3;
+                    return std::pair<unsigned, std::integral_constant<int, second * (NY * 128) + j * 4096>>{w_lds + wk_off[ks], {}};
+                },
+                [&](auto ic, const u32x4& wf) {
+                    constexpr int i = decltype(ic)::value, ks = i / PER_KS, r = i % PER_KS, j = r & 7, second = r >> 3;
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf),
-                                                                     __builtin_bit_cast(bf16x8_t, a1c[ks]), acc[j], 0, 0, 0);
-                }
-            }
+                                                                     __builtin_bit_cast(bf16x8_t, second ? a1c[TWO ? ks : 0] : a0c[ks]),
+                                                                     acc[j], 0, 0, 0);
+                });
         }
 
         // ---- epilogue 1 (two 128-channel halves) + the packed operand of GEMM 2 ----
@@ -250,15 +288,16 @@ __global__ __launch_bounds__(256, 1) void conv1x1_pair_kernel(PairArgs p) {
         for (int n = 0; n < FN2; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc2[n][r] = 0.f;
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const bf16x8_t bop = __builtin_bit_cast(bf16x8_t, P[s >> 1][s & 1]);
-#pragma unroll
-            for (int n = 0; n < FN2; ++n) {
-                const s16x8_t wf = *reinterpret_cast<const s16x8_t*>(sW2 + (s >> 2) * (N2 * 128) + pw_off(32 * n + px, 2 * (s & 3) + h));
-                acc2[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf), bop, acc2[n], 0, 0, 0);
-            }
-        }
+        lds_stream_mfma<16 * FN2, 8>(
+            [&](auto ic) {
+                constexpr int i = decltype(ic)::value, st = i / FN2, n = i % FN2;
+                return std::pair<unsigned, std::integral_constant<int, (st >> 2) * (N2 * 128) + n * 4096>>{w_lds + (unsigned)W0_BYTES + wk_off[st & 3], {}};
+            },
+            [&](auto ic, const u32x4& wf) {
+                constexpr int i = decltype(ic)::value, st = i / FN2, n = i % FN2;
+                acc2[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf),
+                                                                  __builtin_bit_cast(bf16x8_t, P[st >> 1][st & 1]), acc2[n], 0, 0, 0);
+            });
         // ---- epilogue 2 ----
         constexpr int ZP = N2 * 2 + 16;            // staging pitch of a z row
         constexpr int ZC = N2 / 8;                 // 16-B chunks per z row
