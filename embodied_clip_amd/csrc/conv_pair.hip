@@ -425,11 +425,19 @@ __global__ __launch_bounds__(256, 1) void conv1x1_pair512_kernel(Pair2Args p) {
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-        [&]<int... I>(std::integer_sequence<int, I...>) {
-            ((acc[I >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, w0f[I >> 3][I & 7]),
-                                                                    __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const s16x8_t*>(at + px * SP2 + (16 * (I & 7) + 8 * h) * 2)),
-                                                                    acc[I >> 3], 0, 0, 0)), ...);
-        }(std::make_integer_sequence<int, 32>{});
+        {   // pixel-operand fragments as a software-pipelined LDS stream (lds_stream_mfma): one read per K-step, 4 MFMAs on it
+            const unsigned a_lds = (unsigned)(unsigned long)(__attribute__((address_space(3))) const unsigned char*)at +
+                                   (unsigned)(px * SP2 + 16 * h);
+            lds_stream_mfma<8, 6>(
+                [&](auto ic) { return std::pair<unsigned, std::integral_constant<int, 32 * decltype(ic)::value>>{a_lds, {}}; },
+                [&](auto ic, const u32x4& avr) {
+                    constexpr int ks = decltype(ic)::value;
+                    const bf16x8_t av = __builtin_bit_cast(bf16x8_t, avr);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, w0f[j][ks]), av, acc[j], 0, 0, 0);
+                });
+        }
 
         // ---- epilogue 1: residual slice -> staging; bias + residual + ReLU -> bf16 -> staging AND shared y tile ----
         [&]<int... I>(std::integer_sequence<int, I...>) {
@@ -464,11 +472,16 @@ __global__ __launch_bounds__(256, 1) void conv1x1_pair512_kernel(Pair2Args p) {
         f32x16_t acc2;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
-        [&]<int... I>(std::integer_sequence<int, I...>) {
-            ((acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                  __builtin_bit_cast(bf16x8_t, w2f[I]),
-                  __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const s16x8_t*>(yt + px * YP2 + (16 * I + 8 * h) * 2)), acc2, 0, 0, 0)), ...);
-        }(std::make_integer_sequence<int, 32>{});
+        {
+            const unsigned y_lds = (unsigned)(unsigned long)(__attribute__((address_space(3))) const unsigned char*)yt +
+                                   (unsigned)(px * YP2 + 16 * h);
+            lds_stream_mfma<32, 8>(
+                [&](auto ic) { return std::pair<unsigned, std::integral_constant<int, 32 * decltype(ic)::value>>{y_lds, {}}; },
+                [&](auto ic, const u32x4& yv) {
+                    constexpr int I = decltype(ic)::value;
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, w2f[I]), __builtin_bit_cast(bf16x8_t, yv), acc2, 0, 0, 0);
+                });
+        }
         // ---- epilogue 2: 32 pixels x 32 channels -> 64-B row pieces ----
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -590,15 +603,19 @@ __global__ __launch_bounds__(256, 1) void conv1x1_regw_kernel(RegwArgs p) {
         for (int j = 0; j < FJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-        [&]<int... I>(std::integer_sequence<int, I...>) {
-            (([&] {
-                 const bf16x8_t av = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const s16x8_t*>(at + px * AP + (16 * I + 8 * h) * 2));
+        {   // pixel-operand fragments as a software-pipelined LDS stream (see lds_stream_mfma): K-step I = 16 channels
+            const unsigned a_lds = (unsigned)(unsigned long)(__attribute__((address_space(3))) const unsigned char*)at +
+                                   (unsigned)(px * AP + 16 * h);
+            lds_stream_mfma<KS, (KS < 6 ? KS : 6)>(
+                [&](auto ic) { return std::pair<unsigned, std::integral_constant<int, 32 * decltype(ic)::value>>{a_lds, {}}; },
+                [&](auto ic, const u32x4& avr) {
+                    constexpr int I = decltype(ic)::value;
+                    const bf16x8_t av = __builtin_bit_cast(bf16x8_t, avr);
 #pragma unroll
-                 for (int j = 0; j < FJ; ++j)
-                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf[j][I]), av, acc[j], 0, 0, 0);
-             }()),
-             ...);
-        }(std::make_integer_sequence<int, KS>{});
+                    for (int j = 0; j < FJ; ++j)
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf[j][I]), av, acc[j], 0, 0, 0);
+                });
+        }
 
         if constexpr (RES) {
             [&]<int... I>(std::integer_sequence<int, I...>) {
