@@ -83,6 +83,35 @@ __device__ __forceinline__ float dpp_quad_xor2(float v) {   // lane ^ 2 within a
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
 }
 
+// Software-pipelined fragment stream (cf. conv_pair.hip lds_stream_mfma): the compiler sinks every LDS operand read to
+// just before the MFMAs that use it (ds_read x4 -> s_waitcnt -> mfma x4 per k-step, the LDS latency exposed four times per
+// K-tile).  Here the reads are inline asm, one k-step (G fragments) ahead of the MFMAs; the waits carry the fragment
+// registers so that the MFMAs cannot move above them.  LDS returns data in order: lgkmcnt(n) = all but the newest n arrived.
+template <int R>
+struct FragRing { u32x4_t f[R]; };
+template <int I, int R, class AddrFn>
+__device__ __forceinline__ void fr_issue(FragRing<R>& ring, AddrFn& addr) {
+    asm volatile("ds_read_b128 %0, %1" : "=v"(ring.f[I % R]) : "v"(addr(std::integral_constant<int, I>{})));
+}
+template <int I, int R>
+__device__ __forceinline__ void fr_tie(FragRing<R>& ring) { asm volatile("" : "+v"(ring.f[I % R])); }   // orders the consumers after the wait
+template <int K, int NK, int G, int R, class AddrFn, class MmaFn>
+__device__ __forceinline__ void fr_step(FragRing<R>& ring, AddrFn& addr, MmaFn& mma) {
+    if constexpr (K < NK) {
+        // issue the next k-step's fragments first, then wait for this k-step's (G reads may stay in flight)
+        if constexpr (K + 1 < NK) {
+            [&]<int... Q>(std::integer_sequence<int, Q...>) { (fr_issue<(K + 1) * G + Q, R>(ring, addr), ...); }
+            (std::make_integer_sequence<int, G>{});
+        }
+        constexpr int after = (K + 1 < NK) ? G : 0;
+        static_assert(G <= 15, "lgkmcnt is a 4-bit counter");
+        asm volatile("s_waitcnt lgkmcnt(%0)" : : "n"(after));
+        [&]<int... Q>(std::integer_sequence<int, Q...>) { (fr_tie<K * G + Q, R>(ring), ...); }(std::make_integer_sequence<int, G>{});
+        mma(std::integral_constant<int, K>{}, ring);
+        fr_step<K + 1, NK, G, R>(ring, addr, mma);
+    }
+}
+
 // MV = rows of the tile that are real output rows (tile stride in M); MV < BM pads the tile (see dispatch_tile:
 // 196-of-224-row tiles make every RN50 layer's tile count a multiple of the CU count).
 template <int BM, int BN, int WM, int WN, int KS, bool POOL, bool PF, int MV>
@@ -231,23 +260,47 @@ __global__ __launch_bounds__(WM * WN * 64, (BM > 192) ? 2 : ((WM * WN == 8) ? 4 
         // SWAPPED operands: D[n][m] = sum_k W[n][k] * A[m][k].  In the 32x32 C/D layout a lane then owns
         // ONE pixel (col = lane&31) and channels (r&3) + 8*(r>>2) + 4*(lane>>5): every 4 accumulator
         // registers are 4 consecutive channels -> 8-byte packed epilogue traffic.
+        if constexpr (PF || FM + FN > 4) {   // no registers to spare for the fragment ring there (the residual-prefetching variants spill: 68 -> 104 us)
 #pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-            s16x8_t af[FM], bfr[FN];
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                s16x8_t af[FM], bfr[FN];
+                const int c = ks * 2 + fhalf;
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+                    af[i] = *reinterpret_cast<const s16x8_t*>(sa + lds_off(wm * TM + i * 32 + frow, c));
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    bfr[j] = *reinterpret_cast<const s16x8_t*>(sb + lds_off(wn * TN + j * 32 + frow, c));
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8_t, bfr[j]), __builtin_bit_cast(bf16x8_t, af[i]), acc[i][j], 0, 0, 0);
+            }
+            return;
+        }
+        constexpr int G = FM + FN, NKS = BK / 16, R = 2 * G;
+        const unsigned lds_a = (unsigned)(unsigned long)(lds_void_t*)sa, lds_b = (unsigned)(unsigned long)(lds_void_t*)sb;
+        FragRing<R> ring;
+        auto addr = [&](auto ic) -> unsigned {                 // fragment q of k-step ks: q < FM -> A rows, else B rows
+            constexpr int idx = decltype(ic)::value, ks = idx / G, q = idx % G;
             const int c = ks * 2 + fhalf;
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-                af[i] = *reinterpret_cast<const s16x8_t*>(sa + lds_off(wm * TM + i * 32 + frow, c));
-#pragma unroll
-            for (int j = 0; j < FN; ++j)
-                bfr[j] = *reinterpret_cast<const s16x8_t*>(sb + lds_off(wn * TN + j * 32 + frow, c));
+            if constexpr (q < FM) return lds_a + (unsigned)lds_off(wm * TM + q * 32 + frow, c);
+            else return lds_b + (unsigned)lds_off(wn * TN + (q - FM) * 32 + frow, c);
+        };
+        auto mma = [&](auto kc, FragRing<R>& rg) {
+            constexpr int ks = decltype(kc)::value;
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int j = 0; j < FN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                        __builtin_bit_cast(bf16x8_t, bfr[j]), __builtin_bit_cast(bf16x8_t, af[i]), acc[i][j], 0, 0, 0);
-        }
+                        __builtin_bit_cast(bf16x8_t, rg.f[(ks * G + FM + j) % R]), __builtin_bit_cast(bf16x8_t, rg.f[(ks * G + i) % R]),
+                        acc[i][j], 0, 0, 0);
+        };
+        [&]<int... Q>(std::integer_sequence<int, Q...>) { (fr_issue<Q, R>(ring, addr), ...); }(std::make_integer_sequence<int, G>{});
+        fr_step<0, NKS, G, R>(ring, addr, mma);
     };
 
     // K pipeline: LDS-DMA of tile t+1 into LDS[(t+1)&1] is in flight while tile t computes from LDS[t&1];
