@@ -1,5 +1,7 @@
 #!/bin/bash
-# same-box A/B of two builds of the library: ab_libs/old.so vs ab_libs/new.so (alternating runs); BENCH_ARGS="--actors 64"
+# same-box A/B of two builds of the library (alternating runs); BENCH_ARGS="--actors 64" for other operating points.
+# Prepare: mkdir ab_libs; build the reference state -> cp embodied_clip_amd/lib/libec_amd.so ab_libs/old.so; build the
+# candidate -> cp ... ab_libs/new.so (ab_libs/ is git-ignored and travels with the gpurun snapshot); restore the library after.
 cd $GRAFT_REPO_ROOT
 for r in 1 2 3; do
   for v in old new; do
