@@ -69,6 +69,41 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const uint16_t* __restri
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
     constexpr int MAXV = 16;               // D <= 1024
+    if (MODE == 0 && (D & 255) == 0) {
+        // a lane owns D / 64 CONSECUTIVE channels (a multiple of 4): 8-byte bf16 loads / stores and 16-byte fp32 loads of
+        // gamma / beta instead of D / 64 two-byte accesses per lane (the kernel is latency-bound: 18.8 -> ~10 us per call)
+        const int per4 = D / 256;          // groups of 4 channels per lane
+        const uint16_t* p = in + row * D + lane * (4 * per4);
+        float x[MAXV];
+        float s = 0.f;
+#pragma unroll
+        for (int g = 0; g < MAXV / 4; ++g)
+            if (g < per4) {
+                const uint2 u = *reinterpret_cast<const uint2*>(p + 4 * g);
+                x[4 * g + 0] = ec_lo(u.x); x[4 * g + 1] = ec_hi(u.x); x[4 * g + 2] = ec_lo(u.y); x[4 * g + 3] = ec_hi(u.y);
+                s += (x[4 * g + 0] + x[4 * g + 1]) + (x[4 * g + 2] + x[4 * g + 3]);
+            }
+        const float mean = wave_sum_f(s) / (float)D;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i)
+            if (i < 4 * per4) { const float d0 = x[i] - mean; q += d0 * d0; }
+        const float rstd = rsqrtf(wave_sum_f(q) / (float)D + eps);
+        uint16_t* o = out + row * D + lane * (4 * per4);
+        const float* gp = gamma + lane * (4 * per4);
+        const float* bp = beta + lane * (4 * per4);
+#pragma unroll
+        for (int g = 0; g < MAXV / 4; ++g)
+            if (g < per4) {
+                const float4 ga = *reinterpret_cast<const float4*>(gp + 4 * g);
+                const float4 be = *reinterpret_cast<const float4*>(bp + 4 * g);
+                uint2 u;
+                u.x = ec_pack2((x[4 * g + 0] - mean) * rstd * ga.x + be.x, (x[4 * g + 1] - mean) * rstd * ga.y + be.y);
+                u.y = ec_pack2((x[4 * g + 2] - mean) * rstd * ga.z + be.z, (x[4 * g + 3] - mean) * rstd * ga.w + be.w);
+                *reinterpret_cast<uint2*>(o + 4 * g) = u;
+            }
+        return;
+    }
     float v[MAXV];
     const int per = D / 64;
     float s = 0.f;
