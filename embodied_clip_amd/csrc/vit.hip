@@ -143,36 +143,38 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const uint16_t* __restri
 // qkv bf16 [B*L, 3*D] (q | k | v, head h at columns h*64..), out bf16 [B*L, D].
 //   S^T[key][query] = K Q^T   (swapped operands: a lane owns ONE query column and 32 of the 64 keys,
 //                              so the softmax is in-lane + one exchange with the other half-wave)
-//   O[query][d]     = P V     (P stays in registers; V^T is read from LDS with the matching k-permutation)
+//   O[query][d]     = P V     (P stays in registers; V is read from LDS through ds_read_b64_tr_b16 with the matching k-permutation)
 __global__ __launch_bounds__(64) void mha_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int L,
                                                  int D, int heads, float scale) {
-    __shared__ __attribute__((aligned(16))) uint16_t sq[64 * 72];    // [token][d], row pitch 72 (144 B)
-    __shared__ __attribute__((aligned(16))) uint16_t sk[64 * 72];
-    __shared__ __attribute__((aligned(16))) uint16_t svt[64 * 72];   // V^T: [d][token]
+    __shared__ __attribute__((aligned(16))) uint16_t sv[64 * 72];    // V: [token][d], row pitch 72 (144 B)
     const int lane = threadIdx.x;
     const int b = blockIdx.x / heads, h = blockIdx.x % heads;
     const uint16_t* base = qkv + (long)b * L * 3 * D + h * 64;
-    // stage Q, K (row-major) and V (transposed); tokens >= L are zero
+    const int fr = lane & 31, fh = lane >> 5;
+    // Q and K fragments straight from global memory in MFMA operand layout (lane = token fr / fr + 32, 8 consecutive
+    // channels per k-step: one 16-byte load each, all 16 issued before the first use); only V goes through LDS, because
+    // the PV step needs it transposed.  9 KB of LDS per workgroup instead of 27: every (frame, head) wave of a CU is
+    // resident at once.  Tokens >= L are zero.
+    uint4 qg[4][2], kg[4][2];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int t = a * 32 + fr;
+            qg[ks][a] = kg[ks][a] = make_uint4(0, 0, 0, 0);
+            if (t < L) {
+                const uint16_t* r = base + (long)t * 3 * D + ks * 16 + fh * 8;
+                qg[ks][a] = *reinterpret_cast<const uint4*>(r);
+                kg[ks][a] = *reinterpret_cast<const uint4*>(r + D);
+            }
+        }
     for (int e = lane; e < 64 * 8; e += 64) {
         const int t = e >> 3, c = e & 7;
-        uint4 q4 = make_uint4(0, 0, 0, 0), k4 = q4, v4 = q4;
-        if (t < L) {
-            const uint16_t* r = base + (long)t * 3 * D + c * 8;
-            q4 = *reinterpret_cast<const uint4*>(r);
-            k4 = *reinterpret_cast<const uint4*>(r + D);
-            v4 = *reinterpret_cast<const uint4*>(r + 2 * D);
-        }
-        *reinterpret_cast<uint4*>(sq + t * 72 + c * 8) = q4;
-        *reinterpret_cast<uint4*>(sk + t * 72 + c * 8) = k4;
-        const uint32_t vv[4] = {v4.x, v4.y, v4.z, v4.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            svt[(c * 8 + 2 * j) * 72 + t] = (uint16_t)(vv[j] & 0xffffu);
-            svt[(c * 8 + 2 * j + 1) * 72 + t] = (uint16_t)(vv[j] >> 16);
-        }
+        uint4 v4 = make_uint4(0, 0, 0, 0);
+        if (t < L) v4 = *reinterpret_cast<const uint4*>(base + (long)t * 3 * D + 2 * D + c * 8);
+        *reinterpret_cast<uint4*>(sv + t * 72 + c * 8) = v4;     // row-major: the PV step turns it with ds_read_b64_tr_b16
     }
     __syncthreads();
-    const int fr = lane & 31, fh = lane >> 5;
     // ---- S^T = K Q^T : acc[kf][qf], rows = keys, cols = queries ----
     f32x16_t st[2][2];
 #pragma unroll
@@ -183,18 +185,12 @@ __global__ __launch_bounds__(64) void mha_kernel(const uint16_t* __restrict__ qk
             for (int r = 0; r < 16; ++r) st[a][c][r] = 0.f;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-        s16x8_t kfv[2], qfv[2];
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            kfv[a] = *reinterpret_cast<const s16x8_t*>(sk + (a * 32 + fr) * 72 + ks * 16 + fh * 8);
-            qfv[a] = *reinterpret_cast<const s16x8_t*>(sq + (a * 32 + fr) * 72 + ks * 16 + fh * 8);
-        }
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int c = 0; c < 2; ++c)
-                st[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, kfv[a]),
-                                                                  __builtin_bit_cast(bf16x8_t, qfv[c]), st[a][c], 0, 0, 0);
+                st[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, kg[ks][a]),
+                                                                  __builtin_bit_cast(bf16x8_t, qg[ks][c]), st[a][c], 0, 0, 0);
     }
     // ---- softmax over keys, per query column (query = qf*32 + fr) ----
     // this lane's keys: kf*32 + (r&3) + 8*(r>>2) + 4*fh
@@ -244,11 +240,17 @@ __global__ __launch_bounds__(64) void mha_kernel(const uint16_t* __restrict__ qk
         s16x8_t vf[2];
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
-            const uint16_t* vrow = svt + (d * 32 + fr) * 72 + 16 * s + 4 * fh;
-            const uint2 lo = *reinterpret_cast<const uint2*>(vrow);
-            const uint2 hi = *reinterpret_cast<const uint2*>(vrow + 8);
-            const uint4 u = make_uint4(lo.x, lo.y, hi.x, hi.y);
-            vf[d] = __builtin_bit_cast(s16x8_t, u);
+            // transpose read: a 16-lane group reads V[4 keys][16 channels] and lane t receives channel t's 4 keys
+            // (lane t supplies the address of row t >> 2, channels 4 (t & 3)..): keys 16 s + 4 fh + 0..3 and + 8
+            typedef short s16x4_t __attribute__((ext_vector_type(4)));
+            typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
+            const int t16 = lane & 15;
+            const uint16_t* vblk = sv + (16 * s + 4 * fh + (t16 >> 2)) * 72 + d * 32 + (fr & 16) + (t16 & 3) * 4;
+#if defined(__HIP_DEVICE_COMPILE__)
+            const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)vblk);
+            const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(vblk + 8 * 72));
+            vf[d] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#endif
         }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
