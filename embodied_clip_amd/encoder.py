@@ -134,13 +134,22 @@ class RN50Trunk:
     """
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], device="cuda", input_resolution: int = 224,
-                 chunk: int = 0):
+                 chunk: int = 0, weights_from: Optional["RN50Trunk"] = None):
+        """``weights_from``: another trunk on the same device whose packed weight tensors this handle borrows (the
+        engine's per-slice handles then read ONE copy of the 76 MB of weights: one L2 / Infinity-Cache footprint for
+        the two concurrent launches instead of two)."""
         self.lib = _lib.load()
         self.device = torch.device(device)
-        (width, layers), stem_w, w, bias = pack_rn50(state_dict)
-        self.stem_w = stem_w.to(self.device)
-        self.w = w.to(self.device)
-        self.bias = bias.to(self.device)
+        if weights_from is not None:
+            assert weights_from.device == self.device and weights_from.input_resolution == input_resolution
+            width, layers = weights_from._arch
+            self.stem_w, self.w, self.bias = weights_from.stem_w, weights_from.w, weights_from.bias
+        else:
+            (width, layers), stem_w, w, bias = pack_rn50(state_dict)
+            self.stem_w = stem_w.to(self.device)
+            self.w = w.to(self.device)
+            self.bias = bias.to(self.device)
+        self._arch = (width, layers)
         self.input_resolution = input_resolution
         self.chunk = chunk
         h = C.c_void_p()
@@ -296,11 +305,18 @@ def pack_vit(sd: Dict[str, torch.Tensor], drop_last: int = 1):
 class ViTEmbedder:
     """Frozen CLIP VisionTransformer run as [U] ``ClipViTEmbedder`` does: tokens after all but the last block."""
 
-    def __init__(self, state_dict, device="cuda", heads: int = 12, input_resolution: int = 224, drop_last: int = 1):
+    def __init__(self, state_dict, device="cuda", heads: int = 12, input_resolution: int = 224, drop_last: int = 1,
+                 weights_from: Optional["ViTEmbedder"] = None):
+        """``weights_from``: another embedder on the same device whose packed weights this handle borrows (see RN50Trunk)."""
         self.lib = _lib.load()
         self.device = torch.device(device)
-        cfg, w, f = pack_vit(state_dict, drop_last)
-        self.w, self.f = w.to(self.device), f.to(self.device)
+        if weights_from is not None:
+            assert weights_from.device == self.device
+            cfg, self.w, self.f = weights_from._cfg, weights_from.w, weights_from.f
+        else:
+            cfg, w, f = pack_vit(state_dict, drop_last)
+            self.w, self.f = w.to(self.device), f.to(self.device)
+        self._cfg = cfg
         self.D, self.input_resolution = cfg["width"], input_resolution
         h = C.c_void_p()
         _lib.check(self.lib.ec_vit_create(C.byref(h), cfg["width"], cfg["layers_run"], heads, cfg["patch"],

@@ -116,7 +116,9 @@ class Worker:
         pools = [None] * ns
         if encoder == "rn50":
             sd = encoder_sd if encoder_sd is not None else syn.rn50_visual_state_dict(0)
-            encs = [RN50Trunk(sd, device=d, chunk=encoder_chunk) for _ in range(ns)]
+            share = os.environ.get("EC_SHARE_WEIGHTS", "1") != "0"
+            encs = [RN50Trunk(sd, device=d, chunk=encoder_chunk)]
+            encs += [RN50Trunk(sd, device=d, chunk=encoder_chunk, weights_from=encs[0] if share else None) for _ in range(ns - 1)]
             self.S, self.C = encs[0].out_spatial, encs[0].out_channels
             if self.zeroshot:
                 pools = [AttentionPool(sd, device=d) for _ in range(ns)]
@@ -126,7 +128,9 @@ class Worker:
             # BASELINE config 3 (builder-defined fusion, SURVEY.md §8d note): ClipViTEmbedder tokens, CLS dropped,
             # the 49 patch tokens are the 7x7 channels-last "feature map" [n,49,768] of the goal encoder
             sd = encoder_sd if encoder_sd is not None else syn.vit_visual_state_dict(0)
-            encs = [ViTEmbedder(sd, device=d) for _ in range(ns)]
+            share = os.environ.get("EC_SHARE_WEIGHTS", "1") != "0"
+            encs = [ViTEmbedder(sd, device=d)]
+            encs += [ViTEmbedder(sd, device=d, weights_from=encs[0] if share else None) for _ in range(ns - 1)]
             self.S, self.C = 7, encs[0].D
         else:
             raise ValueError(encoder)
