@@ -242,9 +242,16 @@ class AttentionPool:
     """[U] CLIP ``AttentionPool2d`` on bf16 NHWC trunk features (the ``clip_pool`` the reference detaches at
     primitive_probing/generate_data/thor_image_features.py:62 and calls at :112)."""
 
-    def __init__(self, state_dict: Dict[str, torch.Tensor], device="cuda", num_heads: int = 32, prefix="attnpool."):
+    def __init__(self, state_dict: Dict[str, torch.Tensor], device="cuda", num_heads: int = 32, prefix="attnpool.",
+                 weights_from: Optional["AttentionPool"] = None):
         self.lib = _lib.load()
         self.device = torch.device(device)
+        if weights_from is not None:      # borrow the other instance's device tensors (own workspace): see RN50Trunk
+            o = weights_from
+            assert o.device == self.device
+            self.pos, self.wq, self.bq, self.wkv, self.bkv, self.wc, self.bc = o.pos, o.wq, o.bq, o.wkv, o.bkv, o.wc, o.bc
+            self.C, self.out_dim, self.heads, self._ws = o.C, o.out_dim, o.heads, None
+            return
         sd = {k[len("visual."):] if k.startswith("visual.") else k: v for k, v in state_dict.items()}
         g = lambda n: sd[prefix + n].detach().float()
         bf = lambda t: t.to(torch.bfloat16).contiguous().to(self.device)

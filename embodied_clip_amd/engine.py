@@ -121,7 +121,8 @@ class Worker:
             encs += [RN50Trunk(sd, device=d, chunk=encoder_chunk, weights_from=encs[0] if share else None) for _ in range(ns - 1)]
             self.S, self.C = encs[0].out_spatial, encs[0].out_channels
             if self.zeroshot:
-                pools = [AttentionPool(sd, device=d) for _ in range(ns)]
+                pools = [AttentionPool(sd, device=d)]
+                pools += [AttentionPool(sd, device=d, weights_from=pools[0] if share else None) for _ in range(ns - 1)]
                 self.trunk_S, self.trunk_C = self.S, self.C
                 self.S, self.C = 1, pools[0].out_dim
         elif encoder == "vit":
