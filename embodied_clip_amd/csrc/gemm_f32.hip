@@ -40,6 +40,7 @@ struct GemmArgs {
     const float* rowscale;      // [M]
     int relu, accumulate, splitk;
     int ntn;
+    long part_stride;           // > 0: split-K slice z writes its partial sums to C + z * part_stride (no atomics)
 };
 
 // element (r, k) of an operand lives at src[r*sr + k*sk]; tile rows r0.., k0..
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
     const int nk_per = (nk_total + p.splitk - 1) / p.splitk;
     const int kt0 = blockIdx.z * nk_per;
     const int kt1 = min(nk_total, kt0 + nk_per);
-    if (kt0 >= kt1) return;
+    if (kt0 >= kt1 && p.part_stride == 0) return;   // (parts mode: an empty slice still writes its zeros)
 
     const bool a_kc = (p.sak == 1), b_kc = (p.sbk == 1);
     float ra[BM / 8], rb[BN / 8];
@@ -237,7 +238,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
                 if (p.rowscale) v *= p.rowscale[row];
                 const long o = (long)row * p.ldc + col;
                 if (p.dmask) v = (p.dmask[o] > 0.f) ? v : 0.f;
-                if (p.splitk > 1) atomicAdd(p.C + o, v);
+                if (p.part_stride > 0) p.C[(long)blockIdx.z * p.part_stride + o] = v;
+                else if (p.splitk > 1) atomicAdd(p.C + o, v);
                 else if (p.accumulate) p.C[o] += v;
                 else p.C[o] = v;
             }
@@ -387,7 +389,7 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(GemmArgs p) {
     const int nk_per = (nk_total + p.splitk - 1) / p.splitk;
     const int kt0 = blockIdx.z * nk_per;
     const int kt1 = min(nk_total, kt0 + nk_per);
-    if (kt0 >= kt1) return;
+    if (kt0 >= kt1 && p.part_stride == 0) return;   // (parts mode: an empty slice still writes its zeros)
 
     XStage<BM, ABF, AKC> sa;
     XStage<BN, BBF, BKC> sb;
@@ -470,7 +472,8 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(GemmArgs p) {
                 if (p.rowscale) v *= p.rowscale[row];
                 const long o = (long)row * p.ldc + col;
                 if (p.dmask) v = (p.dmask[o] > 0.f) ? v : 0.f;
-                if (p.splitk > 1) atomicAdd(p.C + o, v);
+                if (p.part_stride > 0) p.C[(long)blockIdx.z * p.part_stride + o] = v;
+                else if (p.splitk > 1) atomicAdd(p.C + o, v);
                 else if (p.accumulate) p.C[o] += v;
                 else p.C[o] = v;
             }
@@ -555,6 +558,7 @@ extern "C" int ec_gemm_f32(const void* A, const void* B, float* Cp, int M, int N
     a.b_bf16 = (flags & EC_GEMM_B_BF16) ? 1 : 0;
     a.relu = (flags & EC_GEMM_RELU) ? 1 : 0;
     a.accumulate = (flags & EC_GEMM_ACCUMULATE) ? 1 : 0;
+    const bool parts = (flags & EC_GEMM_SPLIT_PARTS) != 0;
     a.bias = bias; a.gbias = gbias; a.gidx = gidx; a.group = group;
     a.dmask = dmask; a.rowscale = rowscale;
     a.splitk = splitk < 1 ? 1 : splitk;
@@ -562,7 +566,16 @@ extern "C" int ec_gemm_f32(const void* A, const void* B, float* Cp, int M, int N
     if (a.splitk > nk_total) a.splitk = nk_total;
     // split-K partials are atomically ADDED into C: that is only a GEMM when C already holds the value to accumulate
     // onto (ACCUMULATE) and no nonlinearity sits between the partial sums
-    if (a.splitk > 1 && (a.relu || !a.accumulate)) return EC_ERR_ARG;
+    // ... or every slice writes its own partial matrix (EC_GEMM_SPLIT_PARTS: C holds splitk matrices of M x ldc, summed by
+    // the consumer in a fixed order -- deterministic, used by the act step); no epilogue that needs the full sum
+    if (parts) {
+        if (a.relu || a.accumulate || dmask || rowscale || gbias) return EC_ERR_ARG;
+        if (a.splitk != splitk) return EC_ERR_ARG;          // the caller sized C for exactly `splitk` parts
+        a.part_stride = (long)M * ldc;
+    } else {
+        a.part_stride = 0;
+        if (a.splitk > 1 && (a.relu || !a.accumulate)) return EC_ERR_ARG;
+    }
     // vector loads need the contiguous axis to be unit stride, the other stride a multiple of 4
     // elements and a 16-byte (8-byte for bf16) aligned base
     auto vec_ok = [](const void* p, long s_contig, long s_other, int bf16) {
@@ -581,6 +594,10 @@ extern "C" int ec_gemm_f32(const void* A, const void* B, float* Cp, int M, int N
         // N <= 32 (the compressor / combiner 128 -> 32 convs over T*N*49 rows and their input gradients): a 128-wide
         // tile would spend 3/4 of its MFMAs on padding columns
         if (N <= 32 && (long)((M + 255) / 256) * a.splitk >= 512) return launch_x3<256, 32, 4, 1>(a, s);
+        // split-K parts (the act step, which runs beside the other slice's encoder): keep the workgroup count near the
+        // un-split launch -- the slices only shorten the K walk; flooding the CUs with small workgroups slows the encoder
+        // (measured at 256 actors: 784 workgroups -1.3 % end to end).  The tile shape does not change the summation order.
+        if (a.part_stride > 0 && (long)((M + 63) / 64) * ((N + 63) / 64) * a.splitk > 400) return launch_x3<128, 128, 2, 2>(a, s);
         if (blocks128 < 512) return launch_x3<64, 64, 2, 2>(a, s);
         return launch_x3<128, 128, 2, 2>(a, s);
     }

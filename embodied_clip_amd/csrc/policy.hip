@@ -101,7 +101,8 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(const float* __restri
                                                           const float* __restrict__ bhh, const float* __restrict__ hprev,
                                                           const float* __restrict__ mask, float* __restrict__ hout,
                                                           float* __restrict__ gates, float* __restrict__ hn_s,
-                                                          float* __restrict__ hp_s, int N, int H) {
+                                                          float* __restrict__ hp_s, int N, int H, int gi_parts,
+                                                          long gi_pstride) {
     extern __shared__ __attribute__((aligned(16))) float gsm[];
     // K is walked in chunks of KC = 256 (whole K when H is not a multiple of 256): the two tiles then take 66.5 KB, so two
     // workgroups fit a CU and the recurrences of the two actor slices (two HIP streams) overlap instead of queueing
@@ -188,12 +189,17 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(const float* __restri
                 part[(3 * 32 + a_) * 32 + c];
     }
     const float* gir = gi + (long)n * 3 * H;
+    float gi_r = gir[j], gi_z = gir[H + j], gi_n = gir[2 * H + j];
+    for (int p2 = 1; p2 < gi_parts; ++p2) {        // act step: the input projection arrives as split-K parts (fixed order)
+        const float* gp2 = gir + p2 * gi_pstride;
+        gi_r += gp2[j]; gi_z += gp2[H + j]; gi_n += gp2[2 * H + j];
+    }
     const float m = mask[n];
     const float hp = m * hprev[(long)n * H + j];
-    const float r = sigmoidf_(gir[j] + m * gh[0] + bhh[j]);
-    const float z = sigmoidf_(gir[H + j] + m * gh[1] + bhh[H + j]);
+    const float r = sigmoidf_(gi_r + m * gh[0] + bhh[j]);
+    const float z = sigmoidf_(gi_z + m * gh[1] + bhh[H + j]);
     const float hn = m * gh[2] + bhh[2 * H + j];
-    const float nn = tanhf(gir[2 * H + j] + r * hn);
+    const float nn = tanhf(gi_n + r * hn);
     const long o = (long)n * H + j;
     hout[o] = (1.f - z) * nn + z * hp;
     if (gates) {
@@ -293,6 +299,7 @@ __global__ __launch_bounds__(256) void fuse_goal_kernel(const void* __restrict__
 // back to the wave's LDS image (bias + ReLU applied) as the next stage's A operand -- and to HBM, because the backward
 // needs c2 and m1.  No workgroup barrier after the weights are staged.  Geometry fixed to the reference's
 // (128, 32, 128, 32); other widths keep the GEMM path.
+constexpr int ACT_PARTS = 4, ACT_MAX_ROWS = 16384;   // act step: split-K factor of the two long-K GEMMs / row limit of that path
 constexpr int TL_P128 = 132, TL_P32 = 36;     // LDS row pitches (floats): 16-byte slots of 16 consecutive rows differ
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void tail_fwd_kernel(const float* __restrict__ c1, const float* __restrict__ W2,
@@ -301,7 +308,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                                                          const int* __restrict__ goal, int S, int num_goals,
                                                          const float* __restrict__ W4, const float* __restrict__ b4,
                                                          float* __restrict__ c2, float* __restrict__ m1,
-                                                         float* __restrict__ x4, long M) {
+                                                         float* __restrict__ x4, long M, int c1_parts, long c1_pstride,
+                                                         const float* __restrict__ b1) {
     extern __shared__ __attribute__((aligned(16))) float tsm[];
     float* sW2 = tsm;                            // [32][132]
     float* sW3 = sW2 + 32 * TL_P128;             // [128][36]
@@ -338,6 +346,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int idx = lane + 64 * q, r = idx >> 5, c4 = idx & 31;
         st[q] = *reinterpret_cast<const f32x4_t*>(c1 + min(tile * 32 + r, M - 1) * 128 + c4 * 4);
     }
+    // act step (c1_parts > 1): c1 arrives as split-K partial sums WITHOUT bias / ReLU -- folded here in a fixed order
+    // (unconditional code on both paths: with one part the loop below does nothing and b1v stays 0 / relu off)
+    const bool fold = c1_parts > 1;
+    f32x4_t b1v = {0.f, 0.f, 0.f, 0.f};
+    if (fold) b1v = *reinterpret_cast<const f32x4_t*>(b1 + (lane & 31) * 4);
+    auto fold_parts = [&](f32x4_t v, long row, int c4) {
+        for (int p2 = 1; p2 < c1_parts; ++p2) v += *reinterpret_cast<const f32x4_t*>(c1 + p2 * c1_pstride + row * 128 + c4 * 4);
+        v += b1v;
+        v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+        return v;
+    };
+    if (fold) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int idx = lane + 64 * q, r = idx >> 5, c4 = idx & 31;
+            st[q] = fold_parts(st[q], min(tile * 32 + r, M - 1), c4);
+        }
+    }
     for (; tile < ntiles; tile += tstep) {
         const long m0 = tile * 32;
         const long grp_base = m0 / S;                               // wave-uniform
@@ -352,6 +378,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int q = 0; q < 16; ++q) {                             // next tile: in flight under this tile's three contractions
             const int idx = lane + 64 * q, r = idx >> 5, c4 = idx & 31;
             st[q] = *reinterpret_cast<const f32x4_t*>(c1 + min((tile + tstep) * 32 + r, M - 1) * 128 + c4 * 4);
+        }
+        if (fold) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int idx = lane + 64 * q, r = idx >> 5, c4 = idx & 31;
+                st[q] = fold_parts(st[q], min((tile + tstep) * 32 + r, M - 1), c4);
+            }
         }
         // ---- c2 = relu(c1 W2^T + b2) ----
         f32x16_t acc;
@@ -761,12 +794,14 @@ Ws layout(const ec_policy* h, int T, int N, bool bwd) {
     Ws w; size_t o = 0;
     auto take = [&](size_t n) { size_t r = o; o += al(n * 4) / 4; return r; };
     w.E1 = take((size_t)c.num_goals * c.comb_hid);
-    w.c1 = take(M49 * c.compress_hid);
+    // small launches (the act step): room for the split-K partial matrices of c1 and gi (see ec_policy_forward)
+    const size_t parts = (M49 > 0 && M49 <= (size_t)ACT_MAX_ROWS) ? ACT_PARTS : 1;
+    w.c1 = take(M49 * c.compress_hid * parts);
     w.c2 = take(M49 * c.compress_out);
     w.m1 = take(M49 * c.comb_hid);
     w.x4 = take(M49 * c.comb_out);
     w.x = take(B * flat);
-    w.gi = take(B * 3 * H);
+    w.gi = take(B * 3 * H * parts);
     w.gh = take((size_t)N * 3 * H);
     w.gates = take(B * 3 * H);
     w.hn = take(B * H);
@@ -920,6 +955,22 @@ extern "C" int ec_policy_forward(const ec_policy_t* h, const float* params, cons
     const float* P = params;
     auto W = [&](int i) { return P + h->off[i]; };
     int* goal32 = (int*)(ws + w.goal32);
+    // Act-step path: a workspace too small for a backward pass means inference only, so c1 need not be materialised
+    // and the two long-K, small-M GEMMs (compressor conv 1, GRU input projection) run as ACT_PARTS K slices whose
+    // partial matrices the consuming kernels fold in a fixed order.
+    const bool infer_only = ws_bytes < layout(h, T, N, true).end * 4;
+    const bool small = !c.fusion && M49 > 0 && M49 <= ACT_MAX_ROWS;            // (== the condition in layout())
+    const size_t tail_lds_ = ((size_t)2 * 32 * TL_P128 + 128 * TL_P32 + (size_t)c.num_goals * 128 + 64 +
+                              4 * (size_t)(32 * TL_P128 + 32 * TL_P32)) * sizeof(float);
+    static const int act_parts_on = [] { const char* e = getenv("EC_ACT_SPLIT"); return e ? atoi(e) : 1; }();
+    static const int tail_fused_ = [] { const char* e = getenv("EC_TAIL_FUSED"); return e ? atoi(e) : 1; }();
+    static const int gru_fused_ = [] { const char* e = getenv("EC_GRU_FUSED"); return e ? atoi(e) : 1; }();
+    const bool tail_ok = tail_fused_ && c.compress_hid == 128 && c.compress_out == 32 && c.comb_hid == 128 &&
+                         c.comb_out == 32 && tail_lds_ <= 160 * 1024;
+    const size_t gru_lds_ = std::max((size_t)2 * 32 * (((H & 255) == 0 ? 256 : H) + 4) * sizeof(float), (size_t)4 * 32 * 32 * sizeof(float));
+    const bool step_ok = gru_fused_ && (H % 32) == 0 && gru_lds_ <= 160 * 1024;
+    const bool act_split = act_parts_on && infer_only && small && tail_ok && (C % 32) == 0 && C / 32 >= ACT_PARTS;
+    const bool gi_split = act_parts_on && infer_only && small && step_ok && (flat + 31) / 32 >= ACT_PARTS;
     hipLaunchKernelGGL(goal_to_i32_kernel, dim3((B + 255) / 256), dim3(256), 0, s, (const long long*)goal, goal32, B);
     if (c.fusion) {
         if (!h->goal_table) return EC_ERR_ARG;
@@ -940,6 +991,13 @@ extern "C" int ec_policy_forward(const ec_policy_t* h, const float* params, cons
     if (c1_pp && feat_bf16 && c.compress_hid % 128 == 0 && C % 64 == 0 && M49 >= 256 * 128) {
         RC(ec_split3_bf16(W(P_W1), ws + w.w1p, c.compress_hid, C, stream));
         RC(ec_gemm_bf16a_x3(feat, ws + w.w1p, W(P_B1), ws + w.c1, M49, c.compress_hid, C, 1 /* EC_ACT_RELU */, stream));
+    } else if (act_split) {
+        // act step: K = C is long and M small (196 workgroups walking 64 K-steps each): four K slices write four
+        // partial matrices, tail_fwd_kernel folds them (+ b1, ReLU) in a fixed order -- no atomics, bit-reproducible,
+        // and independent of how the actors are sliced
+        RC(ec_gemm_f32(feat, W(P_W1), ws + w.c1, M49, c.compress_hid, C, C, 1, 1, C, c.compress_hid,
+                       EC_GEMM_SPLIT_PARTS | (feat_bf16 ? EC_GEMM_A_BF16 : 0), nullptr, nullptr, nullptr, 0, nullptr, nullptr,
+                       ACT_PARTS, stream));
     } else
     RC(ec_gemm_f32(feat, W(P_W1), ws + w.c1, M49, c.compress_hid, C, C, 1, 1, C, c.compress_hid,
                    EC_GEMM_RELU | (feat_bf16 ? EC_GEMM_A_BF16 : 0), W(P_B1), nullptr, nullptr, 0, nullptr, nullptr, 1,
@@ -958,7 +1016,8 @@ extern "C" int ec_policy_forward(const ec_policy_t* h, const float* params, cons
         long nwg = (ntiles + 3) / 4;
         if (nwg > 512) nwg = 512;
         hipLaunchKernelGGL(tail_fwd_kernel, dim3((unsigned)nwg), dim3(256), tail_lds, s, ws + w.c1, W(P_W2), W(P_B2), W(P_W3), cat,
-                           ws + w.E1, goal32, S, c.num_goals, W(P_W4), W(P_B4), ws + w.c2, ws + w.m1, ws + w.x4, (long)M49);
+                           ws + w.E1, goal32, S, c.num_goals, W(P_W4), W(P_B4), ws + w.c2, ws + w.m1, ws + w.x4, (long)M49,
+                           act_split ? ACT_PARTS : 1, (long)M49 * c.compress_hid, W(P_B1));
     } else {
     RC(ec_gemm_f32(ws + w.c1, W(P_W2), ws + w.c2, M49, c.compress_out, c.compress_hid, c.compress_hid, 1, 1,
                    c.compress_hid, c.compress_out, EC_GEMM_RELU, W(P_B2), nullptr, nullptr, 0, nullptr, nullptr, 1,
@@ -976,9 +1035,11 @@ extern "C" int ec_policy_forward(const ec_policy_t* h, const float* params, cons
     }
     }   // !fusion
     // GRU: input projection for all T at once, then the sequential recurrence
-    // (no split-K here: the act step stays free of float atomics, so rollouts are bit-reproducible)
-    RC(ec_gemm_f32(ws + w.x, W(P_WIH), ws + w.gi, B, 3 * H, flat, flat, 1, 1, flat, 3 * H, 0, W(P_BIH), nullptr,
-                   nullptr, 0, nullptr, nullptr, 1, stream));
+    // (split-K only as separate partial matrices folded by the step kernel: the act step stays free of float atomics, so
+    //  rollouts are bit-reproducible)
+    RC(ec_gemm_f32(ws + w.x, W(P_WIH), ws + w.gi, B, 3 * H, flat, flat, 1, 1, flat, 3 * H,
+                   gi_split ? EC_GEMM_SPLIT_PARTS : 0, W(P_BIH), nullptr, nullptr, 0, nullptr, nullptr, gi_split ? ACT_PARTS : 1,
+                   stream));
     // EC_GRU_FUSED (default 1): one fused launch per step where the geometry allows (H % 32 == 0, tiles fit the LDS)
     static const int gru_fused = [] { const char* e = getenv("EC_GRU_FUSED"); return e ? atoi(e) : 1; }();
     size_t gru_lds = (size_t)2 * 32 * (((H & 255) == 0 ? 256 : H) + 4) * sizeof(float);      // operand tiles (K chunk) ...
@@ -996,7 +1057,8 @@ extern "C" int ec_policy_forward(const ec_policy_t* h, const float* params, cons
         if (fused_step) {
             hipLaunchKernelGGL(gru_step_fwd_kernel, dim3((unsigned)(H / 8), (unsigned)((N + 31) / 32)), dim3(256), gru_lds, s,
                                ws + w.gi + o3, W(P_WHH), W(P_BHH), hprev, masks + (size_t)t * N, ws + w.hs + o1,
-                               ws + w.gates + o3, ws + w.hn + o1, ws + w.hp + o1, N, H);
+                               ws + w.gates + o3, ws + w.hn + o1, ws + w.hp + o1, N, H, gi_split ? ACT_PARTS : 1,
+                               (long)B * 3 * H);
             continue;
         }
         RC(ec_gemm_f32(hprev, W(P_WHH), ws + w.gh, N, 3 * H, H, H, 1, 1, H, 3 * H, 0, nullptr, nullptr, nullptr, 0,

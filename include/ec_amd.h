@@ -197,7 +197,9 @@ enum {
     EC_GEMM_A_BF16 = 1,      /* A stored as bf16 (the frozen CLIP features) */
     EC_GEMM_B_BF16 = 2,
     EC_GEMM_RELU = 4,
-    EC_GEMM_ACCUMULATE = 8   /* C += ... */
+    EC_GEMM_ACCUMULATE = 8,  /* C += ... */
+    EC_GEMM_SPLIT_PARTS = 16 /* splitk > 1: slice z writes its partial sums to C + z * M * ldc (no atomics; the caller folds
+                              * the parts in a fixed order); bias goes into part 0; no ReLU / mask / row scale */
 };
 int ec_gemm_f32(const void* A, const void* B, float* C, int M, int N, int K, long sam, long sak, long sbk, long sbn,
                 int ldc, int flags, const float* bias, const float* gbias, const int* gidx, int group,
