@@ -46,6 +46,36 @@ def test_gemm_f32_nt(dev, M, N, K):
     assert _rel(c, ref) < 2e-5, _rel(c, ref)
 
 
+@pytest.mark.parametrize("M,N,K,bf16a", [(6272, 128, 2048, True), (128, 1536, 1568, False), (70, 96, 160, False)])
+def test_gemm_split_parts_sum_to_the_full_product(dev, M, N, K, bf16a):
+    """EC_GEMM_SPLIT_PARTS (flag 16): K slices write separate partial matrices (bias in part 0, no atomics); their sum in
+    slice order is the GEMM, and two runs are bit-identical (the act step's compressor / GRU input projections).
+    K = 160 with 4 parts leaves the last slice short; invalid combinations are refused."""
+    from embodied_clip_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M + N)
+    a = torch.randn(M, K, generator=g)
+    a = a.abs().to(torch.bfloat16) if bf16a else a
+    w = torch.randn(N, K, generator=g) * K ** -0.5
+    b = torch.randn(N, generator=g)
+    ref = a.double() @ w.double().t() + b.double()
+    ad, wd, bd = a.to(dev), w.to(dev), b.to(dev)
+    parts = torch.full((4, M, N), float("nan"), device=dev)
+    flags = 16 | (1 if bf16a else 0)
+    for _ in range(2):
+        _gemm(dev, ad, wd, parts, M, N, K, K, 1, 1, K, N, flags=flags, bias=bd, splitk=4)
+        if _ == 0:
+            first = parts.clone()
+    assert torch.equal(first, parts)
+    assert torch.isfinite(parts).all()
+    tot = ((parts[0] + parts[1]) + parts[2]) + parts[3]
+    assert (tot.cpu().double() - ref).abs().max() < 3e-5 * max(1.0, ref.abs().max().item())
+    # ReLU / ACCUMULATE cannot be combined with parts
+    rc = lib.ec_gemm_f32(ad.data_ptr(), wd.data_ptr(), parts.data_ptr(), M, N, K, K, 1, 1, K, N, flags | 4, bd.data_ptr(),
+                         None, None, 0, None, None, 4, 0)
+    assert rc != 0
+
+
 def test_gemm_f32_bf16_operands_nn_tn_epilogues(dev):
     g = torch.Generator().manual_seed(5)
     M, N, K = 333, 200, 260
