@@ -29,6 +29,7 @@ SIGNATURES = {
     "ec_gemm_bf16a_x3": (c_int, [c_void_p] * 4 + [C.c_long, c_int, c_int, c_int, c_void_p]),
     "ec_dw_tn_x3_splits": (c_int, [C.c_long, c_int]),
     "ec_dw_tn_x3": (c_int, [c_void_p] * 4 + [C.c_long, c_int, c_void_p]),
+    "ec_conv_set_min_tiles": (c_int, [c_int]),
     "ec_stem_conv1": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
     "ec_avgpool2_bf16": (c_int, [c_void_p] * 2 + [c_int] * 4 + [c_void_p]),
     "ec_nhwc_bf16_to_nchw_f32": (c_int, [c_void_p] * 2 + [c_int] * 3 + [c_void_p]),

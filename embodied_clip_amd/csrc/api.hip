@@ -1,7 +1,7 @@
 // Library-level entry points of the C-ABI (include/ec_amd.h).
 #include "common.h"
 
-extern "C" int ec_version(void) { return 206; }   // 0.2.6 (bump whenever a kernel or a launch plan changes: keys profiles/*traffic*.json)
+extern "C" int ec_version(void) { return 207; }   // 0.2.7 (bump whenever a kernel or a launch plan changes: keys profiles/*traffic*.json)
 
 extern "C" const char* ec_strerror(int code) {
     switch (code) {

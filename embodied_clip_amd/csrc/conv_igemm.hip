@@ -53,6 +53,7 @@ namespace {
 
 constexpr int BK = 64;              // K-tile (bf16 elements) = 128 B rows in LDS
 constexpr int ROW_BYTES = BK * 2;   // 128
+std::atomic<int> g_conv8_min_tiles{150};   // see dispatch_tile / ec_conv_set_min_tiles
 
 struct ConvArgs {
     const uint16_t* in;
@@ -901,7 +902,12 @@ int dispatch_tile(const ConvArgs& a, hipStream_t s) {
         // measured (B = 256, tools/bench_big.sh): wins on the 3x3 convs with Cout % 256 == 0 once there are enough
         // 256-row tiles to occupy most CUs; loses on N = 128, on the short launches of 7x7 maps and ties on 1x1
         const long nt256 = (long)((a.M + 255) / 256) * (a.Cout / 256), nt128 = (long)((a.M + 255) / 256) * (a.Cout / 128);
-        static const long mint = [] { const char* e = getenv("EC_CONV8_MIN_TILES"); return e ? atol(e) : 150L; }();
+        // fewest 256-row tiles for the 8-wave kernel: 150 for a launch that has the chip to itself; a caller that keeps two
+        // launches in flight (the engine's two slices) lowers it with ec_conv_set_min_tiles: alone a 50-100-tile launch of the
+        // 8-wave kernel is 30-40 % slower than the 4-wave kernel, but it leaves the other launch 150-200 whole CUs instead of
+        // sharing all of them (same-box A/B at 2 x 128 frames: +0.4..1.5 % RN50, +3.5 % ViT-B/32 end to end; at 2 x 64: -1.1 %)
+        static const long mint_env = [] { const char* e = getenv("EC_CONV8_MIN_TILES"); return e ? atol(e) : 0L; }();
+        const long mint = mint_env > 0 ? mint_env : (long)g_conv8_min_tiles.load(std::memory_order_relaxed);
         if (KS == 3 && a.Cout % 256 == 0 && nt256 >= mint) return launch8<256, KS, POOL>(a, s);
         // long-K 1x1 convs (tools/bench_l4.sh, B = 256): 1024->2048 @7x7 83.7 -> 70.5 us, 1024->512 @14x14 82.9 -> 70.5,
         // 1024->256 @14x14 40.6 -> 37.0 with 256-wide tiles; 2048->512 @7x7 46.4 -> 40.1 with 128-wide tiles (196 of them);
@@ -968,6 +974,12 @@ int ec_conv3x3_narrow(const void* in, const void* w, const float* bias, void* ou
 // conv_pair.hip: register-weight kernel for a few bandwidth-bound 1x1 shapes (EC_ERR_SHAPE = not handled)
 int ec_conv1x1_regw(const void* a, const void* w, const float* bias, const void* res, void* y, long M, int K, int N, int act,
                     hipStream_t s);
+
+// Tuning hook for callers that keep several encoder launches in flight (see dispatch_tile); n <= 0 restores the default.
+extern "C" int ec_conv_set_min_tiles(int n) {
+    g_conv8_min_tiles.store(n > 0 ? n : 150, std::memory_order_relaxed);
+    return EC_OK;
+}
 
 extern "C" int ec_debug_stamps(unsigned long long* host_dst, int n) {   // profiling only
     if (!host_dst || n <= 0 || n > 2048) return EC_ERR_ARG;

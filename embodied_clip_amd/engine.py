@@ -192,6 +192,9 @@ class Worker:
                 sl.k = 0
             self.slices.append(sl)
         self.encode_frames = n                    # frames per timed encoder launch
+        # two launches in flight with >= 128 frames each: the 8-wave conv kernel from 50 tiles on (ec_conv_set_min_tiles)
+        self._conv8_min_tiles = 50 if (ns == 2 and n >= 128) else 0
+        self.lib.ec_conv_set_min_tiles(self._conv8_min_tiles)
         self.seed = seed + 7919 * rank
         self.total_steps = 0
         self.iter = 0
@@ -282,6 +285,7 @@ class Worker:
     @_lib.on_device
     def collect_rollout(self):
         T = self.T
+        self.lib.ec_conv_set_min_tiles(self._conv8_min_tiles)   # (process-wide tuning value: re-assert it for this worker)
         self.h_start.copy_(self.h)
         self._fork()
         for t in range(T):

@@ -84,6 +84,11 @@ int ec_clip_resize_table(int H, int W, int n_px, int* host_table, size_t n_ints)
 int ec_clip_resize_crop_u8(const uint8_t* frames_u8, const int* table_dev, int table_max_rows, uint8_t* out_u8, int B,
                            int H, int W, int n_px, ec_stream_t stream);
 
+/* Tuning hook (no reference counterpart): fewest 256-row output tiles for which a conv / GEMM launch takes the 8-wave
+ * kernel (default 150).  A caller that keeps two encoder launches in flight on two streams (engine.Worker with 128-frame
+ * slices) sets 50: each launch then occupies fewer, fully used CUs.  n <= 0 restores the default.  Process-wide. */
+int ec_conv_set_min_tiles(int n);
+
 /* profiling only: copies the s_memtime stamps the 8-wave conv kernel records under EC_CONV_ABLATE & 32 */
 int ec_debug_stamps(unsigned long long* host_dst, int n);
 int ec_gemm_bf16(const void* A, const void* W, const float* bias, const void* res, void* out,
