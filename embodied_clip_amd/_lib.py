@@ -29,7 +29,6 @@ SIGNATURES = {
     "ec_gemm_bf16a_x3": (c_int, [c_void_p] * 4 + [C.c_long, c_int, c_int, c_int, c_void_p]),
     "ec_dw_tn_x3_splits": (c_int, [C.c_long, c_int]),
     "ec_dw_tn_x3": (c_int, [c_void_p] * 4 + [C.c_long, c_int, c_void_p]),
-    "ec_conv_set_min_tiles": (c_int, [c_int]),
     "ec_stem_conv1": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
     "ec_avgpool2_bf16": (c_int, [c_void_p] * 2 + [c_int] * 4 + [c_void_p]),
     "ec_nhwc_bf16_to_nchw_f32": (c_int, [c_void_p] * 2 + [c_int] * 3 + [c_void_p]),
@@ -43,6 +42,7 @@ SIGNATURES = {
     "ec_rn50_forward": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p, c_int, c_void_p]),
     "ec_rn50_num_ops": (c_int, [c_void_p]),
     "ec_rn50_plan_hash": (C.c_uint64, [c_void_p]),
+    "ec_rn50_set_conv8_min_tiles": (c_int, [c_void_p, c_int]),
     "ec_text_create": (c_int, [C.POINTER(c_void_p), c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p,
                                c_size_t]),
     "ec_text_destroy": (None, [c_void_p]),
@@ -66,7 +66,7 @@ SIGNATURES = {
     "ec_policy_param_offset": (c_int, [c_void_p, c_int, C.POINTER(c_size_t), C.POINTER(c_size_t)]),
     "ec_policy_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int, c_int]),
     "ec_policy_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
-                                  c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+                                  c_void_p, c_size_t, c_int, c_void_p, c_void_p, c_void_p]),
     "ec_policy_set_goal_table": (c_int, [c_void_p, c_void_p]),
     "ec_policy_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_size_t,
                                    c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -78,6 +78,8 @@ SIGNATURES = {
                               c_size_t]),
     "ec_vit_destroy": (None, [c_void_p]),
     "ec_vit_tokens": (c_int, [c_void_p]),
+    "ec_vit_set_conv8_min_tiles": (c_int, [c_void_p, c_int]),
+    "ec_vit_plan_hash": (C.c_uint64, [c_void_p]),
     "ec_vit_workspace_bytes": (c_size_t, [c_void_p, c_int]),
     "ec_vit_forward": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
     "ec_bf16_to_f32": (c_int, [c_void_p, c_void_p, C.c_long, C.c_long, C.c_long, c_void_p]),

@@ -32,8 +32,7 @@ def load_checkpoint_state_dict(path: str) -> Dict[str, torch.Tensor]:
     try:
         return dict(torch.jit.load(path, map_location="cpu").eval().state_dict())
     except RuntimeError:
-        obj = torch.load(path, map_location="cpu")          # weights_only: a dict of tensors
-        return dict(obj.state_dict() if hasattr(obj, "state_dict") else obj)
+        return dict(torch.load(path, map_location="cpu", weights_only=True))   # a dict of tensors, nothing unpickled beyond that
 
 
 def visual_state_dict(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:

@@ -57,16 +57,39 @@ static inline int ec_ilog2(int v) {
     return l;
 }
 
-// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is PER DEVICE: one flag bit per device ordinal, set the first time a
-// kernel is launched on that device (thread-safe; two racing threads both set the attribute, which is idempotent).
-static inline bool ec_attr_needed(std::atomic<uint64_t>& done) {
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is PER DEVICE: one flag bit per device ordinal.  Usage:
+//     if (auto g = ec_attr_needed(done)) { hipFuncSetAttribute(...); }
+// The guard publishes the device's bit when it goes out of scope, i.e. AFTER the attribute call has returned: a second
+// thread on the same device either sees the bit (the attribute is in force) or sets the attribute itself (idempotent) --
+// it can never skip the call and launch with the old LDS limit.
+struct ec_attr_guard {
+    std::atomic<uint64_t>* a;
+    uint64_t bit;
+    explicit operator bool() const { return a != nullptr; }
+    ec_attr_guard(std::atomic<uint64_t>* a_, uint64_t b_) : a(a_), bit(b_) {}
+    ec_attr_guard(const ec_attr_guard&) = delete;
+    ec_attr_guard& operator=(const ec_attr_guard&) = delete;
+    ~ec_attr_guard() { if (a) a->fetch_or(bit, std::memory_order_release); }
+};
+static inline ec_attr_guard ec_attr_needed(std::atomic<uint64_t>& done) {
     int d = 0;
     (void)hipGetDevice(&d);
     const uint64_t bit = 1ull << (d & 63);
-    if (done.load(std::memory_order_relaxed) & bit) return false;
-    done.fetch_or(bit, std::memory_order_relaxed);
-    return true;
+    if (done.load(std::memory_order_acquire) & bit) return ec_attr_guard(nullptr, 0);
+    return ec_attr_guard(&done, bit);
 }
+
+// Fewest 256-row output tiles for which the conv / GEMM dispatch takes the 8-wave kernel (conv_igemm.hip dispatch_tile).
+// A property of the encoder HANDLE (ec_rn50_set_conv8_min_tiles / ec_vit_set_conv8_min_tiles), in force for the calling
+// thread while that handle's forward issues its launches; everything else sees the default.
+constexpr int EC_CONV8_MIN_TILES_DEFAULT = 150;
+extern thread_local int ec_tls_conv8_min_tiles;
+struct ec_min_tiles_scope {
+    int prev;
+    explicit ec_min_tiles_scope(int n) : prev(ec_tls_conv8_min_tiles) { ec_tls_conv8_min_tiles = n > 0 ? n : EC_CONV8_MIN_TILES_DEFAULT; }
+    ec_min_tiles_scope(const ec_min_tiles_scope&) = delete;
+    ~ec_min_tiles_scope() { ec_tls_conv8_min_tiles = prev; }
+};
 
 #define EC_CHECK_LAUNCH()                                   \
     do {                                                    \

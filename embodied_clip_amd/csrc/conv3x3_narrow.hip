@@ -369,7 +369,7 @@ int launch_rows(const N3Args& p, hipStream_t s) {
     static_assert((NR * RPB + 4 * PITCH) % 16 == 0, "image alignment");
     auto kern = conv3x3_rows_kernel<CIN, COUT, POOL, NW>;
     static std::atomic<uint64_t> attr_done{0};
-    if (ec_attr_needed(attr_done)) {
+    if (auto attr_g_ = ec_attr_needed(attr_done)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
     const int wgs = (p.ntiles + NW - 1) / NW < 256 ? (p.ntiles + NW - 1) / NW : 256;
@@ -384,7 +384,7 @@ int launch_n3(const N3Args& p, hipStream_t s) {
     static_assert(lds <= 160 * 1024, "LDS budget");
     auto kern = conv3x3_narrow_kernel<CIN, COUT, POOL, NW>;
     static std::atomic<uint64_t> attr_done{0};
-    if (ec_attr_needed(attr_done)) {
+    if (auto attr_g_ = ec_attr_needed(attr_done)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
     const int wgs = (p.ntiles + NW - 1) / NW < 256 ? (p.ntiles + NW - 1) / NW : 256;

@@ -49,11 +49,12 @@
 
 #include "common.h"
 
+thread_local int ec_tls_conv8_min_tiles = EC_CONV8_MIN_TILES_DEFAULT;   // common.h: set per call from the encoder handle
+
 namespace {
 
 constexpr int BK = 64;              // K-tile (bf16 elements) = 128 B rows in LDS
 constexpr int ROW_BYTES = BK * 2;   // 128
-std::atomic<int> g_conv8_min_tiles{150};   // see dispatch_tile / ec_conv_set_min_tiles
 
 struct ConvArgs {
     const uint16_t* in;
@@ -450,7 +451,7 @@ int launch(const ConvArgs& a, hipStream_t s) {
     if (lds < epi) lds = epi;
     auto kern = conv_igemm_kernel<BM, BN, WM, WN, KS, POOL, PF, MV>;
     static std::atomic<uint64_t> attr_done{0};
-    if (ec_attr_needed(attr_done)) {
+    if (auto attr_g_ = ec_attr_needed(attr_done)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(lds_max > epi ? lds_max : epi));
     }
@@ -573,6 +574,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
         g_kb = kt * (BK * 2);
         g_toff = kt * (BK * 2);
         g_tapbit = 1u;
+        if constexpr ((ABL & 64) != 0) g_issue_a = (kt % 9 == 0) || (kt % 9 == 4);   // timing only: the A bytes a halo window would move
         if (X3) {                                       // K-tile kt = (A chunk kt / 3) x (weight plane 2 - kt % 3)
             // LDS: [A chunk 0][A chunk 1][B 0][B 1] -- the A chunk is fetched ONCE (with the K-tile of its first plane)
             // and read by the three K-tiles of the chunk; only the 16-KB plane tiles alternate per K-tile
@@ -597,7 +599,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
         // is an out-of-range offset, which the hardware answers with zeros (no zero page, no pointer select)
 #if defined(__HIP_DEVICE_COMPILE__)
         if constexpr (q < A_IT) {
-            if (!X3 || g_issue_a) {
+            if ((!X3 && !(ABL & 64)) || g_issue_a) {
                 const unsigned off = (a_msk[q] & g_tapbit) ? a_off[q] + (unsigned)g_toff : 0xFFFFFFF0u;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void_t*)(g_sa + q * (LR * ROW_BYTES)), 16, off, 0, 0, 0);
             }
@@ -659,10 +661,35 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
         [&]<int... Q>(std::integer_sequence<int, Q...>) { (glds_piece(std::integral_constant<int, Q>{}), ...); }
         (std::make_integer_sequence<int, A_IT + B_IT>{});
     };
-    // 16 MFMAs (the two k-steps held in fa/fb); with PIECES the wave's LDS-DMA pieces of K-tile (pk -> stage pbuf) are
-    // issued in their shadow, one piece per 2 MFMAs
-    auto mfma16 = [&](bool issue, int pk, int pbuf) {   // `issue` is wave-uniform (scalar branch around each piece)
-        if (issue) glds_begin(pk, pbuf);
+    // Piece offsets are prepared one segment AHEAD of their issue (in the wave's MEM segment, whose VALU work hides
+    // behind the partner wave's MFMAs), so that inside a CMP segment a piece is only {s_mov m0, buffer_load ... lds}:
+    // measured (s_memtime stamps, round 3) a CMP segment is 16 x 32 clk of MFMA issue plus whatever the wave issues
+    // between them -- address VALU, mask selects and, above all, taken branches (a skipped `if (issue)` per MFMA pair
+    // cost ~25-30 clk each: 705-780 clk for a piece-free segment instead of 512).
+    unsigned poff[A_IT + B_IT];
+    auto prep = [&](int kt, int buf) {                  // geometry + per-lane offsets of this wave's pieces of K-tile kt
+        glds_begin(kt, buf);
+#pragma unroll
+        for (int q = 0; q < A_IT; ++q) poff[q] = (a_msk[q] & g_tapbit) ? a_off[q] + (unsigned)g_toff : 0xFFFFFFF0u;
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) poff[A_IT + i] = b_off[i] + (unsigned)g_kb;
+    };
+    auto piece_pre = [&](auto qc) {                     // piece q of the K-tile prepared last
+        [[maybe_unused]] constexpr int q = decltype(qc)::value;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (q < A_IT) {
+            if ((!X3 && !(ABL & 64)) || g_issue_a)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void_t*)(g_sa + q * (LR * ROW_BYTES)), 16, poff[q], 0, 0, 0);
+        } else {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_t*)(g_sb + (q - A_IT) * (LR * ROW_BYTES)), 16, poff[q], 0, 0, 0);
+        }
+#endif
+    };
+    // 16 MFMAs (the two k-steps held in fa/fb); ISSUE: the wave's prepared LDS-DMA pieces go out in their shadow, one
+    // piece per 2 MFMAs.  ISSUE is a template flag: the piece-free instance is 16 MFMAs with nothing between them.
+    auto mfma16 = [&](auto issue_c, auto first_c) {
+        constexpr bool ISSUE = decltype(issue_c)::value;
+        constexpr int P0 = decltype(first_c)::value;       // pieces [0, P0) went out in the preceding MEM segment
         [&]<int... Q>(std::integer_sequence<int, Q...>) {
             ([&] {
                 constexpr int u = Q / (FM * FN), r = Q % (FM * FN), i = r / FN, j = r % FN;
@@ -670,12 +697,21 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                         __builtin_bit_cast(bf16x8_t, fb[u][j]), __builtin_bit_cast(bf16x8_t, fa[u][i]), acc[i][j], 0, 0, 0);
                 constexpr int NP = A_IT + B_IT, EVERY = (2 * FM * FN) / NP;
-                if constexpr (Q % EVERY == EVERY - 1 && Q / EVERY < NP) {
-                    if (issue) glds_piece(std::integral_constant<int, Q / EVERY>{});
+                if constexpr (ISSUE && Q % EVERY == EVERY - 1 && Q / EVERY < NP && Q / EVERY >= P0) {
+                    piece_pre(std::integral_constant<int, Q / EVERY>{});
+#ifdef EC_PIECE_PIN
+                    __builtin_amdgcn_sched_barrier(0);   // keep one piece per EVERY MFMAs (else the scheduler clusters them)
+#endif
                 }
             }(), ...);
         }(std::make_integer_sequence<int, 2 * FM * FN>{});
     };
+    using BT = std::true_type;
+    using BF = std::false_type;
+#ifndef EC_NPM0
+#define EC_NPM0 0
+#endif
+    constexpr int NPM0 = (EC_NPM0 < A_IT + B_IT) ? EC_NPM0 : A_IT + B_IT;   // group 0: pieces issued in MEM0 instead of CMP0
     if (grp) {                                          // stagger: group 1 runs one segment behind group 0 ...
         if (nk > 1 && !(ABL & 1)) issue_all(1, 1);      // ... and uses the slot to fetch K-tile 1 (its "CMP1(-1)")
         if constexpr (!(ABL & 16)) __builtin_amdgcn_s_barrier();
@@ -686,11 +722,22 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
     unsigned long long* dbg_lds = reinterpret_cast<unsigned long long*>(smem + 2 * STAGE) + grp * 256;
     int dbg_i = 0;
     auto stamp = [&]() { if constexpr ((abl & 32) != 0) if (dbg && dbg_i < 256) dbg_lds[dbg_i++] = __builtin_amdgcn_s_memtime(); };
-    for (int kt = 0; kt < nk; ++kt) {
+    // One K-tile of group G; ISSUE: this K-tile's issuing CMP segment (CMP0 for group 0, CMP1 for group 1) carries pieces.
+    // Both are compile-time: each group runs its own copy of the loop (steady state + a piece-free tail), so no segment
+    // contains a branch and the accumulators keep their registers across the whole K walk.
+    auto ktile = [&](int kt, auto gc, auto ic) {
+        constexpr int G = decltype(gc)::value;
+        constexpr bool ISSUE = decltype(ic)::value;
         const int cur = kt & 1;
-        const bool more = (kt + 1) < nk && !(abl & 1);
-        // ---- MEM0 ----
+        // ---- MEM0 ---- (group 0 also prepares the offsets of the pieces it issues in CMP0: K-tile kt+1 -> stage cur^1)
         if constexpr (!(abl & 4)) read_half(kt, I0{});
+        if constexpr (G == 0 && ISSUE) {
+            prep(kt + 1, cur ^ 1);
+            // group 0's first NPM0 pieces go out HERE, beside group 1's piece-carrying CMP1 (the longest segment of the
+            // period): this wave's MEM0 has that much slack, and its own CMP0 becomes (nearly) piece-free
+            [&]<int... Q>(std::integer_sequence<int, Q...>) { (piece_pre(std::integral_constant<int, Q>{}), ...); }
+            (std::make_integer_sequence<int, NPM0>{});
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         stamp();
@@ -698,16 +745,17 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
         stamp();
         // ---- CMP0: group 0 issues its pieces of K-tile kt+1 in the MFMA shadow (s = 4kt+1; waited for at s = 4kt+3) ----
         __builtin_amdgcn_s_setprio(1);
-        mfma16(!grp && more, kt + 1, cur ^ 1);
+        mfma16(std::bool_constant<(G == 0 && ISSUE)>{}, std::integral_constant<int, NPM0>{});
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         stamp();
         if constexpr (!(abl & 16)) __builtin_amdgcn_s_barrier();
         stamp();
-        // ---- MEM1 ----
+        // ---- MEM1 ---- (group 1 prepares the pieces of its CMP1: K-tile kt+2 -> stage cur)
         if constexpr (!(abl & 4)) read_half(kt, I1{});
+        if constexpr (G == 1 && ISSUE) prep(kt + 2, cur);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (grp) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (G == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         stamp();
         if constexpr (!(abl & 16)) __builtin_amdgcn_s_barrier();
@@ -715,14 +763,23 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
         // ---- CMP1: group 1 issues its pieces of K-tile kt+2 (its CMP1(kt) is global segment 4(kt+1): the stage of
         //      K-tile kt is free -- its last reader was this group's own MEM1(kt)); waited for at the end of its MEM1(kt+1)
         __builtin_amdgcn_s_setprio(1);
-        mfma16(grp && (kt + 2) < nk && !(abl & 1), kt + 2, cur);
+        mfma16(std::bool_constant<(G == 1 && ISSUE)>{}, I0{});
         __builtin_amdgcn_s_setprio(0);
-        if (!grp) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (G == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         stamp();
         if constexpr (!(abl & 16)) __builtin_amdgcn_s_barrier();
         stamp();
-    }
+    };
+    auto kloop = [&](auto gc) {
+        constexpr int G = decltype(gc)::value;
+        // group 0 fetches K-tile kt+1 during K-tile kt, group 1 K-tile kt+2: the last 1 (2) K-tiles issue nothing
+        const int n_issue = (abl & 1) ? 0 : nk - 1 - G;
+        int kt = 0;
+        for (; kt < n_issue; ++kt) ktile(kt, gc, BT{});
+        for (; kt < nk; ++kt) ktile(kt, gc, BF{});
+    };
+    if (grp) kloop(I1{}); else kloop(I0{});
     if (!grp && !(ABL & 16)) __builtin_amdgcn_s_barrier();   // matches group 1's extra entry barrier
     __syncthreads();                                    // every wave is done with the stages: LDS becomes the epilogue image
     const unsigned long long t_loop_end = (ABL & 32) ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -858,7 +915,7 @@ int launch8(const ConvArgs& a, hipStream_t s) {
     const size_t lds = (stages > epi ? stages : epi) + 4096;   // + stamp area (profiling)
     auto go = [&](auto kern) {
         static std::atomic<uint64_t> attr_done{0};
-        if (ec_attr_needed(attr_done))
+        if (auto attr_g_ = ec_attr_needed(attr_done))
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kern, dim3((unsigned)p.ntiles), dim3(512), lds, s, p);
     };
@@ -875,6 +932,8 @@ int launch8(const ConvArgs& a, hipStream_t s) {
             case 16: go(conv_igemm8_kernel<BN, KS, POOL, 16>); break;
             case 32: go(conv_igemm8_kernel<BN, KS, POOL, 32>); break;
             case 48: go(conv_igemm8_kernel<BN, KS, POOL, 48>); break;
+            case 64: go(conv_igemm8_kernel<BN, KS, POOL, 64>); break;
+            case 96: go(conv_igemm8_kernel<BN, KS, POOL, 96>); break;
             default: go(conv_igemm8_kernel<BN, KS, POOL, 0>);
         }
         EC_CHECK_LAUNCH();
@@ -903,11 +962,11 @@ int dispatch_tile(const ConvArgs& a, hipStream_t s) {
         // 256-row tiles to occupy most CUs; loses on N = 128, on the short launches of 7x7 maps and ties on 1x1
         const long nt256 = (long)((a.M + 255) / 256) * (a.Cout / 256), nt128 = (long)((a.M + 255) / 256) * (a.Cout / 128);
         // fewest 256-row tiles for the 8-wave kernel: 150 for a launch that has the chip to itself; a caller that keeps two
-        // launches in flight (the engine's two slices) lowers it with ec_conv_set_min_tiles: alone a 50-100-tile launch of the
+        // launches in flight (the engine's two slices) lowers it on its encoder handles (ec_rn50_set_conv8_min_tiles): alone a 50-100-tile launch of the
         // 8-wave kernel is 30-40 % slower than the 4-wave kernel, but it leaves the other launch 150-200 whole CUs instead of
         // sharing all of them (same-box A/B at 2 x 128 frames: +0.4..1.5 % RN50, +3.5 % ViT-B/32 end to end; at 2 x 64: -1.1 %)
         static const long mint_env = [] { const char* e = getenv("EC_CONV8_MIN_TILES"); return e ? atol(e) : 0L; }();
-        const long mint = mint_env > 0 ? mint_env : (long)g_conv8_min_tiles.load(std::memory_order_relaxed);
+        const long mint = mint_env > 0 ? mint_env : (long)ec_tls_conv8_min_tiles;
         if (KS == 3 && a.Cout % 256 == 0 && nt256 >= mint) return launch8<256, KS, POOL>(a, s);
         // long-K 1x1 convs (tools/bench_l4.sh, B = 256): 1024->2048 @7x7 83.7 -> 70.5 us, 1024->512 @14x14 82.9 -> 70.5,
         // 1024->256 @14x14 40.6 -> 37.0 with 256-wide tiles; 2048->512 @7x7 46.4 -> 40.1 with 128-wide tiles (196 of them);
@@ -974,12 +1033,6 @@ int ec_conv3x3_narrow(const void* in, const void* w, const float* bias, void* ou
 // conv_pair.hip: register-weight kernel for a few bandwidth-bound 1x1 shapes (EC_ERR_SHAPE = not handled)
 int ec_conv1x1_regw(const void* a, const void* w, const float* bias, const void* res, void* y, long M, int K, int N, int act,
                     hipStream_t s);
-
-// Tuning hook for callers that keep several encoder launches in flight (see dispatch_tile); n <= 0 restores the default.
-extern "C" int ec_conv_set_min_tiles(int n) {
-    g_conv8_min_tiles.store(n > 0 ? n : 150, std::memory_order_relaxed);
-    return EC_OK;
-}
 
 extern "C" int ec_debug_stamps(unsigned long long* host_dst, int n) {   // profiling only
     if (!host_dst || n <= 0 || n > 2048) return EC_ERR_ARG;

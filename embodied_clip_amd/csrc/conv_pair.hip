@@ -329,7 +329,7 @@ int launch_pair(const PairArgs& p, hipStream_t s) {
     static_assert(lds <= 160 * 1024, "LDS budget");
     auto kern = conv1x1_pair_kernel<TWO, RES, N2, PL>;
     static std::atomic<uint64_t> attr_done{0};
-    if (ec_attr_needed(attr_done)) {
+    if (auto attr_g_ = ec_attr_needed(attr_done)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
     const int wgs = (p.ntiles + 3) / 4 < 256 ? (p.ntiles + 3) / 4 : 256;
@@ -507,7 +507,7 @@ int launch_pair512(const Pair2Args& p, hipStream_t s) {
     constexpr size_t lds = 2 * (size_t)PX * YP2 + (NY2 + NZ2) * 4 + 4 * (size_t)PX * SP2 + 2 * (size_t)PX * SP2;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static std::atomic<uint64_t> attr_done{0};
-    if (ec_attr_needed(attr_done)) {
+    if (auto attr_g_ = ec_attr_needed(attr_done)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_pair512_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
     const int wgs = p.ntiles < 256 ? p.ntiles : 256;
@@ -660,7 +660,7 @@ int launch_regw(const RegwArgs& p, hipStream_t s, int groups = 1) {
     static_assert(lds <= 160 * 1024, "LDS budget");
     auto kern = conv1x1_regw_kernel<K, N, RES, RELU>;
     static std::atomic<uint64_t> attr_done{0};
-    if (ec_attr_needed(attr_done)) {
+    if (auto attr_g_ = ec_attr_needed(attr_done)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
     int wgs = 256 / groups;

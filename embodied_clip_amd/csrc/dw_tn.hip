@@ -241,7 +241,7 @@ extern "C" int ec_dw_tn_x3(const void* dYplanes, const void* X, float* part, flo
     if (a.tok_per_split * (long)NX * 2 >= (1L << 32) - (1L << 20)) return EC_ERR_SHAPE;   // 32-bit offsets inside a split
     const size_t lds = (size_t)NSTG * STG;
     static std::atomic<uint64_t> attr_done{0};
-    if (ec_attr_needed(attr_done))
+    if (auto attr_g_ = ec_attr_needed(attr_done))
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dw_tn_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     a.ntile = NX / NXT;
     a.nsplit = ns;

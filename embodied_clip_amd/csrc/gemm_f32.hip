@@ -493,7 +493,7 @@ int launch_x3(GemmArgs& a, hipStream_t s) {
     do {                                                                                                     \
         auto kern = gemm_x3_kernel<BM, BN, WM, WN, ABF, BBF, AKC, BKC>;                                      \
         static std::atomic<uint64_t> attr_done{0};                                                                        \
-        if (ec_attr_needed(attr_done)) {                                                                                     \
+        if (auto attr_g_ = ec_attr_needed(attr_done)) {                                                                                     \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                   \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)((3 * BM + 3 * BN) * 64)); \
         }                                                                                                    \
@@ -527,7 +527,7 @@ int launch_cfg(GemmArgs& a, hipStream_t s) {
     do {                                                                                                    \
         auto kern = gemm_f32_kernel<BM, BN, WM, WN, ABF, BBF>;                                              \
         static std::atomic<uint64_t> attr_done{0};                                                                       \
-        if (ec_attr_needed(attr_done)) {                                                                                    \
+        if (auto attr_g_ = ec_attr_needed(attr_done)) {                                                                                    \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                  \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
         }                                                                                                   \

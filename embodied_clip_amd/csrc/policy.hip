@@ -941,12 +941,13 @@ extern "C" size_t ec_policy_workspace_bytes(const ec_policy_t* h, int T, int N, 
 
 extern "C" int ec_policy_forward(const ec_policy_t* h, const float* params, const void* feat, int feat_bf16,
                                  const int64_t* goal, const float* h0, const float* masks, int T, int N,
-                                 void* workspace, size_t ws_bytes, float* hv, float* h_final, ec_stream_t stream) {
+                                 void* workspace, size_t ws_bytes, int for_backward, float* hv, float* h_final,
+                                 ec_stream_t stream) {
     if (!h || !params || !feat || !goal || !h0 || !masks || !workspace || !hv) return EC_ERR_ARG;
     if (T <= 0 || N <= 0) return EC_ERR_SHAPE;
     const ec_policy_cfg& c = h->c;
     const Ws w = layout(h, T, N, false);
-    if (ws_bytes < w.end * 4) return EC_ERR_WORKSPACE;
+    if (ws_bytes < layout(h, T, N, for_backward != 0).end * 4) return EC_ERR_WORKSPACE;
     float* ws = (float*)workspace;
     hipStream_t s = (hipStream_t)stream;
     const int B = T * N, S = c.spatial * c.spatial, H = c.hidden, A1 = c.num_actions + 1;
@@ -955,10 +956,10 @@ extern "C" int ec_policy_forward(const ec_policy_t* h, const float* params, cons
     const float* P = params;
     auto W = [&](int i) { return P + h->off[i]; };
     int* goal32 = (int*)(ws + w.goal32);
-    // Act-step path: a workspace too small for a backward pass means inference only, so c1 need not be materialised
-    // and the two long-K, small-M GEMMs (compressor conv 1, GRU input projection) run as ACT_PARTS K slices whose
-    // partial matrices the consuming kernels fold in a fixed order.
-    const bool infer_only = ws_bytes < layout(h, T, N, true).end * 4;
+    // Act-step path (for_backward == 0, stated by the caller -- never inferred from the workspace size): inference only,
+    // so c1 need not be materialised and the two long-K, small-M GEMMs (compressor conv 1, GRU input projection) run as
+    // ACT_PARTS K slices whose partial matrices the consuming kernels fold in a fixed order.
+    const bool infer_only = for_backward == 0;
     const bool small = !c.fusion && M49 > 0 && M49 <= ACT_MAX_ROWS;            // (== the condition in layout())
     const size_t tail_lds_ = ((size_t)2 * 32 * TL_P128 + 128 * TL_P32 + (size_t)c.num_goals * 128 + 64 +
                               4 * (size_t)(32 * TL_P128 + 32 * TL_P32)) * sizeof(float);
@@ -1009,7 +1010,7 @@ extern "C" int ec_policy_forward(const ec_policy_t* h, const float* params, cons
     if (tail_fused && c.compress_hid == 128 && c.compress_out == 32 && c.comb_hid == 128 && c.comb_out == 32 &&
         tail_lds <= 160 * 1024) {
         static std::atomic<uint64_t> attr_done{0};
-        if (ec_attr_needed(attr_done))
+        if (auto attr_g_ = ec_attr_needed(attr_done))
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tail_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       160 * 1024);
         const long ntiles = ((long)M49 + 31) / 32;
@@ -1047,7 +1048,7 @@ extern "C" int ec_policy_forward(const ec_policy_t* h, const float* params, cons
     const bool fused_step = gru_fused && (H % 32) == 0 && gru_lds <= 160 * 1024;
     if (fused_step) {
         static std::atomic<uint64_t> attr_done{0};
-        if (ec_attr_needed(attr_done))
+        if (auto attr_g_ = ec_attr_needed(attr_done))
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gru_step_fwd_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
@@ -1164,7 +1165,7 @@ extern "C" int ec_policy_backward(const ec_policy_t* h, const float* params, con
     if (fused_bwd) {
         // EC_TAIL_FUSED (default 1): dm1 / dc2 / dc1 and all small weight gradients of the tail in one pass
         static std::atomic<uint64_t> attr_done{0};
-        if (ec_attr_needed(attr_done))
+        if (auto attr_g_ = ec_attr_needed(attr_done))
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tail_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       160 * 1024);
         const long ntiles = ((long)M49 + 31) / 32;

@@ -186,7 +186,7 @@ extern "C" int ec_clip_resize_crop_u8(const uint8_t* frames_u8, const int* table
     const size_t lds = (size_t)table_max_rows * n_px * 3;
     if (lds > 160 * 1024) return EC_ERR_SHAPE;
     static std::atomic<uint64_t> attr_done{0};
-    if (ec_attr_needed(attr_done))
+    if (auto attr_g_ = ec_attr_needed(attr_done))
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(resize_crop_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024);
     dim3 grid((unsigned)((n_px + ROWS - 1) / ROWS), (unsigned)B);

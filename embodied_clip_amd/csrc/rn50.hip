@@ -44,6 +44,7 @@ struct ec_rn50 {
     const uint16_t* w;
     const float* bias;
     size_t n_w, n_b;
+    int conv8_min_tiles = 0;      // 0 = library default (ec_rn50_set_conv8_min_tiles)
 };
 
 namespace {
@@ -201,12 +202,18 @@ extern "C" uint64_t ec_rn50_plan_hash(const ec_rn50_t* h) {
         for (int i = 0; i < 8; ++i) { x ^= (uint64_t)((v >> (8 * i)) & 0xff); x *= 1099511628211ull; }
     };
     mix(ec_version());
-    mix(h->width); mix(h->res);
+    mix(h->width); mix(h->res); mix(h->conv8_min_tiles);
     for (const Op& o : h->ops) {
         mix(o.kind); mix(o.src); mix(o.dst); mix(o.res); mix(o.H); mix(o.W); mix(o.Cin); mix(o.Cout); mix(o.ks);
         mix(o.pool); mix(o.act); mix(o.src1); mix(o.dst2); mix(o.N2); mix(o.dst3);
     }
     return x;
+}
+
+extern "C" int ec_rn50_set_conv8_min_tiles(ec_rn50_t* h, int n) {
+    if (!h) return EC_ERR_ARG;
+    h->conv8_min_tiles = n > 0 ? n : 0;
+    return EC_OK;
 }
 
 extern "C" size_t ec_rn50_workspace_bytes(const ec_rn50_t* h, int batch) {
@@ -245,6 +252,7 @@ int rn50_run(const ec_rn50_t* h, const void* rgb, bool u8, const float* mean3, c
         if (chunk > maxc) chunk = (int)(maxc > 0 ? maxc : 1);
     }
     if (ws_bytes < ec_rn50_workspace_bytes(h, chunk)) return EC_ERR_WORKSPACE;
+    const ec_min_tiles_scope mint_scope(h->conv8_min_tiles);   // this handle's dispatch threshold, for this call only
     const size_t bufsz = align_up(h->max_elems_per_frame * 2 * (size_t)chunk, 256);
     unsigned char* base = (unsigned char*)workspace;
     const size_t rgb_stride = (size_t)h->res * h->res * 3;

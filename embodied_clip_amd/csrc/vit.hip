@@ -464,6 +464,7 @@ struct ec_vit {
     const uint16_t* w;
     const float* f;
     size_t n_w, n_f;
+    int conv8_min_tiles = 0;      // 0 = library default (ec_vit_set_conv8_min_tiles)
 };
 
 #define RC(x) do { int rc__ = (x); if (rc__ != EC_OK) return rc__; } while (0)
@@ -483,7 +484,7 @@ int run_blocks(const uint16_t*& w, const float*& f, int layers, int heads, uint1
     if (general) {
         if (L > MHA_GENERAL_MAX_TOKENS) return EC_ERR_SHAPE;
         static std::atomic<uint64_t> attr_done{0};
-        if (ec_attr_needed(attr_done)) {
+        if (auto attr_g_ = ec_attr_needed(attr_done)) {
             const int mx = (int)mha_general_lds(MHA_GENERAL_MAX_TOKENS);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mha_general_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mha_general_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
@@ -536,6 +537,23 @@ extern "C" int ec_vit_create(ec_vit_t** out, int width, int layers_run, int head
 }
 extern "C" void ec_vit_destroy(ec_vit_t* h) { delete h; }
 extern "C" int ec_vit_tokens(const ec_vit_t* h) { return h ? h->L : 0; }
+extern "C" int ec_vit_set_conv8_min_tiles(ec_vit_t* h, int n) {
+    if (!h) return EC_ERR_ARG;
+    h->conv8_min_tiles = n > 0 ? n : 0;
+    return EC_OK;
+}
+// FNV-1a over what fixes the launch plan of ec_vit_forward (geometry, dispatch threshold, library version): the key of
+// the PMC summaries under profiles/ (as ec_rn50_plan_hash).
+extern "C" uint64_t ec_vit_plan_hash(const ec_vit_t* h) {
+    if (!h) return 0;
+    uint64_t x = 1469598103934665603ull;
+    auto mix = [&](long v) {
+        for (int i = 0; i < 8; ++i) { x ^= (uint64_t)((v >> (8 * i)) & 0xff); x *= 1099511628211ull; }
+    };
+    mix(ec_version());
+    mix(h->width); mix(h->layers); mix(h->heads); mix(h->patch); mix(h->res); mix(h->L); mix(h->conv8_min_tiles);
+    return x;
+}
 
 extern "C" size_t ec_vit_workspace_bytes(const ec_vit_t* h, int batch) {
     if (!h || batch <= 0) return 0;
@@ -549,6 +567,7 @@ extern "C" int ec_vit_forward(const ec_vit_t* h, const float* rgb, int batch, vo
     if (!h || !rgb || !workspace || !tokens_bf16) return EC_ERR_ARG;
     if (batch <= 0) return EC_ERR_SHAPE;
     if (ws_bytes < ec_vit_workspace_bytes(h, batch)) return EC_ERR_WORKSPACE;
+    const ec_min_tiles_scope mint_scope(h->conv8_min_tiles);   // this handle's dispatch threshold, for this call only
     hipStream_t s = (hipStream_t)stream;
     const int D = h->width, P = h->patch, G = h->grid, L = h->L, B = batch;
     const int Kp = P * P * 3, G2 = G * G;

@@ -175,6 +175,10 @@ class RN50Trunk:
         """Hex hash of the launch plan + library version (keys the PMC summaries under profiles/)."""
         return f"{self.lib.ec_rn50_plan_hash(self.h):016x}"
 
+    def set_conv8_min_tiles(self, n: int) -> None:
+        """Dispatch threshold of THIS handle's conv launches (0 = default; see ``ec_rn50_set_conv8_min_tiles``)."""
+        _lib.check(self.lib.ec_rn50_set_conv8_min_tiles(self.h, int(n)), "ec_rn50_set_conv8_min_tiles")
+
     def _workspace(self, n: int) -> torch.Tensor:
         need = self.lib.ec_rn50_workspace_bytes(self.h, n)
         if self._ws is None or self._ws.numel() < need:
@@ -332,6 +336,14 @@ class ViTEmbedder:
         self.h = h
         self.L = self.lib.ec_vit_tokens(h)
         self._ws = None
+
+    def plan_hash(self) -> str:
+        """Hex hash of what fixes the launch plan + library version (keys the PMC summaries under profiles/)."""
+        return f"{self.lib.ec_vit_plan_hash(self.h):016x}"
+
+    def set_conv8_min_tiles(self, n: int) -> None:
+        """Dispatch threshold of THIS handle's GEMM launches (0 = default; see ``ec_vit_set_conv8_min_tiles``)."""
+        _lib.check(self.lib.ec_vit_set_conv8_min_tiles(self.h, int(n)), "ec_vit_set_conv8_min_tiles")
 
     def __del__(self):
         try:

@@ -95,7 +95,10 @@ class Worker:
         # [U] allenact RolloutStorage.recurrent_generator(num_mini_batch): contiguous sampler ranges, shuffled order
         assert 1 <= num_mini_batch <= n_actors, "num_mini_batch must not exceed the number of samplers"
         self.num_mini_batch = num_mini_batch
-        self._mb_rng = random.Random(seed + 104729 * rank)
+        # ONE shuffle stream for all ranks: every rank visits the same minibatch range at the same optimiser step, so the
+        # SUM all-reduce with the fixed 1/world scale is the global minibatch mean also when N % num_mini_batch != 0
+        # (ranges of different sizes) -- with per-rank streams it would be a mean of differently-sized means
+        self._mb_rng = random.Random(seed)                  # (`seed` is the job's seed: identical on every rank)
         self.dev = self.device = torch.device(device)
         if self.dev.index is None:
             self.dev = self.device = torch.device("cuda", torch.cuda.current_device())
@@ -192,9 +195,11 @@ class Worker:
                 sl.k = 0
             self.slices.append(sl)
         self.encode_frames = n                    # frames per timed encoder launch
-        # two launches in flight with >= 128 frames each: the 8-wave conv kernel from 50 tiles on (ec_conv_set_min_tiles)
+        # two launches in flight with >= 128 frames each: the 8-wave conv kernel from 50 tiles on -- a property of THIS
+        # worker's encoder handles (ec_rn50/vit_set_conv8_min_tiles), not of the process
         self._conv8_min_tiles = 50 if (ns == 2 and n >= 128) else 0
-        self.lib.ec_conv_set_min_tiles(self._conv8_min_tiles)
+        for e in encs:
+            e.set_conv8_min_tiles(self._conv8_min_tiles)
         self.seed = seed + 7919 * rank
         self.total_steps = 0
         self.iter = 0
@@ -274,7 +279,7 @@ class Worker:
         rs = slice(o, o + n)
         h_in, h_out = (self.h, self.h_next) if (t & 1) == 0 else (self.h_next, self.h)   # ping-pong by step parity
         self.policy.forward(self.params, sl.feat[t], self.env.goals[t][rs], h_in[rs], self.env.masks[t][rs], 1, n,
-                            sl.ws_act, hv=self.hv_act[rs], h_final=h_out[rs])
+                            sl.ws_act, hv=self.hv_act[rs], h_final=h_out[rs], for_backward=False)
         if sample:
             _lib.check(self.lib.ec_sample_actions(self.hv_act[rs].data_ptr(), self.actions[t][rs].data_ptr(),
                                                   self.logp[t][rs].data_ptr(), self.values[t][rs].data_ptr(), n, self.A,
@@ -285,7 +290,6 @@ class Worker:
     @_lib.on_device
     def collect_rollout(self):
         T = self.T
-        self.lib.ec_conv_set_min_tiles(self._conv8_min_tiles)   # (process-wide tuning value: re-assert it for this worker)
         self.h_start.copy_(self.h)
         self._fork()
         for t in range(T):
@@ -329,6 +333,16 @@ class Worker:
         self._mb_rng.shuffle(pairs)
         return pairs
 
+    def _max_partial_range(self, sl) -> int:
+        N, M = self.N, self.num_mini_batch
+        inds = [int(round(i * N / M)) for i in range(M + 1)]
+        best = 1
+        for s0, s1 in zip(inds[:-1], inds[1:]):
+            a, b = max(s0, sl.o) - sl.o, min(s1, sl.o + sl.n) - sl.o
+            if b > a and not (a == 0 and b == sl.n):
+                best = max(best, b - a)
+        return best
+
     def _gather_part(self, sl, a: int, b: int):
         """Contiguous [T * (b - a)] batch of actors [a, b) of slice ``sl`` (slice-local indices) in the slice's staging
         buffers; the whole slice is used in place."""
@@ -337,8 +351,9 @@ class Worker:
             return (sl.feat[:T].view(T * sl.n, self.S * self.S, self.C), sl.goal, sl.masks, sl.actions, sl.logp, sl.old_v,
                     sl.ret, sl.nadv)
         m = b - a
-        if getattr(sl, "feat_mb", None) is None:                   # staging for partial-slice minibatches (allocated on first use)
-            sl.feat_mb = torch.empty((T, sl.n, self.S * self.S, self.C), dtype=sl.feat.dtype, device=self.dev)
+        if getattr(sl, "feat_mb", None) is None:                   # staging for partial-slice minibatches (allocated on first use),
+            mmax = self._max_partial_range(sl)                      # sized to the largest PARTIAL range, not the whole slice
+            sl.feat_mb = torch.empty((T, mmax, self.S * self.S, self.C), dtype=sl.feat.dtype, device=self.dev)
         fm = sl.feat_mb.view(-1)[:T * m * self.S * self.S * self.C].view(T, m, self.S * self.S, self.C)
         fm.copy_(sl.feat[:T, a:b])
         c = lambda x: x.view(T, sl.n)[:, a:b].reshape(-1).contiguous()

@@ -96,22 +96,25 @@ class PolicyHandle:
     def views(self, flat: torch.Tensor) -> "OrderedDict[str, torch.Tensor]":
         return OrderedDict((n, flat[o:o + k].view(self.shapes[n])) for n, (o, k) in self.offsets.items())
 
-    def forward(self, flat_params, feat, goal, h0, masks, T, N, ws, hv=None, h_final=None):
-        """feat: bf16 or fp32 NHWC rows [T*N, S*S, C]; returns (hv [T*N, A+1], h_final [N,H])."""
+    def forward(self, flat_params, feat, goal, h0, masks, T, N, ws, hv=None, h_final=None, for_backward: bool = True):
+        """feat: bf16 or fp32 NHWC rows [T*N, S*S, C]; returns (hv [T*N, A+1], h_final [N,H]).
+        ``for_backward=True`` (default) keeps every activation ``backward`` needs and wants a workspace of
+        ``workspace_bytes(T, N, True)``; ``False`` is the inference-only act step (``workspace_bytes(T, N, False)``).
+        The kernel plan follows this flag, never the size of ``ws``."""
         assert feat.is_contiguous() and feat.dtype in (torch.bfloat16, torch.float32)
         dev = flat_params.device
         with _lib.tensor_guard(flat_params):
-            return self._forward(flat_params, feat, goal, h0, masks, T, N, ws, hv, h_final, dev)
+            return self._forward(flat_params, feat, goal, h0, masks, T, N, ws, hv, h_final, dev, for_backward)
 
-    def _forward(self, flat_params, feat, goal, h0, masks, T, N, ws, hv, h_final, dev):
+    def _forward(self, flat_params, feat, goal, h0, masks, T, N, ws, hv, h_final, dev, for_backward=True):
         if hv is None:
             hv = torch.empty((T * N, self.A + 1), dtype=torch.float32, device=dev)
         if h_final is None:
             h_final = torch.empty((N, self.H), dtype=torch.float32, device=dev)
         _lib.check(self.lib.ec_policy_forward(
             self.h, flat_params.data_ptr(), feat.data_ptr(), int(feat.dtype == torch.bfloat16), goal.data_ptr(),
-            h0.data_ptr(), masks.data_ptr(), T, N, ws.data_ptr(), ws.numel() * ws.element_size(), hv.data_ptr(),
-            h_final.data_ptr(), _lib.stream_ptr()), "ec_policy_forward")
+            h0.data_ptr(), masks.data_ptr(), T, N, ws.data_ptr(), ws.numel() * ws.element_size(), int(bool(for_backward)),
+            hv.data_ptr(), h_final.data_ptr(), _lib.stream_ptr()), "ec_policy_forward")
         return hv, h_final
 
     def backward(self, flat_params, feat, masks, T, N, ws, dhv, dh_final, flat_grads):
@@ -127,28 +130,20 @@ class PolicyHandle:
 
 
 class _PolicyFn(torch.autograd.Function):
-    """Autograd bridge: HIP forward, HIP backward.  ``owner`` (the nn.Module, or None) lends a workspace pool and a
-    scratch gradient bucket so that the steady state of act -> learn -> backward allocates nothing."""
+    """Autograd bridge: HIP forward, HIP backward.  ``owner`` (the nn.Module, or None) lends a scratch gradient
+    bucket.  Workspaces come from torch's caching allocator, one per forward: a learn workspace lives exactly as long
+    as the autograd node that saved it (so ``retain_graph`` / two live forwards can never share one), an act workspace
+    dies with the call; reuse is the allocator's, stream-ordered.  Whether the forward keeps the activations of a
+    backward is stated explicitly (``for_backward=need_grad``), so an act step always takes the act-step kernel plan."""
 
     @staticmethod
     def forward(ctx, handle: PolicyHandle, owner, flat, feat, goal, h0, masks, T, N, *params):
         need_grad = any(ctx.needs_input_grad)   # (grad mode is always off inside Function.forward)
-        nbytes = handle.workspace_bytes(T, N, need_grad)
-        pool = owner._ws_pool if owner is not None else None
-        ws = None
-        if pool is not None:
-            for i, t in enumerate(pool):
-                if t.numel() >= nbytes and t.device == flat.device:
-                    ws = pool.pop(i)
-                    break
-        if ws is None:
-            ws = torch.empty(nbytes, dtype=torch.uint8, device=flat.device)
-        hv, h_final = handle.forward(flat, feat, goal, h0, masks, T, N, ws)
+        ws = torch.empty(handle.workspace_bytes(T, N, need_grad), dtype=torch.uint8, device=flat.device)
+        hv, h_final = handle.forward(flat, feat, goal, h0, masks, T, N, ws, for_backward=need_grad)
         if need_grad:
             ctx.handle, ctx.owner, ctx.T, ctx.N = handle, owner, T, N
             ctx.save_for_backward(flat, feat, masks, ws)
-        elif pool is not None:
-            pool.append(ws)         # stream-ordered reuse: the next launch on this stream runs after this one
         return hv, h_final
 
     @staticmethod
@@ -168,8 +163,6 @@ class _PolicyFn(torch.autograd.Function):
         dhv = dhv.contiguous() if dhv is not None else torch.zeros((ctx.T * ctx.N, h.A + 1), device=flat.device)
         dhf = dh_final.contiguous() if dh_final is not None else None
         h.backward(flat, feat, masks, ctx.T, ctx.N, ws, dhv, dhf, g)
-        if owner is not None and len(owner._ws_pool) < 4:
-            owner._ws_pool.append(ws)
         grads = tuple(g[o:o + k].view(h.shapes[n]) for n, (o, k) in h.offsets.items())
         return (None,) * 9 + grads
 
@@ -214,7 +207,6 @@ class ResnetTensorObjectNavActorCritic(ActorCriticModel):
         self.resnet_uuid = (rgb_resnet_preprocessor_uuid if rgb_resnet_preprocessor_uuid is not None
                             else depth_resnet_preprocessor_uuid)
         self._hidden_size = hidden_size
-        self._ws_pool: list = []
         self._g_scratch: Optional[torch.Tensor] = None
         if self.resnet_uuid not in observation_space.spaces:
             raise NotImplementedError("blind agent (no visual tensor in the observation space) is not built")

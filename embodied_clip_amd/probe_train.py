@@ -86,7 +86,9 @@ def main(argv=None):
     model = LinearEncoder(a.embedding_type, a.prediction_type, a.batch_size, lr, device=dev)
     train = dm.train_dataloader()
     n_batches = len(train)
-    check_at = sorted({max(1, n_batches // 2), n_batches})            # val_check_interval=0.5 (train.py:157)
+    # val_check_interval=0.5 (train.py:157): Lightning validates every int(n_batches * 0.5) training batches, i.e. after
+    # batches k, 2k, ... <= n_batches (for an odd n_batches the second check falls one batch BEFORE the epoch's end)
+    val_every = max(1, int(n_batches * 0.5))
     best = {"val_loss": float("inf"), "val_acc": 0.0, "epoch": -1, "sd": None}
 
     def validate(epoch):
@@ -101,7 +103,7 @@ def main(argv=None):
         for i, batch in enumerate(train):
             model.training_step(batch, i)
             steps += 1
-            if (i + 1) in check_at:
+            if (i + 1) % val_every == 0:
                 validate(ep)
     torch.cuda.synchronize()
     dt = time.time() - t0

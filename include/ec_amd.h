@@ -84,11 +84,6 @@ int ec_clip_resize_table(int H, int W, int n_px, int* host_table, size_t n_ints)
 int ec_clip_resize_crop_u8(const uint8_t* frames_u8, const int* table_dev, int table_max_rows, uint8_t* out_u8, int B,
                            int H, int W, int n_px, ec_stream_t stream);
 
-/* Tuning hook (no reference counterpart): fewest 256-row output tiles for which a conv / GEMM launch takes the 8-wave
- * kernel (default 150).  A caller that keeps two encoder launches in flight on two streams (engine.Worker with 128-frame
- * slices) sets 50: each launch then occupies fewer, fully used CUs.  n <= 0 restores the default.  Process-wide. */
-int ec_conv_set_min_tiles(int n);
-
 /* profiling only: copies the s_memtime stamps the 8-wave conv kernel records under EC_CONV_ABLATE & 32 */
 int ec_debug_stamps(unsigned long long* host_dst, int n);
 int ec_gemm_bf16(const void* A, const void* W, const float* bias, const void* res, void* out,
@@ -187,6 +182,11 @@ int ec_rn50_num_ops(const ec_rn50_t* h);
 /* 64-bit hash of the handle's launch plan (op kinds, shapes, buffer routing) and the library version: identifies
  * what a profiler summary under profiles/ was measured on (bench.py rejects a stale one). */
 uint64_t ec_rn50_plan_hash(const ec_rn50_t* h);
+/* Tuning property of the handle (no reference counterpart): fewest 256-row output tiles for which this trunk's conv
+ * launches take the 8-wave kernel (0 = library default, 150).  A caller that keeps two encoder launches in flight on
+ * two streams (engine.Worker with 128-frame slices) sets 50 on both handles: each launch then occupies fewer, fully
+ * used CUs.  Part of the plan hash; affects only this handle's forwards (it is not process state). */
+int ec_rn50_set_conv8_min_tiles(ec_rn50_t* h, int n);
 
 
 /* ------------------------------------------------------------------------
@@ -251,10 +251,12 @@ size_t ec_policy_workspace_bytes(const ec_policy_t* h, int T, int N, int for_bac
 /* feat [T*N, S*S, C] NHWC (bf16 if feat_bf16 else f32); goal int64 [T*N]; h0 f32 [N,H];
  * masks f32 [T*N] (h is multiplied by masks[t] before step t: episode reset);
  * hv f32 [T*N, A+1] out: logits in cols 0..A-1, value in col A; h_final f32 [N,H] or NULL.
- * The workspace keeps every activation the backward needs. */
+ * for_backward != 0: the workspace (ec_policy_workspace_bytes(.., 1)) keeps every activation ec_policy_backward
+ * needs; for_backward == 0: inference only (act step; workspace of ec_policy_workspace_bytes(.., 0) suffices) -- the
+ * kernel plan depends on this flag alone, never on the size of the buffer handed in. */
 int ec_policy_forward(const ec_policy_t* h, const float* params, const void* feat, int feat_bf16,
                       const int64_t* goal, const float* h0, const float* masks, int T, int N,
-                      void* workspace, size_t ws_bytes, float* hv, float* h_final, ec_stream_t stream);
+                      void* workspace, size_t ws_bytes, int for_backward, float* hv, float* h_final, ec_stream_t stream);
 /* dhv f32 [T*N, A+1] = dLoss/dhv; dh_final [N,H] or NULL; grads += dLoss/dparams.
  * `workspace` must be the one the matching ec_policy_forward filled (for_backward size). */
 int ec_policy_backward(const ec_policy_t* h, const float* params, const void* feat, int feat_bf16,
@@ -309,6 +311,8 @@ int ec_vit_create(ec_vit_t** out, int width, int layers_run, int heads, int patc
                   const void* w_bf16, size_t n_w, const float* params_f32, size_t n_f);
 void ec_vit_destroy(ec_vit_t* h);
 int ec_vit_tokens(const ec_vit_t* h);                       /* L = (R/P)^2 + 1 */
+int ec_vit_set_conv8_min_tiles(ec_vit_t* h, int n);          /* as ec_rn50_set_conv8_min_tiles */
+uint64_t ec_vit_plan_hash(const ec_vit_t* h);                /* as ec_rn50_plan_hash */
 size_t ec_vit_workspace_bytes(const ec_vit_t* h, int batch);
 /* rgb f32 NHWC [B,R,R,3] -> tokens bf16 [B, L, D] */
 int ec_vit_forward(const ec_vit_t* h, const float* rgb_nhwc, int batch, void* workspace, size_t ws_bytes,

@@ -28,7 +28,7 @@ def _forward(cfg, sd, feat, goal, h0, masks, T, N):
     rows = feat.permute(0, 1, 3, 4, 2).reshape(T * N, cfg["spatial"] ** 2, cfg["in_channels"]).contiguous()
     ws = torch.empty(h.workspace_bytes(T, N, False), dtype=torch.uint8, device=DEV)
     hv, hf = h.forward(flat, rows.to(DEV), goal.reshape(-1).to(DEV), h0[0].contiguous().to(DEV),
-                       masks.reshape(-1).to(DEV), T, N, ws)
+                       masks.reshape(-1).to(DEV), T, N, ws, for_backward=False)
     torch.cuda.synchronize()
     return hv.view(T, N, -1), hf
 

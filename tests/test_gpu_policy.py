@@ -179,7 +179,7 @@ def test_policy_forward_matches_oracle(dev, T, N, bf16, S):
     rows = rows.to(torch.bfloat16) if bf16 else rows
     ws = torch.empty(h.workspace_bytes(T, N, False), dtype=torch.uint8, device=dev)
     hv, hf = h.forward(flat, rows.to(dev), goal.reshape(-1).to(dev), h0[0].contiguous().to(dev),
-                       masks.reshape(-1).to(dev), T, N, ws)
+                       masks.reshape(-1).to(dev), T, N, ws, for_backward=False)
     torch.cuda.synchronize()
     hv = hv.view(T, N, -1)
     assert _rel(hv[..., :6], ref_logits) < 2e-5

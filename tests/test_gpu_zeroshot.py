@@ -85,7 +85,7 @@ def test_zeroshot_requires_goal_table_and_unit_spatial():
     ws = torch.empty(h.workspace_bytes(1, 2, False), dtype=torch.uint8, device=dev)
     z = torch.zeros(2, device=dev)
     with pytest.raises(_lib.EcError):                                   # no goal table set
-        h.forward(flat, torch.zeros(2, 1, 64, device=dev), z.long(), torch.zeros(2, 32, device=dev), z + 1, 1, 2, ws)
+        h.forward(flat, torch.zeros(2, 1, 64, device=dev), z.long(), torch.zeros(2, 32, device=dev), z + 1, 1, 2, ws, for_backward=False)
 
 
 def test_config5_zeroshot_worker_iteration_matches_oracle():
