@@ -85,6 +85,88 @@ __device__ __forceinline__ float dpp_quad_xor2(float v) {   // lane ^ 2 within a
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
 }
 
+// ---- epilogue staging, shared by both kernels --------------------------------------------------------------------
+// One wave's accumulators -> the workgroup's LDS output image: + bias (+ residual already staged in the image) ->
+// activation (or ReLU + 2x2 average pool over the lane quad) -> ONE rounding to bf16 -> 8-byte slots.  ACT / RES are
+// COMPILE-TIME: the previous version tested p.act / p.res / p.bias per 4-channel group (a three-way branch with the
+// whole QuickGELU body behind it, a waited bias load and a waited residual read per group: ~20k clk per 256x256 tile,
+// s_memtime stamps of round 3); here the biases are fetched up front and the body is straight-line code.
+__device__ __forceinline__ float ec_relu(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, __builtin_inff()); }
+template <int ACT, bool RES, bool POOL, int FM, int FN, int PITCH>
+__device__ __forceinline__ void epi_stage(const f32x16_t (&acc)[FM][FN], unsigned char* smem, const float* bias_n0,
+                                          int row0, int col0, int lane) {
+    const int frow = lane & 31, fhalf = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        float4 bvj[4];                      // the four bias vectors of this 32-channel block: one exposed load latency per j
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            bvj[g] = bias_n0 ? *reinterpret_cast<const float4*>(bias_n0 + col0 + j * 32 + 8 * g + 4 * fhalf)
+                             : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int lcol = col0 + j * 32 + 8 * g + 4 * fhalf;          // 4 consecutive channels
+            uint2 rr[FM];
+            if constexpr (RES) {
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+                    rr[i] = *reinterpret_cast<const uint2*>(smem + (row0 + i * 32 + frow) * PITCH + lcol * 2);
+            }
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int lrow_px = row0 + i * 32 + frow;                // this lane's pixel (tile-local row)
+                float v0 = acc[i][j][4 * g + 0] + bvj[g].x, v1 = acc[i][j][4 * g + 1] + bvj[g].y;
+                float v2 = acc[i][j][4 * g + 2] + bvj[g].z, v3 = acc[i][j][4 * g + 3] + bvj[g].w;
+                if constexpr (POOL) {
+                    // the 4 pixels of a pooling window are the 4 lanes of a quad (m = 4*q + dy*2+dx)
+                    v0 = ec_relu(v0); v1 = ec_relu(v1); v2 = ec_relu(v2); v3 = ec_relu(v3);
+                    v0 += dpp_quad_xor1(v0); v1 += dpp_quad_xor1(v1); v2 += dpp_quad_xor1(v2); v3 += dpp_quad_xor1(v3);
+                    v0 += dpp_quad_xor2(v0); v1 += dpp_quad_xor2(v1); v2 += dpp_quad_xor2(v2); v3 += dpp_quad_xor2(v3);
+                    if ((lane & 3) == 0) {
+                        uint2 o;
+                        o.x = ec_pack2(0.25f * v0, 0.25f * v1);
+                        o.y = ec_pack2(0.25f * v2, 0.25f * v3);
+                        *reinterpret_cast<uint2*>(smem + (lrow_px >> 2) * PITCH + lcol * 2) = o;
+                    }
+                } else {
+                    if constexpr (RES) {
+                        v0 += ec_lo(rr[i].x); v1 += ec_hi(rr[i].x); v2 += ec_lo(rr[i].y); v3 += ec_hi(rr[i].y);
+                    }
+                    if constexpr (ACT == EC_ACT_RELU) {
+                        v0 = ec_relu(v0); v1 = ec_relu(v1); v2 = ec_relu(v2); v3 = ec_relu(v3);
+                    } else if constexpr (ACT == EC_ACT_QUICKGELU) {
+                        v0 = v0 / (1.f + __expf(-1.702f * v0)); v1 = v1 / (1.f + __expf(-1.702f * v1));
+                        v2 = v2 / (1.f + __expf(-1.702f * v2)); v3 = v3 / (1.f + __expf(-1.702f * v3));
+                    }
+                    uint2 o;
+                    o.x = ec_pack2(v0, v1);
+                    o.y = ec_pack2(v2, v3);
+                    *reinterpret_cast<uint2*>(smem + lrow_px * PITCH + lcol * 2) = o;
+                }
+            }
+        }
+    }
+}
+// runtime (act, residual) -> the matching straight-line instance: ONE wave-uniform branch per tile
+template <bool POOL, int FM, int FN, int PITCH>
+__device__ __forceinline__ void epi_stage_dispatch(const f32x16_t (&acc)[FM][FN], unsigned char* smem, const float* bias_n0,
+                                                   int row0, int col0, int lane, int act, bool has_res) {
+    if constexpr (POOL) {
+        epi_stage<EC_ACT_RELU, false, true, FM, FN, PITCH>(acc, smem, bias_n0, row0, col0, lane);   // (pool => ReLU, no residual)
+    } else {
+        if (act == EC_ACT_RELU) {
+            if (has_res) epi_stage<EC_ACT_RELU, true, false, FM, FN, PITCH>(acc, smem, bias_n0, row0, col0, lane);
+            else epi_stage<EC_ACT_RELU, false, false, FM, FN, PITCH>(acc, smem, bias_n0, row0, col0, lane);
+        } else if (act == EC_ACT_QUICKGELU) {
+            if (has_res) epi_stage<EC_ACT_QUICKGELU, true, false, FM, FN, PITCH>(acc, smem, bias_n0, row0, col0, lane);
+            else epi_stage<EC_ACT_QUICKGELU, false, false, FM, FN, PITCH>(acc, smem, bias_n0, row0, col0, lane);
+        } else {
+            if (has_res) epi_stage<EC_ACT_NONE, true, false, FM, FN, PITCH>(acc, smem, bias_n0, row0, col0, lane);
+            else epi_stage<EC_ACT_NONE, false, false, FM, FN, PITCH>(acc, smem, bias_n0, row0, col0, lane);
+        }
+    }
+}
+
 // Software-pipelined fragment stream (cf. conv_pair.hip lds_stream_mfma): the compiler sinks every LDS operand read to
 // just before the MFMAs that use it (ds_read x4 -> s_waitcnt -> mfma x4 per k-step, the LDS latency exposed four times per
 // K-tile).  Here the reads are inline asm, one k-step (G fragments) ahead of the MFMAs; the waits carry the fragment
@@ -378,49 +460,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM > 192) ? 2 : ((WM * WN == 8) ? 4 
         }
         __syncthreads();
     }
-#pragma unroll
-    for (int j = 0; j < FN; ++j) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int lcol = wn * TN + j * 32 + 8 * g + 4 * fhalf;          // 4 consecutive channels
-            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + e_n0 + lcol);
-#pragma unroll
-            for (int i = 0; i < FM; ++i) {
-                const int lrow_px = wm * TM + i * 32 + frow;                 // this lane's pixel (tile-local row)
-                float v0 = acc[i][j][4 * g + 0] + bv.x, v1 = acc[i][j][4 * g + 1] + bv.y;
-                float v2 = acc[i][j][4 * g + 2] + bv.z, v3 = acc[i][j][4 * g + 3] + bv.w;
-                if (POOL) {
-                    // the 4 pixels of a pooling window are the 4 lanes of a quad (m = 4*q + dy*2+dx)
-                    v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
-                    v0 += dpp_quad_xor1(v0); v1 += dpp_quad_xor1(v1); v2 += dpp_quad_xor1(v2); v3 += dpp_quad_xor1(v3);
-                    v0 += dpp_quad_xor2(v0); v1 += dpp_quad_xor2(v1); v2 += dpp_quad_xor2(v2); v3 += dpp_quad_xor2(v3);
-                    if ((lane & 3) == 0) {
-                        uint2 o;
-                        o.x = ec_pack2(0.25f * v0, 0.25f * v1);
-                        o.y = ec_pack2(0.25f * v2, 0.25f * v3);
-                        *reinterpret_cast<uint2*>(smem + (lrow_px >> 2) * PITCH + lcol * 2) = o;
-                    }
-                } else {
-                    uint2* slot = reinterpret_cast<uint2*>(smem + lrow_px * PITCH + lcol * 2);
-                    if (has_res) {
-                        const uint2 rr = *slot;
-                        v0 += ec_lo(rr.x); v1 += ec_hi(rr.x); v2 += ec_lo(rr.y); v3 += ec_hi(rr.y);
-                    }
-                    if (p.act == EC_ACT_RELU) {
-                        v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
-                    } else if (p.act == EC_ACT_QUICKGELU) {
-                        v0 = v0 / (1.f + __expf(-1.702f * v0)); v1 = v1 / (1.f + __expf(-1.702f * v1));
-                        v2 = v2 / (1.f + __expf(-1.702f * v2)); v3 = v3 / (1.f + __expf(-1.702f * v3));
-                    }
-                    uint2 o;
-                    o.x = ec_pack2(v0, v1);
-                    o.y = ec_pack2(v2, v3);
-                    *slot = o;
-                }
-            }
-        }
-    }
+    epi_stage_dispatch<POOL, FM, FN, PITCH>(acc, smem, p.bias ? p.bias + e_n0 : nullptr, wm * TM, wn * TN, lane, p.act, has_res);
     __syncthreads();
 #pragma unroll
     for (int r0 = 0; r0 < OUT_ROWS; r0 += RPP) {
@@ -687,9 +727,8 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
     };
     // 16 MFMAs (the two k-steps held in fa/fb); ISSUE: the wave's prepared LDS-DMA pieces go out in their shadow, one
     // piece per 2 MFMAs.  ISSUE is a template flag: the piece-free instance is 16 MFMAs with nothing between them.
-    auto mfma16 = [&](auto issue_c, auto first_c) {
+    auto mfma16 = [&](auto issue_c) {
         constexpr bool ISSUE = decltype(issue_c)::value;
-        constexpr int P0 = decltype(first_c)::value;       // pieces [0, P0) went out in the preceding MEM segment
         [&]<int... Q>(std::integer_sequence<int, Q...>) {
             ([&] {
                 constexpr int u = Q / (FM * FN), r = Q % (FM * FN), i = r / FN, j = r % FN;
@@ -697,21 +736,17 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                         __builtin_bit_cast(bf16x8_t, fb[u][j]), __builtin_bit_cast(bf16x8_t, fa[u][i]), acc[i][j], 0, 0, 0);
                 constexpr int NP = A_IT + B_IT, EVERY = (2 * FM * FN) / NP;
-                if constexpr (ISSUE && Q % EVERY == EVERY - 1 && Q / EVERY < NP && Q / EVERY >= P0) {
+                if constexpr (ISSUE && Q % EVERY == EVERY - 1 && Q / EVERY < NP) {
                     piece_pre(std::integral_constant<int, Q / EVERY>{});
-#ifdef EC_PIECE_PIN
-                    __builtin_amdgcn_sched_barrier(0);   // keep one piece per EVERY MFMAs (else the scheduler clusters them)
-#endif
+                    // keep one piece per EVERY MFMAs: left alone the scheduler clusters all of them behind the first MFMAs
+                    // (measured: 64.6 vs 60.1 us on 3x3 256->256 @14x14, piece segment 1060 vs 852 clk)
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }(), ...);
         }(std::make_integer_sequence<int, 2 * FM * FN>{});
     };
     using BT = std::true_type;
     using BF = std::false_type;
-#ifndef EC_NPM0
-#define EC_NPM0 0
-#endif
-    constexpr int NPM0 = (EC_NPM0 < A_IT + B_IT) ? EC_NPM0 : A_IT + B_IT;   // group 0: pieces issued in MEM0 instead of CMP0
     if (grp) {                                          // stagger: group 1 runs one segment behind group 0 ...
         if (nk > 1 && !(ABL & 1)) issue_all(1, 1);      // ... and uses the slot to fetch K-tile 1 (its "CMP1(-1)")
         if constexpr (!(ABL & 16)) __builtin_amdgcn_s_barrier();
@@ -731,13 +766,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
         const int cur = kt & 1;
         // ---- MEM0 ---- (group 0 also prepares the offsets of the pieces it issues in CMP0: K-tile kt+1 -> stage cur^1)
         if constexpr (!(abl & 4)) read_half(kt, I0{});
-        if constexpr (G == 0 && ISSUE) {
-            prep(kt + 1, cur ^ 1);
-            // group 0's first NPM0 pieces go out HERE, beside group 1's piece-carrying CMP1 (the longest segment of the
-            // period): this wave's MEM0 has that much slack, and its own CMP0 becomes (nearly) piece-free
-            [&]<int... Q>(std::integer_sequence<int, Q...>) { (piece_pre(std::integral_constant<int, Q>{}), ...); }
-            (std::make_integer_sequence<int, NPM0>{});
-        }
+        if constexpr (G == 0 && ISSUE) prep(kt + 1, cur ^ 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         stamp();
@@ -745,7 +774,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
         stamp();
         // ---- CMP0: group 0 issues its pieces of K-tile kt+1 in the MFMA shadow (s = 4kt+1; waited for at s = 4kt+3) ----
         __builtin_amdgcn_s_setprio(1);
-        mfma16(std::bool_constant<(G == 0 && ISSUE)>{}, std::integral_constant<int, NPM0>{});
+        mfma16(std::bool_constant<(G == 0 && ISSUE)>{});
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         stamp();
@@ -763,7 +792,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
         // ---- CMP1: group 1 issues its pieces of K-tile kt+2 (its CMP1(kt) is global segment 4(kt+1): the stage of
         //      K-tile kt is free -- its last reader was this group's own MEM1(kt)); waited for at the end of its MEM1(kt+1)
         __builtin_amdgcn_s_setprio(1);
-        mfma16(std::bool_constant<(G == 1 && ISSUE)>{}, I0{});
+        mfma16(std::bool_constant<(G == 1 && ISSUE)>{});
         __builtin_amdgcn_s_setprio(0);
         if constexpr (G == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
@@ -830,6 +859,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
         return;
     }
     // ---- epilogue (as conv_igemm_kernel) ----
+    if constexpr ((ABL & 8) != 0) return;               // profiling only: no epilogue at all
     constexpr int CH = BN / 8;
     constexpr int PITCH = BN * 2 + 16;
     constexpr int RPP = NT / CH;
@@ -850,53 +880,12 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
         }
         __syncthreads();
     }
-#pragma unroll
-    for (int j = 0; j < FN; ++j) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int lcol = wn * TN + j * 32 + 8 * g + 4 * fhalf;
-            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + n0 + lcol);
-#pragma unroll
-            for (int i = 0; i < FM; ++i) {
-                const int lrow_px = wm * TM + i * 32 + frow;
-                float v0 = acc[i][j][4 * g + 0] + bv.x, v1 = acc[i][j][4 * g + 1] + bv.y;
-                float v2 = acc[i][j][4 * g + 2] + bv.z, v3 = acc[i][j][4 * g + 3] + bv.w;
-                if (POOL) {
-                    v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
-                    v0 += dpp_quad_xor1(v0); v1 += dpp_quad_xor1(v1); v2 += dpp_quad_xor1(v2); v3 += dpp_quad_xor1(v3);
-                    v0 += dpp_quad_xor2(v0); v1 += dpp_quad_xor2(v1); v2 += dpp_quad_xor2(v2); v3 += dpp_quad_xor2(v3);
-                    if ((lane & 3) == 0) {
-                        uint2 o;
-                        o.x = ec_pack2(0.25f * v0, 0.25f * v1);
-                        o.y = ec_pack2(0.25f * v2, 0.25f * v3);
-                        *reinterpret_cast<uint2*>(smem + (lrow_px >> 2) * PITCH + lcol * 2) = o;
-                    }
-                } else {
-                    uint2* slot = reinterpret_cast<uint2*>(smem + lrow_px * PITCH + lcol * 2);
-                    if (has_res) {
-                        const uint2 rr = *slot;
-                        v0 += ec_lo(rr.x); v1 += ec_hi(rr.x); v2 += ec_lo(rr.y); v3 += ec_hi(rr.y);
-                    }
-                    if (p.act == EC_ACT_RELU) {
-                        v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
-                    } else if (p.act == EC_ACT_QUICKGELU) {
-                        v0 = v0 / (1.f + __expf(-1.702f * v0)); v1 = v1 / (1.f + __expf(-1.702f * v1));
-                        v2 = v2 / (1.f + __expf(-1.702f * v2)); v3 = v3 / (1.f + __expf(-1.702f * v3));
-                    }
-                    uint2 o;
-                    o.x = ec_pack2(v0, v1);
-                    o.y = ec_pack2(v2, v3);
-                    *slot = o;
-                }
-            }
-        }
-    }
+    epi_stage_dispatch<POOL, FM, FN, PITCH>(acc, smem, p.bias ? p.bias + n0 : nullptr, wm * TM, wn * TN, lane, p.act, has_res);
     __syncthreads();
 #pragma unroll
     for (int r0 = 0; r0 < OUT_ROWS; r0 += RPP) {
         const int row = r0 + srow;
-        if (orow0 + row < Mout)
+        if (orow0 + row < Mout && !(ABL & 128))         // (ABL & 128, profiling only: LDS staging without the global stores)
             *reinterpret_cast<uint4*>(p.out + (long)(orow0 + row) * p.Cout + n0 + schunk * 8) =
                 *reinterpret_cast<const uint4*>(smem + row * PITCH + schunk * 16);
     }
@@ -933,6 +922,10 @@ int launch8(const ConvArgs& a, hipStream_t s) {
             case 32: go(conv_igemm8_kernel<BN, KS, POOL, 32>); break;
             case 48: go(conv_igemm8_kernel<BN, KS, POOL, 48>); break;
             case 64: go(conv_igemm8_kernel<BN, KS, POOL, 64>); break;
+            case 8: go(conv_igemm8_kernel<BN, KS, POOL, 8>); break;
+            case 128: go(conv_igemm8_kernel<BN, KS, POOL, 128>); break;
+            case 40: go(conv_igemm8_kernel<BN, KS, POOL, 40>); break;
+            case 160: go(conv_igemm8_kernel<BN, KS, POOL, 160>); break;
             case 96: go(conv_igemm8_kernel<BN, KS, POOL, 96>); break;
             default: go(conv_igemm8_kernel<BN, KS, POOL, 0>);
         }
