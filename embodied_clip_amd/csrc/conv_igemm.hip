@@ -44,6 +44,7 @@
 // co-resident workgroups, wave specialisation, a split-K tail reduced by the last arriver, 64-row tiles.
 #include <stdlib.h>
 
+#include <algorithm>
 #include <type_traits>
 #include <utility>
 
@@ -198,8 +199,14 @@ __device__ __forceinline__ void fr_step(FragRing<R>& ring, AddrFn& addr, MmaFn& 
 
 // MV = rows of the tile that are real output rows (tile stride in M); MV < BM pads the tile (see dispatch_tile:
 // 196-of-224-row tiles make every RN50 layer's tile count a multiple of the CU count).
-template <int BM, int BN, int WM, int WN, int KS, bool POOL, bool PF, int MV>
-__global__ __launch_bounds__(WM * WN * 64, (BM > 192) ? 2 : ((WM * WN == 8) ? 4 : 3)) void conv_igemm_kernel(ConvArgs p) {
+// NS >= 3: RING mode for launches with at most 1-2 workgroups per CU (small per-GPU batches, the 7x7 maps): NS LDS stages,
+// the LDS-DMA of K-tile kt+NS-1 is issued while K-tile kt computes, each wave waits for its OWN pieces of K-tile kt with a
+// COUNTED s_waitcnt vmcnt (the younger NS-2 tiles stay in flight) and one raw s_barrier per K-tile orders them for the other
+// waves.  The K walk and the per-element summation order are those of the other modes (bit-identical results); what changes
+// is that a K-tile no longer costs a full L2 round trip: measured (round 3, rocprofv3) a 64x64 tile of the single-stage mode
+// takes ~750 ns per K-tile with one workgroup per CU -- 128 clk of MFMA issue per wave.
+template <int BM, int BN, int WM, int WN, int KS, bool POOL, bool PF, int MV, int NS>
+__global__ __launch_bounds__(WM * WN * 64, (BM > 192) ? 2 : ((WM * WN == 8) ? 4 : (NS >= 3 ? 2 : 3))) void conv_igemm_kernel(ConvArgs p) {
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int FM = TM / 32, FN = TN / 32;
     constexpr int NT = WM * WN * 64;                // threads per workgroup
@@ -344,6 +351,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM > 192) ? 2 : ((WM * WN == 8) ? 4 
         // SWAPPED operands: D[n][m] = sum_k W[n][k] * A[m][k].  In the 32x32 C/D layout a lane then owns
         // ONE pixel (col = lane&31) and channels (r&3) + 8*(r>>2) + 4*(lane>>5): every 4 accumulator
         // registers are 4 consecutive channels -> 8-byte packed epilogue traffic.
+        static_assert(NS < 3 || !(PF || FM + FN > 4), "ring mode needs the inline-asm fragment stream");
         if constexpr (PF || FM + FN > 4) {   // no registers to spare for the fragment ring there (the residual-prefetching variants spill: 68 -> 104 us)
 #pragma unroll
             for (int ks = 0; ks < BK / 16; ++ks) {
@@ -408,6 +416,25 @@ __global__ __launch_bounds__(WM * WN * 64, (BM > 192) ? 2 : ((WM * WN == 8) ? 4 
                     rres[i] = *reinterpret_cast<const uint4*>(p.res + (long)(orow0 + row) * p.Cout + e_n0 + schunk * 8);
             }
         }
+        if constexpr (NS >= 3) {
+            constexpr int PIECES = A_IT + B_IT;                 // LDS-DMA instructions per wave per K-tile
+            static_assert((NS - 2) * PIECES <= 60, "vmcnt is a 6-bit counter");
+            // K-tiles past the end are all out-of-range offsets (zeros into a free stage): every K-tile then has exactly
+            // PIECES younger-by-one-tile instructions behind it and the counted wait needs no tail cases
+#pragma unroll
+            for (int t = 0; t < NS - 1; ++t) glds_tile(t, t);
+            int st_c = 0, st_l = NS - 1;                        // stage of the K-tile computed / loaded next
+            for (int kt = 0; kt < nk; ++kt) {
+                asm volatile("s_waitcnt vmcnt(%0)" : : "n"((NS - 2) * PIECES) : "memory");   // own pieces of K-tile kt
+                __builtin_amdgcn_s_barrier();                   // everyone's landed; everyone is done with K-tile kt-1
+                if (!(p.ablate & 1)) glds_tile(kt + NS - 1, st_l);   // into the stage K-tile kt-1 just left
+                if (!(p.ablate & 2)) compute(st_c);
+                st_c = (st_c + 1 == NS) ? 0 : st_c + 1;
+                st_l = (st_l + 1 == NS) ? 0 : st_l + 1;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the zero-filled tail tiles too: LDS becomes the epilogue image
+            __syncthreads();
+        } else {
         glds_tile(0, 0);
         __syncthreads();
         if (p.nbuf == 1) {
@@ -430,6 +457,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM > 192) ? 2 : ((WM * WN == 8) ? 4 
                 __syncthreads();
             }
         }
+        }   // NS < 3
         tile += (int)grid;
         const bool has_next = tile < p.ntiles;
         if (has_next) {
@@ -475,7 +503,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM > 192) ? 2 : ((WM * WN == 8) ? 4 
     }
 }
 
-template <int BM, int BN, int WM, int WN, int KS, bool POOL, bool PF = false, int MV = BM>
+template <int BM, int BN, int WM, int WN, int KS, bool POOL, bool PF = false, int MV = BM, int NS = 0>
 int launch(const ConvArgs& a, hipStream_t s) {
     ConvArgs p = a;
     p.ntn = a.Cout / BN;
@@ -487,17 +515,19 @@ int launch(const ConvArgs& a, hipStream_t s) {
     p.nbuf = nbuf_force ? nbuf_force : ((BM * BN >= 256 * 256) ? 2 : 1);
     static const int ablate = [] { const char* e = getenv("EC_CONV_ABLATE"); return e ? atoi(e) : 0; }();
     p.ablate = ablate;
-    size_t lds = (size_t)p.nbuf * (BM + BN) * ROW_BYTES;   // (set after nbuf below)
+    size_t lds = (size_t)(NS >= 3 ? NS : p.nbuf) * (BM + BN) * ROW_BYTES;
     if (lds < epi) lds = epi;
-    auto kern = conv_igemm_kernel<BM, BN, WM, WN, KS, POOL, PF, MV>;
+    auto kern = conv_igemm_kernel<BM, BN, WM, WN, KS, POOL, PF, MV, NS>;
     static std::atomic<uint64_t> attr_done{0};
     if (auto attr_g_ = ec_attr_needed(attr_done)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)(lds_max > epi ? lds_max : epi));
+        const size_t want = NS >= 3 ? lds : (lds_max > epi ? lds_max : epi);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
     }
     // persistent: 3 workgroups per CU (<= 168 VGPRs, single 35-KB LDS stage), each walking several tiles
     static const int wg_cap = [] { const char* e = getenv("EC_CONV_WGS"); return e ? atoi(e) : 768; }();
-    const int cap = (BM * BN >= 256 * 256) ? 256 : wg_cap;      // 8-wave 256x256 tiles: one workgroup per CU
+    // ring mode: as many workgroups per CU as its NS stages fit (160 KiB of LDS, 2 waves per SIMD by registers)
+    const int ring_per_cu = NS >= 3 ? (int)std::min<size_t>(2, (160 * 1024) / lds) : 0;
+    const int cap = NS >= 3 ? 256 * ring_per_cu : ((BM * BN >= 256 * 256) ? 256 : wg_cap);      // 8-wave 256x256 tiles: one workgroup per CU
     const int nwg = p.ntiles < cap ? p.ntiles : cap;
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(WM * WN * 64), lds, s, p);
     EC_CHECK_LAUNCH();
@@ -999,9 +1029,20 @@ int dispatch_tile(const ConvArgs& a, hipStream_t s) {
         // long serial K chain and most of the chip idles -> 64x64 tiles give 4x the workgroups for the long-K layers
         // (batch 32: layer-4 3x3 52 tiles x 72 K-tiles = 76 us).  EC_CONV_T64: tile-count threshold (0 = off).
         static const int t64 = [] { const char* e = getenv("EC_CONV_T64"); return e ? atoi(e) : 150; }();
+        // EC_CONV_RING (default 1): those launches, and 128x128 launches with at most one workgroup per CU, run the
+        // multi-stage ring pipeline (conv_igemm_kernel NS >= 3): with so few waves per CU nothing hides the L2 round trip
+        // of the single-stage loop.  2: every non-prefetching 128x128 launch (A/B).
+        static const int ring = [] { const char* e = getenv("EC_CONV_RING"); return e ? atoi(e) : 1; }();
         if constexpr (!POOL) {
             const long t128 = (long)((a.M + 127) / 128) * (a.Cout / 128);
-            if (t128 < t64 && a.K >= 512 && a.Cout % 64 == 0) return launch<64, 64, 2, 2, KS, POOL>(a, s);
+            if (t128 < t64 && a.K >= 512 && a.Cout % 64 == 0)
+                return ring ? launch<64, 64, 2, 2, KS, POOL, false, 64, 4>(a, s) : launch<64, 64, 2, 2, KS, POOL>(a, s);
+        }
+        {
+            const long t128 = (long)((a.M + 127) / 128) * (a.Cout / 128);
+            const bool pf = (KS == 1 && !POOL && a.res && a.K <= 256);
+            if (force != 8 && !pf && a.K >= 512 && ((ring == 1 && t128 <= 256) || ring == 2))
+                return launch<128, 128, 2, 2, KS, POOL, false, 128, 3>(a, s);
         }
         // residual register prefetch only for the short-K, bandwidth-bound expanding 1x1 convs
         if (force != 8) {
