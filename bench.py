@@ -116,18 +116,23 @@ def measured_traffic(encoder: str, plan_hash, frames_per_launch: int):
     returns (None, note) when no summary exists for this encoder."""
     path = TRAFFIC_FILES[encoder]
     if not os.path.exists(path):
-        return None, f"no PMC summary at {os.path.relpath(path, ROOT)} (run tools/pmc_collect.sh + tools/pmc_summary.py)"
+        return None, f"no PMC summary at {os.path.relpath(path, ROOT)} (run tools/pmc_collect.sh + tools/pmc_summary.py)", None
     rec = json.load(open(path))
-    if plan_hash is not None and rec.get("plan_hash") not in (None, plan_hash):
-        raise SystemExit(f"{os.path.relpath(path, ROOT)} is STALE: measured on launch plan {rec.get('plan_hash')}, the "
-                         f"library now runs plan {plan_hash}. Re-run tools/pmc_collect.sh + tools/pmc_summary.py and commit "
-                         "the new summary (or pass --no-traffic).")
+    if plan_hash is not None and rec.get("plan_hash") not in (None, "", plan_hash):
+        # stale evidence is never quoted: the line carries traffic = null and says why (and how to refresh it)
+        msg = (f"{os.path.relpath(path, ROOT)} is STALE: measured on launch plan {rec.get('plan_hash')}, the library now runs "
+               f"plan {plan_hash} -- not quoted. Refresh: tools/pmc_collect.sh + tools/pmc_summary.py, then commit the summary.")
+        print("bench.py: " + msg, file=sys.stderr, flush=True)
+        return None, msg, rec
     per_frame = rec["hbm_bytes_per_launch"] / rec["frames_per_launch"]
     return per_frame * frames_per_launch, (
-        f"HBM bytes per launch = PMC-measured {rec['hbm_bytes_per_launch'] / 1e9:.2f} GB per {rec['frames_per_launch']}-frame "
-        f"launch ({os.path.relpath(path, ROOT)}: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc passes) "
+        f"bytes per launch = PMC-measured {rec['hbm_bytes_per_launch'] / 1e9:.2f} GB per {rec['frames_per_launch']}-frame "
+        f"launch ({os.path.relpath(path, ROOT)}: FETCH_SIZE x{rec.get('fetch_factor', 2)} + WRITE_SIZE, separate --pmc passes; "
+        "these are the L2s' memory-side (fabric) request bytes -- L2 MISS traffic, Infinity-Cache hits included -- i.e. an "
+        "upper bound of the HBM bytes; FETCH_SIZE factor: MI355X_MICROARCH.md, re-checked on this library's own access "
+        f"patterns: {rec.get('fetch_calibration', 'see profiles/README.md')}) "
         f"scaled to {frames_per_launch} frames; algorithmic bytes {rec.get('algorithmic_mb_per_frame', 45.7)} MB/frame "
-        "layer by layer")
+        "layer by layer"), rec
 
 
 def _time_iterations(w, steps, warmup, barrier):
@@ -251,8 +256,8 @@ def run_rank(a, rank: int, local_rank: int, world: int, init_method=None):
         gc.collect(); torch.cuda.empty_cache()
         u8 = a.encoder != "vit"          # (the ViT patch-embed kernel takes the sensor's fp32 frames only)
         wh = Worker(per_gpu, frames_host=True, **{**wkw, "frames_u8": u8})
-        dth = maxreduce(_time_iterations(wh, 1, 1, barrier))
-        h2d = {"value": round(a.rollout * per_gpu * world / dth, 1), "unit": "env-frames/s", "steps": 1,
+        dth = maxreduce(_time_iterations(wh, a.h2d_steps, 1, barrier))
+        h2d = {"value": round(a.rollout * per_gpu * world * a.h2d_steps / dth, 1), "unit": "env-frames/s", "steps": a.h2d_steps,
                "frames": ("uint8 HWC" if u8 else "fp32 normalised HWC") + " in PINNED HOST memory, copied per slice on its "
                          "own copy stream (double-buffered) while the other slice computes" +
                          ("; /255 + CLIP mean/std fused into the stem kernel" if u8 else ""),
@@ -269,17 +274,33 @@ def run_rank(a, rank: int, local_rank: int, world: int, init_method=None):
                 "actors_per_gpu": total, "global_actors": total * world, "ms_per_step": round(dtw / a.steps * 1e3, 2)}
         del ww
 
+    plugin = None
+    if world == 1 and a.encoder == "rn50" and not a.no_plugin:
+        w = None
+        gc.collect(); torch.cuda.empty_cache()
+        from embodied_clip_amd.plugin_path import time_plugin_path
+        plugin = time_plugin_path(per_gpu, a.rollout, dev, steps=a.plugin_steps, warmup=1, update_repeats=a.update_repeats)
+        gc.collect(); torch.cuda.empty_cache()
+
     if rank == 0:
         frames = a.rollout * per_gpu * world * a.steps
         value = frames / dt
         enc_mac = {"rn50": TRUNK_MAC_PER_FRAME, "vit": VIT_MAC_PER_FRAME,
                    "zeroshot": TRUNK_MAC_PER_FRAME + ATTNPOOL_MAC_PER_FRAME}[a.encoder]
-        trunk_mac = TRUNK_MAC_PER_FRAME if a.encoder != "vit" else VIT_MAC_PER_FRAME
+        # flop of what one timed launch covers (zero-shot: the events bracket trunk + AttentionPool2d)
+        trunk_mac = {"rn50": TRUNK_MAC_PER_FRAME, "vit": VIT_MAC_PER_FRAME,
+                     "zeroshot": TRUNK_MAC_PER_FRAME + ATTNPOOL_MAC_PER_FRAME}[a.encoder]
         flops_call = 2.0 * trunk_mac * enc_frames          # one timed launch = one (slice of the) encoder forward
         achieved_launch = flops_call / (avg_trunk_ms * 1e-3) / 1e12
         achieved = flops_call * n_conc / (avg_union_ms * 1e-3) / 1e12
-        traffic, tnote = (None, "--no-traffic") if a.no_traffic else measured_traffic(
+        traffic, tnote, trec = (None, "--no-traffic", None) if a.no_traffic else measured_traffic(
             "vit" if a.encoder == "vit" else "rn50", plan_hash, enc_frames)
+        # the same fraction from the COMMITTED profile alone (reproducible from profiles/): algorithmic flop of the
+        # profiled single launch / its summed kernel time (rocprofv3 kernel trace)
+        frac_profiles = None
+        if trec and trec.get("kernel_time_us") and trec.get("plan_hash") in (None, "", plan_hash):
+            frac_profiles = round(2.0 * trunk_mac * trec["frames_per_launch"] / (trec["kernel_time_us"] * 1e-6) / 1e12
+                                  / MFMA_BF16_PEAK_TFLOPS, 4)
         workload = {"rn50": "RoboTHOR ObjectNav: frozen CLIP-RN50 encoder",
                     "vit": "RoboTHOR ObjectNav: frozen CLIP ViT-B/32 encoder (11 blocks)",
                     "zeroshot": "Zero-shot ObjectNav: frozen CLIP-RN50 trunk + AttentionPool2d image embedding, goal = "
@@ -304,7 +325,12 @@ def run_rank(a, rank: int, local_rank: int, world: int, init_method=None):
                                     if a.encoder != "vit" else "ec_vit_forward (conv_igemm GEMMs + mha/layernorm kernels)"),
                          "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
-                         "traffic": traffic, "traffic_note": tnote, "plan_hash": plan_hash,
+                         "frac_profiles": frac_profiles,
+                         "frac_note": "frac = live HIP-event UNION of the concurrent encoder launches of an env step; "
+                                      "frac_profiles = the committed rocprofv3 kernel trace of ONE single-stream launch "
+                                      "(profiles/*_hbm_traffic.json kernel_time_us), reproducible from profiles/ alone",
+                         "traffic": traffic, "traffic_kind": "L2-miss (fabric-side) bytes, Infinity-Cache hits included",
+                         "traffic_note": tnote, "plan_hash": plan_hash,
                          "avg_launch_ms": round(avg_trunk_ms, 3), "avg_step_union_ms": round(avg_union_ms, 3),
                          "launches_timed": len(trunk_ms), "frames_per_launch": enc_frames,
                          "concurrent_launches": n_conc, "achieved_per_launch": round(achieved_launch, 1),
@@ -313,6 +339,7 @@ def run_rank(a, rank: int, local_rank: int, world: int, init_method=None):
             "loss": {k: round(v, 6) for k, v in info.items()},
             **({"phases": phases} if phases else {}),
             **({"h2d_inclusive": h2d} if h2d else {}),
+            **({"plugin_path": {**plugin, "fraction_of_engine": round(plugin["value"] / value, 3)}} if plugin else {}),
             **({"weak": weak} if weak else {}),
         }
         if world == 1 and not a.no_cpu_baseline:
@@ -353,6 +380,11 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-h2d", action="store_true", help="skip the secondary h2d_inclusive measurement")
     ap.add_argument("--no-weak", action="store_true", help="skip the secondary weak-scaling measurement (N > 1)")
+    ap.add_argument("--no-plugin", action="store_true",
+                    help="skip the secondary `plugin_path` measurement: the same iteration driven through the drop-in plugin "
+                         "classes with the reference's tensor contracts (embodied_clip_amd/plugin_path.py)")
+    ap.add_argument("--plugin-steps", type=int, default=1)
+    ap.add_argument("--h2d-steps", type=int, default=5, help="timed iterations of the h2d_inclusive measurement")
     ap.add_argument("--no-traffic", action="store_true", help="do not read profiles/*_hbm_traffic.json")
     ap.add_argument("--phase-times", action="store_true", help="extra untimed iteration with per-phase sync timing")
     ap.add_argument("--cpu-actors", type=int, default=32)

@@ -45,13 +45,16 @@ class SyntheticEnv:
                  frames_u8: bool = False, host: bool = False):
         self.N, self.T = n_actors, T
         self.host = host
-        # frames_u8: raw uint8 frames (what the simulator renders); normalisation is then fused into the stem kernel
-        base = (syn.synthetic_rgb_u8 if frames_u8 else syn.synthetic_rgb)(seed, min(n_actors, 32), res)
-        reps = (n_actors + base.shape[0] - 1) // base.shape[0]
+        # frames_u8: raw uint8 frames (what the simulator renders); normalisation is then fused into the stem kernel.
+        # Every actor has its OWN frame in every pool entry (n_actors distinct images per env step: no replicated
+        # images flattering the cache hit rates of the stem); the pool entries are shifted copies of one another, so
+        # consecutive steps differ.  The fp32 wire form is the same arithmetic as synthetic.normalize_rgb.
+        base = syn.synthetic_rgb_u8(seed, n_actors, res)
+        if not frames_u8:   # (on the device when the pool lives there: 256 frames take 6 s on the host)
+            base = syn.normalize_rgb(base if host else base.to(device))
         frames = []
         for s in range(pool_steps):   # distinct frame batches so consecutive steps differ
-            f = base.roll(shifts=s + 1, dims=0).roll(shifts=7 * (s + 1), dims=2)
-            frames.append(f.repeat(reps, 1, 1, 1)[:n_actors])
+            frames.append(base.roll(shifts=s + 1, dims=0).roll(shifts=7 * (s + 1), dims=2))
         # host=True: the pool stays in PINNED HOST memory (what the simulators hand over through the plugin contract);
         # the worker then streams each step's frames over PCIe on a copy stream (Worker._encode_slice)
         self.frames = (torch.stack(frames).contiguous().pin_memory() if host

@@ -323,8 +323,8 @@ def synthetic_rgb_u8(seed: int, n: int, res: int = 224) -> torch.Tensor:
 
 def normalize_rgb(u8: torch.Tensor) -> torch.Tensor:
     """The sensor's wire form: fp32 NHWC, (u8/255 - mean)/std with CLIP consts."""
-    mean = torch.tensor(CLIP_RGB_MEANS, dtype=torch.float32)
-    std = torch.tensor(CLIP_RGB_STDS, dtype=torch.float32)
+    mean = torch.tensor(CLIP_RGB_MEANS, dtype=torch.float32, device=u8.device)
+    std = torch.tensor(CLIP_RGB_STDS, dtype=torch.float32, device=u8.device)
     return (u8.to(torch.float32) / 255.0 - mean) / std
 
 

@@ -196,3 +196,43 @@ def test_sharded_hip_gradients_sum_to_unsharded():
     for name, (o, k) in h.offsets.items():
         a, b = bucket[o:o + k], full[o:o + k]
         assert _rel(a, b) < 2e-4, (name, _rel(a, b))
+    # ... and, so that this is not the HIP path agreeing with itself: the ORACLE's unsharded gradient (torch-CPU
+    # autograd through oracle/policy.py + oracle/ppo.py on the same batch) is what the summed bucket must equal
+    sd = syn.policy_state_dict(0)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    feat_nchw = feat.float().cpu().view(T, N, 7, 7, 2048).permute(0, 1, 4, 2, 3).contiguous()
+    lg, vv, _ = opol.actor_critic_forward(feat_nchw, goal.cpu(), h0.cpu().unsqueeze(0), masks.cpu().unsqueeze(-1), leaves)
+    u = lambda t: t.cpu().unsqueeze(-1)
+    total, _ = oppo.ppo_loss(lg, vv, actions.cpu(), u(old_lp), u(old_v), u(ret), u(nadv))
+    names = list(h.offsets.keys())
+    ref = dict(zip(names, torch.autograd.grad(total, [leaves[k] for k in names])))
+    for name, (o, k) in h.offsets.items():
+        a, b = bucket[o:o + k].cpu(), ref[name].reshape(-1)
+        assert _rel(a, b) < 2e-4, (name, _rel(a, b))
+
+
+def test_config5_zeroshot_fullsize_properties():
+    """BASELINE config 5 at its full single-GPU size: 256 actors x rollout 128, CLIP-RN50 trunk + AttentionPool2d image
+    embeddings in the rollout buffer, goal = CLIP text-tower table (same property set as configs 2 / 3)."""
+    from embodied_clip_amd.engine import Worker
+    w = Worker(256, T=128, device="cuda:0", seed=0, zeroshot=True)
+    assert (w.S, w.C) == (1, 1024) and w.ns == 2 and w.encode_frames == 128
+    w.collect_rollout()
+    w.compute_returns()
+    torch.cuda.synchronize()
+    assert w.feat.shape == (129, 256, 1, 1024) and w.feat.dtype == torch.float32
+    # goal table: unit rows (the policy multiplies normalised image embeddings with it)
+    assert torch.allclose(w.goal_table.norm(dim=-1), torch.ones(12, device=w.goal_table.device), atol=1e-3)
+    # an embedding produced inside the 128-frame launch equals the same frame embedded alone (best pool match)
+    sl = w.slices[1]
+    b = sl.feat[1][9].reshape(-1)
+    rels = []
+    for pidx in range(w.env.pool_steps):
+        alone = sl.pool.forward(sl.enc.forward(w.env.frames[pidx][sl.o + 9:sl.o + 10].contiguous()))
+        torch.cuda.synchronize()
+        a = alone[0].reshape(-1)
+        rels.append(((a - b).norm() / b.norm()).item())
+    assert min(rels) < 2e-3, rels
+    _check_properties(w)
+    del w
+    torch.cuda.empty_cache()

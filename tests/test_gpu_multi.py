@@ -1,7 +1,9 @@
 """GPU, world size 2 over RCCL: `python bench.py --gpus 2` self-launches two ranks, each owning half of the actors
 (strong scaling), and the flat-bucket SUM all-reduce keeps the replicas' parameters identical.  Needs >= 2 MI355X:
 the driver's 1-GPU test box skips it (the N > 1 path is covered on CPU by tests/test_dist_gloo.py and
-tests/test_bench_launch.py)."""
+tests/test_bench_launch.py).  Also here, behind device-count guards: BASELINE config 4 (512 actors sharded 8-way),
+config 5's 2-GPU leg (zero-shot worker) and the a18 check proper -- HIP shard gradients summed THROUGH RCCL compared
+with the oracle's unsharded gradient (the 1-GPU form of it runs in tests/test_gpu_configs.py)."""
 import json
 import os
 import subprocess
@@ -14,18 +16,98 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs")
-def test_bench_two_ranks_over_rccl():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--actors", "64", "--rollout", "8",
-                        "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-h2d", "--no-traffic"],
-                       capture_output=True, text=True, timeout=900, cwd=ROOT,
+def _bench(*flags, timeout=1500):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags, "--no-cpu-baseline", "--no-h2d", "--no-traffic"],
+                       capture_output=True, text=True, timeout=timeout, cwd=ROOT,
                        env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs")
+def test_bench_two_ranks_over_rccl():
+    line = _bench("--gpus", "2", "--actors", "64", "--rollout", "8", "--steps", "1", "--warmup", "1", timeout=900)
     assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["scaling"] == "strong"
     assert line["config"]["actors_per_gpu"] == 32 and line["config"]["global_actors"] == 64
     assert len(line["allreduce_ms_per_rank"]) == 2 and all(0 < x < 50 for x in line["allreduce_ms_per_rank"])
     assert line["weak"]["actors_per_gpu"] == 64 and line["value"] > 0
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 8, reason="needs 8 GPUs")
+def test_config4_512_actors_sharded_8_way_over_rccl():
+    """BASELINE config 4: Habitat ObjectNav shape -- 512 actors sharded 8-way (64 per GPU), RCCL gradient all-reduce."""
+    line = _bench("--gpus", "8", "--actors-total", "512", "--rollout", "16", "--steps", "1", "--warmup", "1", "--no-weak")
+    assert line["n_gpus"] == 8 and line["rccl_ranks"] == 8 and line["scaling"] == "strong"
+    assert line["config"]["actors_per_gpu"] == 64 and line["config"]["global_actors"] == 512
+    assert len(line["allreduce_ms_per_rank"]) == 8 and all(0 < x < 50 for x in line["allreduce_ms_per_rank"])
+    assert line["value"] > 0 and abs(line["loss"]["ratio"] - 1.0) < 0.2
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs")
+def test_config5_zeroshot_two_ranks_over_rccl():
+    """BASELINE config 5's 2-GPU leg: the zero-shot dual-encoder worker, 256 actors sharded over two ranks."""
+    line = _bench("--config", "zeroshot", "--gpus", "2", "--actors", "256", "--rollout", "8", "--steps", "1", "--warmup", "1",
+                  "--no-weak")
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2
+    assert line["config"]["actors_per_gpu"] == 128 and line["config"]["global_actors"] == 256
+    assert "Zero-shot" in line["config"]["workload"] and line["value"] > 0
+
+
+def _rank_grads(rank, world, store, q):
+    """One rank of the a18 check: HIP gradients of this rank's actor shard -> flat bucket -> RCCL SUM."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    torch.distributed.init_process_group("nccl", init_method=f"file://{store}", rank=rank, world_size=world)
+    from embodied_clip_amd import synthetic as syn
+    from embodied_clip_amd.dist import allreduce_flat, grad_scale, shard_actors
+    from embodied_clip_amd.policy import PolicyHandle
+    from embodied_clip_amd.ppo import ppo_loss_raw
+    import _a18_case
+    dev = torch.device(f"cuda:{rank}")
+    T, N, case = _a18_case.make()
+    h = PolicyHandle()
+    flat = h.flatten(syn.policy_state_dict(0), dev)
+    lo, cnt = shard_actors(N, rank, world)
+    sl = slice(lo, lo + cnt)
+    c = lambda t: t[:, sl].reshape(-1).contiguous().to(dev)
+    rows = case["feat"][:, sl].reshape(T * cnt, 49, 2048).contiguous().to(dev)
+    ws = torch.empty(h.workspace_bytes(T, cnt, True), dtype=torch.uint8, device=dev)
+    hv, _ = h.forward(flat, rows, c(case["goal"]), case["h0"][sl].contiguous().to(dev), c(case["masks"]), T, cnt, ws)
+    dhv, _ = ppo_loss_raw(hv, c(case["actions"]), c(case["old_lp"]), c(case["old_v"]), c(case["ret"]), c(case["nadv"]), 6,
+                          grad_scale=grad_scale(T * cnt, T * N))
+    bucket = torch.zeros_like(flat)
+    h.backward(flat, rows, c(case["masks"]), T, cnt, ws, dhv, None, bucket)
+    allreduce_flat(bucket)                                   # the single exchange step of the path, over RCCL
+    torch.cuda.synchronize()
+    q.put((rank, bucket.cpu(), {k: v for k, v in h.offsets.items()}))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs")
+def test_rccl_summed_hip_gradients_equal_the_oracles_unsharded_gradient(tmp_path):
+    """Row a18 end to end: HIP shard gradients -> flat bucket -> RCCL SUM all-reduce == the ORACLE's gradient of the
+    unsharded batch (torch-CPU autograd), on every rank."""
+    import torch.multiprocessing as mp
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import _a18_case
+    from embodied_clip_amd import synthetic as syn
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    store = str(tmp_path / "store_a18")
+    ps = [ctx.Process(target=_rank_grads, args=(r, 2, store, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = [q.get() for _ in range(2)]
+    for p in ps:
+        p.join(120)
+        assert p.exitcode == 0
+    ref = _a18_case.oracle_gradient(syn.policy_state_dict(0))
+    assert torch.equal(got[0][1], got[1][1])
+    for name, (o, k) in got[0][2].items():
+        a, b = got[0][1][o:o + k], ref[name].reshape(-1)
+        rel = ((a - b).norm() / b.norm().clamp_min(1e-20)).item()
+        assert rel < 2e-4, (name, rel)
 
 
 def _rank(rank, world, store, q):
