@@ -75,6 +75,7 @@ class _PreprocessorBase(Preprocessor):
     def to(self, device: torch.device):
         self.device = torch.device(device)
         self._model = None   # rebuilt lazily on the new device
+        self._twin = None
         return self
 
 
@@ -117,10 +118,56 @@ class ClipResNetPreprocessor(_PreprocessorBase):
             self._model = RN50Trunk(sd, device=self.device, chunk=self._chunk)
         return self._model
 
+    def _process_host_pipelined(self, x: torch.Tensor) -> torch.Tensor:
+        """HOST frames (what the simulators hand over), >= 64 of them, full feature maps: the batch is cut in two halves
+        that run copy -> trunk -> NCHW conversion on two HIP streams, so one half's PCIe copy hides behind the other
+        half's encoder and the two encoder launches overlap as they do in ``engine.Worker`` (same per-frame results:
+        a frame's features do not depend on how the batch is sliced)."""
+        from .encoder import RN50Trunk
+        trunk = self.resnet
+        if getattr(self, "_twin", None) is None:
+            self._twin = RN50Trunk(None, device=self.device, chunk=self._chunk, weights_from=trunk)
+            self._streams = [torch.cuda.Stream(device=self.device) for _ in range(2)]
+            for t in (trunk, self._twin):
+                t.set_conv8_min_tiles(50)         # two launches in flight (see ec_rn50_set_conv8_min_tiles)
+        N = x.shape[0]
+        h = N // 2
+        out = torch.empty((N, trunk.out_channels, trunk.out_spatial, trunk.out_spatial), dtype=torch.float32, device=self.device)
+        cur = torch.cuda.current_stream(self.device)
+        if getattr(self, "_copy_stream", None) is None:
+            self._copy_stream = torch.cuda.Stream(device=self.device)
+        # both copies go back to back on ONE copy stream (the SDMA queue); each compute stream waits for its half only
+        self._copy_stream.wait_stream(cur)
+        halves, copied = [], []
+        with torch.cuda.stream(self._copy_stream):
+            for (a, b) in ((0, h), (h, N)):
+                xs = torch.empty((b - a,) + tuple(x.shape[1:]), dtype=x.dtype, device=self.device)
+                xs.copy_(x[a:b], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self._copy_stream)
+                halves.append(xs); copied.append(ev)
+        for (a, b), tr, st, xs, ev in zip(((0, h), (h, N)), (trunk, self._twin), self._streams, halves, copied):
+            st.wait_stream(cur)
+            st.wait_event(ev)
+            with torch.cuda.stream(st):
+                if xs.dtype == torch.uint8:
+                    f = tr.forward_u8(xs, mean=self.CLIP_RGB_MEANS, std=self.CLIP_RGB_STDS)
+                else:
+                    f = tr.forward(xs if xs.dtype == torch.float32 else xs.to(torch.float32))
+                tr.to_nchw_f32(f, out[a:b])
+            xs.record_stream(st)
+            out.record_stream(st)          # (allocated on the caller's stream, written on this one)
+        for st in self._streams:
+            cur.wait_stream(st)
+        return out
+
     def process(self, obs: Dict[str, Any], *args: Any, **kwargs: Any) -> torch.Tensor:
         x = obs[self.input_uuids[0]]
         if x.shape[-1] == 1:      # depth input: repeated to 3 channels, as upstream does
             x = x.expand(*x.shape[:-1], 3)
+        if (not self.pool and isinstance(x, torch.Tensor) and not x.is_cuda and x.dim() == 4 and x.shape[0] >= 64
+                and x.shape[-1] == 3 and self.device.type == "cuda"):
+            return self._process_host_pipelined(x)
         trunk = self.resnet
         if x.dtype == torch.uint8:   # raw frames: /255 and CLIP mean/std are fused into the stem kernel
             feat = trunk.forward_u8(x.to(self.device).contiguous(), mean=self.CLIP_RGB_MEANS, std=self.CLIP_RGB_STDS)

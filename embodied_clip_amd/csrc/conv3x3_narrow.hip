@@ -33,6 +33,7 @@ struct N3Args {
     const float* bias;
     uint16_t* out;
     int H, W, ntiles;
+    int dbg = 0;      // profiling only (EC_ROWS_DBG): 1 no global fetch, 2 no global stores, 4 no MFMA stream
 };
 
 __device__ __forceinline__ float dppq_xor1(float v) {
@@ -361,6 +362,228 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_rows_kernel(N3Args p) {
     }
 }
 
+// -----------------------------------------------------------------------------------------------------------------
+// Multi-row tiles (round 3).  The row-tile kernel above reads 1.5 LDS fragments per MFMA (one im2col fragment per K-step
+// plus one weight fragment per MFMA: a 28-pixel tile has ONE 32-row block, so a weight fragment is used once): at 6
+// waves per CU that is ~260 B/clk of ds_read_b128 -- the LDS port, not the matrix pipe, paces it (MFMA busy 40 %).
+// Here a wave owns RT consecutive image rows of a 28-pixel segment: a weight fragment feeds RT MFMAs, the (RT + 2)-row
+// footprint is fetched once for RT output rows (input re-read 3x -> (RT + 2) / RT), and the fragment reads are an
+// inline-asm stream LEADK K-steps ahead of their MFMAs (one wave per SIMD has no partner to hide LDS latency behind;
+// cf. conv_pair.hip lds_stream_mfma).  Same K order as every other kernel of the layer (tap-major, 16 channels per
+// K-step), same epilogue arithmetic: results are bit-identical to conv3x3_rows_kernel.
+// -----------------------------------------------------------------------------------------------------------------
+template <int R>
+struct FragRingN { u32x4 f[R]; };
+template <int CIN, int COUT, int RT, int NW, int LEADK>
+__global__ __launch_bounds__(NW * 64, 1) void conv3x3_rowsN_kernel(N3Args p) {
+    constexpr int KSTEPS = 9 * CIN / 16, CB = CIN / 16, FN = COUT / 32, K = 9 * CIN;
+    constexpr int CPP = CIN / 8;                              // 16-B chunks per pixel
+    constexpr int PITCH = CIN * 2 + 16;                       // bytes per pixel in the LDS image
+    constexpr int RW = 30, RPB = RW * PITCH, NR = RT + 2;
+    constexpr int REGION = NR * RPB + 4 * PITCH;              // + overrun of the 4 padding lanes
+    constexpr int NCH = NR * RW * CPP;                        // 16-B chunks of the footprint
+    constexpr int IT = (NCH + 63) / 64;
+    constexpr int W_BYTES = KSTEPS * COUT * 32;
+    constexpr int OP = COUT * 2 + 16;
+    constexpr int G = RT + FN;                                // fragments per K-step: RT im2col blocks, FN weight blocks
+    constexpr int RING = (LEADK + 1) * G;
+    static_assert(RT * 32 * OP <= REGION, "epilogue image fits the footprint region");
+    static_assert(G * LEADK <= 15, "lgkmcnt is a 4-bit counter");
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    float* sB = reinterpret_cast<float*>(sm + W_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned char* img = sm + W_BYTES + COUT * 4 + wave * REGION;
+    const int px = lane & 31, h = lane >> 5;
+
+    for (int idx = tid; idx < COUT * (K / 8); idx += NW * 64) {
+        const int n = idx / (K / 8), c = idx % (K / 8);
+        const u32x4 v = *reinterpret_cast<const u32x4*>(p.w + (long)n * K + c * 8);
+        *reinterpret_cast<u32x4*>(sm + (c >> 1) * (COUT * 32) + wunit(n, c & 1)) = v;
+    }
+    for (int i = tid; i < COUT; i += NW * 64) sB[i] = p.bias[i];
+    __syncthreads();
+
+    const int GW = gridDim.x * NW;
+    const int lb = (int)ec_xcd_remap(blockIdx.x, gridDim.x);
+    const int nseg = p.W / 28, nrow = p.H / RT;
+
+    int f_r[IT], f_px[IT], f_lds[IT], f_goff[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int g = i * 64 + lane;
+        const int r = g / (RW * CPP), rem = g - r * (RW * CPP);
+        f_r[i] = (g < NCH) ? r : -100000;
+        f_px[i] = rem / CPP;
+        f_lds[i] = r * RPB + (rem / CPP) * PITCH + (rem % CPP) * 16;
+        f_goff[i] = ((r * p.W + rem / CPP) * CIN + (rem % CPP) * 8) * 2;
+    }
+    // LDS byte addresses of this lane's operand slots: the rest of every fragment address is an instruction immediate
+    const unsigned a_lds = (unsigned)(unsigned long)(__attribute__((address_space(3))) unsigned char*)img + (unsigned)(px * PITCH + h * 16);
+    const unsigned w_lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) unsigned char*)sm + (unsigned)wunit(px, h);
+    constexpr int WSEG = 32768;                               // ds_read immediates are 16 bits: weight image in 32-KB segments
+    struct { unsigned v[(W_BYTES + WSEG - 1) / WSEG]; } w_lds;
+#pragma unroll
+    for (int q = 0; q < (W_BYTES + WSEG - 1) / WSEG; ++q) w_lds.v[q] = w_lds0 + q * WSEG;
+
+    f32x16_t bias_acc[FN];
+#pragma unroll
+    for (int n = 0; n < FN; ++n)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 bv = *reinterpret_cast<const float4*>(sB + 32 * n + 8 * g + 4 * h);
+            bias_acc[n][4 * g + 0] = bv.x; bias_acc[n][4 * g + 1] = bv.y; bias_acc[n][4 * g + 2] = bv.z; bias_acc[n][4 * g + 3] = bv.w;
+        }
+
+    u32x4 nxt[IT];
+    const unsigned char* in_b = reinterpret_cast<const unsigned char*>(p.in);
+    const unsigned char* zp = reinterpret_cast<const unsigned char*>(ec_zero_page3);
+    struct Coord { int sg, rr, b; };
+    auto decode = [&](int t_) {
+        const int t = __builtin_amdgcn_readfirstlane(t_);
+        return Coord{t % nseg, (t / nseg) % nrow, t / (nseg * nrow)};
+    };
+    const Coord step = decode(GW);
+    auto advance = [&](Coord c) {
+        c.sg += step.sg; c.rr += step.rr; c.b += step.b;
+        if (c.sg >= nseg) { c.sg -= nseg; ++c.rr; }
+        if (c.rr >= nrow) { c.rr -= nrow; ++c.b; }
+        return c;
+    };
+    auto fetch = [&](Coord c) {
+        const int sgi = __builtin_amdgcn_readfirstlane(c.sg), rr = __builtin_amdgcn_readfirstlane(c.rr);
+        const int b = __builtin_amdgcn_readfirstlane(c.b);
+        const int y0 = RT * rr - 1, x0 = 28 * sgi - 1;
+        const unsigned char* base = in_b + (((long)b * p.H + y0) * p.W + x0) * (CIN * 2);
+        [&]<int... I>(std::integer_sequence<int, I...>) {
+            (([&] {
+                 const bool ok = (unsigned)(y0 + f_r[I]) < (unsigned)p.H && (unsigned)(x0 + f_px[I]) < (unsigned)p.W && !(p.dbg & 1);
+                 nxt[I] = *reinterpret_cast<const u32x4*>(ok ? base + f_goff[I] : zp);
+             }()),
+             ...);
+        }(std::make_integer_sequence<int, IT>{});
+    };
+
+    int t = lb * NW + wave;
+    if (t >= p.ntiles) return;
+    Coord cn = decode(t);
+    fetch(cn);
+    for (;;) {
+        [&]<int... I>(std::integer_sequence<int, I...>) {
+            (([&] {
+                 if (I * 64 + lane < NCH) *reinterpret_cast<u32x4*>(img + f_lds[I]) = nxt[I];
+             }()),
+             ...);
+        }(std::make_integer_sequence<int, IT>{});
+        const Coord cc = cn;
+        t += GW;
+        const bool more = t < p.ntiles;
+        if (more) { cn = advance(cn); fetch(cn); }
+        asm volatile("" ::: "memory");                       // the image stores above stay above the asm fragment reads
+
+        f32x16_t acc[RT][FN];
+        FragRingN<RING> ring;
+        // fragment q of K-step S: q < RT -> im2col block q (image row q + ky of the footprint), else weight block q - RT
+        auto issue = [&](auto sc, auto qc) {
+            constexpr int S = decltype(sc)::value, q = decltype(qc)::value;
+            constexpr int tap = S / CB, cb = S % CB, ky = tap / 3, kx = tap % 3;
+            constexpr int slot = (S % (LEADK + 1)) * G + q;
+            const auto& wl = w_lds;      // (named outside the discarded branch: implicit capture in a generic lambda)
+            const unsigned al = a_lds;
+            if constexpr (q < RT) {
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring.f[slot]) : "v"(al), "n"((q + ky) * RPB + kx * PITCH + cb * 32));
+            } else {
+                constexpr int off = S * (COUT * 32) + (q - RT) * 1024;
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring.f[slot]) : "v"(wl.v[off / WSEG]), "n"(off % WSEG));
+            }
+        };
+        auto issue_step = [&](auto sc) {
+            [&]<int... Q>(std::integer_sequence<int, Q...>) { (issue(sc, std::integral_constant<int, Q>{}), ...); }
+            (std::make_integer_sequence<int, G>{});
+        };
+        if (p.dbg & 4) {
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+                for (int n = 0; n < FN; ++n) acc[i][n] = bias_acc[n];
+        } else {
+        [&]<int... S>(std::integer_sequence<int, S...>) { (issue_step(std::integral_constant<int, S>{}), ...); }
+        (std::make_integer_sequence<int, (LEADK < KSTEPS ? LEADK : KSTEPS)>{});
+        [&]<int... S>(std::integer_sequence<int, S...>) {
+            (([&] {
+                 if constexpr (S + LEADK < KSTEPS) issue_step(std::integral_constant<int, S + LEADK>{});
+                 constexpr int ahead = (S + LEADK < KSTEPS ? LEADK : KSTEPS - 1 - S) * G;   // reads issued after K-step S's
+                 asm volatile("s_waitcnt lgkmcnt(%0)" : : "n"(ahead));
+                 constexpr int base = (S % (LEADK + 1)) * G;
+#pragma unroll
+                 for (int q = 0; q < G; ++q) asm volatile("" : "+v"(ring.f[base + q]));   // ties the fragments to the wait: the MFMAs stay below it
+#pragma unroll
+                 for (int i = 0; i < RT; ++i)
+#pragma unroll
+                     for (int n = 0; n < FN; ++n)
+                         acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ring.f[base + RT + n]),
+                                                                            __builtin_bit_cast(bf16x8_t, ring.f[base + i]),
+                                                                            S == 0 ? bias_acc[n] : acc[i][n], 0, 0, 0);
+             }()),
+             ...);
+        }(std::make_integer_sequence<int, KSTEPS>{});
+        }
+
+        // epilogue through the (now free) image region: RT blocks of 32 pixel rows (28 real each)
+        unsigned char* stg = img;
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+            for (int n = 0; n < FN; ++n)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int lc = 32 * n + 8 * g + 4 * h;
+                    uint2 o;
+                    o.x = ec_pack2(relu1(acc[i][n][4 * g + 0]), relu1(acc[i][n][4 * g + 1]));
+                    o.y = ec_pack2(relu1(acc[i][n][4 * g + 2]), relu1(acc[i][n][4 * g + 3]));
+                    *reinterpret_cast<uint2*>(stg + (i * 32 + px) * OP + lc * 2) = o;
+                }
+        {
+            const int sgi = __builtin_amdgcn_readfirstlane(cc.sg), rr = __builtin_amdgcn_readfirstlane(cc.rr);
+            const int b = __builtin_amdgcn_readfirstlane(cc.b);
+            constexpr int ZC = COUT / 8;
+            const long opix0 = ((long)b * p.H + RT * rr) * p.W + 28 * sgi;
+#pragma unroll
+            for (int i = 0; i < RT; ++i) {
+                const long opix = opix0 + (long)i * p.W;
+#pragma unroll
+                for (int j = 0; j < (28 * ZC + 63) / 64; ++j) {
+                    const int idx = j * 64 + lane;
+                    if (idx < 28 * ZC && !(p.dbg & 2)) {
+                        const u32x4 v = *reinterpret_cast<const u32x4*>(stg + (i * 32 + idx / ZC) * OP + (idx % ZC) * 16);
+                        *reinterpret_cast<u32x4*>(p.out + (opix + idx / ZC) * COUT + (idx % ZC) * 8) = v;
+                    }
+                }
+            }
+        }
+        if (!more) break;
+    }
+}
+
+template <int CIN, int COUT, int RT, int NW, int LEADK>
+int launch_rowsN(const N3Args& p, hipStream_t s) {
+    constexpr int PITCH = CIN * 2 + 16, RPB = 30 * PITCH;
+    constexpr size_t lds = (size_t)(9 * CIN / 16) * COUT * 32 + COUT * 4 + (size_t)NW * ((RT + 2) * RPB + 4 * PITCH);
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    static_assert(((RT + 2) * RPB + 4 * PITCH) % 16 == 0, "image alignment");
+    auto kern = conv3x3_rowsN_kernel<CIN, COUT, RT, NW, LEADK>;
+    static const int dbg = [] { const char* e = getenv("EC_ROWS_DBG"); return e ? atoi(e) : 0; }();
+    N3Args q = p;
+    q.dbg = dbg;
+    static std::atomic<uint64_t> attr_done{0};
+    if (auto attr_g_ = ec_attr_needed(attr_done)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    const int wgs = (p.ntiles + NW - 1) / NW < 256 ? (p.ntiles + NW - 1) / NW : 256;
+    hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(NW * 64), lds, s, q);
+    EC_CHECK_LAUNCH();
+    return EC_OK;
+}
+
 template <int CIN, int COUT, bool POOL, int NW>
 int launch_rows(const N3Args& p, hipStream_t s) {
     constexpr int PITCH = CIN * 2 + 16, RW = POOL ? 16 : 30, RPB = POOL ? RW * PITCH + 128 : RW * PITCH, NR = POOL ? 4 : 3;
@@ -406,6 +629,18 @@ int ec_conv3x3_narrow(const void* in, const void* w, const float* bias, void* ou
     if (mode >= 3) {
         const bool fits = pool ? (W % 14 == 0) : (W % 28 == 0);
         const long nt = pool ? (long)B * (H / 2) * (W / 14) : (long)B * H * (W / 28);
+        // EC_CONV_ROWSN (default 1): multi-row tiles (conv3x3_rowsN_kernel) for the un-pooled layers whose height allows
+        static const int rowsn = [] { const char* e = getenv("EC_CONV_ROWSN"); return e ? atoi(e) : 1; }();
+        if (fits && !pool && rowsn && nt <= 0x7fffffffL) {
+            if (Cin == 64 && Cout == 64 && H % 2 == 0) {
+                N3Args p{(const uint16_t*)in, (const uint16_t*)w, bias, (uint16_t*)out, H, W, (int)(nt / 2)};
+                return rowsn == 3 ? launch_rowsN<64, 64, 2, 4, 3>(p, s) : launch_rowsN<64, 64, 2, 4, 2>(p, s);
+            }
+            if (Cin == 32 && Cout == 32 && H % 4 == 0) {
+                N3Args p{(const uint16_t*)in, (const uint16_t*)w, bias, (uint16_t*)out, H, W, (int)(nt / 4)};
+                return rowsn == 2 ? launch_rowsN<32, 32, 4, 4, 2>(p, s) : launch_rowsN<32, 32, 4, 8, 1>(p, s);
+            }
+        }
         if (fits && nt <= 0x7fffffffL) {
             N3Args p{(const uint16_t*)in, (const uint16_t*)w, bias, (uint16_t*)out, H, W, (int)nt};
             if (Cin == 32 && Cout == 32 && !pool) return launch_rows<32, 32, false, 16>(p, s);

@@ -224,10 +224,11 @@ class RN50Trunk:
         return out
 
     @_lib.on_device
-    def to_nchw_f32(self, feat: torch.Tensor) -> torch.Tensor:
+    def to_nchw_f32(self, feat: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         B = feat.shape[0]
         S, Cc = self.out_spatial, self.out_channels
-        o = torch.empty((B, Cc, S, S), dtype=torch.float32, device=self.device)
+        o = out if out is not None else torch.empty((B, Cc, S, S), dtype=torch.float32, device=self.device)
+        assert o.is_contiguous() and o.dtype == torch.float32 and o.numel() == B * Cc * S * S
         _lib.check(self.lib.ec_nhwc_bf16_to_nchw_f32(feat.data_ptr(), o.data_ptr(), B, S * S, Cc, _lib.stream_ptr()),
                    "ec_nhwc_bf16_to_nchw_f32")
         return o
