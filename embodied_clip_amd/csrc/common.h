@@ -91,6 +91,38 @@ struct ec_min_tiles_scope {
     ~ec_min_tiles_scope() { ec_tls_conv8_min_tiles = prev; }
 };
 
+// ---- library configuration -------------------------------------------------------------------------------------------
+// Every tuning / experiment switch of the library, read from the environment ONCE (first use) into one immutable
+// struct; the dispatch functions read fields of ec_config() instead of keeping getenv-initialised statics each.
+// ec_config_hash() goes into ec_rn50_plan_hash / ec_vit_plan_hash, so a profile under profiles/ names the switch
+// settings it was measured with.  DESIGN.md section 5.1 documents each variable.
+struct EcConfig {
+    int conv_narrow;      // EC_CONV_NARROW   (3)   narrow 3x3 kernels: 0 off, 1 gather (32 ch), 2 gather (also 64 ch), 3 row tiles
+    int conv_rowsn;       // EC_CONV_ROWSN    (1)   multi-row tiles for the un-pooled narrow 3x3 layers (2, 3: A/B variants)
+    int rows_dbg;         // EC_ROWS_DBG      (0)   profiling only: 1 no fetch, 2 no stores, 4 no MFMA stream
+    int conv_nbuf;        // EC_CONV_NBUF     (0)   force the LDS stage count of conv_igemm_kernel (0 = by tile size)
+    int conv_ablate;      // EC_CONV_ABLATE   (0)   profiling only (bit mask, see conv_igemm.hip)
+    int conv_wgs;         // EC_CONV_WGS      (768) persistent workgroup cap of conv_igemm_kernel
+    int conv_waves;       // EC_CONV_WAVES    (0)   8: 8-wave workgroups in conv_igemm_kernel
+    int conv_big;         // EC_CONV_BIG      (1)   0 no conv_igemm8, 1 where measured faster, 4 wherever it applies
+    long conv8_min_tiles; // EC_CONV8_MIN_TILES (0) overrides the handles' dispatch threshold when > 0
+    int conv8_bn128;      // EC_CONV8_BN128   (0)   with EC_CONV_BIG=4: force 128-wide tiles
+    int conv_t224;        // EC_CONV_T224     (2)   196-of-224-row tiles: 0 off, 1 everywhere, 2 rule, 3 also 256-tile launches
+    int conv_t64;         // EC_CONV_T64      (150) launches with fewer 128x128 tiles use 64x64 tiles
+    int conv_ring;        // EC_CONV_RING     (1)   ring pipeline for launches with <= 1-2 workgroups per CU (2: all, A/B)
+    int conv_regw;        // EC_CONV_REGW     (1)   register-weight 1x1 kernel
+    int conv_regw_wide;   // EC_CONV_REGW_WIDE(0)   ... also for the wide (channel-group) shapes
+    int gemm_no_x3;       // EC_GEMM_NO_X3    (0)   policy GEMMs on the fp32 MFMA instead of bf16x3
+    int act_split;        // EC_ACT_SPLIT     (1)   act step: fixed 4-way K split of the two long-K GEMMs
+    int tail_fused;       // EC_TAIL_FUSED    (1)   compressor tail / combiner fused kernels
+    int gru_fused;        // EC_GRU_FUSED     (1)   fused GRU forward step
+    int c1_pingpong;      // EC_C1_PINGPONG   (1)   compressor conv 1 over stored features on the 8-wave kernel
+    int dw1_tr;           // EC_DW1_TR        (1)   dW1 on the transpose-read kernel
+    int rn50_fuse;        // EC_RN50_FUSE     (1)   fused layer-1 / layer-2 block boundaries in the trunk plan
+};
+const EcConfig& ec_config();          // api.hip
+uint64_t ec_config_hash();            // FNV-1a over the fields above
+
 #define EC_CHECK_LAUNCH()                                   \
     do {                                                    \
         hipError_t e__ = hipGetLastError();                 \

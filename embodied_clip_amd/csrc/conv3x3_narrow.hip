@@ -571,7 +571,7 @@ int launch_rowsN(const N3Args& p, hipStream_t s) {
     static_assert(lds <= 160 * 1024, "LDS budget");
     static_assert(((RT + 2) * RPB + 4 * PITCH) % 16 == 0, "image alignment");
     auto kern = conv3x3_rowsN_kernel<CIN, COUT, RT, NW, LEADK>;
-    static const int dbg = [] { const char* e = getenv("EC_ROWS_DBG"); return e ? atoi(e) : 0; }();
+    const int dbg = ec_config().rows_dbg;
     N3Args q = p;
     q.dbg = dbg;
     static std::atomic<uint64_t> attr_done{0};
@@ -623,14 +623,14 @@ int ec_conv3x3_narrow(const void* in, const void* w, const float* bias, void* ou
                       int pool, hipStream_t s) {
     // EC_CONV_NARROW: 0 off; 1 gather kernel only; 2 gather kernel also for Cin = 64; 3 (default) row-tile kernel
     // where the image width allows (W % 28 == 0, POOL: W % 14 == 0), gather kernel for the other 32-channel layers
-    static const int mode = [] { const char* e = getenv("EC_CONV_NARROW"); return e ? atoi(e) : 3; }();
+    const int mode = ec_config().conv_narrow;
     const long M = (long)B * H * W;
     if (!mode || !bias || (pool && ((H | W) & 1))) return EC_ERR_SHAPE;
     if (mode >= 3) {
         const bool fits = pool ? (W % 14 == 0) : (W % 28 == 0);
         const long nt = pool ? (long)B * (H / 2) * (W / 14) : (long)B * H * (W / 28);
         // EC_CONV_ROWSN (default 1): multi-row tiles (conv3x3_rowsN_kernel) for the un-pooled layers whose height allows
-        static const int rowsn = [] { const char* e = getenv("EC_CONV_ROWSN"); return e ? atoi(e) : 1; }();
+        const int rowsn = ec_config().conv_rowsn;
         if (fits && !pool && rowsn && nt <= 0x7fffffffL) {
             if (Cin == 64 && Cout == 64 && H % 2 == 0) {
                 N3Args p{(const uint16_t*)in, (const uint16_t*)w, bias, (uint16_t*)out, H, W, (int)(nt / 2)};

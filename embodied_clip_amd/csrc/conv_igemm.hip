@@ -511,9 +511,9 @@ int launch(const ConvArgs& a, hipStream_t s) {
     p.ntiles = ntm * p.ntn;
     const size_t lds_max = 2 * (size_t)(BM + BN) * ROW_BYTES;
     const size_t epi = (size_t)(POOL ? BM / 4 : BM) * (BN * 2 + 16);
-    static const int nbuf_force = [] { const char* e = getenv("EC_CONV_NBUF"); return e ? atoi(e) : 0; }();
+    const int nbuf_force = ec_config().conv_nbuf;
     p.nbuf = nbuf_force ? nbuf_force : ((BM * BN >= 256 * 256) ? 2 : 1);
-    static const int ablate = [] { const char* e = getenv("EC_CONV_ABLATE"); return e ? atoi(e) : 0; }();
+    const int ablate = ec_config().conv_ablate;
     p.ablate = ablate;
     size_t lds = (size_t)(NS >= 3 ? NS : p.nbuf) * (BM + BN) * ROW_BYTES;
     if (lds < epi) lds = epi;
@@ -524,7 +524,7 @@ int launch(const ConvArgs& a, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
     }
     // persistent: 3 workgroups per CU (<= 168 VGPRs, single 35-KB LDS stage), each walking several tiles
-    static const int wg_cap = [] { const char* e = getenv("EC_CONV_WGS"); return e ? atoi(e) : 768; }();
+    const int wg_cap = ec_config().conv_wgs;
     // ring mode: as many workgroups per CU as its NS stages fit (160 KiB of LDS, 2 waves per SIMD by registers)
     const int ring_per_cu = NS >= 3 ? (int)std::min<size_t>(2, (160 * 1024) / lds) : 0;
     const int cap = NS >= 3 ? 256 * ring_per_cu : ((BM * BN >= 256 * 256) ? 256 : wg_cap);      // 8-wave 256x256 tiles: one workgroup per CU
@@ -927,7 +927,7 @@ int launch8(const ConvArgs& a, hipStream_t s) {
     ConvArgs p = a;
     p.ntn = a.Cout / BN;
     p.ntiles = ((a.M + 255) / 256) * p.ntn;
-    static const int ablate = [] { const char* e = getenv("EC_CONV_ABLATE"); return e ? atoi(e) : 0; }();
+    const int ablate = ec_config().conv_ablate;
     p.ablate = ablate;
     const size_t stages = 2 * (size_t)(256 + BN) * ROW_BYTES;
     const size_t epi = X3 ? (size_t)128 * (BN * 4 + 16) : (size_t)(POOL ? 64 : 256) * (BN * 2 + 16);
@@ -971,7 +971,7 @@ int launch8(const ConvArgs& a, hipStream_t s) {
 
 template <int KS, bool POOL>
 int dispatch_tile(const ConvArgs& a, hipStream_t s) {
-    static const int force = [] { const char* e = getenv("EC_CONV_WAVES"); return e ? atoi(e) : 0; }();
+    const int force = ec_config().conv_waves;
     // Tile choice: 128x128 wherever Cout allows; 256-row tiles for the narrow early layers.
     // (Fatter 128x256 / 256x128 tiles were measured: no gain, and they spill once loads run two tiles ahead.)
     // EC_CONV_BIG: 0 off; 1 (default) the 8-wave ping-pong kernel (conv_igemm8) where it was measured to win; 4 conv_igemm8
@@ -979,7 +979,7 @@ int dispatch_tile(const ConvArgs& a, hipStream_t s) {
     // double-buffered 256x256 configuration of conv_igemm_kernel (8 waves, one barrier per K-tile: 77.9 us where the
     // ping-pong schedule takes 72-75) and a one-wave-per-SIMD 4-wave kernel with in-wave software pipelining (87.8 us:
     // every LDS-DMA piece blocks its issuing wave for ~150 clk and there is no partner wave to keep the matrix pipe busy).
-    static const int big = [] { const char* e = getenv("EC_CONV_BIG"); return e ? atoi(e) : 1; }();
+    const int big = ec_config().conv_big;
     if (big == 1 && a.Cin % 64 == 0 && (KS == 1 || a.cin_log2 >= 0) && a.K >= 512 && a.M % (POOL ? 4 : 1) == 0) {
         // measured (B = 256, tools/bench_big.sh): wins on the 3x3 convs with Cout % 256 == 0 once there are enough
         // 256-row tiles to occupy most CUs; loses on N = 128, on the short launches of 7x7 maps and ties on 1x1
@@ -988,7 +988,7 @@ int dispatch_tile(const ConvArgs& a, hipStream_t s) {
         // launches in flight (the engine's two slices) lowers it on its encoder handles (ec_rn50_set_conv8_min_tiles): alone a 50-100-tile launch of the
         // 8-wave kernel is 30-40 % slower than the 4-wave kernel, but it leaves the other launch 150-200 whole CUs instead of
         // sharing all of them (same-box A/B at 2 x 128 frames: +0.4..1.5 % RN50, +3.5 % ViT-B/32 end to end; at 2 x 64: -1.1 %)
-        static const long mint_env = [] { const char* e = getenv("EC_CONV8_MIN_TILES"); return e ? atol(e) : 0L; }();
+        const long mint_env = ec_config().conv8_min_tiles;
         const long mint = mint_env > 0 ? mint_env : (long)ec_tls_conv8_min_tiles;
         if (KS == 3 && a.Cout % 256 == 0 && nt256 >= mint) return launch8<256, KS, POOL>(a, s);
         // long-K 1x1 convs (tools/bench_l4.sh, B = 256): 1024->2048 @7x7 83.7 -> 70.5 us, 1024->512 @14x14 82.9 -> 70.5,
@@ -1003,7 +1003,7 @@ int dispatch_tile(const ConvArgs& a, hipStream_t s) {
         }
     }
     if (big == 4 && a.Cin % 64 == 0 && (KS == 1 || a.cin_log2 >= 0) && a.K >= 512 && a.M >= 256 * 32 && a.M % (POOL ? 4 : 1) == 0) {
-        static const int bn128 = [] { const char* e = getenv("EC_CONV8_BN128"); return e ? atoi(e) : 0; }();
+        const int bn128 = ec_config().conv8_bn128;
         if (a.Cout % 256 == 0 && !bn128) return launch8<256, KS, POOL>(a, s);     // (A/B: everywhere its preconditions hold)
         if (a.Cout % 128 == 0) return launch8<128, KS, POOL>(a, s);
     }
@@ -1017,7 +1017,7 @@ int dispatch_tile(const ConvArgs& a, hipStream_t s) {
         // padded tiles cost ~0.7 % (measured on the 28x28 3x3 convs, which also have 512 padded tiles at 128 frames):
         // the rule is therefore limited to 14x14 maps, i.e. to single launches of 256 frames.
         // EC_CONV_T224: 0 off, 1 everywhere (tests/experiments), 2 (default) the rule below, 3 also 256-tile launches.
-        static const int t224 = [] { const char* e = getenv("EC_CONV_T224"); return e ? atoi(e) : 2; }();
+        const int t224 = ec_config().conv_t224;
         if constexpr (!POOL) {
             const long t196 = (long)(a.M / 196) * (a.Cout / 128), t128 = (long)((a.M + 127) / 128) * (a.Cout / 128);
             if (a.M % 196 == 0 &&
@@ -1028,11 +1028,11 @@ int dispatch_tile(const ConvArgs& a, hipStream_t s) {
         // Small launches (strong scaling: 32-64 frames per GPU): with fewer 128x128 tiles than CUs every workgroup is one
         // long serial K chain and most of the chip idles -> 64x64 tiles give 4x the workgroups for the long-K layers
         // (batch 32: layer-4 3x3 52 tiles x 72 K-tiles = 76 us).  EC_CONV_T64: tile-count threshold (0 = off).
-        static const int t64 = [] { const char* e = getenv("EC_CONV_T64"); return e ? atoi(e) : 150; }();
+        const int t64 = ec_config().conv_t64;
         // EC_CONV_RING (default 1): those launches, and 128x128 launches with at most one workgroup per CU, run the
         // multi-stage ring pipeline (conv_igemm_kernel NS >= 3): with so few waves per CU nothing hides the L2 round trip
         // of the single-stage loop.  2: every non-prefetching 128x128 launch (A/B).
-        static const int ring = [] { const char* e = getenv("EC_CONV_RING"); return e ? atoi(e) : 1; }();
+        const int ring = ec_config().conv_ring;
         if constexpr (!POOL) {
             const long t128 = (long)((a.M + 127) / 128) * (a.Cout / 128);
             if (t128 < t64 && a.K >= 512 && a.Cout % 64 == 0)

@@ -716,10 +716,10 @@ extern "C" int ec_conv1x1_pair_pool_bf16(const void* a0, const void* w0, const f
 // uses conv_igemm).  Only worth it when the launch has enough 32-pixel tiles to keep 256 workgroups busy.
 int ec_conv1x1_regw(const void* a, const void* w, const float* bias, const void* res, void* y, long M, int K, int N, int act,
                     hipStream_t s) {
-    static const bool on = [] { const char* e = getenv("EC_CONV_REGW"); return !e || atoi(e) != 0; }();
+    const bool on = ec_config().conv_regw != 0;
     // Channel groups (grid y) extend the scheme to wider layers; measured for layer-3 conv3 (256 -> 1024 + residual,
     // two groups of 512): 66 us vs 64.5 us on conv_igemm at 256 frames, 42 vs 36 us at 128 -- not used by default.
-    static const int wide = [] { const char* e = getenv("EC_CONV_REGW_WIDE"); return e ? atoi(e) : 0; }();
+    const int wide = ec_config().conv_regw_wide;
     if (!on || (M % PX) != 0 || M / PX > 0x7fffffffL) return EC_ERR_SHAPE;
     const long tiles = M / PX;
     RegwArgs p{(const uint16_t*)a, (const uint16_t*)w, (const uint16_t*)res, bias, (uint16_t*)y, (int)tiles, N};

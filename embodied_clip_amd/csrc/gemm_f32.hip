@@ -586,7 +586,7 @@ extern "C" int ec_gemm_f32(const void* A, const void* B, float* Cp, int M, int N
     a.b_vec = (sbk == 1) ? vec_ok(B, sbk, sbn, a.b_bf16) : vec_ok(B, sbn, sbk, a.b_bf16);
     hipStream_t s = (hipStream_t)stream;
     // bf16x3 path for regular shapes: vector-loadable operands, contiguous extents multiple of 4, not tiny
-    static const int x3_off = [] { const char* e = getenv("EC_GEMM_NO_X3"); return e ? atoi(e) : 0; }();
+    const int x3_off = ec_config().gemm_no_x3;
     const bool a_ok = a.a_vec && ((sak == 1) ? (K % 4 == 0) : (M % 4 == 0 && sam == 1));
     const bool b_ok = a.b_vec && ((sbk == 1) ? (K % 4 == 0) : (N % 4 == 0 && sbn == 1));
     if (!x3_off && a_ok && b_ok && M >= 32 && N >= 32 && K >= 32 && !(a.a_bf16 && sak != 1) && !(a.b_bf16 && sbk == 1)) {

@@ -963,9 +963,9 @@ extern "C" int ec_policy_forward(const ec_policy_t* h, const float* params, cons
     const bool small = !c.fusion && M49 > 0 && M49 <= ACT_MAX_ROWS;            // (== the condition in layout())
     const size_t tail_lds_ = ((size_t)2 * 32 * TL_P128 + 128 * TL_P32 + (size_t)c.num_goals * 128 + 64 +
                               4 * (size_t)(32 * TL_P128 + 32 * TL_P32)) * sizeof(float);
-    static const int act_parts_on = [] { const char* e = getenv("EC_ACT_SPLIT"); return e ? atoi(e) : 1; }();
-    static const int tail_fused_ = [] { const char* e = getenv("EC_TAIL_FUSED"); return e ? atoi(e) : 1; }();
-    static const int gru_fused_ = [] { const char* e = getenv("EC_GRU_FUSED"); return e ? atoi(e) : 1; }();
+    const int act_parts_on = ec_config().act_split;
+    const int tail_fused_ = ec_config().tail_fused;
+    const int gru_fused_ = ec_config().gru_fused;
     const bool tail_ok = tail_fused_ && c.compress_hid == 128 && c.compress_out == 32 && c.comb_hid == 128 &&
                          c.comb_out == 32 && tail_lds_ <= 160 * 1024;
     const size_t gru_lds_ = std::max((size_t)2 * 32 * (((H & 255) == 0 ? 256 : H) + 4) * sizeof(float), (size_t)4 * 32 * 32 * sizeof(float));
@@ -988,7 +988,7 @@ extern "C" int ec_policy_forward(const ec_policy_t* h, const float* params, cons
     // resnet_compressor
     // EC_C1_PINGPONG (default 1): bf16 features x fp32 W1 as three bf16 planes on the 8-wave ping-pong kernel
     // (conv_igemm8, X3 mode) once there are enough 256-row tiles to fill the chip; else the generic x3 GEMM
-    static const int c1_pp = [] { const char* e = getenv("EC_C1_PINGPONG"); return e ? atoi(e) : 1; }();
+    const int c1_pp = ec_config().c1_pingpong;
     if (c1_pp && feat_bf16 && c.compress_hid % 128 == 0 && C % 64 == 0 && M49 >= 256 * 128) {
         RC(ec_split3_bf16(W(P_W1), ws + w.w1p, c.compress_hid, C, stream));
         RC(ec_gemm_bf16a_x3(feat, ws + w.w1p, W(P_B1), ws + w.c1, M49, c.compress_hid, C, 1 /* EC_ACT_RELU */, stream));
@@ -1004,7 +1004,7 @@ extern "C" int ec_policy_forward(const ec_policy_t* h, const float* params, cons
                    EC_GEMM_RELU | (feat_bf16 ? EC_GEMM_A_BF16 : 0), W(P_B1), nullptr, nullptr, 0, nullptr, nullptr, 1,
                    stream));
     // EC_TAIL_FUSED (default 1): c2 / m1 / x4 in one pass over c1 for the reference's widths
-    static const int tail_fused = [] { const char* e = getenv("EC_TAIL_FUSED"); return e ? atoi(e) : 1; }();
+    const int tail_fused = ec_config().tail_fused;
     const size_t tail_lds = ((size_t)2 * 32 * TL_P128 + 128 * TL_P32 + (size_t)c.num_goals * 128 + 64 +
                              4 * (size_t)(32 * TL_P128 + 32 * TL_P32)) * sizeof(float);
     if (tail_fused && c.compress_hid == 128 && c.compress_out == 32 && c.comb_hid == 128 && c.comb_out == 32 &&
@@ -1042,7 +1042,7 @@ extern "C" int ec_policy_forward(const ec_policy_t* h, const float* params, cons
                    gi_split ? EC_GEMM_SPLIT_PARTS : 0, W(P_BIH), nullptr, nullptr, 0, nullptr, nullptr, gi_split ? ACT_PARTS : 1,
                    stream));
     // EC_GRU_FUSED (default 1): one fused launch per step where the geometry allows (H % 32 == 0, tiles fit the LDS)
-    static const int gru_fused = [] { const char* e = getenv("EC_GRU_FUSED"); return e ? atoi(e) : 1; }();
+    const int gru_fused = ec_config().gru_fused;
     size_t gru_lds = (size_t)2 * 32 * (((H & 255) == 0 ? 256 : H) + 4) * sizeof(float);      // operand tiles (K chunk) ...
     if (gru_lds < 4 * 32 * 32 * sizeof(float)) gru_lds = 4 * 32 * 32 * sizeof(float);   // ... reused for the 4 partial tiles
     const bool fused_step = gru_fused && (H % 32) == 0 && gru_lds <= 160 * 1024;
@@ -1152,13 +1152,13 @@ extern "C" int ec_policy_backward(const ec_policy_t* h, const float* params, con
         hipLaunchKernelGGL(from_cmajor_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ws + w.dx,
                            ws + w.dx4, S, c.comb_out, total);
     }
-    static const int tail_fused = [] { const char* e = getenv("EC_TAIL_FUSED"); return e ? atoi(e) : 1; }();
+    const int tail_fused = ec_config().tail_fused;
     const size_t tb_lds = ((size_t)2 * 128 * TL_P32 + 32 * TL_P128 + (size_t)c.num_goals * 128 +
                            4 * (size_t)(32 * TL_P128 + 32 * TL_P32)) * sizeof(float);
     const bool fused_bwd = tail_fused && c.compress_hid == 128 && c.compress_out == 32 && c.comb_hid == 128 &&
                            c.comb_out == 32 && S >= 32 && tb_lds <= 160 * 1024;
     // EC_DW1_TR (default 1): dW1 through the transpose-read kernel (dw_tn.hip); dc1 then only exists as bf16 planes
-    static const int dw1_tr = [] { const char* e = getenv("EC_DW1_TR"); return e ? atoi(e) : 1; }();
+    const int dw1_tr = ec_config().dw1_tr;
     const bool dw1_planes = fused_bwd && dw1_tr && feat_bf16 && C % 256 == 0 && M49 >= 2048 &&
                             (size_t)ec_dw_tn_x3_splits(M49, C) * 128 * C <= (size_t)TB_MAX_WG * 4 * TB_PART;
     (void)hipMemsetAsync(ws + w.dE1, 0, (size_t)c.num_goals * c.comb_hid * 4, s);

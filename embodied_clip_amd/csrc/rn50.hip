@@ -86,8 +86,7 @@ extern "C" int ec_rn50_create(ec_rn50_t** out, int width, const int* layers4, in
     }
     // Layer-1 block boundaries (56x56, bandwidth-bound 1x1 convs) run as ONE fused launch per boundary:
     // conv3 (+ the block-0 downsample conv) + identity + ReLU, chained in registers into the next block's conv1.
-    const char* fuse_e = getenv("EC_RN50_FUSE");   // read per handle so both plans can be compared in one process
-    const bool fuse_env = !fuse_e || atoi(fuse_e) != 0;
+    const bool fuse_env = ec_config().rn50_fuse != 0;
     const bool fuse_l1 = fuse_env && width == 64 && (R % 8) == 0;   // K = 64, N = 256; 32-pixel tiles divide R*R
     bool conv1_done = false;   // the previous boundary launch already produced this block's conv1 output in buffer 1
     int pooled_in = -1;        // ... and (layer-1 -> layer-2) the pooled block input for the downsample path, in this buffer
@@ -201,7 +200,7 @@ extern "C" uint64_t ec_rn50_plan_hash(const ec_rn50_t* h) {
     auto mix = [&](long v) {
         for (int i = 0; i < 8; ++i) { x ^= (uint64_t)((v >> (8 * i)) & 0xff); x *= 1099511628211ull; }
     };
-    mix(ec_version());
+    mix(ec_version()); mix((long)ec_config_hash());
     mix(h->width); mix(h->res); mix(h->conv8_min_tiles);
     for (const Op& o : h->ops) {
         mix(o.kind); mix(o.src); mix(o.dst); mix(o.res); mix(o.H); mix(o.W); mix(o.Cin); mix(o.Cout); mix(o.ks);

@@ -550,7 +550,7 @@ extern "C" uint64_t ec_vit_plan_hash(const ec_vit_t* h) {
     auto mix = [&](long v) {
         for (int i = 0; i < 8; ++i) { x ^= (uint64_t)((v >> (8 * i)) & 0xff); x *= 1099511628211ull; }
     };
-    mix(ec_version());
+    mix(ec_version()); mix((long)ec_config_hash());
     mix(h->width); mix(h->layers); mix(h->heads); mix(h->patch); mix(h->res); mix(h->L); mix(h->conv8_min_tiles);
     return x;
 }

@@ -310,24 +310,78 @@ def test_conv1x1_pair_rejects_unsupported_shapes(dev):
     assert args(32, 128, 256, 64) != 0 and args(32, 64, 512, 64) != 0 and args(32, 64, 256, 32) != 0
 
 
-def test_rn50_fused_layer1_boundaries_match_unfused_plan(dev, monkeypatch):
+def test_rn50_fused_layer1_boundaries_match_unfused_plan(dev, tmp_path):
     """EC_RN50_FUSE=0 builds the plain one-launch-per-conv plan; the default plan fuses the three layer-1 block
-    boundaries (conv_pair.hip).  Same bf16 roundings except the block-0 identity, which the fused plan keeps in fp32."""
+    boundaries (conv_pair.hip).  Same bf16 roundings except the block-0 identity, which the fused plan keeps in fp32.
+    The library reads its switches ONCE per process (ec_config), so the plain plan runs in a child process."""
+    import os
+    import subprocess
+    import sys
     from embodied_clip_amd.encoder import RN50Trunk
     sd = syn.rn50_visual_state_dict(0)
     x = syn.synthetic_rgb(5, 3).to(dev)
     fused = RN50Trunk(sd, device=dev)
-    monkeypatch.setenv("EC_RN50_FUSE", "0")
-    plain = RN50Trunk(sd, device=dev)
-    monkeypatch.delenv("EC_RN50_FUSE")
+    out = str(tmp_path / "plain.pt")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, torch; sys.path.insert(0, %r)\n"
+            "from embodied_clip_amd import synthetic as syn\n"
+            "from embodied_clip_amd.encoder import RN50Trunk\n"
+            "t = RN50Trunk(syn.rn50_visual_state_dict(0), device='cuda:0')\n"
+            "x = syn.synthetic_rgb(5, 3).to('cuda:0')\n"
+            "f = t.forward(x)\n"
+            "torch.save({'feat': f.float().cpu(), 'nchw': t.to_nchw_f32(f).cpu(), 'ops': t.lib.ec_rn50_num_ops(t.h),"
+            " 'hash': t.plan_hash()}, %r)\n") % (root, out)
+    r = subprocess.run([sys.executable, "-c", code], env={**os.environ, "EC_RN50_FUSE": "0"}, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    plain = torch.load(out)
     # layer 1: 3 conv1 + 1 downsample + 1 avgpool (emitted by the layer-1 -> layer-2 boundary launch) launches gone;
     # layer 2: 3 conv1 launches gone
-    assert fused.lib.ec_rn50_num_ops(fused.h) == plain.lib.ec_rn50_num_ops(plain.h) - 8
-    a, b = fused.forward(x).float().cpu(), plain.forward(x).float().cpu()
+    assert fused.lib.ec_rn50_num_ops(fused.h) == plain["ops"] - 8
+    assert fused.plan_hash() != plain["hash"]           # the switch is part of the plan hash
+    a, b = fused.forward(x).float().cpu(), plain["feat"]
     assert _rel(a, b) < 1e-2, _rel(a, b)
     ref = ocr.clip_resnet_preprocessor(x.cpu(), sd)
-    ra, rb = _rel(fused.to_nchw_f32(fused.forward(x)).cpu(), ref), _rel(plain.to_nchw_f32(plain.forward(x)).cpu(), ref)
+    ra, rb = _rel(fused.to_nchw_f32(fused.forward(x)).cpu(), ref), _rel(plain["nchw"], ref)
     assert ra < 2e-2 and rb < 2e-2, (ra, rb)
+
+
+def _conv_in_child(env, cases, tmp_path, tag):
+    """Runs ec_conv_bf16 over `cases` in a child process with extra environment switches; returns the outputs."""
+    import os
+    import subprocess
+    import sys
+    out = str(tmp_path / f"conv_{tag}.pt")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, torch; sys.path.insert(0, %r)\n"
+            "from embodied_clip_amd import encoder as enc\n"
+            "res = []\n"
+            "for (B, H, Cin, Cout, ks, pool) in %r:\n"
+            "    g = torch.Generator().manual_seed(B * 1000 + H)\n"
+            "    x = torch.randn(B, H, H, Cin, generator=g).to(torch.bfloat16).cuda()\n"
+            "    w = (torch.randn(Cout, ks * ks * Cin, generator=g) * 0.05).to(torch.bfloat16).cuda()\n"
+            "    b = torch.randn(Cout, generator=g).cuda()\n"
+            "    res.append(enc.conv_bf16(x, w, b, None, ksize=ks, pool=bool(pool), act=1).cpu())\n"
+            "torch.save(res, %r)\n") % (root, cases, out)
+    r = subprocess.run([sys.executable, "-c", code], env={**os.environ, **env}, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return torch.load(out)
+
+
+def test_ring_and_multirow_kernels_are_bit_identical_to_the_single_stage_kernels(dev, tmp_path):
+    """Round-3 kernels that change the SCHEDULE only: the multi-stage ring pipeline of conv_igemm (small launches) and the
+    multi-row tiles of the narrow 3x3 layers walk K in the same order as the kernels they replace, so their outputs are
+    bit-identical (what keeps a frame's features independent of the batch it was encoded in)."""
+    cases = [(2, 14, 256, 256, 3, 0),      # 64x64 ring tiles (4 stages)
+             (8, 7, 512, 512, 3, 0),       # 64x64 ring, 72 K-tiles
+             (16, 14, 1024, 256, 1, 0),    # 1x1, ring
+             (40, 14, 256, 256, 3, 0),     # 128x128 ring tiles (3 stages)
+             (3, 56, 64, 64, 3, 0),        # layer-1 conv2: multi-row tiles (RT = 2)
+             (2, 112, 32, 32, 3, 0)]       # stem conv2: multi-row tiles (RT = 4)
+    new = _conv_in_child({}, cases, tmp_path, "new")
+    old = _conv_in_child({"EC_CONV_RING": "0", "EC_CONV_ROWSN": "0"}, cases, tmp_path, "old")
+    for c, a, b in zip(cases, new, old):
+        assert torch.equal(a, b), c
 
 
 def test_rn50x16_style_width96_trunk_and_preprocessor(dev):
