@@ -45,8 +45,8 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0               # MI355X_MICROARCH.md: dense bf16 M
 POLICY_FLAT_PARAMS = 3_480_775
 # PMC-measured HBM bytes per encoder launch: written by tools/pmc_summary.py from separate rocprofv3 --pmc passes
 # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), keyed by the library's launch-plan hash
-TRAFFIC_FILES = {"rn50": os.path.join(ROOT, "profiles", "trunk_b256_hbm_traffic.json"),
-                 "vit": os.path.join(ROOT, "profiles", "vit_b256_hbm_traffic.json")}
+TRAFFIC_FILES = {"rn50": os.path.join(ROOT, "profiles", "trunk_hbm_traffic.json"),
+                 "vit": os.path.join(ROOT, "profiles", "vit_hbm_traffic.json")}
 
 
 def _usable_cpus() -> int:
@@ -297,10 +297,13 @@ def run_rank(a, rank: int, local_rank: int, world: int, init_method=None):
             "vit" if a.encoder == "vit" else "rn50", plan_hash, enc_frames)
         # the same fraction from the COMMITTED profile alone (reproducible from profiles/): algorithmic flop of the
         # profiled single launch / its summed kernel time (rocprofv3 kernel trace)
-        frac_profiles = None
+        frac_profiles = frac_profiles_256 = None
         if trec and trec.get("kernel_time_us") and trec.get("plan_hash") in (None, "", plan_hash):
             frac_profiles = round(2.0 * trunk_mac * trec["frames_per_launch"] / (trec["kernel_time_us"] * 1e-6) / 1e12
                                   / MFMA_BF16_PEAK_TFLOPS, 4)
+            if trec.get("single_launch_256"):
+                frac_profiles_256 = round(2.0 * trunk_mac * 256 / (trec["single_launch_256"]["kernel_time_us"] * 1e-6) / 1e12
+                                          / MFMA_BF16_PEAK_TFLOPS, 4)
         workload = {"rn50": "RoboTHOR ObjectNav: frozen CLIP-RN50 encoder",
                     "vit": "RoboTHOR ObjectNav: frozen CLIP ViT-B/32 encoder (11 blocks)",
                     "zeroshot": "Zero-shot ObjectNav: frozen CLIP-RN50 trunk + AttentionPool2d image embedding, goal = "
@@ -325,10 +328,12 @@ def run_rank(a, rank: int, local_rank: int, world: int, init_method=None):
                                     if a.encoder != "vit" else "ec_vit_forward (conv_igemm GEMMs + mha/layernorm kernels)"),
                          "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
-                         "frac_profiles": frac_profiles,
+                         "frac_profiles": frac_profiles, "frac_profiles_single_256_launch": frac_profiles_256,
                          "frac_note": "frac = live HIP-event UNION of the concurrent encoder launches of an env step; "
-                                      "frac_profiles = the committed rocprofv3 kernel trace of ONE single-stream launch "
-                                      "(profiles/*_hbm_traffic.json kernel_time_us), reproducible from profiles/ alone",
+                                      "frac_profiles = the committed rocprofv3 kernel trace of ONE engine launch (the plan "
+                                      "with this hash) running ALONE on the chip, frac_profiles_single_256_launch = one "
+                                      "256-frame launch (profiles/*_hbm_traffic.json kernel_time_us): both reproducible "
+                                      "from profiles/ alone",
                          "traffic": traffic, "traffic_kind": "L2-miss (fabric-side) bytes, Infinity-Cache hits included",
                          "traffic_note": tnote, "plan_hash": plan_hash,
                          "avg_launch_ms": round(avg_trunk_ms, 3), "avg_step_union_ms": round(avg_union_ms, 3),

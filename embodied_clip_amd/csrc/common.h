@@ -106,7 +106,7 @@ struct EcConfig {
     int conv_waves;       // EC_CONV_WAVES    (0)   8: 8-wave workgroups in conv_igemm_kernel
     int conv_big;         // EC_CONV_BIG      (1)   0 no conv_igemm8, 1 where measured faster, 4 wherever it applies
     long conv8_min_tiles; // EC_CONV8_MIN_TILES (0) overrides the handles' dispatch threshold when > 0
-    int conv8_bn128;      // EC_CONV8_BN128   (0)   with EC_CONV_BIG=4: force 128-wide tiles
+    int conv8_bn128;      // EC_CONV8_BN128   (0)   1 with EC_CONV_BIG=4: force 128-wide tiles; -1: layer-2 3x3 convs stay on the 4-wave kernel
     int conv_t224;        // EC_CONV_T224     (2)   196-of-224-row tiles: 0 off, 1 everywhere, 2 rule, 3 also 256-tile launches
     int conv_t64;         // EC_CONV_T64      (150) launches with fewer 128x128 tiles use 64x64 tiles
     int conv_ring;        // EC_CONV_RING     (1)   ring pipeline for launches with <= 1-2 workgroups per CU (2: all, A/B)

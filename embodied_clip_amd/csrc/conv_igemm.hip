@@ -991,6 +991,9 @@ int dispatch_tile(const ConvArgs& a, hipStream_t s) {
         const long mint_env = ec_config().conv8_min_tiles;
         const long mint = mint_env > 0 ? mint_env : (long)ec_tls_conv8_min_tiles;
         if (KS == 3 && a.Cout % 256 == 0 && nt256 >= mint) return launch8<256, KS, POOL>(a, s);
+        // 128-channel 3x3 convs (layer 2): 128-wide tiles of the 8-wave kernel (same-box A/B in the engine, round 3:
+        // +0.4..0.8 % at 2 x 128 frames, neutral at 2 x 32; alone 52 -> 42 us at 128 frames).  EC_CONV8_BN128 = -1: off
+        if (KS == 3 && a.Cout == 128 && ec_config().conv8_bn128 >= 0 && nt128 >= 2 * mint) return launch8<128, KS, POOL>(a, s);
         // long-K 1x1 convs (tools/bench_l4.sh, B = 256): 1024->2048 @7x7 83.7 -> 70.5 us, 1024->512 @14x14 82.9 -> 70.5,
         // 1024->256 @14x14 40.6 -> 37.0 with 256-wide tiles; 2048->512 @7x7 46.4 -> 40.1 with 128-wide tiles (196 of them);
         // K = 512 and residual launches stay on the 4-wave kernel (slower here)

@@ -10,9 +10,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=256)
 ap.add_argument("--chunk", type=int, default=0)
 ap.add_argument("--iters", type=int, default=5)
+ap.add_argument("--min-tiles", type=int, default=0, help="ec_rn50_set_conv8_min_tiles (the engine sets 50 for 2 x >= 128 frames)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 trunk = RN50Trunk(syn.rn50_visual_state_dict(0), device=dev, chunk=a.chunk)
+trunk.set_conv8_min_tiles(a.min_tiles)
 rgb = syn.synthetic_rgb(1, 8).to(dev).repeat((a.batch + 7) // 8, 1, 1, 1)[:a.batch].contiguous()
 out = trunk.forward(rgb)
 torch.cuda.synchronize()

@@ -15,6 +15,20 @@ import json
 import os
 import sys
 
+# FETCH_SIZE factor per kernel family, MEASURED on known byte counts (tools/calibrate_fetch.sh -> profiles/r03_fetch_calibration.json):
+# the counter tallies a 128-B request as 64 B, so the factor is 2 for 16-B-per-lane streaming loads (global_load_dwordx4 and
+# buffer_load ... lds alike: 1.94 measured on conv_igemm8) and smaller where part of the traffic is narrower requests
+FETCH_FACTOR = {'stem_conv1': 1.25, 'conv3x3_rows': 1.40}
+FETCH_FACTOR_DEFAULT = 2.0
+
+
+def fetch_factor(name):
+    for k, v in FETCH_FACTOR.items():
+        if k in name:
+            return v
+    return FETCH_FACTOR_DEFAULT
+
+
 root, n_last, frames, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
 plan_hash = sys.argv[5] if len(sys.argv) > 5 else None
 alg_mb = float(sys.argv[6]) if len(sys.argv) > 6 else 45.7
@@ -51,7 +65,7 @@ if kt:
         per.setdefault(i, {})['dur_us'] = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
         per[i].setdefault('name', r['Kernel_Name'])
 
-lines = ['idx kernel                               grid |  dur_us | mfma_busy%%(busy CUs) mfma%%(all SIMDs,wall) | wait_any%% active%% valu%% | valu/mfma lds/mfma bankconf | fetchMiB(x2) writeMiB']
+lines = ['idx kernel                               grid |  dur_us | mfma_busy%%(busy CUs) mfma%%(all SIMDs,wall) | wait_any%% active%% valu%% | valu/mfma lds/mfma bankconf | fetchMiB(calibrated) writeMiB']
 tot_f = tot_w = tot_us = 0.0
 agg = collections.OrderedDict()
 for i, r in per.items():
@@ -63,7 +77,7 @@ for i, r in per.items():
     gui = r.get('GRBM_GUI_ACTIVE', 0.0)
     u1 = 100 * mb / (4 * busy_cu) if busy_cu else float('nan')
     u2 = 100 * mb / (1024 * gui) if gui else float('nan')
-    fmb, wmb = 2 * r.get('FETCH_SIZE', 0) / 1024, r.get('WRITE_SIZE', 0) / 1024
+    fmb, wmb = fetch_factor(r.get('name', '')) * r.get('FETCH_SIZE', 0) / 1024, r.get('WRITE_SIZE', 0) / 1024
     tot_f += fmb; tot_w += wmb; tot_us += r.get('dur_us', 0)
     a = agg.setdefault(nm, [0, 0.0, 0.0, 0.0, 0.0, 0.0])
     a[0] += 1; a[1] += r.get('dur_us', 0); a[2] += mb; a[3] += busy_cu; a[4] += fmb; a[5] += wmb
@@ -79,12 +93,15 @@ for nm, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
 mb_all = sum(a[2] for a in agg.values()); cu_all = sum(a[3] for a in agg.values())
 GB = 1024 * 1024 / 1e9      # table columns are MiB (rocprofv3 reports KiB); totals in GB = 1e9 bytes
 lines.append(f"TOTAL per forward ({frames} frames, {len(per)} launches): {tot_us:.1f} us kernel time; HBM fetch {tot_f * GB:.2f} GB "
-             f"(FETCH_SIZE x2) + write {tot_w * GB:.2f} GB = {(tot_f + tot_w) * GB:.2f} GB; "
+             f"(FETCH_SIZE x calibrated factor: 2 for 16-B/lane loads, 1.25 stem_conv1, 1.40 conv3x3_rows) + write {tot_w * GB:.2f} GB = {(tot_f + tot_w) * GB:.2f} GB; "
              f"MFMA busy {100 * mb_all / (4 * cu_all) if cu_all else float('nan'):.1f} % of the SIMD-cycles of busy CUs")
 open(out + '_per_kernel.txt', 'w').write('\n'.join(lines) + '\n')
 rec = {"plan_hash": plan_hash, "frames_per_launch": frames, "launches": len(per),
-       "hbm_bytes_per_launch": (tot_f + tot_w) * 1024 * 1024, "fetch_bytes_x2": tot_f * 1024 * 1024,
+       "hbm_bytes_per_launch": (tot_f + tot_w) * 1024 * 1024, "fetch_bytes_calibrated": tot_f * 1024 * 1024,
        "write_bytes": tot_w * 1024 * 1024, "kernel_time_us": tot_us, "algorithmic_mb_per_frame": alg_mb,
+       "fetch_factor": "2 (16-B/lane loads; 1.94 measured on conv_igemm8), 1.25 stem_conv1, 1.40 conv3x3_rows",
+       "fetch_calibration": "profiles/r03_fetch_calibration.json (exact bytes of single launches past the Infinity Cache / FETCH_SIZE)",
+       "traffic_kind": "L2-miss (fabric-side) request bytes, Infinity-Cache hits included",
        "mfma_busy_frac_of_busy_cus": (mb_all / (4 * cu_all)) if cu_all else None,
        "source": "tools/pmc_collect.sh + tools/pmc_summary.py (rocprofv3 --pmc passes, counters only)"}
 json.dump(rec, open(out + '_hbm_traffic.json', 'w'), indent=1)
