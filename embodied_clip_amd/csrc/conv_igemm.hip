@@ -99,13 +99,22 @@ __device__ __forceinline__ void epi_stage(const f32x16_t (&acc)[FM][FN], unsigne
     const int frow = lane & 31, fhalf = lane >> 5;
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
-        float4 bvj[4];                      // the four bias vectors of this 32-channel block: one exposed load latency per j
+        // the four bias vectors of this 32-channel block up front (one exposed load latency per j) -- except in the residual
+        // variants of the 3-workgroups-per-CU kernel, which have no registers for them (they spill: 72 -> 80 us on
+        // layer-3 conv3) and fetch one vector per group instead
+        constexpr bool BIAS_UP_FRONT = !(RES && FM * FN <= 4);
+        float4 bvj[4];
+        if constexpr (BIAS_UP_FRONT) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-            bvj[g] = bias_n0 ? *reinterpret_cast<const float4*>(bias_n0 + col0 + j * 32 + 8 * g + 4 * fhalf)
-                             : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int g = 0; g < 4; ++g)
+                bvj[g] = bias_n0 ? *reinterpret_cast<const float4*>(bias_n0 + col0 + j * 32 + 8 * g + 4 * fhalf)
+                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
+            if constexpr (!BIAS_UP_FRONT)
+                bvj[g] = bias_n0 ? *reinterpret_cast<const float4*>(bias_n0 + col0 + j * 32 + 8 * g + 4 * fhalf)
+                                 : make_float4(0.f, 0.f, 0.f, 0.f);
             const int lcol = col0 + j * 32 + 8 * g + 4 * fhalf;          // 4 consecutive channels
             uint2 rr[FM];
             if constexpr (RES) {
@@ -149,18 +158,23 @@ __device__ __forceinline__ void epi_stage(const f32x16_t (&acc)[FM][FN], unsigne
     }
 }
 // runtime (act, residual) -> the matching straight-line instance: ONE wave-uniform branch per tile
-template <bool POOL, int FM, int FN, int PITCH>
+// (QuickGELU never comes with a residual: ec_conv_bf16 / ec_gemm_bf16 reject the pair.  RES_ONLY: the residual-prefetching
+//  instances are only ever launched with a residual, so they carry two variants instead of five -- every variant inlined here
+//  counts towards the kernel's register allocation, and those instances have none to spare.)
+template <bool POOL, bool RES_ONLY, int FM, int FN, int PITCH>
 __device__ __forceinline__ void epi_stage_dispatch(const f32x16_t (&acc)[FM][FN], unsigned char* smem, const float* bias_n0,
                                                    int row0, int col0, int lane, int act, bool has_res) {
     if constexpr (POOL) {
         epi_stage<EC_ACT_RELU, false, true, FM, FN, PITCH>(acc, smem, bias_n0, row0, col0, lane);   // (pool => ReLU, no residual)
+    } else if constexpr (RES_ONLY) {
+        if (act == EC_ACT_RELU) epi_stage<EC_ACT_RELU, true, false, FM, FN, PITCH>(acc, smem, bias_n0, row0, col0, lane);
+        else epi_stage<EC_ACT_NONE, true, false, FM, FN, PITCH>(acc, smem, bias_n0, row0, col0, lane);
     } else {
         if (act == EC_ACT_RELU) {
             if (has_res) epi_stage<EC_ACT_RELU, true, false, FM, FN, PITCH>(acc, smem, bias_n0, row0, col0, lane);
             else epi_stage<EC_ACT_RELU, false, false, FM, FN, PITCH>(acc, smem, bias_n0, row0, col0, lane);
         } else if (act == EC_ACT_QUICKGELU) {
-            if (has_res) epi_stage<EC_ACT_QUICKGELU, true, false, FM, FN, PITCH>(acc, smem, bias_n0, row0, col0, lane);
-            else epi_stage<EC_ACT_QUICKGELU, false, false, FM, FN, PITCH>(acc, smem, bias_n0, row0, col0, lane);
+            epi_stage<EC_ACT_QUICKGELU, false, false, FM, FN, PITCH>(acc, smem, bias_n0, row0, col0, lane);
         } else {
             if (has_res) epi_stage<EC_ACT_NONE, true, false, FM, FN, PITCH>(acc, smem, bias_n0, row0, col0, lane);
             else epi_stage<EC_ACT_NONE, false, false, FM, FN, PITCH>(acc, smem, bias_n0, row0, col0, lane);
@@ -488,7 +502,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM > 192) ? 2 : ((WM * WN == 8) ? 4 
         }
         __syncthreads();
     }
-    epi_stage_dispatch<POOL, FM, FN, PITCH>(acc, smem, p.bias ? p.bias + e_n0 : nullptr, wm * TM, wn * TN, lane, p.act, has_res);
+    epi_stage_dispatch<POOL, PF, FM, FN, PITCH>(acc, smem, p.bias ? p.bias + e_n0 : nullptr, wm * TM, wn * TN, lane, p.act, has_res);
     __syncthreads();
 #pragma unroll
     for (int r0 = 0; r0 < OUT_ROWS; r0 += RPP) {
@@ -910,7 +924,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
         }
         __syncthreads();
     }
-    epi_stage_dispatch<POOL, FM, FN, PITCH>(acc, smem, p.bias ? p.bias + n0 : nullptr, wm * TM, wn * TN, lane, p.act, has_res);
+    epi_stage_dispatch<POOL, false, FM, FN, PITCH>(acc, smem, p.bias ? p.bias + n0 : nullptr, wm * TM, wn * TN, lane, p.act, has_res);
     __syncthreads();
 #pragma unroll
     for (int r0 = 0; r0 < OUT_ROWS; r0 += RPP) {
@@ -991,6 +1005,9 @@ int dispatch_tile(const ConvArgs& a, hipStream_t s) {
         const long mint_env = ec_config().conv8_min_tiles;
         const long mint = mint_env > 0 ? mint_env : (long)ec_tls_conv8_min_tiles;
         if (KS == 3 && a.Cout % 256 == 0 && nt256 >= mint) return launch8<256, KS, POOL>(a, s);
+        // 3x3 convs with too few 256-wide tiles (layer 4 @7x7 in a single 256-frame launch: 98) but enough 128-wide ones:
+        // 196 tiles x 72 K-tiles, 84.7 -> 64.6 us (tools/bench_shapes.py, B = 256)
+        if (KS == 3 && !POOL && a.Cout % 256 == 0 && nt256 < mint && nt128 >= mint && a.K >= 2304) return launch8<128, KS, POOL>(a, s);
         // 128-channel 3x3 convs (layer 2): 128-wide tiles of the 8-wave kernel (same-box A/B in the engine, round 3:
         // +0.4..0.8 % at 2 x 128 frames, neutral at 2 x 32; alone 52 -> 42 us at 128 frames).  EC_CONV8_BN128 = -1: off
         if (KS == 3 && a.Cout == 128 && ec_config().conv8_bn128 >= 0 && nt128 >= 2 * mint) return launch8<128, KS, POOL>(a, s);
@@ -1083,6 +1100,7 @@ extern "C" int ec_conv_bf16(const void* in, const void* w, const float* bias, co
     if (ksize != 1 && ksize != 3) return EC_ERR_SHAPE;
     if (Cin < 8 || Cin % 8 != 0 || Cout % 32 != 0) return EC_ERR_SHAPE;
     if (pool && ((H & 1) || (W & 1) || res != nullptr || act != EC_ACT_RELU)) return EC_ERR_SHAPE;
+    if (res && act == EC_ACT_QUICKGELU) return EC_ERR_UNSUPPORTED;   // (no caller: CLIP applies QuickGELU to c_fc only)
     if (H >= 4096 || W >= 65536) return EC_ERR_SHAPE;
     if ((long)B * H * W >= (1L << 31) / 4) return EC_ERR_SHAPE;
     ConvArgs a;
@@ -1145,6 +1163,7 @@ extern "C" int ec_gemm_bf16(const void* A, const void* Wt, const float* bias, co
                             int K, int act, ec_stream_t stream) {
     if (!A || !Wt || !out) return EC_ERR_ARG;
     if (M <= 0 || N % 32 != 0 || K % 8 != 0 || K < 8) return EC_ERR_SHAPE;
+    if (res && act == EC_ACT_QUICKGELU) return EC_ERR_UNSUPPORTED;
     // GEMM = 1x1 conv over a [1, 1, M] "image" with Cin = K (no power-of-two need: KS==1 never splits k).
     ConvArgs a;
     a.in = (const uint16_t*)A;
