@@ -70,6 +70,7 @@ struct ConvArgs {
     int ntiles; // total output tiles
     int nbuf;  // LDS stages: 2 (double buffer) or 1
     unsigned in_bytes, w_bytes;   // buffer-descriptor extents (out-of-range loads return 0)
+    unsigned res_bytes;           // ... of the residual tensor (= output extent)
     int ablate;                   // profiling only (EC_CONV_ABLATE): 1 no global loads, 2 no MFMA, 4 no LDS stores, 8 no epilogue
 };
 
@@ -145,8 +146,10 @@ __device__ __forceinline__ void epi_stage(const f32x16_t (&acc)[FM][FN], unsigne
                     if constexpr (ACT == EC_ACT_RELU) {
                         v0 = ec_relu(v0); v1 = ec_relu(v1); v2 = ec_relu(v2); v3 = ec_relu(v3);
                     } else if constexpr (ACT == EC_ACT_QUICKGELU) {
-                        v0 = v0 / (1.f + __expf(-1.702f * v0)); v1 = v1 / (1.f + __expf(-1.702f * v1));
-                        v2 = v2 / (1.f + __expf(-1.702f * v2)); v3 = v3 / (1.f + __expf(-1.702f * v3));
+                        // x * sigmoid(1.702 x) with v_exp + v_rcp (1 ulp each; the result is rounded to bf16 next): a true
+                        // IEEE division costs ~15 instructions per value here
+                        v0 *= __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v0)); v1 *= __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v1));
+                        v2 *= __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v2)); v3 *= __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v3));
                     }
                     uint2 o;
                     o.x = ec_pack2(v0, v1);
@@ -295,6 +298,10 @@ __global__ __launch_bounds__(WM * WN * 64, (BM > 192) ? 2 : ((WM * WN == 8) ? 4 
 #if defined(__HIP_DEVICE_COMPILE__)
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+    // residual rows come through a descriptor too: rows past the tensor (ragged last tile) are out-of-range offsets that
+    // read as zeros -- no per-load predicate, so the compiler issues all of a tile's loads back to back (with an
+    // exec-masked branch around each it waited vmcnt(0) per load: 16 serial round trips in the 8-wave kernel's epilogue)
+    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, p.res ? p.res_bytes : 0u, 0x00020000);
 #endif
     const int wave_lds = wave * 1024;                       // 64 lanes x 16 B
     // per-K-tile addressing state shared by the pieces of one tile
@@ -425,9 +432,10 @@ __global__ __launch_bounds__(WM * WN * 64, (BM > 192) ? 2 : ((WM * WN == 8) ? 4 
 #pragma unroll
             for (int i = 0; i < (PREFETCH ? NPASS : 1); ++i) {
                 const int row = i * RPP + srow;
-                rres[i] = make_uint4(0, 0, 0, 0);
-                if (orow0 + row < Mout && (MV == BM || row < MV))
-                    rres[i] = *reinterpret_cast<const uint4*>(p.res + (long)(orow0 + row) * p.Cout + e_n0 + schunk * 8);
+#if defined(__HIP_DEVICE_COMPILE__)
+                const unsigned off = (MV == BM || row < MV) ? ((unsigned)(orow0 + row) * (unsigned)p.Cout + (unsigned)(e_n0 + schunk * 8)) * 2u : 0xFFFFFFF0u;
+                rres[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, (int)off, 0, 0));
+#endif
             }
         }
         if constexpr (NS >= 3) {
@@ -495,8 +503,10 @@ __global__ __launch_bounds__(WM * WN * 64, (BM > 192) ? 2 : ((WM * WN == 8) ? 4 
             for (int i = 0; i < NPASS; ++i) {
                 const int row = i * RPP + srow;
                 uint4 v = make_uint4(0, 0, 0, 0);
-                if (orow0 + row < Mout && (MV == BM || row < MV))
-                    v = *reinterpret_cast<const uint4*>(p.res + (long)(orow0 + row) * p.Cout + e_n0 + schunk * 8);
+#if defined(__HIP_DEVICE_COMPILE__)
+                const unsigned off = (MV == BM || row < MV) ? ((unsigned)(orow0 + row) * (unsigned)p.Cout + (unsigned)(e_n0 + schunk * 8)) * 2u : 0xFFFFFFF0u;
+                v = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, (int)off, 0, 0));
+#endif
                 *reinterpret_cast<uint4*>(smem + row * PITCH + schunk * 16) = v;
             }
         }
@@ -913,13 +923,18 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
     const int orow0 = POOL ? (m0 >> 2) : m0;
     const int srow = tid / CH, schunk = tid % CH;
     const bool has_res = !POOL && (p.res != nullptr);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __amdgpu_buffer_rsrc_t rs_res8 = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, p.res ? p.res_bytes : 0u, 0x00020000);
+#endif
     if (has_res) {
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) {
             const int row = i * RPP + srow;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (orow0 + row < Mout)
-                v = *reinterpret_cast<const uint4*>(p.res + (long)(orow0 + row) * p.Cout + n0 + schunk * 8);
+#if defined(__HIP_DEVICE_COMPILE__)   // (descriptor load: rows past the tensor read as zeros, all NPASS loads in flight at once)
+            const unsigned off = ((unsigned)(orow0 + row) * (unsigned)p.Cout + (unsigned)(n0 + schunk * 8)) * 2u;
+            v = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_res8, (int)off, 0, 0));
+#endif
             *reinterpret_cast<uint4*>(smem + row * PITCH + schunk * 16) = v;
         }
         __syncthreads();
@@ -1017,7 +1032,7 @@ int dispatch_tile(const ConvArgs& a, hipStream_t s) {
         // K = 512 and short-K residual launches stay on the 4-wave kernel (slower here).  ViT-B/32 GEMMs (tools/bench_vitgemm.sh,
         // 12800 tokens): in_proj 768->2304 78.6 -> 57.6 us, c_fc 768->3072 105 -> 82, c_proj 3072->768 + residual 91.7 -> 85.1;
         // out_proj 768->768 + residual is slower (31 -> 35) and keeps the 4-wave kernel
-        if (KS == 1 && !POOL && ((!a.res && a.K >= 768) || (a.res && a.K >= 2048))) {
+        if (KS == 1 && !POOL && ((!a.res && a.K >= 768) || (a.res && a.K >= 512))) {   // (residual: 49.5 -> 45.7 us on 512 -> 2048 @7x7 once its residual loads were all in flight)
             if (a.Cout % 256 == 0 && nt256 >= mint) return launch8<256, KS, POOL>(a, s);
             if (!a.res && a.K >= 1024 && a.Cout % 128 == 0 && nt256 < mint && nt128 >= mint) return launch8<128, KS, POOL>(a, s);
         }
@@ -1118,6 +1133,8 @@ extern "C" int ec_conv_bf16(const void* in, const void* w, const float* bias, co
     if ((long)B * H * W * Cin * 2 >= (1L << 31) || (long)Cout * a.K * 2 >= (1L << 31)) return EC_ERR_SHAPE;
     a.in_bytes = (unsigned)((long)B * H * W * Cin * 2);
     a.w_bytes = (unsigned)((long)Cout * a.K * 2);
+    if (res && (long)B * H * W * Cout * 2 >= (1L << 32) - 16) return EC_ERR_SHAPE;
+    a.res_bytes = res ? (unsigned)((long)B * H * W * Cout * 2) : 0u;
     hipStream_t s = (hipStream_t)stream;
     if (ksize == 1 && !pool && ec_conv1x1_regw(in, w, bias, res, out, (long)B * H * W, Cin, Cout, act, s) == EC_OK) return EC_OK;
     if (ksize == 3 && !res && act == EC_ACT_RELU && Cin <= 64 && Cout <= 64 &&
@@ -1153,6 +1170,7 @@ extern "C" int ec_gemm_bf16a_x3(const void* A, const void* Wplanes, const float*
         a.ntn = 0;
         a.in_bytes = (unsigned)(rows * K * 2);
         a.w_bytes = (unsigned)((long)N * 3 * K * 2);
+        a.res_bytes = 0u;
         int rc = launch8<128, 1, false, true>(a, (hipStream_t)stream);
         if (rc != EC_OK) return rc;
     }
@@ -1179,5 +1197,7 @@ extern "C" int ec_gemm_bf16(const void* A, const void* Wt, const float* bias, co
     if ((long)M * K * 2 >= (1L << 31) || (long)N * K * 2 >= (1L << 31)) return EC_ERR_SHAPE;
     a.in_bytes = (unsigned)((long)M * K * 2);
     a.w_bytes = (unsigned)((long)N * K * 2);
+    if (res && (long)M * N * 2 >= (1L << 32) - 16) return EC_ERR_SHAPE;
+    a.res_bytes = res ? (unsigned)((long)M * N * 2) : 0u;
     return dispatch_tile<1, false>(a, (hipStream_t)stream);
 }
