@@ -91,6 +91,28 @@ struct ec_min_tiles_scope {
     ~ec_min_tiles_scope() { ec_tls_conv8_min_tiles = prev; }
 };
 
+// Once-per-workgroup staging loops (weights -> LDS).  Written as `for (idx = tid; ...) lds[f(idx)] = global[g(idx)]` hipcc
+// emits load -> s_waitcnt vmcnt(0) -> ds_write per iteration: TOTAL / NT serial L2 round trips at the head of EVERY
+// launch (18 of them, ~15 us, in the narrow 3x3 kernels -- round-3 EC_ROWS_DBG ablation).  Here all of a thread's loads
+// are issued before its first store (compile-time trip count, fully unrolled; the ragged last pass re-reads the last
+// valid element and only its STORE is predicated, so no load sits behind an exec-masked branch).
+template <int TOTAL, int NT, class T, class LoadFn, class StoreFn>
+__device__ __forceinline__ void ec_stage_all(int tid, LoadFn load, StoreFn store) {
+    constexpr int IT = (TOTAL + NT - 1) / NT;
+    T v[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        int idx = tid + i * NT;
+        if (TOTAL % NT != 0) idx = idx < TOTAL ? idx : TOTAL - 1;
+        v[i] = load(idx);
+    }
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int idx = tid + i * NT;
+        if (TOTAL % NT == 0 || idx < TOTAL) store(idx, v[i]);
+    }
+}
+
 // ---- library configuration -------------------------------------------------------------------------------------------
 // Every tuning / experiment switch of the library, read from the environment ONCE (first use) into one immutable
 // struct; the dispatch functions read fields of ec_config() instead of keeping getenv-initialised statics each.

@@ -33,7 +33,8 @@ struct N3Args {
     const float* bias;
     uint16_t* out;
     int H, W, ntiles;
-    int dbg = 0;      // profiling only (EC_ROWS_DBG): 1 no global fetch, 2 no global stores, 4 no MFMA stream
+    unsigned in_bytes = 0;   // extent of the input tensor (buffer-descriptor loads of conv3x3_rowsN_kernel)
+    int dbg = 0;      // profiling only (EC_ROWS_DBG): 1 no global fetch, 2 no global stores, 4 no MFMA stream, 8 no epilogue staging, 16 no footprint writes, 32 no store pass
 };
 
 __device__ __forceinline__ float dppq_xor1(float v) {
@@ -64,11 +65,13 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_narrow_kernel(N3Args p) {
     const int px = lane & 31, h = lane >> 5;
 
     // ---- weights -> LDS once: w[n][k], k = (tap, ci);  K-step ks = k / 16, half = (k / 8) & 1 ----
-    for (int idx = tid; idx < COUT * (K / 8); idx += NW * 64) {
-        const int n = idx / (K / 8), c = idx % (K / 8);
-        const u32x4 v = *reinterpret_cast<const u32x4*>(p.w + (long)n * K + c * 8);
-        *reinterpret_cast<u32x4*>(sm + (c >> 1) * (COUT * 32) + wunit(n, c & 1)) = v;
-    }
+    ec_stage_all<COUT * (K / 8), NW * 64, u32x4>(
+        tid,
+        [&](int idx) { return *reinterpret_cast<const u32x4*>(p.w + (long)(idx / (K / 8)) * K + (idx % (K / 8)) * 8); },
+        [&](int idx, const u32x4& v) {
+            const int n = idx / (K / 8), c = idx % (K / 8);
+            *reinterpret_cast<u32x4*>(sm + (c >> 1) * (COUT * 32) + wunit(n, c & 1)) = v;
+        });
     for (int i = tid; i < COUT; i += NW * 64) sB[i] = p.bias[i];
     __syncthreads();
 
@@ -211,11 +214,13 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_rows_kernel(N3Args p) {
     unsigned char* img = sm + W_BYTES + COUT * 4 + wave * REGION;
     const int px = lane & 31, h = lane >> 5;
 
-    for (int idx = tid; idx < COUT * (K / 8); idx += NW * 64) {
-        const int n = idx / (K / 8), c = idx % (K / 8);
-        const u32x4 v = *reinterpret_cast<const u32x4*>(p.w + (long)n * K + c * 8);
-        *reinterpret_cast<u32x4*>(sm + (c >> 1) * (COUT * 32) + wunit(n, c & 1)) = v;
-    }
+    ec_stage_all<COUT * (K / 8), NW * 64, u32x4>(
+        tid,
+        [&](int idx) { return *reinterpret_cast<const u32x4*>(p.w + (long)(idx / (K / 8)) * K + (idx % (K / 8)) * 8); },
+        [&](int idx, const u32x4& v) {
+            const int n = idx / (K / 8), c = idx % (K / 8);
+            *reinterpret_cast<u32x4*>(sm + (c >> 1) * (COUT * 32) + wunit(n, c & 1)) = v;
+        });
     for (int i = tid; i < COUT; i += NW * 64) sB[i] = p.bias[i];
     __syncthreads();
 
@@ -395,11 +400,13 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_rowsN_kernel(N3Args p) {
     unsigned char* img = sm + W_BYTES + COUT * 4 + wave * REGION;
     const int px = lane & 31, h = lane >> 5;
 
-    for (int idx = tid; idx < COUT * (K / 8); idx += NW * 64) {
-        const int n = idx / (K / 8), c = idx % (K / 8);
-        const u32x4 v = *reinterpret_cast<const u32x4*>(p.w + (long)n * K + c * 8);
-        *reinterpret_cast<u32x4*>(sm + (c >> 1) * (COUT * 32) + wunit(n, c & 1)) = v;
-    }
+    ec_stage_all<COUT * (K / 8), NW * 64, u32x4>(
+        tid,
+        [&](int idx) { return *reinterpret_cast<const u32x4*>(p.w + (long)(idx / (K / 8)) * K + (idx % (K / 8)) * 8); },
+        [&](int idx, const u32x4& v) {
+            const int n = idx / (K / 8), c = idx % (K / 8);
+            *reinterpret_cast<u32x4*>(sm + (c >> 1) * (COUT * 32) + wunit(n, c & 1)) = v;
+        });
     for (int i = tid; i < COUT; i += NW * 64) sB[i] = p.bias[i];
     __syncthreads();
 
@@ -407,16 +414,24 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_rowsN_kernel(N3Args p) {
     const int lb = (int)ec_xcd_remap(blockIdx.x, gridDim.x);
     const int nseg = p.W / 28, nrow = p.H / RT;
 
-    int f_r[IT], f_px[IT], f_lds[IT], f_goff[IT];
+    // per-lane footprint geometry (tile-invariant).  Only the footprint's FIRST / LAST row and column can fall outside
+    // the frame, and whether they do is a property of the tile (wave-uniform): a chunk carries 4 edge bits, the tile a
+    // 4-bit mask, and an invalid chunk is an out-of-range descriptor offset (reads as zeros) -- 4 VALU per chunk where the
+    // two range compares + 64-bit pointer select + 64-bit add took ~10 (the per-tile glue of this kernel is as long as
+    // its MFMA stream: EC_ROWS_DBG ablations, DESIGN.md section 4.6 d)
+    int f_lds[IT];
+    unsigned f_goff[IT], f_edge[IT];
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
         const int g = i * 64 + lane;
-        const int r = g / (RW * CPP), rem = g - r * (RW * CPP);
-        f_r[i] = (g < NCH) ? r : -100000;
-        f_px[i] = rem / CPP;
-        f_lds[i] = r * RPB + (rem / CPP) * PITCH + (rem % CPP) * 16;
-        f_goff[i] = ((r * p.W + rem / CPP) * CIN + (rem % CPP) * 8) * 2;
+        const int r = g / (RW * CPP), rem = g - r * (RW * CPP), fpx = rem / CPP;
+        f_edge[i] = (g >= NCH ? 16u : 0u) | (r == 0 ? 1u : 0u) | (r == NR - 1 ? 2u : 0u) | (fpx == 0 ? 4u : 0u) | (fpx == RW - 1 ? 8u : 0u);
+        f_lds[i] = r * RPB + fpx * PITCH + (rem % CPP) * 16;
+        f_goff[i] = (unsigned)(((r * p.W + fpx) * CIN + (rem % CPP) * 8) * 2);
     }
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+#endif
     // LDS byte addresses of this lane's operand slots: the rest of every fragment address is an instruction immediate
     const unsigned a_lds = (unsigned)(unsigned long)(__attribute__((address_space(3))) unsigned char*)img + (unsigned)(px * PITCH + h * 16);
     const unsigned w_lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) unsigned char*)sm + (unsigned)wunit(px, h);
@@ -435,8 +450,6 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_rowsN_kernel(N3Args p) {
         }
 
     u32x4 nxt[IT];
-    const unsigned char* in_b = reinterpret_cast<const unsigned char*>(p.in);
-    const unsigned char* zp = reinterpret_cast<const unsigned char*>(ec_zero_page3);
     struct Coord { int sg, rr, b; };
     auto decode = [&](int t_) {
         const int t = __builtin_amdgcn_readfirstlane(t_);
@@ -453,14 +466,18 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_rowsN_kernel(N3Args p) {
         const int sgi = __builtin_amdgcn_readfirstlane(c.sg), rr = __builtin_amdgcn_readfirstlane(c.rr);
         const int b = __builtin_amdgcn_readfirstlane(c.b);
         const int y0 = RT * rr - 1, x0 = 28 * sgi - 1;
-        const unsigned char* base = in_b + (((long)b * p.H + y0) * p.W + x0) * (CIN * 2);
+        const unsigned base = (unsigned)((((long)b * p.H + y0) * p.W + x0) * (CIN * 2));      // (mod 2^32: edge chunks are masked)
+        const unsigned tmask = 16u | (y0 < 0 ? 1u : 0u) | (y0 + NR - 1 >= p.H ? 2u : 0u) | (x0 < 0 ? 4u : 0u) |
+                               (x0 + RW - 1 >= p.W ? 8u : 0u) | ((p.dbg & 1) ? 15u : 0u);
+#if defined(__HIP_DEVICE_COMPILE__)
         [&]<int... I>(std::integer_sequence<int, I...>) {
             (([&] {
-                 const bool ok = (unsigned)(y0 + f_r[I]) < (unsigned)p.H && (unsigned)(x0 + f_px[I]) < (unsigned)p.W && !(p.dbg & 1);
-                 nxt[I] = *reinterpret_cast<const u32x4*>(ok ? base + f_goff[I] : zp);
+                 const unsigned off = (f_edge[I] & tmask) ? 0xFFFFFFF0u : base + f_goff[I];
+                 nxt[I] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)off, 0, 0);
              }()),
              ...);
         }(std::make_integer_sequence<int, IT>{});
+#endif
     };
 
     int t = lb * NW + wave;
@@ -470,7 +487,7 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_rowsN_kernel(N3Args p) {
     for (;;) {
         [&]<int... I>(std::integer_sequence<int, I...>) {
             (([&] {
-                 if (I * 64 + lane < NCH) *reinterpret_cast<u32x4*>(img + f_lds[I]) = nxt[I];
+                 if (I * 64 + lane < NCH && !(p.dbg & 16)) *reinterpret_cast<u32x4*>(img + f_lds[I]) = nxt[I];
              }()),
              ...);
         }(std::make_integer_sequence<int, IT>{});
@@ -530,6 +547,7 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_rowsN_kernel(N3Args p) {
 
         // epilogue through the (now free) image region: RT blocks of 32 pixel rows (28 real each)
         unsigned char* stg = img;
+        if (!(p.dbg & 8))
 #pragma unroll
         for (int i = 0; i < RT; ++i)
 #pragma unroll
@@ -553,7 +571,7 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_rowsN_kernel(N3Args p) {
 #pragma unroll
                 for (int j = 0; j < (28 * ZC + 63) / 64; ++j) {
                     const int idx = j * 64 + lane;
-                    if (idx < 28 * ZC && !(p.dbg & 2)) {
+                    if (idx < 28 * ZC && !(p.dbg & 2) && !(p.dbg & 32)) {
                         const u32x4 v = *reinterpret_cast<const u32x4*>(stg + (i * 32 + idx / ZC) * OP + (idx % ZC) * 16);
                         *reinterpret_cast<u32x4*>(p.out + (opix + idx / ZC) * COUT + (idx % ZC) * 8) = v;
                     }
@@ -631,13 +649,15 @@ int ec_conv3x3_narrow(const void* in, const void* w, const float* bias, void* ou
         const long nt = pool ? (long)B * (H / 2) * (W / 14) : (long)B * H * (W / 28);
         // EC_CONV_ROWSN (default 1): multi-row tiles (conv3x3_rowsN_kernel) for the un-pooled layers whose height allows
         const int rowsn = ec_config().conv_rowsn;
-        if (fits && !pool && rowsn && nt <= 0x7fffffffL) {
+        if (fits && !pool && rowsn && nt <= 0x7fffffffL && M * Cin * 2 < (1L << 32) - 16) {
             if (Cin == 64 && Cout == 64 && H % 2 == 0) {
                 N3Args p{(const uint16_t*)in, (const uint16_t*)w, bias, (uint16_t*)out, H, W, (int)(nt / 2)};
+                p.in_bytes = (unsigned)(M * Cin * 2);
                 return rowsn == 3 ? launch_rowsN<64, 64, 2, 4, 3>(p, s) : launch_rowsN<64, 64, 2, 4, 2>(p, s);
             }
             if (Cin == 32 && Cout == 32 && H % 4 == 0) {
                 N3Args p{(const uint16_t*)in, (const uint16_t*)w, bias, (uint16_t*)out, H, W, (int)(nt / 4)};
+                p.in_bytes = (unsigned)(M * Cin * 2);
                 return rowsn == 2 ? launch_rowsN<32, 32, 4, 4, 2>(p, s) : launch_rowsN<32, 32, 4, 8, 1>(p, s);
             }
         }

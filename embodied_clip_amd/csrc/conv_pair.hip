@@ -132,21 +132,33 @@ __global__ __launch_bounds__(256, 1) void conv1x1_pair_kernel(PairArgs p) {
     };
 
     // ---- prologue: weights -> LDS (once per workgroup) ----
-    for (int idx = tid; idx < (TWO ? 2 : 1) * NY * 8; idx += 256) {
-        const int kt = idx / (NY * 8), r = (idx / 8) % NY, c = idx & 7;
-        const uint16_t* src = (kt == 0 ? p.w0 : p.w1) + r * KA + c * 8;
-        *reinterpret_cast<uint4*>(sW0 + kt * (NY * 128) + pw_off(r, c)) = *reinterpret_cast<const uint4*>(src);
-    }
+    ec_stage_all<(TWO ? 2 : 1) * NY * 8, 256, uint4>(
+        tid,
+        [&](int idx) {
+            const int kt = idx / (NY * 8), r = (idx / 8) % NY, c = idx & 7;
+            return *reinterpret_cast<const uint4*>((kt == 0 ? p.w0 : p.w1) + r * KA + c * 8);
+        },
+        [&](int idx, const uint4& v) {
+            const int kt = idx / (NY * 8), r = (idx / 8) % NY, c = idx & 7;
+            *reinterpret_cast<uint4*>(sW0 + kt * (NY * 128) + pw_off(r, c)) = v;
+        });
     // w2 with the K permutation of the register-chained operand: K-step s = (j, gp), half hh, element e
     //   <->  channel 32 j + 16 gp + 8 (e >> 2) + 4 hh + (e & 3)
-    for (int idx = tid; idx < N2 * 32; idx += 256) {
-        const int n = idx >> 5, q = idx & 31;
-        const int s = q >> 1, hh = q & 1;
-        const int c0 = 32 * (s >> 1) + 16 * (s & 1) + 4 * hh;
-        const uint2 lo = *reinterpret_cast<const uint2*>(p.w2 + n * NY + c0);
-        const uint2 hi = *reinterpret_cast<const uint2*>(p.w2 + n * NY + c0 + 8);
-        *reinterpret_cast<uint4*>(sW2 + (s >> 2) * (N2 * 128) + pw_off(n, 2 * (s & 3) + hh)) = make_uint4(lo.x, lo.y, hi.x, hi.y);
-    }
+    ec_stage_all<N2 * 32, 256, uint4>(
+        tid,
+        [&](int idx) {
+            const int n = idx >> 5, q = idx & 31;
+            const int s = q >> 1, hh = q & 1;
+            const int c0 = 32 * (s >> 1) + 16 * (s & 1) + 4 * hh;
+            const uint2 lo = *reinterpret_cast<const uint2*>(p.w2 + n * NY + c0);
+            const uint2 hi = *reinterpret_cast<const uint2*>(p.w2 + n * NY + c0 + 8);
+            return make_uint4(lo.x, lo.y, hi.x, hi.y);
+        },
+        [&](int idx, const uint4& v) {
+            const int n = idx >> 5, q = idx & 31;
+            const int s = q >> 1, hh = q & 1;
+            *reinterpret_cast<uint4*>(sW2 + (s >> 2) * (N2 * 128) + pw_off(n, 2 * (s & 3) + hh)) = v;
+        });
     for (int i = tid; i < NY; i += 256) sBy[i] = p.b0[i] + (TWO ? p.b1[i] : 0.f);
     for (int i = tid; i < N2; i += 256) sBz[i] = p.b2[i];
     __syncthreads();
