@@ -320,15 +320,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float* T1 = wave_base + wave * (32 * TL_P128 + 32 * TL_P32);   // c1 tile, later the m1 tile
     float* T2 = T1 + 32 * TL_P128;                                 // c2 tile
-    for (int idx = tid; idx < 32 * 32; idx += 256) {               // W2, W4: [32][128]
-        const int r = idx >> 5, c4 = idx & 31;
-        *reinterpret_cast<float4*>(sW2 + r * TL_P128 + c4 * 4) = *reinterpret_cast<const float4*>(W2 + r * 128 + c4 * 4);
-        *reinterpret_cast<float4*>(sW4 + r * TL_P128 + c4 * 4) = *reinterpret_cast<const float4*>(W4 + r * 128 + c4 * 4);
-    }
-    for (int idx = tid; idx < 128 * 8; idx += 256) {               // W3[:, :32]: [128][32] out of rows of w3_ld floats
-        const int r = idx >> 3, c4 = idx & 7;
-        *reinterpret_cast<float4*>(sW3 + r * TL_P32 + c4 * 4) = *reinterpret_cast<const float4*>(W3 + (long)r * w3_ld + c4 * 4);
-    }
+    // (all of a thread's weight loads in flight before its first LDS store: ec_stage_all, common.h -- the act step's
+    //  instance of this kernel is 13-25 workgroups whose prologue is on the rollout's critical chain)
+    ec_stage_all<32 * 32, 256, float4>(tid,                        // W2: [32][128]
+        [&](int idx) { return *reinterpret_cast<const float4*>(W2 + (idx >> 5) * 128 + (idx & 31) * 4); },
+        [&](int idx, const float4& v) { *reinterpret_cast<float4*>(sW2 + (idx >> 5) * TL_P128 + (idx & 31) * 4) = v; });
+    ec_stage_all<32 * 32, 256, float4>(tid,                        // W4: [32][128]
+        [&](int idx) { return *reinterpret_cast<const float4*>(W4 + (idx >> 5) * 128 + (idx & 31) * 4); },
+        [&](int idx, const float4& v) { *reinterpret_cast<float4*>(sW4 + (idx >> 5) * TL_P128 + (idx & 31) * 4) = v; });
+    ec_stage_all<128 * 8, 256, float4>(tid,                        // W3[:, :32]: [128][32] out of rows of w3_ld floats
+        [&](int idx) { return *reinterpret_cast<const float4*>(W3 + (long)(idx >> 3) * w3_ld + (idx & 7) * 4); },
+        [&](int idx, const float4& v) { *reinterpret_cast<float4*>(sW3 + (idx >> 3) * TL_P32 + (idx & 7) * 4) = v; });
     for (int idx = tid; idx < num_goals * 32; idx += 256)
         *reinterpret_cast<float4*>(sE1 + idx * 4) = *reinterpret_cast<const float4*>(E1 + idx * 4);
     if (tid < 32) { sB[tid] = b2[tid]; sB[32 + tid] = b4[tid]; }
@@ -853,11 +855,27 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(const float* __restrict_
 #pragma unroll
     for (int o = 0; o < MAXO; ++o) acc[o] = 0.f;
     const float* x = hs + row * H;
-    for (int k = lane; k < H; k += 64) {
-        const float v = x[k];
+    if ((H & 255) == 0) {
+        // lane l owns the 4 elements [4 l, 4 l + 4) of every 256-wide chunk: one float4 of the row and one of each output's
+        // weight row per chunk, all MAXO + 1 loads of a chunk in flight together (the scalar-per-lane loop waited for
+        // 8 dependent rounds of 8 loads: 17 us for a 9-us GRU step in front of it); outputs past A read Wc (discarded)
+        for (int k0 = 0; k0 < H; k0 += 256) {
+            const float4 v = *reinterpret_cast<const float4*>(x + k0 + 4 * lane);
+            float4 wv[MAXO];
 #pragma unroll
-        for (int o = 0; o < MAXO; ++o)
-            if (o <= A) acc[o] = fmaf(v, (o < A ? Wa[(long)o * H + k] : Wc[k]), acc[o]);
+            for (int o = 0; o < MAXO; ++o)
+                wv[o] = *reinterpret_cast<const float4*>((o < A ? Wa + (long)o * H : Wc) + k0 + 4 * lane);
+#pragma unroll
+            for (int o = 0; o < MAXO; ++o)
+                acc[o] = fmaf(v.w, wv[o].w, fmaf(v.z, wv[o].z, fmaf(v.y, wv[o].y, fmaf(v.x, wv[o].x, acc[o]))));
+        }
+    } else {
+        for (int k = lane; k < H; k += 64) {
+            const float v = x[k];
+#pragma unroll
+            for (int o = 0; o < MAXO; ++o)
+                if (o <= A) acc[o] = fmaf(v, (o < A ? Wa[(long)o * H + k] : Wc[k]), acc[o]);
+        }
     }
 #pragma unroll
     for (int o = 0; o < MAXO; ++o) {
@@ -947,7 +965,8 @@ extern "C" int ec_policy_forward(const ec_policy_t* h, const float* params, cons
     if (T <= 0 || N <= 0) return EC_ERR_SHAPE;
     const ec_policy_cfg& c = h->c;
     const Ws w = layout(h, T, N, false);
-    if (ws_bytes < layout(h, T, N, for_backward != 0).end * 4) return EC_ERR_WORKSPACE;
+    if (for_backward < 0 || for_backward > EC_POLICY_INFER_REUSE) return EC_ERR_ARG;
+    if (ws_bytes < layout(h, T, N, for_backward == EC_POLICY_LEARN).end * 4) return EC_ERR_WORKSPACE;
     float* ws = (float*)workspace;
     hipStream_t s = (hipStream_t)stream;
     const int B = T * N, S = c.spatial * c.spatial, H = c.hidden, A1 = c.num_actions + 1;
@@ -959,7 +978,10 @@ extern "C" int ec_policy_forward(const ec_policy_t* h, const float* params, cons
     // Act-step path (for_backward == 0, stated by the caller -- never inferred from the workspace size): inference only,
     // so c1 need not be materialised and the two long-K, small-M GEMMs (compressor conv 1, GRU input projection) run as
     // ACT_PARTS K slices whose partial matrices the consuming kernels fold in a fixed order.
-    const bool infer_only = for_backward == 0;
+    const bool infer_only = for_backward == 0 || for_backward == EC_POLICY_INFER_REUSE;
+    // EC_POLICY_INFER_REUSE: the weight-derived table E1 that an EC_POLICY_INFER call left in THIS workspace is still valid
+    // (same parameters: every act step of a rollout after the first) -- one GEMM launch less on the act step's chain
+    const bool reuse_tables = for_backward == EC_POLICY_INFER_REUSE;
     const bool small = !c.fusion && M49 > 0 && M49 <= ACT_MAX_ROWS;            // (== the condition in layout())
     const size_t tail_lds_ = ((size_t)2 * 32 * TL_P128 + 128 * TL_P32 + (size_t)c.num_goals * 128 + 64 +
                               4 * (size_t)(32 * TL_P128 + 32 * TL_P32)) * sizeof(float);
@@ -983,6 +1005,7 @@ extern "C" int ec_policy_forward(const ec_policy_t* h, const float* params, cons
                                goal32, ws + w.x, (long)B, flat, c.num_goals);
     } else {
     // E1 = embed_class @ W3[:, co:]^T + b3
+    if (!reuse_tables)
     RC(ec_gemm_f32(W(P_EMB), W(P_W3) + c.compress_out, ws + w.E1, c.num_goals, c.comb_hid, c.goal_dims, c.goal_dims, 1,
                    1, cat, c.comb_hid, 0, W(P_B3), nullptr, nullptr, 0, nullptr, nullptr, 1, stream));
     // resnet_compressor
@@ -1052,12 +1075,15 @@ extern "C" int ec_policy_forward(const ec_policy_t* h, const float* params, cons
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gru_step_fwd_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
+    // inference with T == 1 (the act step): the new state goes straight to h_final (no copy launch afterwards) and the
+    // heads read it there
+    float* hs_base = (infer_only && T == 1 && h_final && h_final != h0) ? h_final : ws + w.hs;
     for (int t = 0; t < T; ++t) {
-        const float* hprev = (t == 0) ? h0 : ws + w.hs + (size_t)(t - 1) * N * H;
+        const float* hprev = (t == 0) ? h0 : hs_base + (size_t)(t - 1) * N * H;
         const size_t o3 = (size_t)t * N * 3 * H, o1 = (size_t)t * N * H;
         if (fused_step) {
             hipLaunchKernelGGL(gru_step_fwd_kernel, dim3((unsigned)(H / 8), (unsigned)((N + 31) / 32)), dim3(256), gru_lds, s,
-                               ws + w.gi + o3, W(P_WHH), W(P_BHH), hprev, masks + (size_t)t * N, ws + w.hs + o1,
+                               ws + w.gi + o3, W(P_WHH), W(P_BHH), hprev, masks + (size_t)t * N, hs_base + o1,
                                ws + w.gates + o3, ws + w.hn + o1, ws + w.hp + o1, N, H, gi_split ? ACT_PARTS : 1,
                                (long)B * 3 * H);
             continue;
@@ -1065,20 +1091,20 @@ extern "C" int ec_policy_forward(const ec_policy_t* h, const float* params, cons
         RC(ec_gemm_f32(hprev, W(P_WHH), ws + w.gh, N, 3 * H, H, H, 1, 1, H, 3 * H, 0, nullptr, nullptr, nullptr, 0,
                        nullptr, nullptr, 1, stream));
         hipLaunchKernelGGL(gru_gates_fwd_kernel, dim3((N * H + 255) / 256), dim3(256), 0, s, ws + w.gi + o3, ws + w.gh,
-                           W(P_BHH), hprev, masks + (size_t)t * N, ws + w.hs + o1, ws + w.gates + o3, ws + w.hn + o1,
+                           W(P_BHH), hprev, masks + (size_t)t * N, hs_base + o1, ws + w.gates + o3, ws + w.hn + o1,
                            ws + w.hp + o1, N, H);
     }
     // heads: hv[:, :A] = actor logits, hv[:, A] = critic value
     if (A1 <= 8) {
-        hipLaunchKernelGGL(heads_fwd_kernel<8>, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s, ws + w.hs, W(P_WA), W(P_BA),
+        hipLaunchKernelGGL(heads_fwd_kernel<8>, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s, hs_base, W(P_WA), W(P_BA),
                            W(P_WC), W(P_BC), hv, (long)B, H, c.num_actions);
     } else {
-        RC(ec_gemm_f32(ws + w.hs, W(P_WA), hv, B, c.num_actions, H, H, 1, 1, H, A1, 0, W(P_BA), nullptr, nullptr, 0,
+        RC(ec_gemm_f32(hs_base, W(P_WA), hv, B, c.num_actions, H, H, 1, 1, H, A1, 0, W(P_BA), nullptr, nullptr, 0,
                        nullptr, nullptr, 1, stream));
-        RC(ec_gemm_f32(ws + w.hs, W(P_WC), hv + c.num_actions, B, 1, H, H, 1, 1, H, A1, 0, W(P_BC), nullptr, nullptr, 0,
+        RC(ec_gemm_f32(hs_base, W(P_WC), hv + c.num_actions, B, 1, H, H, 1, 1, H, A1, 0, W(P_BC), nullptr, nullptr, 0,
                        nullptr, nullptr, 1, stream));
     }
-    if (h_final)
+    if (h_final && hs_base != h_final)
         (void)hipMemcpyAsync(h_final, ws + w.hs + (size_t)(T - 1) * N * H, (size_t)N * H * 4, hipMemcpyDeviceToDevice, s);
     EC_CHECK_LAUNCH();
     return EC_OK;

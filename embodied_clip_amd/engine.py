@@ -183,6 +183,7 @@ class Worker:
                             if self.zeroshot else None)
             sl.tok = (torch.empty((n, encs[i].L, encs[i].D), dtype=torch.bfloat16, device=d) if encoder == "vit" else None)
             sl.ws_act = torch.empty(self.policy.workspace_bytes(1, n, False), dtype=torch.uint8, device=d)
+            sl.act_tables_valid = False     # weight-derived tables in ws_act (rebuilt by the first act step after an update)
             sl.ws_learn = torch.empty(self.policy.workspace_bytes(T, n, True), dtype=torch.uint8, device=d)
             sl.hv = torch.empty((T * n, self.A + 1), dtype=torch.float32, device=d)
             sl.dhv = torch.empty_like(sl.hv)
@@ -282,7 +283,9 @@ class Worker:
         rs = slice(o, o + n)
         h_in, h_out = (self.h, self.h_next) if (t & 1) == 0 else (self.h_next, self.h)   # ping-pong by step parity
         self.policy.forward(self.params, sl.feat[t], self.env.goals[t][rs], h_in[rs], self.env.masks[t][rs], 1, n,
-                            sl.ws_act, hv=self.hv_act[rs], h_final=h_out[rs], for_backward=False)
+                            sl.ws_act, hv=self.hv_act[rs], h_final=h_out[rs], for_backward=False,
+                            reuse_tables=sl.act_tables_valid)      # (E1 depends on the parameters only)
+        sl.act_tables_valid = True
         if sample:
             _lib.check(self.lib.ec_sample_actions(self.hv_act[rs].data_ptr(), self.actions[t][rs].data_ptr(),
                                                   self.logp[t][rs].data_ptr(), self.values[t][rs].data_ptr(), n, self.A,
@@ -403,6 +406,8 @@ class Worker:
                 if self.world > 1:
                     allreduce_flat(self.grads)                   # one flat 13.9 MB bucket over RCCL/xGMI
                 self.opt.step(self.grads, lr=linear_decay_lr(self.base_lr, self.total_steps, self.lr_total_steps))
+                for sl in self.slices:
+                    sl.act_tables_valid = False
 
     @_lib.on_device
     def after_update(self):

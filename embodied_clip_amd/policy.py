@@ -96,15 +96,19 @@ class PolicyHandle:
     def views(self, flat: torch.Tensor) -> "OrderedDict[str, torch.Tensor]":
         return OrderedDict((n, flat[o:o + k].view(self.shapes[n])) for n, (o, k) in self.offsets.items())
 
-    def forward(self, flat_params, feat, goal, h0, masks, T, N, ws, hv=None, h_final=None, for_backward: bool = True):
+    def forward(self, flat_params, feat, goal, h0, masks, T, N, ws, hv=None, h_final=None, for_backward: bool = True,
+                reuse_tables: bool = False):
         """feat: bf16 or fp32 NHWC rows [T*N, S*S, C]; returns (hv [T*N, A+1], h_final [N,H]).
         ``for_backward=True`` (default) keeps every activation ``backward`` needs and wants a workspace of
         ``workspace_bytes(T, N, True)``; ``False`` is the inference-only act step (``workspace_bytes(T, N, False)``).
-        The kernel plan follows this flag, never the size of ``ws``."""
+        The kernel plan follows this flag, never the size of ``ws``.  ``reuse_tables`` (inference only): the weight-derived
+        tables a previous ``for_backward=False`` call left in THIS ``ws`` are still valid (same parameters: the later act
+        steps of a rollout)."""
         assert feat.is_contiguous() and feat.dtype in (torch.bfloat16, torch.float32)
         dev = flat_params.device
         with _lib.tensor_guard(flat_params):
-            return self._forward(flat_params, feat, goal, h0, masks, T, N, ws, hv, h_final, dev, for_backward)
+            mode = 1 if for_backward else (2 if reuse_tables else 0)
+            return self._forward(flat_params, feat, goal, h0, masks, T, N, ws, hv, h_final, dev, mode)
 
     def _forward(self, flat_params, feat, goal, h0, masks, T, N, ws, hv, h_final, dev, for_backward=True):
         if hv is None:
@@ -113,7 +117,7 @@ class PolicyHandle:
             h_final = torch.empty((N, self.H), dtype=torch.float32, device=dev)
         _lib.check(self.lib.ec_policy_forward(
             self.h, flat_params.data_ptr(), feat.data_ptr(), int(feat.dtype == torch.bfloat16), goal.data_ptr(),
-            h0.data_ptr(), masks.data_ptr(), T, N, ws.data_ptr(), ws.numel() * ws.element_size(), int(bool(for_backward)),
+            h0.data_ptr(), masks.data_ptr(), T, N, ws.data_ptr(), ws.numel() * ws.element_size(), int(for_backward),
             hv.data_ptr(), h_final.data_ptr(), _lib.stream_ptr()), "ec_policy_forward")
         return hv, h_final
 

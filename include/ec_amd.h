@@ -251,9 +251,12 @@ size_t ec_policy_workspace_bytes(const ec_policy_t* h, int T, int N, int for_bac
 /* feat [T*N, S*S, C] NHWC (bf16 if feat_bf16 else f32); goal int64 [T*N]; h0 f32 [N,H];
  * masks f32 [T*N] (h is multiplied by masks[t] before step t: episode reset);
  * hv f32 [T*N, A+1] out: logits in cols 0..A-1, value in col A; h_final f32 [N,H] or NULL.
- * for_backward != 0: the workspace (ec_policy_workspace_bytes(.., 1)) keeps every activation ec_policy_backward
- * needs; for_backward == 0: inference only (act step; workspace of ec_policy_workspace_bytes(.., 0) suffices) -- the
- * kernel plan depends on this flag alone, never on the size of the buffer handed in. */
+ * for_backward (the kernel plan depends on this flag alone, never on the size of the buffer handed in):
+ *   EC_POLICY_LEARN (1)        the workspace (ec_policy_workspace_bytes(.., 1)) keeps every activation ec_policy_backward needs;
+ *   EC_POLICY_INFER (0)        inference only (act step; a workspace of ec_policy_workspace_bytes(.., 0) suffices);
+ *   EC_POLICY_INFER_REUSE (2)  inference, and the weight-derived tables an EC_POLICY_INFER call left in THIS workspace are
+ *                              still valid (unchanged parameters: the later act steps of a rollout) -- they are not rebuilt. */
+enum { EC_POLICY_INFER = 0, EC_POLICY_LEARN = 1, EC_POLICY_INFER_REUSE = 2 };
 int ec_policy_forward(const ec_policy_t* h, const float* params, const void* feat, int feat_bf16,
                       const int64_t* goal, const float* h0, const float* masks, int T, int N,
                       void* workspace, size_t ws_bytes, int for_backward, float* hv, float* h_final, ec_stream_t stream);
