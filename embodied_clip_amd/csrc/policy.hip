@@ -233,6 +233,113 @@ __global__ void gru_gates_bwd_kernel(const float* __restrict__ dhs, float* __res
     dh_carry[i] = mask[n] * dh * z;
 }
 
+// out[c][r] = in[r][c] (fp32, R x C -> C x R): W_hh^T for the fused backward step, once per ec_policy_backward
+__global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int C) {
+    __shared__ float t[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + 8 * i, c = c0 + tx;
+        t[ty + 8 * i][tx] = (r < R && c < C) ? in[(long)r * C + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, r = r0 + tx;
+        if (r < R && c < C) out[(long)c * R + r] = t[tx][ty + 8 * i];
+    }
+}
+
+// Fused GRU BACKWARD step (round 3): the recurrent back-projection of step t+1 and the gate math of step t in ONE launch,
+// replacing the [N x H x 3H] split-K GEMM (fp32 atomics: 17 us) + gru_gates_bwd_kernel (5 us) pair of every step:
+//   dh[n, j] = dhs_t[n, j] + carry[n, j] + m_{t+1}[n] * sum_k dghb_{t+1}[n, k] W_hh[k, j]
+// (carry = the element-wise part m_{t+1} dh_{t+1} z_{t+1} the previous launch left), then the cell's gate gradients.
+// Workgroup (blockIdx.x, blockIdx.y) owns hidden units j0..j0+31 of actors n0..n0+31; K = 3H is walked in 256-wide chunks
+// through LDS-DMA exactly as gru_step_fwd_kernel does (A tile = dghb rows, B tile = rows j0.. of W_hh^T), the four waves
+// contract a quarter of each chunk on the exact-fp32 MFMA and their partial tiles are summed through LDS in a fixed
+// order: no atomics, so the policy gradients are now bit-reproducible run to run.
+__global__ __launch_bounds__(256) void gru_step_bwd_kernel(const float* __restrict__ dghb_next, const float* __restrict__ WhhT,
+                                                          const float* __restrict__ mask_next, const float* __restrict__ dhs,
+                                                          float* __restrict__ carry, const float* __restrict__ gates,
+                                                          const float* __restrict__ hn_s, const float* __restrict__ hp_s,
+                                                          const float* __restrict__ mask, float* __restrict__ dgi,
+                                                          float* __restrict__ dghb, int N, int H) {
+    extern __shared__ __attribute__((aligned(16))) float gsm[];
+    constexpr int KC = 256, P = KC + 4;
+    const int K = 3 * H;
+    float* sA = gsm;
+    float* sB = gsm + 32 * P;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const int i = lane & 31, hh = lane >> 5;
+    f32x16_t acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int k0 = 0; k0 < K; k0 += KC) {
+        if (k0) __syncthreads();
+        typedef __attribute__((address_space(3))) void lds_v;
+        typedef const __attribute__((address_space(1))) void gbl_v;
+        const int uwave = __builtin_amdgcn_readfirstlane(wave);
+        for (int r = uwave; r < 64; r += 4) {                      // one 1-KiB LDS-DMA piece per tile row
+            const float* src;
+            float* dst;
+            if (r < 32) {
+                const int n = min(n0 + r, N - 1);                  // rows past N are never read back
+                src = dghb_next + (long)n * K + k0 + lane * 4;
+                dst = sA + r * P;
+            } else {
+                src = WhhT + (long)(j0 + r - 32) * K + k0 + lane * 4;
+                dst = sB + (r - 32) * P;
+            }
+            __builtin_amdgcn_global_load_lds((gbl_v*)src, (lds_v*)dst, 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const float* pa = sA + i * P + wave * (KC >> 2) + 4 * hh;
+        const float* pb = sB + i * P + wave * (KC >> 2) + 4 * hh;
+#pragma unroll
+        for (int kb = 0; kb < (KC >> 2); kb += 8) {
+            const float4 a = *reinterpret_cast<const float4*>(pa + kb);
+            const float4 b = *reinterpret_cast<const float4*>(pb + kb);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+        }
+    }
+    __syncthreads();                       // the operand tiles are dead: LDS becomes the 4 partial [32 x 32] tiles
+    float* part = gsm;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;     // actor (C/D layout of the 32x32 MFMA), column = lane & 31
+        part[(wave * 32 + row) * 32 + i] = acc[r];
+    }
+    __syncthreads();
+    const int a_ = tid >> 3, u0 = tid & 7;
+    const int n = n0 + a_;
+    if (n >= N) return;
+    const float mn = mask_next[n], m = mask[n];
+    const float* g = gates + (long)n * 3 * H;
+    float* ga = dgi + (long)n * 3 * H;
+    float* gb = dghb + (long)n * 3 * H;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = u0 + 8 * q, j = j0 + c;
+        const float proj = ((part[(0 * 32 + a_) * 32 + c] + part[(1 * 32 + a_) * 32 + c]) + part[(2 * 32 + a_) * 32 + c]) +
+                           part[(3 * 32 + a_) * 32 + c];
+        const long o = (long)n * H + j;
+        const float r = g[j], z = g[H + j], nn = g[2 * H + j];
+        const float hn = hn_s[o], hp = hp_s[o];
+        const float dh = dhs[o] + (carry[o] + mn * proj);
+        const float dn_pre = dh * (1.f - z) * (1.f - nn * nn);
+        const float dz_pre = dh * (hp - nn) * z * (1.f - z);
+        const float dr_pre = dn_pre * hn * r * (1.f - r);
+        ga[j] = dr_pre; ga[H + j] = dz_pre; ga[2 * H + j] = dn_pre;
+        gb[j] = dr_pre; gb[H + j] = dz_pre; gb[2 * H + j] = dn_pre * r;
+        carry[o] = m * dh * z;
+    }
+}
+
 // out[n] += sum_m Y[m*ld + n]
 __global__ void colsum_kernel(const float* __restrict__ Y, float* __restrict__ out, long M, int N, int ld,
                               int rows_per_block) {
@@ -786,7 +893,7 @@ namespace {
 
 struct Ws {   // float offsets into the workspace
     size_t E1, c1, c2, m1, x4, x, gi, gh, gates, hn, hp, hs, goal32, w1p;
-    size_t dhs, dhc, dgi, dghb, dx, dx4, dm1, dc2, dc1, dE1, tpart, tpartE, end;
+    size_t dhs, dhc, dgi, dghb, dx, dx4, dm1, dc2, dc1, dE1, tpart, tpartE, whhT, end;
 };
 
 Ws layout(const ec_policy* h, int T, int N, bool bwd) {
@@ -811,7 +918,7 @@ Ws layout(const ec_policy* h, int T, int N, bool bwd) {
     w.hs = take(B * H);
     w.goal32 = take(B);
     w.w1p = take(c.fusion ? 0 : ((size_t)c.compress_hid * 3 * c.in_channels + 1) / 2);   // W1 as three bf16 planes
-    w.dhs = w.dhc = w.dgi = w.dghb = w.dx = w.dx4 = w.dm1 = w.dc2 = w.dc1 = w.dE1 = w.tpart = w.tpartE = o;
+    w.dhs = w.dhc = w.dgi = w.dghb = w.dx = w.dx4 = w.dm1 = w.dc2 = w.dc1 = w.dE1 = w.tpart = w.tpartE = w.whhT = o;
     if (bwd) {
         w.dhs = take(B * H);
         w.dhc = take((size_t)N * H);
@@ -825,6 +932,7 @@ Ws layout(const ec_policy* h, int T, int N, bool bwd) {
         w.dE1 = take((size_t)c.num_goals * c.comb_hid);
         w.tpart = take(c.fusion ? 0 : (size_t)TB_MAX_WG * 4 * TB_PART);              // tail_bwd_kernel's partial sets
         w.tpartE = take(c.fusion ? 0 : (size_t)TB_MAX_WG * c.num_goals * 128);
+        w.whhT = take(H * 3 * H);                                                       // W_hh^T (fused backward step)
     }
     w.end = o;
     return w;
@@ -1145,11 +1253,31 @@ extern "C" int ec_policy_backward(const ec_policy_t* h, const float* params, con
     // ---- GRU, reverse time ----
     if (dh_final) (void)hipMemcpyAsync(ws + w.dhc, dh_final, (size_t)N * H * 4, hipMemcpyDeviceToDevice, s);
     else (void)hipMemsetAsync(ws + w.dhc, 0, (size_t)N * H * 4, s);
+    // EC_GRU_FUSED (default 1) and H % 256 == 0: step T-1 is the plain gate kernel (its carry is dh_final), every earlier
+    // step ONE fused launch (gru_step_bwd_kernel: back-projection of step t+1 + gates of step t); else GEMM + gate kernel
+    const bool fused_bstep = ec_config().gru_fused && (H % 256) == 0 && T > 1;
+    if (fused_bstep) {
+        hipLaunchKernelGGL(transpose_f32_kernel, dim3((unsigned)(H / 32), (unsigned)(3 * H / 32)), dim3(256), 0, s, W(P_WHH),
+                           ws + w.whhT, 3 * H, H);
+        static std::atomic<uint64_t> attr_done{0};
+        if (auto attr_g_ = ec_attr_needed(attr_done))
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gru_step_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      160 * 1024);
+    }
+    const size_t gb_lds = (size_t)2 * 32 * (256 + 4) * sizeof(float);
     for (int t = T - 1; t >= 0; --t) {
         const size_t o3 = (size_t)t * N * 3 * H, o1 = (size_t)t * N * H;
+        if (fused_bstep && t < T - 1) {
+            hipLaunchKernelGGL(gru_step_bwd_kernel, dim3((unsigned)(H / 32), (unsigned)((N + 31) / 32)), dim3(256), gb_lds, s,
+                               ws + w.dghb + o3 + (size_t)N * 3 * H, ws + w.whhT, masks + (size_t)(t + 1) * N, ws + w.dhs + o1,
+                               ws + w.dhc, ws + w.gates + o3, ws + w.hn + o1, ws + w.hp + o1, masks + (size_t)t * N,
+                               ws + w.dgi + o3, ws + w.dghb + o3, N, H);
+            continue;
+        }
         hipLaunchKernelGGL(gru_gates_bwd_kernel, dim3((N * H + 255) / 256), dim3(256), 0, s, ws + w.dhs + o1, ws + w.dhc,
                            ws + w.gates + o3, ws + w.hn + o1, ws + w.hp + o1, masks + (size_t)t * N, ws + w.dgi + o3,
                            ws + w.dghb + o3, N, H);
+        if (fused_bstep) continue;          // (step T-1: its back-projection runs inside the next launch)
         // dh_carry += m * (dghb @ W_hh)
         RC(ec_gemm_f32(ws + w.dghb + o3, W(P_WHH), ws + w.dhc, N, H, 3 * H, 3 * H, 1, H, 1, H, EC_GEMM_ACCUMULATE, nullptr,
                        nullptr, nullptr, 0, nullptr, masks + (size_t)t * N, step_splitk(N, H, 3 * H), stream));

@@ -7,7 +7,7 @@ import csv,glob
 f=glob.glob("$GRAFT_REPO_ROOT/gpurun_out/prof_act$N/*kernel_trace.csv")[0]
 rows=sorted(csv.DictReader(open(f)), key=lambda r:int(r["Start_Timestamp"]))
 # last 14 dispatches = one act step
-last=rows[-14:]
+last=rows[-12:]
 t0=int(last[0]["Start_Timestamp"])
 print("== N=$N")
 for r in last:
