@@ -9,6 +9,8 @@
 
 namespace {
 
+typedef unsigned int u32x4_stem __attribute__((ext_vector_type(4)));
+
 // ---------------------------------------------------------------------------
 // stem conv1: 3x3, stride 2, pad 1, Cin = 3 -> COUT, folded BN + ReLU.
 // K = 27 is too thin for MFMA and the op is bandwidth-bound (602 KB in,
@@ -43,7 +45,53 @@ __global__ __launch_bounds__(256) void stem_conv1_kernel(const void* __restrict_
     const long img_off = (long)b * H * W * 3;
     const int c0 = ix0 * 3 - 1;            // first staged element of a row (multiple of 4)
     const bool vec = (W & 3) == 0;
-    if (vec) {
+    if (vec && ((long)gridDim.x / (tiles_x * tiles_y)) * H * W * 3 * (U8 ? 1 : 4) < (1L << 32) - 16) {
+        // all of a thread's patch loads in flight before its first LDS store (the `for e` loop issued load -> wait ->
+        // store four times in turn); they go through a buffer descriptor, so a vector outside the frame is an
+        // out-of-range offset that reads as zeros instead of a branch around the load
+#if defined(__HIP_DEVICE_COMPILE__)
+        const unsigned nbytes = (unsigned)(((long)gridDim.x / (tiles_x * tiles_y)) * H * W * 3 * (U8 ? 1 : 4));
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)rgb_, 0, nbytes, 0x00020000);
+        constexpr int NV = SP * 26, IT = (NV + 255) / 256;
+        u32x4_stem raw[IT];
+        int col_[IT];
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int e = min((int)threadIdx.x + 256 * i, NV - 1);
+            const int r = e / 26, q = e - r * 26;
+            const int iy = iy0 + r, col = c0 + 4 * q;
+            col_[i] = col;
+            const bool ok = iy >= 0 && iy < H && col >= 0 && col < W * 3;
+            const unsigned off = ok ? (unsigned)((img_off + (long)iy * W * 3 + col) * (U8 ? 1 : 4)) : 0xFFFFFFF0u;
+            if (U8) raw[i] = u32x4_stem{__builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0), 0u, 0u, 0u};
+            else raw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int e = threadIdx.x + 256 * i;
+            if (e < NV) {
+                const int r = e / 26, q = e - r * 26;
+                float4 v;
+                if (U8) {
+                    const int col = col_[i];
+                    const bool ok = (iy0 + r) >= 0 && (iy0 + r) < H && col >= 0 && col < W * 3;
+                    const unsigned u = raw[i][0];
+                    const int ch0 = ((col % 3) + 3) % 3;     // channel of element 0
+                    const float sc[3] = {nscale.x, nscale.y, nscale.z}, sh[3] = {nshift.x, nshift.y, nshift.z};
+                    const int c1 = ch0 == 2 ? 0 : ch0 + 1, c2 = c1 == 2 ? 0 : c1 + 1;
+                    // (padding stays exactly zero in the NORMALISED domain, as in the reference)
+                    v.x = ok ? (float)(u & 0xffu) * sc[ch0] + sh[ch0] : 0.f;
+                    v.y = ok ? (float)((u >> 8) & 0xffu) * sc[c1] + sh[c1] : 0.f;
+                    v.z = ok ? (float)((u >> 16) & 0xffu) * sc[c2] + sh[c2] : 0.f;
+                    v.w = ok ? (float)(u >> 24) * sc[ch0] + sh[ch0] : 0.f;
+                } else {
+                    v = __builtin_bit_cast(float4, raw[i]);
+                }
+                *reinterpret_cast<float4*>(patch + r * SROW4 + 4 * q) = v;
+            }
+        }
+#endif
+    } else if (vec) {
         for (int e = threadIdx.x; e < SP * 26; e += 256) {
             const int r = e / 26, q = e - r * 26;
             const int iy = iy0 + r, col = c0 + 4 * q;
@@ -86,6 +134,91 @@ __global__ __launch_bounds__(256) void stem_conv1_kernel(const void* __restrict_
         }
     }
     __syncthreads();
+    if constexpr (COUT % 32 == 0) {
+        // ---- MFMA path (round 3): the 3x3x3 window is a K = 27 (-> 32) contraction on the bf16 MFMA --------------------
+        // The fp32 VALU version issued 432 packed FMAs per lane for a kernel whose floor is its 359 MB of traffic
+        // (137 us at 256 frames, 2.6 TB/s, "VALU 8.9 % active, waiting 60 %").  Here a wave owns two 32-pixel blocks of the
+        // 16 x 16 tile; lane (px, h) gathers its 8 + 8 window values (k = 16 s + 8 h + e  <->  tap k / 3, channel k % 3)
+        // from the fp32 LDS patch, rounds them to bf16 (the precision every later layer runs at; the reference feeds fp16
+        // frames to CLIP) and two MFMAs per 32-channel block do the rest.  Swapped operands (D[channel][pixel]) as in the
+        // other conv kernels: a lane ends up with one pixel and 4 consecutive channels per 4 accumulator registers.
+        constexpr int FN = COUT / 32;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, px = lane & 31, h = lane >> 5;
+        // patch offset (floats) of window element k relative to the pixel's window origin; k >= 27 -> a zero word
+        int koff[2][8];
+        bool kval[2][8];
+#pragma unroll
+        for (int sidx = 0; sidx < 2; ++sidx)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = 16 * sidx + 8 * h + e;
+                kval[sidx][e] = k < 27;
+                koff[sidx][e] = (k / 9) * SROW4 + (k % 9);
+            }
+        // weight fragments: W[n][k] = w[k * COUT + n] as bf16, K padded with zeros
+        s16x8_t wf[FN][2];
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int sidx = 0; sidx < 2; ++sidx) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int k = 16 * sidx + 8 * h + e;
+                    v[e] = (k < 27) ? w[k * COUT + 32 * j + px] : 0.f;
+                }
+                const u32x4_stem pk = {ec_pack2(v[0], v[1]), ec_pack2(v[2], v[3]), ec_pack2(v[4], v[5]), ec_pack2(v[6], v[7])};
+                wf[j][sidx] = __builtin_bit_cast(s16x8_t, pk);
+            }
+        s16x8_t af[2][2];
+#pragma unroll
+        for (int b2 = 0; b2 < 2; ++b2) {
+            const int p_ = (wave * 2 + b2) * 32 + px;              // pixel of the 16 x 16 tile this lane gathers for
+            const int ly = p_ >> 4, lx = p_ & 15;
+            const float* win = patch + (2 * ly) * SROW4 + (2 * lx) * 3 + 1;
+#pragma unroll
+            for (int sidx = 0; sidx < 2; ++sidx) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = kval[sidx][e] ? win[koff[sidx][e]] : 0.f;
+                const u32x4_stem pk = {ec_pack2(v[0], v[1]), ec_pack2(v[2], v[3]), ec_pack2(v[4], v[5]), ec_pack2(v[6], v[7])};
+                af[b2][sidx] = __builtin_bit_cast(s16x8_t, pk);
+            }
+        }
+        __syncthreads();                                           // every wave has gathered: the patch becomes 4 staging images
+        // output through a wave-private LDS image (32 pixels x 64 B, 80-B pitch): the tile's pixel rows are contiguous in
+        // memory, so a wave then stores 16 pixels x 64 B = 1 KiB per instruction instead of 32 scattered 16-B pieces
+        unsigned char* stg = reinterpret_cast<unsigned char*>(patch) + wave * (32 * 80);
+#pragma unroll
+        for (int b2 = 0; b2 < 2; ++b2) {
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                f32x16_t acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf[j][0]), __builtin_bit_cast(bf16x8_t, af[b2][0]), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf[j][1]), __builtin_bit_cast(bf16x8_t, af[b2][1]), acc, 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 bv = *reinterpret_cast<const float4*>(bias + 32 * j + 8 * g + 4 * h);
+                    uint2 o;
+                    o.x = ec_pack2(fmaxf(acc[4 * g + 0] + bv.x, 0.f), fmaxf(acc[4 * g + 1] + bv.y, 0.f));
+                    o.y = ec_pack2(fmaxf(acc[4 * g + 2] + bv.z, 0.f), fmaxf(acc[4 * g + 3] + bv.w, 0.f));
+                    *reinterpret_cast<uint2*>(stg + px * 80 + (8 * g + 4 * h) * 2) = o;
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {                      // (same wave wrote it: LDS is in order per wave)
+                    const int c = lane + 64 * i, q = c >> 2, part = c & 3;
+                    const int p2 = (wave * 2 + b2) * 32 + q;
+                    const int oy = oy0 + (p2 >> 4), ox = ox0 + (p2 & 15);
+                    const u32x4_stem v = *reinterpret_cast<const u32x4_stem*>(stg + q * 80 + part * 16);
+                    if (oy < Ho && ox < Wo)
+                        *reinterpret_cast<u32x4_stem*>(out + ((long)(b * Ho + oy) * Wo + ox) * COUT + 32 * j + part * 8) = v;
+                }
+            }
+        }
+        return;
+    }
     const int ly = threadIdx.x / ST, lx = threadIdx.x % ST;
     const int oy = oy0 + ly, ox = ox0 + lx;
     // packed fp32 FMAs (v_pk_fma_f32: two channels per instruction); weights are wave-uniform (scalar loads)

@@ -92,10 +92,10 @@ def rn50_trunk(x_nchw: torch.Tensor, sd: Dict[str, torch.Tensor], emulate_bf16: 
     x: fp32 [B,3,R,R] (CLIP-normalised).  Returns fp32 [B, 32*w, R/32, R/32]."""
     e = emulate_bf16
     stages = {}
-    # the HIP stem conv1 is an fp32 VALU kernel on the fp32 frame with fp32
-    # folded weights; only its OUTPUT is rounded to bf16 in emulation mode.
-    x = x_nchw.float()
-    x = _r(F.relu(_conv_bn(x, sd, "conv1", "bn1", stride=2, padding=1, emulate=False, fold=fold)), e)
+    # the HIP stem conv1 runs on the bf16 MFMA like every other conv (round 3): in emulation mode the frame and the
+    # folded weights are rounded to bf16, the accumulation stays fp32 and the output is rounded to bf16.
+    x = _r(x_nchw.float(), e)
+    x = _r(F.relu(_conv_bn(x, sd, "conv1", "bn1", stride=2, padding=1, emulate=e, fold=fold)), e)
     stages["stem1"] = x
     x = _r(F.relu(_conv_bn(x, sd, "conv2", "bn2", padding=1, emulate=e, fold=fold)), e)
     stages["stem2"] = x
