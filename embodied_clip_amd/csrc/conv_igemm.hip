@@ -1032,6 +1032,11 @@ int dispatch_tile(const ConvArgs& a, hipStream_t s) {
         // K = 512 and short-K residual launches stay on the 4-wave kernel (slower here).  ViT-B/32 GEMMs (tools/bench_vitgemm.sh,
         // 12800 tokens): in_proj 768->2304 78.6 -> 57.6 us, c_fc 768->3072 105 -> 82, c_proj 3072->768 + residual 91.7 -> 85.1;
         // out_proj 768->768 + residual is slower (31 -> 35) and keeps the 4-wave kernel
+        // long-K 1x1 launches that would fill less than ~40 % of the chip with 256-wide tiles take 128-wide ones (twice the
+        // tiles, same per-tile efficiency): ViT-B/32 c_proj at 6,400 tokens is 75 tiles x 48 K-tiles (same-box A/B: +2.4 % on the ViT config, +0.4 % RN50)
+        if (KS == 1 && !POOL && ec_config().conv8_bn128 >= 0 && a.K >= 2048 && a.Cout % 256 == 0 && nt256 >= mint && nt256 < 100 &&
+            nt128 >= mint)
+            return launch8<128, KS, POOL>(a, s);
         if (KS == 1 && !POOL && ((!a.res && a.K >= 768) || (a.res && a.K >= 512))) {   // (residual: 49.5 -> 45.7 us on 512 -> 2048 @7x7 once its residual loads were all in flight)
             if (a.Cout % 256 == 0 && nt256 >= mint) return launch8<256, KS, POOL>(a, s);
             if (!a.res && a.K >= 1024 && a.Cout % 128 == 0 && nt256 < mint && nt128 >= mint) return launch8<128, KS, POOL>(a, s);
