@@ -1037,7 +1037,7 @@ int dispatch_tile(const ConvArgs& a, hipStream_t s) {
         if (KS == 1 && !POOL && ec_config().conv8_bn128 >= 0 && a.K >= 2048 && a.Cout % 256 == 0 && nt256 >= mint && nt256 < 100 &&
             nt128 >= mint)
             return launch8<128, KS, POOL>(a, s);
-        if (KS == 1 && !POOL && ((!a.res && a.K >= 768) || (a.res && a.K >= 512))) {   // (residual: 49.5 -> 45.7 us on 512 -> 2048 @7x7 once its residual loads were all in flight)
+        if (KS == 1 && !POOL && ((!a.res && a.K >= 768) || (a.res && (a.K >= 2048 || (a.K >= 512 && nt256 >= 150))))) {   // (residual, K = 512: 49.5 -> 45.7 us on 512 -> 2048 @7x7; ViT out_proj, 75 tiles x 12 K-tiles, stays on the 4-wave kernel: 19.8 vs 23.3 us)
             if (a.Cout % 256 == 0 && nt256 >= mint) return launch8<256, KS, POOL>(a, s);
             if (!a.res && a.K >= 1024 && a.Cout % 128 == 0 && nt256 < mint && nt128 >= mint) return launch8<128, KS, POOL>(a, s);
         }
