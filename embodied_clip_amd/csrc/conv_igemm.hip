@@ -862,6 +862,9 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
         for (; kt < n_issue; ++kt) ktile(kt, gc, BT{});
         for (; kt < nk; ++kt) ktile(kt, gc, BF{});
     };
+    // (a static s_setprio 1 for group 1 instead of the per-segment flips: -2..-5 % on single launches, but -4 % END TO END --
+    //  a wave that stays at raised priority through its memory segments also wins arbitration against the OTHER stream's
+    //  kernels; measured round 3, not kept)
     if (grp) kloop(I1{}); else kloop(I0{});
     if (!grp && !(ABL & 16)) __builtin_amdgcn_s_barrier();   // matches group 1's extra entry barrier
     __syncthreads();                                    // every wave is done with the stages: LDS becomes the epilogue image
