@@ -3,7 +3,7 @@
 
 #include "common.h"
 
-extern "C" int ec_version(void) { return 300; }   // 0.3.0 (bump whenever a kernel or a launch plan changes: keys profiles/*traffic*.json)
+extern "C" int ec_version(void) { return 301; }   // 0.3.0 (bump whenever a kernel or a launch plan changes: keys profiles/*traffic*.json)
 
 extern "C" const char* ec_strerror(int code) {
     switch (code) {
@@ -43,10 +43,11 @@ EcConfig read_config() {
     c.gemm_no_x3 = env_int("EC_GEMM_NO_X3", 0);
     c.act_split = env_int("EC_ACT_SPLIT", 1);
     c.tail_fused = env_int("EC_TAIL_FUSED", 1);
-    c.gru_fused = env_int("EC_GRU_FUSED", 1);
+    c.gru_fused = env_int("EC_GRU_FUSED", 2);
     c.c1_pingpong = env_int("EC_C1_PINGPONG", 1);
     c.dw1_tr = env_int("EC_DW1_TR", 1);
     c.rn50_fuse = env_int("EC_RN50_FUSE", 1);
+    c.wih_perm = env_int("EC_WIH_PERM", 1);
     return c;
 }
 }  // namespace
@@ -66,6 +67,6 @@ uint64_t ec_config_hash() {
     mix(c.conv_narrow); mix(c.conv_rowsn); mix(c.rows_dbg); mix(c.conv_nbuf); mix(c.conv_ablate); mix(c.conv_wgs);
     mix(c.conv_waves); mix(c.conv_big); mix(c.conv8_min_tiles); mix(c.conv8_bn128); mix(c.conv_t224); mix(c.conv_t64);
     mix(c.conv_ring); mix(c.conv_regw); mix(c.conv_regw_wide); mix(c.gemm_no_x3); mix(c.act_split); mix(c.tail_fused);
-    mix(c.gru_fused); mix(c.c1_pingpong); mix(c.dw1_tr); mix(c.rn50_fuse);
+    mix(c.gru_fused); mix(c.c1_pingpong); mix(c.dw1_tr); mix(c.rn50_fuse); mix(c.wih_perm);
     return x;
 }

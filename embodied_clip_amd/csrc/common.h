@@ -137,10 +137,11 @@ struct EcConfig {
     int gemm_no_x3;       // EC_GEMM_NO_X3    (0)   policy GEMMs on the fp32 MFMA instead of bf16x3
     int act_split;        // EC_ACT_SPLIT     (1)   act step: fixed 4-way K split of the two long-K GEMMs
     int tail_fused;       // EC_TAIL_FUSED    (1)   compressor tail / combiner fused kernels
-    int gru_fused;        // EC_GRU_FUSED     (1)   fused GRU forward step
+    int gru_fused;        // EC_GRU_FUSED     (2)   0 GEMM + gate kernels, 1 fused 32x32-tile step kernels, 2 + 16x16-tile kernels in the update
     int c1_pingpong;      // EC_C1_PINGPONG   (1)   compressor conv 1 over stored features on the 8-wave kernel
     int dw1_tr;           // EC_DW1_TR        (1)   dW1 on the transpose-read kernel
     int rn50_fuse;        // EC_RN50_FUSE     (1)   fused layer-1 / layer-2 block boundaries in the trunk plan
+    int wih_perm;         // EC_WIH_PERM      (1)   learn pass: re-ordered weight_ih instead of activation transposes
 };
 const EcConfig& ec_config();          // api.hip
 uint64_t ec_config_hash();            // FNV-1a over the fields above

@@ -58,6 +58,24 @@ __global__ void from_cmajor_kernel(const float* __restrict__ dx, float* __restri
     dx4[i] = dx[b * per + c * S + p];
 }
 
+// EC_WIH_PERM (learn pass): instead of re-ordering the [T*N x 1568] activations between the combiner's pixel-major rows and
+// nn.Flatten's channel-major order (to_cmajor / from_cmajor: 2 x 206 MB of strided traffic per optimiser step, 0.5 ms),
+// the 9.6-MB weight_ih is re-ordered once per step: mode 0  out[r, p*Cc + c] = in[r, c*S + p];  mode 1 (its gradient,
+// back to the parameter's order)  out[r, c*S + p] += in[r, p*Cc + c].  One row per workgroup, staged through LDS.
+__global__ __launch_bounds__(256) void permute_row_kernel(const float* __restrict__ in, float* __restrict__ out, int S, int Cc,
+                                                         int mode) {
+    extern __shared__ float prow[];
+    const int flat = S * Cc;
+    const long base = (long)blockIdx.x * flat;
+    for (int i = threadIdx.x; i < flat; i += 256) prow[i] = in[base + i];
+    __syncthreads();
+    if (mode == 0) {
+        for (int i = threadIdx.x; i < flat; i += 256) out[base + i] = prow[(i % Cc) * S + i / Cc];
+    } else {
+        for (int i = threadIdx.x; i < flat; i += 256) out[base + i] += prow[(i % S) * Cc + i / S];
+    }
+}
+
 // torch.nn.GRU cell with the RNNStateEncoder episode mask:
 //   hp = m*h_prev;  r = s(gi_r + m*gh_r + b_hr);  z = s(gi_z + m*gh_z + b_hz)
 //   hn = m*gh_n + b_hn;  n = tanh(gi_n + r*hn);  h = (1-z)*n + z*hp
@@ -340,6 +358,240 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(const float* __restri
     }
 }
 
+// ---- 16 x 16-tile GRU step kernels for the UPDATE's recurrences (H == 512, EC_GRU_FUSED >= 2, round 3) ----
+// The 32 x 32-tile kernels above put 256 (forward) / 64 (backward) workgroups on the chip and wait for every K chunk with
+// nothing else in flight: 15 us a step, 2 x 1024 dependent steps per update.  These two use the 16x16x4 fp32 MFMA so that
+// 16 actors x 16 hidden units make a workgroup (256 of them for 128 actors, forward AND backward), and give every wave a
+// PRIVATE quarter of K: a wave's LDS-DMA pieces land in its own LDS slice (no workgroup barrier between load and MFMA; the
+// wave waits with counted s_waitcnt vmcnt while later pieces are still in flight).  Rows are stored unpadded, 512 B per
+// row and wave, with the 16-B units XOR-swizzled by (row & 15) on the GLOBAL side of the DMA (LDS side is contiguous by
+// construction), which makes the ds_read_b128 operand reads conflict-free.  The epilogue's operands are fetched before the
+// first piece is issued.  Same fp32 arithmetic as above, K summed in a different (fixed) order.
+typedef __attribute__((address_space(3))) void gru_lds_v;
+typedef const __attribute__((address_space(1))) void gru_gbl_v;
+
+__device__ __forceinline__ f32x4_t mfma16f(float a, float b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+// Loads the compiler must neither sink to their first use (the epilogue operands: fetched under the pieces) nor fence with a
+// vmcnt(0) of its own (it puts one in front of every ds_read that follows an LDS-DMA): issued as asm, waited for by the
+// kernels' counted s_waitcnt, and tied to their consumers through gru_tie().
+__device__ __forceinline__ float gru_gload(const float* p) {
+    float v;
+    asm volatile("global_load_dword %0, %1, off" : "=&v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ f32x4_t gru_lread(unsigned lds_addr) {
+    f32x4_t v;
+    asm volatile("ds_read_b128 %0, %1" : "=&v"(v) : "v"(lds_addr) : "memory");
+    return v;
+}
+__device__ __forceinline__ unsigned gru_lds_addr(const float* p) {
+    return (unsigned)(unsigned long)(__attribute__((address_space(3))) const float*)p;
+}
+template <int CNT> __device__ __forceinline__ void gru_lwait(f32x4_t& a, f32x4_t& b) {   // ds_reads up to here have returned
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(CNT));
+}
+
+__global__ __launch_bounds__(256) void gru_step_fwd512_kernel(const float* __restrict__ gi, const float* __restrict__ Whh,
+                                                             const float* __restrict__ bhh, const float* __restrict__ hprev,
+                                                             const float* __restrict__ mask, float* __restrict__ hout,
+                                                             float* __restrict__ gates, float* __restrict__ hn_s,
+                                                             float* __restrict__ hp_s, int N) {
+    constexpr int H = 512, KW = 128;                       // KW: the k range of one wave (512 B of every row)
+    extern __shared__ __attribute__((aligned(16))) float gsm[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j0 = blockIdx.x * 16, n0 = blockIdx.y * 16;
+    float* wl = gsm + wave * (64 * KW);                    // 64 rows (16 actors + 3 x 16 W rows) x 128 floats = 32 KB / wave
+    float* part = gsm + 4 * 64 * KW;                       // [wave][gate][16 actors][16 units]
+    // epilogue operands first (oldest in the vmcnt order: complete before any piece that is waited for)
+    const int a_ = tid >> 4, u_ = tid & 15;
+    const int n = min(n0 + a_, N - 1), j = j0 + u_;
+    // 32 pieces of 1 KiB: two rows each (lanes 0..31 / 32..63), 8 for the actors' h rows, then 8 per gate
+    const int half = lane >> 5, unit = lane & 31;
+    const int kw0 = wave * KW;
+#pragma unroll
+    for (int p = 0; p < 32; ++p) {
+        const int r = 2 * p + half;                        // row of this lane
+        const float* row;
+        if (p < 8) row = hprev + (long)min(n0 + r, N - 1) * H;
+        else {
+            const int c = r - 16;
+            row = Whh + ((long)(c >> 4) * H + j0 + (c & 15)) * H;
+        }
+        const float* src = row + kw0 + 4 * (unit ^ (r & 15));
+        __builtin_amdgcn_global_load_lds((gru_gbl_v*)src, (gru_lds_v*)(wl + 2 * p * KW), 16, 0, 0);
+    }
+    // the epilogue's operands go LAST (gi is an HBM miss; vmcnt retires in order, so in front they would hold every piece back)
+    const float* gir = gi + (long)n * 3 * H;
+    float gi_r = gru_gload(gir + j), gi_z = gru_gload(gir + H + j), gi_n = gru_gload(gir + 2 * H + j);
+    float m = gru_gload(mask + n);
+    float hp_raw = gru_gload(hprev + (long)n * H + j);
+    float b_r = gru_gload(bhh + j), b_z = gru_gload(bhh + H + j), b_n = gru_gload(bhh + 2 * H + j);
+    const int i = lane & 15, q = lane >> 4;
+    const unsigned la = gru_lds_addr(wl + i * KW);
+    unsigned sw[8];
+#pragma unroll
+    for (int s2 = 0; s2 < 8; ++s2) sw[s2] = 16u * (unsigned)((4 * s2 + q) ^ i);
+    f32x4_t av[8], bv[8];
+    asm volatile("s_waitcnt vmcnt(32)" ::: "memory");      // 8 scalar loads + 24 pieces may still be in flight
+#pragma unroll
+    for (int s2 = 0; s2 < 8; ++s2) av[s2] = gru_lread(la + sw[s2]);
+    f32x4_t acc[3], acd[3];                                 // two chains per tile: the 16x16x4 MFMA issues every 32 cycles, depends at 40
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        acc[g] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        acd[g] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (g == 0) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        else if (g == 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        const unsigned lb = la + (unsigned)((16 + 16 * g) * KW * 4);
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2) bv[s2] = gru_lread(lb + sw[s2]);
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2) {
+            switch (s2) {                                   // (8 reads in flight; the s2-th has returned when 7 - s2 remain)
+                case 0: gru_lwait<7>(av[0], bv[0]); break;
+                case 1: gru_lwait<6>(av[1], bv[1]); break;
+                case 2: gru_lwait<5>(av[2], bv[2]); break;
+                case 3: gru_lwait<4>(av[3], bv[3]); break;
+                case 4: gru_lwait<3>(av[4], bv[4]); break;
+                case 5: gru_lwait<2>(av[5], bv[5]); break;
+                case 6: gru_lwait<1>(av[6], bv[6]); break;
+                default: gru_lwait<0>(av[7], bv[7]); break;
+            }
+            acc[g] = mfma16f(av[s2][0], bv[s2][0], acc[g]);
+            acd[g] = mfma16f(av[s2][1], bv[s2][1], acd[g]);
+            acc[g] = mfma16f(av[s2][2], bv[s2][2], acc[g]);
+            acd[g] = mfma16f(av[s2][3], bv[s2][3], acd[g]);
+        }
+        __builtin_amdgcn_sched_barrier(0);                  // (keep this tile's MFMAs in front of the next tile's piece wait)
+    }
+    // the scalar loads: landed after this wait; hand the epilogue operands to the compiler
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" : "+v"(gi_r), "+v"(gi_z), "+v"(gi_n), "+v"(m), "+v"(hp_raw), "+v"(b_r), "+v"(b_z), "+v"(b_n));
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[((wave * 3 + g) * 16 + 4 * q + r) * 16 + i] = acc[g][r] + acd[g][r];   // (actor 4q + r, unit i)
+    __syncthreads();
+    if (n0 + a_ >= N) return;
+    float gh[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        const int o = (g * 16 + a_) * 16 + u_;
+        gh[g] = ((part[o] + part[3 * 256 + o]) + part[6 * 256 + o]) + part[9 * 256 + o];
+    }
+    const float hp = m * hp_raw;
+    const float r = sigmoidf_(gi_r + m * gh[0] + b_r);
+    const float z = sigmoidf_(gi_z + m * gh[1] + b_z);
+    const float hn = m * gh[2] + b_n;
+    const float nn = tanhf(gi_n + r * hn);
+    const long o = (long)n * H + j;
+    hout[o] = (1.f - z) * nn + z * hp;
+    float* gp = gates + (long)n * 3 * H;
+    gp[j] = r; gp[H + j] = z; gp[2 * H + j] = nn;
+    hn_s[o] = hn;
+    hp_s[o] = hp;
+}
+
+// Backward step, same scheme: dh[n, j] = dhs + carry + m_{t+1} sum_k dghb_{t+1}[n, k] W_hh^T[j, k] with K = 3H = 1536; a
+// wave owns 384 k, walked as three 128-k sub-chunks through two private 16-KB buffers (the third sub-chunk's pieces are
+// issued into buffer 0 as soon as the wave has read sub-chunk 0 out of it).  Two accumulators alternate so that the
+// dependent-issue latency of the 16x16x4 MFMA (40 vs 32 cycles) stays hidden.
+__global__ __launch_bounds__(256) void gru_step_bwd512_kernel(const float* __restrict__ dghb_next, const float* __restrict__ WhhT,
+                                                             const float* __restrict__ mask_next, const float* __restrict__ dhs,
+                                                             float* __restrict__ carry, const float* __restrict__ gates,
+                                                             const float* __restrict__ hn_s, const float* __restrict__ hp_s,
+                                                             const float* __restrict__ mask, float* __restrict__ dgi,
+                                                             float* __restrict__ dghb, int N) {
+    constexpr int H = 512, K = 3 * H, KS = 128;
+    extern __shared__ __attribute__((aligned(16))) float gsm[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j0 = blockIdx.x * 16, n0 = blockIdx.y * 16;
+    float* wl = gsm + wave * (2 * 32 * KS);                // two buffers of 32 rows x 128 floats
+    float* part = gsm + 4 * 2 * 32 * KS;
+    const int a_ = tid >> 4, u_ = tid & 15;
+    const int n = min(n0 + a_, N - 1), j = j0 + u_;
+    const long o = (long)n * H + j;
+    const int half = lane >> 5, unit = lane & 31;
+    const int kw0 = wave * (3 * KS);
+    auto issue = [&](int sc, int buf) {
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const int rr = 2 * p + half;
+            const float* row = (p < 8) ? dghb_next + (long)min(n0 + rr, N - 1) * K : WhhT + (long)(j0 + rr - 16) * K;
+            const float* src = row + kw0 + sc * KS + 4 * (unit ^ (rr & 15));
+            __builtin_amdgcn_global_load_lds((gru_gbl_v*)src, (gru_lds_v*)(wl + buf * (32 * KS) + 2 * p * KS), 16, 0, 0);
+        }
+    };
+    const int i = lane & 15, q = lane >> 4;
+    const unsigned la = gru_lds_addr(wl + i * KS);
+    unsigned sw[8];
+#pragma unroll
+    for (int s2 = 0; s2 < 8; ++s2) sw[s2] = 16u * (unsigned)((4 * s2 + q) ^ i);
+    f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    auto contract = [&](int buf) {
+        const unsigned pa = la + (unsigned)(buf * 32 * KS * 4), pb = pa + 16u * KS * 4;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {                    // 2 x (4 A + 4 B reads in flight, then 16 MFMAs)
+            f32x4_t av[4], bv[4];
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                av[s2] = gru_lread(pa + sw[4 * hf + s2]);
+                bv[s2] = gru_lread(pb + sw[4 * hf + s2]);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                switch (s2) {
+                    case 0: gru_lwait<6>(av[0], bv[0]); break;
+                    case 1: gru_lwait<4>(av[1], bv[1]); break;
+                    case 2: gru_lwait<2>(av[2], bv[2]); break;
+                    default: gru_lwait<0>(av[3], bv[3]); break;
+                }
+                acc0 = mfma16f(av[s2][0], bv[s2][0], acc0);
+                acc1 = mfma16f(av[s2][1], bv[s2][1], acc1);
+                acc0 = mfma16f(av[s2][2], bv[s2][2], acc0);
+                acc1 = mfma16f(av[s2][3], bv[s2][3], acc1);
+            }
+        }
+    };
+    issue(0, 0);
+    issue(1, 1);
+    // the epilogue's operands (HBM misses) behind the first two sub-chunks in the in-order vmcnt queue
+    const float* g = gates + (long)n * 3 * H;
+    float r = gru_gload(g + j), z = gru_gload(g + H + j), nn = gru_gload(g + 2 * H + j);
+    float hn = gru_gload(hn_s + o), hp = gru_gload(hp_s + o);
+    float dhs_v = gru_gload(dhs + o), carry_v = gru_gload(carry + o);
+    float mn = gru_gload(mask_next + n), m = gru_gload(mask + n);
+    asm volatile("s_waitcnt vmcnt(25)" ::: "memory");      // sub-chunk 1 (16 pieces) + 9 scalar loads may be in flight
+    contract(0);                                           // (ends on lgkmcnt(0): this wave's reads of buffer 0 have returned)
+    __builtin_amdgcn_sched_barrier(0);
+    issue(2, 0);
+    asm volatile("s_waitcnt vmcnt(25)" ::: "memory");      // 9 scalar loads + sub-chunk 2
+    contract(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    contract(0);
+    asm volatile("" : "+v"(r), "+v"(z), "+v"(nn), "+v"(hn), "+v"(hp), "+v"(dhs_v), "+v"(carry_v), "+v"(mn), "+v"(m));
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) part[(wave * 16 + 4 * q + rr) * 16 + i] = acc0[rr] + acc1[rr];
+    __syncthreads();
+    if (n0 + a_ >= N) return;
+    const int po = a_ * 16 + u_;
+    const float proj = ((part[po] + part[256 + po]) + part[512 + po]) + part[768 + po];
+    const float dh = dhs_v + (carry_v + mn * proj);
+    const float dn_pre = dh * (1.f - z) * (1.f - nn * nn);
+    const float dz_pre = dh * (hp - nn) * z * (1.f - z);
+    const float dr_pre = dn_pre * hn * r * (1.f - r);
+    float* ga = dgi + (long)n * 3 * H;
+    float* gb = dghb + (long)n * 3 * H;
+    ga[j] = dr_pre; ga[H + j] = dz_pre; ga[2 * H + j] = dn_pre;
+    gb[j] = dr_pre; gb[H + j] = dz_pre; gb[2 * H + j] = dn_pre * r;
+    carry[o] = m * dh * z;
+}
+
 // out[n] += sum_m Y[m*ld + n]
 __global__ void colsum_kernel(const float* __restrict__ Y, float* __restrict__ out, long M, int N, int ld,
                               int rows_per_block) {
@@ -354,6 +606,34 @@ __global__ void colsum_kernel(const float* __restrict__ Y, float* __restrict__ o
     red[sub][threadIdx.x & 63] = s;
     __syncthreads();
     if (sub == 0 && n < N) atomicAdd(out + n, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// The same for wide matrices (N % 4 == 0, ld % 4 == 0: the GRU's [T*N x 3H] gate gradients, 100 MB each per optimiser step):
+// 16-B loads, 8 of them in flight per lane, 64 x 4 columns per wave and rows_per_block / 4 rows per wave -- HBM-bound
+// instead of latency-bound (280 -> ~30 us per call).
+__global__ __launch_bounds__(256) void colsum4_kernel(const float* __restrict__ Y, float* __restrict__ out, long M, int N, int ld,
+                                                     int rows_per_block) {
+    const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
+    const int c = (blockIdx.x * 64 + lane) * 4;
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    const long r1 = min(M, r0 + rows_per_block);
+    f32x4_t s = {0.f, 0.f, 0.f, 0.f};
+    if (c < N) {
+        const float* base = Y + c;
+        long r = r0 + sub;
+        for (; r + 28 < r1; r += 32) {
+            f32x4_t v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const f32x4_t*>(base + (r + 4 * k) * ld);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += v[k];
+        }
+        for (; r < r1; r += 4) s += *reinterpret_cast<const f32x4_t*>(base + r * ld);
+    }
+    __shared__ f32x4_t red[4][64];
+    red[sub][lane] = s;
+    __syncthreads();
+    if (c < N) atomicAdd(out + c + sub, ((red[0][lane][sub] + red[1][lane][sub]) + red[2][lane][sub]) + red[3][lane][sub]);
 }
 
 // dE1[goal[b], n] += sum_p dm1[(b*S + p)*N + n]
@@ -893,7 +1173,7 @@ namespace {
 
 struct Ws {   // float offsets into the workspace
     size_t E1, c1, c2, m1, x4, x, gi, gh, gates, hn, hp, hs, goal32, w1p;
-    size_t dhs, dhc, dgi, dghb, dx, dx4, dm1, dc2, dc1, dE1, tpart, tpartE, whhT, end;
+    size_t dhs, dhc, dgi, dghb, dx, dx4, dm1, dc2, dc1, dE1, tpart, tpartE, whhT, wihP, gwihP, end;
 };
 
 Ws layout(const ec_policy* h, int T, int N, bool bwd) {
@@ -918,7 +1198,7 @@ Ws layout(const ec_policy* h, int T, int N, bool bwd) {
     w.hs = take(B * H);
     w.goal32 = take(B);
     w.w1p = take(c.fusion ? 0 : ((size_t)c.compress_hid * 3 * c.in_channels + 1) / 2);   // W1 as three bf16 planes
-    w.dhs = w.dhc = w.dgi = w.dghb = w.dx = w.dx4 = w.dm1 = w.dc2 = w.dc1 = w.dE1 = w.tpart = w.tpartE = w.whhT = o;
+    w.dhs = w.dhc = w.dgi = w.dghb = w.dx = w.dx4 = w.dm1 = w.dc2 = w.dc1 = w.dE1 = w.tpart = w.tpartE = w.whhT = w.wihP = w.gwihP = o;
     if (bwd) {
         w.dhs = take(B * H);
         w.dhc = take((size_t)N * H);
@@ -933,6 +1213,8 @@ Ws layout(const ec_policy* h, int T, int N, bool bwd) {
         w.tpart = take(c.fusion ? 0 : (size_t)TB_MAX_WG * 4 * TB_PART);              // tail_bwd_kernel's partial sets
         w.tpartE = take(c.fusion ? 0 : (size_t)TB_MAX_WG * c.num_goals * 128);
         w.whhT = take(H * 3 * H);                                                       // W_hh^T (fused backward step)
+        w.wihP = take(c.fusion ? 0 : 3 * H * flat);                                     // weight_ih in pixel-major column order (EC_WIH_PERM)
+        w.gwihP = take(c.fusion ? 0 : 3 * H * flat);                                    // ... and its gradient
     }
     w.end = o;
     return w;
@@ -1090,6 +1372,10 @@ extern "C" int ec_policy_forward(const ec_policy_t* h, const float* params, cons
     // EC_POLICY_INFER_REUSE: the weight-derived table E1 that an EC_POLICY_INFER call left in THIS workspace is still valid
     // (same parameters: every act step of a rollout after the first) -- one GEMM launch less on the act step's chain
     const bool reuse_tables = for_backward == EC_POLICY_INFER_REUSE;
+    // learn pass: the GRU's input projection reads the combiner output where it lies (pixel-major rows) against a re-ordered
+    // weight_ih (permute_row_kernel) -- no activation transposes in either direction
+    const bool wih_perm = ec_config().wih_perm && !infer_only && !c.fusion && (size_t)c.comb_out * S * 4 <= 64 * 1024;
+    const Ws wb = layout(h, T, N, !infer_only);
     const bool small = !c.fusion && M49 > 0 && M49 <= ACT_MAX_ROWS;            // (== the condition in layout())
     const size_t tail_lds_ = ((size_t)2 * 32 * TL_P128 + 128 * TL_P32 + (size_t)c.num_goals * 128 + 64 +
                               4 * (size_t)(32 * TL_P128 + 32 * TL_P32)) * sizeof(float);
@@ -1160,7 +1446,10 @@ extern "C" int ec_policy_forward(const ec_policy_t* h, const float* params, cons
     RC(ec_gemm_f32(ws + w.m1, W(P_W4), ws + w.x4, M49, c.comb_out, c.comb_hid, c.comb_hid, 1, 1, c.comb_hid,
                    c.comb_out, 0, W(P_B4), nullptr, nullptr, 0, nullptr, nullptr, 1, stream));
     }
-    {
+    if (wih_perm) {
+        hipLaunchKernelGGL(permute_row_kernel, dim3((unsigned)(3 * H)), dim3(256), flat * sizeof(float), s, W(P_WIH),
+                           ws + wb.wihP, S, c.comb_out, 0);
+    } else {
         const long total = (long)B * flat;
         hipLaunchKernelGGL(to_cmajor_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ws + w.x4, ws + w.x,
                            S, c.comb_out, total);
@@ -1169,7 +1458,7 @@ extern "C" int ec_policy_forward(const ec_policy_t* h, const float* params, cons
     // GRU: input projection for all T at once, then the sequential recurrence
     // (split-K only as separate partial matrices folded by the step kernel: the act step stays free of float atomics, so
     //  rollouts are bit-reproducible)
-    RC(ec_gemm_f32(ws + w.x, W(P_WIH), ws + w.gi, B, 3 * H, flat, flat, 1, 1, flat, 3 * H,
+    RC(ec_gemm_f32(wih_perm ? ws + w.x4 : ws + w.x, wih_perm ? ws + wb.wihP : W(P_WIH), ws + w.gi, B, 3 * H, flat, flat, 1, 1, flat, 3 * H,
                    gi_split ? EC_GEMM_SPLIT_PARTS : 0, W(P_BIH), nullptr, nullptr, 0, nullptr, nullptr, gi_split ? ACT_PARTS : 1,
                    stream));
     // EC_GRU_FUSED (default 1): one fused launch per step where the geometry allows (H % 32 == 0, tiles fit the LDS)
@@ -1186,9 +1475,25 @@ extern "C" int ec_policy_forward(const ec_policy_t* h, const float* params, cons
     // inference with T == 1 (the act step): the new state goes straight to h_final (no copy launch afterwards) and the
     // heads read it there
     float* hs_base = (infer_only && T == 1 && h_final && h_final != h0) ? h_final : ws + w.hs;
+    // the update's recurrences (learn pass, H == 512): 16 x 16-tile kernel, one workgroup per CU with 140 KB of LDS; the act
+    // step keeps the 66-KB kernel, which co-resides with the encoder launches of the other actor slice
+    const bool tile16 = fused_step && gru_fused >= 2 && H == 512 && !infer_only;
+    const size_t gru16_lds = (size_t)(4 * 64 * 128 + 4 * 3 * 256) * sizeof(float);
+    if (tile16) {
+        static std::atomic<uint64_t> attr16_done{0};
+        if (auto attr_g_ = ec_attr_needed(attr16_done))
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gru_step_fwd512_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
     for (int t = 0; t < T; ++t) {
         const float* hprev = (t == 0) ? h0 : hs_base + (size_t)(t - 1) * N * H;
         const size_t o3 = (size_t)t * N * 3 * H, o1 = (size_t)t * N * H;
+        if (tile16) {
+            hipLaunchKernelGGL(gru_step_fwd512_kernel, dim3(32u, (unsigned)((N + 15) / 16)), dim3(256), gru16_lds, s,
+                               ws + w.gi + o3, W(P_WHH), W(P_BHH), hprev, masks + (size_t)t * N, hs_base + o1,
+                               ws + w.gates + o3, ws + w.hn + o1, ws + w.hp + o1, N);
+            continue;
+        }
         if (fused_step) {
             hipLaunchKernelGGL(gru_step_fwd_kernel, dim3((unsigned)(H / 8), (unsigned)((N + 31) / 32)), dim3(256), gru_lds, s,
                                ws + w.gi + o3, W(P_WHH), W(P_BHH), hprev, masks + (size_t)t * N, hs_base + o1,
@@ -1235,6 +1540,12 @@ extern "C" int ec_policy_backward(const ec_policy_t* h, const float* params, con
     auto G = [&](int i) { return grads + h->off[i]; };
     const int* goal32 = (const int*)(ws + w.goal32);
     auto colsum = [&](const float* Y, float* out, long M, int Ncol, int ld) {
+        if ((Ncol & 3) == 0 && (ld & 3) == 0 && Ncol >= 256 && M >= 1024) {
+            const int rpb4 = 256;
+            dim3 grid4((unsigned)((Ncol + 255) / 256), (unsigned)((M + rpb4 - 1) / rpb4));
+            hipLaunchKernelGGL(colsum4_kernel, grid4, dim3(256), 0, s, Y, out, M, Ncol, ld, rpb4);
+            return;
+        }
         const int rpb = 2048;
         dim3 grid((unsigned)((Ncol + 63) / 64), (unsigned)((M + rpb - 1) / rpb));
         hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, s, Y, out, M, Ncol, ld, rpb);
@@ -1265,8 +1576,23 @@ extern "C" int ec_policy_backward(const ec_policy_t* h, const float* params, con
                                       160 * 1024);
     }
     const size_t gb_lds = (size_t)2 * 32 * (256 + 4) * sizeof(float);
+    const bool btile16 = fused_bstep && ec_config().gru_fused >= 2 && H == 512;
+    const size_t gb16_lds = (size_t)(4 * 2 * 32 * 128 + 4 * 256) * sizeof(float);
+    if (btile16) {
+        static std::atomic<uint64_t> attr16_done{0};
+        if (auto attr_g_ = ec_attr_needed(attr16_done))
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gru_step_bwd512_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
     for (int t = T - 1; t >= 0; --t) {
         const size_t o3 = (size_t)t * N * 3 * H, o1 = (size_t)t * N * H;
+        if (btile16 && t < T - 1) {
+            hipLaunchKernelGGL(gru_step_bwd512_kernel, dim3(32u, (unsigned)((N + 15) / 16)), dim3(256), gb16_lds, s,
+                               ws + w.dghb + o3 + (size_t)N * 3 * H, ws + w.whhT, masks + (size_t)(t + 1) * N, ws + w.dhs + o1,
+                               ws + w.dhc, ws + w.gates + o3, ws + w.hn + o1, ws + w.hp + o1, masks + (size_t)t * N,
+                               ws + w.dgi + o3, ws + w.dghb + o3, N);
+            continue;
+        }
         if (fused_bstep && t < T - 1) {
             hipLaunchKernelGGL(gru_step_bwd_kernel, dim3((unsigned)(H / 32), (unsigned)((N + 31) / 32)), dim3(256), gb_lds, s,
                                ws + w.dghb + o3 + (size_t)N * 3 * H, ws + w.whhT, masks + (size_t)(t + 1) * N, ws + w.dhs + o1,
@@ -1292,6 +1618,13 @@ extern "C" int ec_policy_backward(const ec_policy_t* h, const float* params, con
     };
     RC(tn(ws + w.dghb, 3 * H, ws + w.hp, H, 0, G(P_WHH), 3 * H, H, B, H));
     colsum(ws + w.dghb, G(P_BHH), B, 3 * H, 3 * H);
+    const bool wih_perm = ec_config().wih_perm && !c.fusion && (size_t)c.comb_out * S * 4 <= 64 * 1024;   // (== ec_policy_forward's)
+    if (wih_perm) {   // gradient in the re-ordered weight's column order, then added back in the parameter's order
+        (void)hipMemsetAsync(ws + w.gwihP, 0, (size_t)3 * H * flat * 4, s);
+        RC(tn(ws + w.dgi, 3 * H, ws + w.x4, flat, 0, ws + w.gwihP, 3 * H, flat, B, flat));
+        hipLaunchKernelGGL(permute_row_kernel, dim3((unsigned)(3 * H)), dim3(256), flat * sizeof(float), s, ws + w.gwihP,
+                           G(P_WIH), S, c.comb_out, 1);
+    } else
     RC(tn(ws + w.dgi, 3 * H, ws + w.x, flat, 0, G(P_WIH), 3 * H, flat, B, flat));
     colsum(ws + w.dgi, G(P_BIH), B, 3 * H, 3 * H);
     if (c.fusion) {   // the image embedding and the goal table are frozen: nothing trainable upstream of the GRU
@@ -1299,9 +1632,12 @@ extern "C" int ec_policy_backward(const ec_policy_t* h, const float* params, con
         return EC_OK;
     }
     // dx = dgi @ W_ih
-    RC(ec_gemm_f32(ws + w.dgi, W(P_WIH), ws + w.dx, B, flat, 3 * H, 3 * H, 1, flat, 1, flat, 0, nullptr, nullptr, nullptr,
-                   0, nullptr, nullptr, 1, stream));
-    {
+    if (wih_perm)   // dx4 = dgi @ (re-ordered weight_ih): already pixel-major
+        RC(ec_gemm_f32(ws + w.dgi, ws + w.wihP, ws + w.dx4, B, flat, 3 * H, 3 * H, 1, flat, 1, flat, 0, nullptr, nullptr,
+                       nullptr, 0, nullptr, nullptr, 1, stream));
+    else {
+        RC(ec_gemm_f32(ws + w.dgi, W(P_WIH), ws + w.dx, B, flat, 3 * H, 3 * H, 1, flat, 1, flat, 0, nullptr, nullptr, nullptr,
+                       0, nullptr, nullptr, 1, stream));
         const long total = (long)B * flat;
         hipLaunchKernelGGL(from_cmajor_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ws + w.dx,
                            ws + w.dx4, S, c.comb_out, total);

@@ -388,6 +388,9 @@ class Worker:
                         # d(total)/d(hv) carries 1/B_part inside the loss kernel: rescale to the mean over the WHOLE
                         # local minibatch, then local_bsize / global_bsize for the SUM all-reduce (global mean gradient)
                         grad_scale = (m / nmb) * (1.0 / self.world)
+                        # (staggering the slices -- slice 1's forward starting when slice 0's is done, so that wide GEMMs
+                        #  run beside the other slice's GRU recurrence -- was measured in round 3: 53 -> 58 ms per update;
+                        #  the step kernels wait for CUs the GEMM workgroups hold)
                         self.policy.forward(self.params, feat, goal, self.h_start[sl.o + a:sl.o + b], masks, T, m,
                                             sl.ws_learn, hv=hv)
                         ppo_loss_raw(hv, actions, logp, old_v, ret, nadv, self.A, grad_scale=grad_scale, dhv=dhv,
