@@ -142,8 +142,13 @@ struct EcConfig {
     int dw1_tr;           // EC_DW1_TR        (1)   dW1 on the transpose-read kernel
     int rn50_fuse;        // EC_RN50_FUSE     (1)   fused layer-1 / layer-2 block boundaries in the trunk plan
     int wih_perm;         // EC_WIH_PERM      (1)   learn pass: re-ordered weight_ih instead of activation transposes
+    int conv8_dirb;       // EC_CONV8_DIRB    (0)   conv_igemm8: weight fragments global -> VGPR (only the im2col operand through LDS)
 };
 const EcConfig& ec_config();          // api.hip
+// conv_igemm.hip (internal): ec_conv_bf16 with an optional fragment-order copy of the weights (ec_pack_wfrag)
+int ec_conv_bf16_wf(const void* in, const void* w, const void* wf, const float* bias, const void* res, void* out, int B, int H,
+                    int W, int Cin, int Cout, int ksize, int pool, int act, ec_stream_t stream);
+int ec_pack_wfrag(const void* w, void* wf, int Cout, int K, hipStream_t s);
 uint64_t ec_config_hash();            // FNV-1a over the fields above
 
 #define EC_CHECK_LAUNCH()                                   \

@@ -72,6 +72,7 @@ struct ConvArgs {
     unsigned in_bytes, w_bytes;   // buffer-descriptor extents (out-of-range loads return 0)
     unsigned res_bytes;           // ... of the residual tensor (= output extent)
     int ablate;                   // profiling only (EC_CONV_ABLATE): 1 no global loads, 2 no MFMA, 4 no LDS stores, 8 no epilogue
+    const uint16_t* wf = nullptr; // the weights in MFMA-fragment order (ec_pack_wfrag), or null: conv_igemm8's DIRECT-B variant
 };
 
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
@@ -714,6 +715,30 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int frow = lane & 31, fhalf = lane >> 5;
+    // ABL bit 256 (a production variant, not an ablation): DIRECT-B -- the weight fragments of a wave go global -> VGPR
+    // (one 16-B buffer load per fragment, issued a K-tile ahead into the registers the MFMAs of the same half K-tile have
+    // just read), only the im2col operand is staged through LDS: half the LDS-DMA pieces and a third of the fragment
+    // reads per K-tile leave the loop
+    constexpr bool DB = (ABL & 256) != 0 && !X3;
+    // (fragment-order weights, ec_pack_wfrag: the 64 x 16 B of fragment (32-column block nb, k-step ks) are contiguous, so a
+    //  fragment load is ONE coalesced 1-KiB access; straight out of the [Cout][K] layout the same load touches 32 lines and
+    //  the texture path becomes the bound: 57.6 -> 94.8 us on the 3x3 256 -> 256 @14 layer, measured round 3)
+    unsigned bfo[FN];
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+        bfo[j] = (unsigned)((n0 >> 5) + wn * (TN / 32) + j) * (unsigned)(p.K >> 4) * 1024u + (unsigned)lane * 16u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __amdgpu_buffer_rsrc_t rs_wf = __builtin_amdgcn_make_buffer_rsrc((void*)(DB ? p.wf : p.w), 0, p.w_bytes, 0x00020000);
+#endif
+    s16x8_t fbd[2][2][FN];                              // [half][k-step][fragment]
+    auto bload = [&](int kt, int h, int u) {            // fragments (kt, k-step 2h + u) of this wave's FN column blocks
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int soff = (kt * 4 + h * 2 + u) * 1024;
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+            fbd[h][u][j] = __builtin_bit_cast(s16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_wf, (int)bfo[j], soff, 0));
+#endif
+    };
     // fragment byte offsets inside a stage: row-dependent part (the swizzle XOR depends on (row>>1)&7 == (frow>>1)&7
     // for rows that are multiples of 32 apart), k-step part added per read
     int fa_base[FM], fb_base[FN];
@@ -737,23 +762,27 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
             const int c = ((h * 2 + u) * 2 + fhalf) ^ fsw;
 #pragma unroll
             for (int i = 0; i < FM; ++i) fa[u][i] = *reinterpret_cast<const s16x8_t*>(sta + fa_base[i] + (c << 4));
+            if constexpr (!DB) {
 #pragma unroll
-            for (int j = 0; j < FN; ++j) fb[u][j] = *reinterpret_cast<const s16x8_t*>(stb + fb_base[j] + (c << 4));
+                for (int j = 0; j < FN; ++j) fb[u][j] = *reinterpret_cast<const s16x8_t*>(stb + fb_base[j] + (c << 4));
+            }
         }
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
 
     // ---- prologue: K-tile 0 into stage 0 ----
+    constexpr int NPIECE = DB ? A_IT : A_IT + B_IT;     // LDS-DMA pieces per wave and K-tile
     glds_begin(0, 0);
     [&]<int... Q>(std::integer_sequence<int, Q...>) { (glds_piece(std::integral_constant<int, Q>{}), ...); }
-    (std::make_integer_sequence<int, A_IT + B_IT>{});
+    (std::make_integer_sequence<int, NPIECE>{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if constexpr (DB) { bload(0, 0, 0); bload(0, 0, 1); bload(0, 1, 0); bload(0, 1, 1); }
     auto issue_all = [&](int kt, int buf) {             // all of this wave's pieces of K-tile kt, back to back
         glds_begin(kt, buf);
         [&]<int... Q>(std::integer_sequence<int, Q...>) { (glds_piece(std::integral_constant<int, Q>{}), ...); }
-        (std::make_integer_sequence<int, A_IT + B_IT>{});
+        (std::make_integer_sequence<int, NPIECE>{});
     };
     // Piece offsets are prepared one segment AHEAD of their issue (in the wave's MEM segment, whose VALU work hides
     // behind the partner wave's MFMAs), so that inside a CMP segment a piece is only {s_mov m0, buffer_load ... lds}:
@@ -765,8 +794,10 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
         glds_begin(kt, buf);
 #pragma unroll
         for (int q = 0; q < A_IT; ++q) poff[q] = (a_msk[q] & g_tapbit) ? a_off[q] + (unsigned)g_toff : 0xFFFFFFF0u;
+        if constexpr (!DB) {
 #pragma unroll
-        for (int i = 0; i < B_IT; ++i) poff[A_IT + i] = b_off[i] + (unsigned)g_kb;
+            for (int i = 0; i < B_IT; ++i) poff[A_IT + i] = b_off[i] + (unsigned)g_kb;
+        }
     };
     auto piece_pre = [&](auto qc) {                     // piece q of the K-tile prepared last
         [[maybe_unused]] constexpr int q = decltype(qc)::value;
@@ -781,15 +812,20 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
     };
     // 16 MFMAs (the two k-steps held in fa/fb); ISSUE: the wave's prepared LDS-DMA pieces go out in their shadow, one
     // piece per 2 MFMAs.  ISSUE is a template flag: the piece-free instance is 16 MFMAs with nothing between them.
-    auto mfma16 = [&](auto issue_c) {
+    auto mfma16 = [&](auto issue_c, auto hc, int kt) {
         constexpr bool ISSUE = decltype(issue_c)::value;
+        [[maybe_unused]] constexpr int H = decltype(hc)::value;
         [&]<int... Q>(std::integer_sequence<int, Q...>) {
             ([&] {
                 constexpr int u = Q / (FM * FN), r = Q % (FM * FN), i = r / FN, j = r % FN;
                 if constexpr (!(ABL & 2))
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                        __builtin_bit_cast(bf16x8_t, fb[u][j]), __builtin_bit_cast(bf16x8_t, fa[u][i]), acc[i][j], 0, 0, 0);
-                constexpr int NP = A_IT + B_IT, EVERY = (2 * FM * FN) / NP;
+                        __builtin_bit_cast(bf16x8_t, DB ? fbd[H][u][j] : fb[u][j]), __builtin_bit_cast(bf16x8_t, fa[u][i]), acc[i][j], 0, 0, 0);
+                if constexpr (DB && r == FM * FN - 1) {          // k-step u of this half is consumed: refill it for K-tile kt + 1
+                    bload(kt + 1, H, u);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                constexpr int NP = NPIECE, EVERY = (2 * FM * FN) / NP;
                 if constexpr (ISSUE && Q % EVERY == EVERY - 1 && Q / EVERY < NP) {
                     piece_pre(std::integral_constant<int, Q / EVERY>{});
                     // keep one piece per EVERY MFMAs: left alone the scheduler clusters all of them behind the first MFMAs
@@ -828,7 +864,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
         stamp();
         // ---- CMP0: group 0 issues its pieces of K-tile kt+1 in the MFMA shadow (s = 4kt+1; waited for at s = 4kt+3) ----
         __builtin_amdgcn_s_setprio(1);
-        mfma16(std::bool_constant<(G == 0 && ISSUE)>{});
+        mfma16(std::bool_constant<(G == 0 && ISSUE)>{}, I0{}, kt);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         stamp();
@@ -838,7 +874,8 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
         if constexpr (!(abl & 4)) read_half(kt, I1{});
         if constexpr (G == 1 && ISSUE) prep(kt + 2, cur);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if constexpr (G == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // (DIRECT-B: the 2 FN fragment loads of the CMP segment in between are younger than the pieces and stay in flight)
+        if constexpr (G == 1) { if constexpr (DB) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * FN) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
         __builtin_amdgcn_sched_barrier(0);
         stamp();
         if constexpr (!(abl & 16)) __builtin_amdgcn_s_barrier();
@@ -846,9 +883,9 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
         // ---- CMP1: group 1 issues its pieces of K-tile kt+2 (its CMP1(kt) is global segment 4(kt+1): the stage of
         //      K-tile kt is free -- its last reader was this group's own MEM1(kt)); waited for at the end of its MEM1(kt+1)
         __builtin_amdgcn_s_setprio(1);
-        mfma16(std::bool_constant<(G == 1 && ISSUE)>{});
+        mfma16(std::bool_constant<(G == 1 && ISSUE)>{}, I1{}, kt);
         __builtin_amdgcn_s_setprio(0);
-        if constexpr (G == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (G == 0) { if constexpr (DB) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * FN) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
         __builtin_amdgcn_sched_barrier(0);
         stamp();
         if constexpr (!(abl & 16)) __builtin_amdgcn_s_barrier();
@@ -995,6 +1032,13 @@ int launch8(const ConvArgs& a, hipStream_t s) {
         return EC_OK;
     }
 #endif
+    if constexpr (!X3 && BN == 256) {
+        if (ec_config().conv8_dirb && a.wf) {
+            go(conv_igemm8_kernel<BN, KS, POOL, 256, X3>);
+            EC_CHECK_LAUNCH();
+            return EC_OK;
+        }
+    }
     go(conv_igemm8_kernel<BN, KS, POOL, 0, X3>);
     EC_CHECK_LAUNCH();
     return EC_OK;
@@ -1079,6 +1123,9 @@ int dispatch_tile(const ConvArgs& a, hipStream_t s) {
         if constexpr (!POOL) {
             const long t128 = (long)((a.M + 127) / 128) * (a.Cout / 128);
             if (t128 < t64 && a.K >= 512 && a.Cout % 64 == 0)
+                // (deeper rings -- 6 / 8 stages for launches with at most one workgroup per CU, 4 stages for the 128x128 ring --
+                //  measured round 3: 0.944 -> 0.95-0.96 ms at 32 frames, 1.50 -> 1.50-1.51 at 64: stages in flight are not
+                //  what bounds these launches any more; what is left per K-tile is barrier + piece issue)
                 return ring ? launch<64, 64, 2, 2, KS, POOL, false, 64, 4>(a, s) : launch<64, 64, 2, 2, KS, POOL>(a, s);
         }
         {
@@ -1116,8 +1163,34 @@ extern "C" int ec_debug_stamps(unsigned long long* host_dst, int n) {   // profi
     return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(ec_dbg_stamps), (size_t)n * 8) == hipSuccess ? EC_OK : EC_ERR_LAUNCH;
 }
 
+// Fragment-order copy of a [Cout][K] bf16 weight matrix for conv_igemm8's DIRECT-B variant (Cout % 32 == 0, K % 16 == 0):
+// 16-byte unit ((nb * K/16 + ks) * 64 + l) = row nb * 32 + (l & 31), k = ks * 16 + (l >> 5) * 8 .. + 7.
+__global__ void pack_wfrag_kernel(const uint4* __restrict__ w, uint4* __restrict__ wf, int Cout, int K) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)Cout * K / 8;
+    if (t >= total) return;
+    const int l = (int)(t & 63);
+    const long f = t >> 6;
+    const int kf = K >> 4;
+    const int nb = (int)(f / kf), ks = (int)(f - (long)nb * kf);
+    const long row = (long)nb * 32 + (l & 31);
+    wf[t] = w[(row * K + ks * 16 + (l >> 5) * 8) >> 3];
+}
+int ec_pack_wfrag(const void* w, void* wf, int Cout, int K, hipStream_t s) {
+    if (!w || !wf || Cout % 32 != 0 || K % 16 != 0) return EC_ERR_SHAPE;
+    const long total = (long)Cout * K / 8;
+    hipLaunchKernelGGL(pack_wfrag_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const uint4*)w, (uint4*)wf, Cout, K);
+    EC_CHECK_LAUNCH();
+    return EC_OK;
+}
+
 extern "C" int ec_conv_bf16(const void* in, const void* w, const float* bias, const void* res, void* out, int B,
                             int H, int W, int Cin, int Cout, int ksize, int pool, int act, ec_stream_t stream) {
+    return ec_conv_bf16_wf(in, w, nullptr, bias, res, out, B, H, W, Cin, Cout, ksize, pool, act, stream);
+}
+
+int ec_conv_bf16_wf(const void* in, const void* w, const void* wf, const float* bias, const void* res, void* out, int B,
+                    int H, int W, int Cin, int Cout, int ksize, int pool, int act, ec_stream_t stream) {
     if (!in || !w || !out) return EC_ERR_ARG;
     if (B <= 0 || H <= 0 || W <= 0) return EC_ERR_SHAPE;
     if (ksize != 1 && ksize != 3) return EC_ERR_SHAPE;
@@ -1129,6 +1202,7 @@ extern "C" int ec_conv_bf16(const void* in, const void* w, const float* bias, co
     ConvArgs a;
     a.in = (const uint16_t*)in;
     a.w = (const uint16_t*)w;
+    a.wf = (const uint16_t*)wf;
     a.bias = bias;
     a.res = (const uint16_t*)res;
     a.out = (uint16_t*)out;

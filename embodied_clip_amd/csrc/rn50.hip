@@ -45,6 +45,8 @@ struct ec_rn50 {
     const float* bias;
     size_t n_w, n_b;
     int conv8_min_tiles = 0;      // 0 = library default (ec_rn50_set_conv8_min_tiles)
+    uint16_t* wfrag = nullptr;    // EC_CONV8_DIRB: fragment-order copies of the 256-multiple-Cout convs' weights (same offsets as w)
+    ~ec_rn50() { if (wfrag) (void)hipFree(wfrag); }
 };
 
 namespace {
@@ -183,6 +185,13 @@ extern "C" int ec_rn50_create(ec_rn50_t** out, int width, const int* layers4, in
     h->max_elems_per_frame = mx;
     h->n_w = wo; h->n_b = bo;
     if (n_w != wo || n_bias != bo) { delete h; return EC_ERR_SHAPE; }
+    if (ec_config().conv8_dirb) {   // fragment-order weights of every conv the 8-wave kernel's direct-B variant can take
+        if (hipMalloc(&h->wfrag, wo * sizeof(uint16_t)) != hipSuccess) { h->wfrag = nullptr; delete h; return EC_ERR_LAUNCH; }
+        for (const Op& o : h->ops)
+            if (o.kind == OP_CONV && o.Cin % 64 == 0 && o.Cout % 256 == 0)
+                if (ec_pack_wfrag(h->w + o.w_off, h->wfrag + o.w_off, o.Cout, o.ks * o.ks * o.Cin, nullptr) != EC_OK) { delete h; return EC_ERR_LAUNCH; }
+        (void)hipStreamSynchronize(nullptr);
+    }
     *out = h;
     return EC_OK;
 }
@@ -298,8 +307,10 @@ int rn50_run(const ec_rn50_t* h, const void* rgb, bool u8, const float* mean3, c
                     }
                     break;
                 default:
-                    rc = ec_conv_bf16(buf(o.src), h->w + o.w_off, h->bias + o.b_off, o.res >= 0 ? buf(o.res) : nullptr,
-                                      buf(o.dst), nb, o.H, o.W, o.Cin, o.Cout, o.ks, o.pool, o.act, stream);
+                    rc = ec_conv_bf16_wf(buf(o.src), h->w + o.w_off,
+                                         (h->wfrag && o.Cin % 64 == 0 && o.Cout % 256 == 0) ? h->wfrag + o.w_off : nullptr,
+                                         h->bias + o.b_off, o.res >= 0 ? buf(o.res) : nullptr,
+                                         buf(o.dst), nb, o.H, o.W, o.Cin, o.Cout, o.ks, o.pool, o.act, stream);
             }
             if (rc != EC_OK) return rc;
         }

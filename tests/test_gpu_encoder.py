@@ -488,3 +488,35 @@ def test_real_clip_rn50_checkpoint_if_present(dev):
     cos = F.cosine_similarity(out, ref, dim=1)
     print("real RN50.pt: cosine vs fp32 oracle", cos.tolist())
     assert cos.min() > 0.999 and _rel(out, ref) < 2e-2
+
+
+def test_direct_b_variant_of_the_8wave_kernel_is_bit_identical(dev, tmp_path):
+    """EC_CONV8_DIRB=1 (round-3 experiment, off by default: DESIGN 4.6): conv_igemm8 fetches its weight fragments
+    global -> VGPR out of a fragment-order copy of the weights (ec_pack_wfrag) and stages only the im2col operand through
+    LDS.  Same K walk, same products, same accumulation order: the trunk's features must be bit-identical to the default
+    kernel's.  The switch is read once per process, so the variant runs in a child; both sides set the 8-wave dispatch
+    threshold to 1 tile so that 8 frames already take the 8-wave kernel in layers 3-4."""
+    import os
+    import subprocess
+    import sys
+    from embodied_clip_amd.encoder import RN50Trunk
+    sd = syn.rn50_visual_state_dict(0)
+    x = syn.synthetic_rgb(11, 8).to(dev)
+    base = RN50Trunk(sd, device=dev)
+    base.set_conv8_min_tiles(1)
+    ref = base.forward(x).float().cpu()
+    out = str(tmp_path / "dirb.pt")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, torch; sys.path.insert(0, %r)\n"
+            "from embodied_clip_amd import synthetic as syn\n"
+            "from embodied_clip_amd.encoder import RN50Trunk\n"
+            "t = RN50Trunk(syn.rn50_visual_state_dict(0), device='cuda:0')\n"
+            "t.set_conv8_min_tiles(1)\n"
+            "f = t.forward(syn.synthetic_rgb(11, 8).to('cuda:0'))\n"
+            "torch.save({'feat': f.float().cpu(), 'hash': t.plan_hash()}, %r)\n") % (root, out)
+    r = subprocess.run([sys.executable, "-c", code], env={**os.environ, "EC_CONV8_DIRB": "1"}, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = torch.load(out)
+    assert got["hash"] != base.plan_hash()              # the switch is part of the plan hash
+    assert torch.equal(got["feat"], ref)
