@@ -36,6 +36,7 @@ import torch  # noqa: E402
 
 TRUNK_MAC_PER_FRAME = 5_367_226_368          # SURVEY.md §8d (RN50 trunk, 224x224)
 VIT_MAC_PER_FRAME = 4_050_683_904            # SURVEY.md §8d (ViT-B/32, 11 of 12 blocks)
+RN50X16_MAC_PER_FRAME = 23_859_892_224       # RN50x16 trunk (width 96, layers (6, 8, 18, 8)) on the plugin's 224x224 frames
 ATTNPOOL_MAC_PER_FRAME = 425_984_000 + 49 * 2048 * 2048   # CLS-only query + k/v projections
 POLICY_ACT_MAC = 16_846_336
 POLICY_UPDATE_MAC = 150_775_808              # 4 x (fwd + bwd)
@@ -285,16 +286,19 @@ def run_rank(a, rank: int, local_rank: int, world: int, init_method=None):
     if rank == 0:
         frames = a.rollout * per_gpu * world * a.steps
         value = frames / dt
-        enc_mac = {"rn50": TRUNK_MAC_PER_FRAME, "vit": VIT_MAC_PER_FRAME,
+        enc_mac = {"rn50": TRUNK_MAC_PER_FRAME, "vit": VIT_MAC_PER_FRAME, "rn50x16": RN50X16_MAC_PER_FRAME,
                    "zeroshot": TRUNK_MAC_PER_FRAME + ATTNPOOL_MAC_PER_FRAME}[a.encoder]
         # flop of what one timed launch covers (zero-shot: the events bracket trunk + AttentionPool2d)
-        trunk_mac = {"rn50": TRUNK_MAC_PER_FRAME, "vit": VIT_MAC_PER_FRAME,
+        trunk_mac = {"rn50": TRUNK_MAC_PER_FRAME, "vit": VIT_MAC_PER_FRAME, "rn50x16": RN50X16_MAC_PER_FRAME,
                      "zeroshot": TRUNK_MAC_PER_FRAME + ATTNPOOL_MAC_PER_FRAME}[a.encoder]
         flops_call = 2.0 * trunk_mac * enc_frames          # one timed launch = one (slice of the) encoder forward
         achieved_launch = flops_call / (avg_trunk_ms * 1e-3) / 1e12
         achieved = flops_call * n_conc / (avg_union_ms * 1e-3) / 1e12
-        traffic, tnote, trec = (None, "--no-traffic", None) if a.no_traffic else measured_traffic(
-            "vit" if a.encoder == "vit" else "rn50", plan_hash, enc_frames)
+        if a.encoder == "rn50x16":
+            traffic, tnote, trec = None, "no PMC summary for the RN50x16 trunk (functional, not tuned)", None
+        else:
+            traffic, tnote, trec = (None, "--no-traffic", None) if a.no_traffic else measured_traffic(
+                "vit" if a.encoder == "vit" else "rn50", plan_hash, enc_frames)
         # the same fraction from the COMMITTED profile alone (reproducible from profiles/): algorithmic flop of the
         # profiled single launch / its summed kernel time (rocprofv3 kernel trace)
         frac_profiles = frac_profiles_256 = None
@@ -306,6 +310,8 @@ def run_rank(a, rank: int, local_rank: int, world: int, init_method=None):
                                           / MFMA_BF16_PEAK_TFLOPS, 4)
         workload = {"rn50": "RoboTHOR ObjectNav: frozen CLIP-RN50 encoder",
                     "vit": "RoboTHOR ObjectNav: frozen CLIP ViT-B/32 encoder (11 blocks)",
+                    "rn50x16": "RoboTHOR ObjectNav: frozen CLIP-RN50x16 encoder (width 96, layers 6/8/18/8, 3072 x 7 x 7 features; "
+                               "functional path, not tuned)",
                     "zeroshot": "Zero-shot ObjectNav: frozen CLIP-RN50 trunk + AttentionPool2d image embedding, goal = "
                                 "CLIP text-tower embedding table"}[a.encoder]
         out = {
@@ -321,7 +327,9 @@ def run_rank(a, rank: int, local_rank: int, world: int, init_method=None):
                                  ("uint8 HWC (normalisation fused)" if a.frames_u8 else "fp32 normalised HWC"),
                        "parallelism": f"dp{world} (actors sharded; one flat 13.9 MB grad all-reduce per optimiser step)",
                        "flop_per_frame": 2 * (enc_mac + (ZS_POLICY_ACT_MAC + ZS_POLICY_UPDATE_MAC if a.encoder == "zeroshot"
-                                                         else POLICY_ACT_MAC + POLICY_UPDATE_MAC))},
+                                                         else POLICY_ACT_MAC + POLICY_UPDATE_MAC +
+                                                         # RN50x16: 3072 input channels of the compressor's first conv
+                                                         (9 * 49 * 1024 * 128 if a.encoder == "rn50x16" else 0)))},
             "rccl_ranks": rccl_ranks, "allreduce_ms_per_rank": ar_ms,
             "roofline": {"bound": "mfma",
                          "kernel": ("ec_rn50_forward (conv_igemm / conv_pair / conv3x3_narrow MFMA kernels)"
@@ -379,7 +387,7 @@ def parse_args(argv=None):
     ap.add_argument("--frames-host", action="store_true",
                     help="frames live in pinned HOST memory and cross PCIe every env step (the plugin contract); the "
                          "default keeps them resident in HBM (SURVEY.md 8d) and reports this as `h2d_inclusive`")
-    ap.add_argument("--encoder", "--config", dest="encoder", choices=("rn50", "vit", "zeroshot"), default="rn50",
+    ap.add_argument("--encoder", "--config", dest="encoder", choices=("rn50", "vit", "zeroshot", "rn50x16"), default="rn50",
                     help="rn50 = BASELINE headline config; vit = config 3 (ViT-B/32); zeroshot = config 5 "
                          "(RN50 + attnpool image embedding, CLIP-text goal table)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -120,8 +120,12 @@ class Worker:
         n = n_actors // ns
         d = self.dev
         pools = [None] * ns
-        if encoder == "rn50":
-            sd = encoder_sd if encoder_sd is not None else syn.rn50_visual_state_dict(0)
+        if encoder in ("rn50", "rn50x16"):
+            # "rn50x16": CLIP RN50x16's tower (width 96, layers (6, 8, 18, 8)) on the plugin's 224 x 224 frames -> a
+            # 3072 x 7 x 7 map ([U] ClipResNetPreprocessor's second model type; functional path, not tuned)
+            sd = encoder_sd if encoder_sd is not None else (
+                syn.rn50_visual_state_dict(0) if encoder == "rn50" else
+                syn.rn50_visual_state_dict(0, width=96, layers=(6, 8, 18, 8), output_dim=768, heads=48))
             share = os.environ.get("EC_SHARE_WEIGHTS", "1") != "0"
             encs = [RN50Trunk(sd, device=d, chunk=encoder_chunk)]
             encs += [RN50Trunk(sd, device=d, chunk=encoder_chunk, weights_from=encs[0] if share else None) for _ in range(ns - 1)]
@@ -263,7 +267,7 @@ class Worker:
         if self.zeroshot:
             (sl.enc.forward_u8 if src.dtype == torch.uint8 else sl.enc.forward)(src, sl.trunk_out)
             sl.pool.forward(sl.trunk_out, sl.feat[t].view(sl.n, self.C))     # AttentionPool2d -> rollout slice
-        elif self.encoder == "rn50":
+        elif self.encoder in ("rn50", "rn50x16"):
             # the last conv writes straight into the rollout slice
             (sl.enc.forward_u8 if src.dtype == torch.uint8 else sl.enc.forward)(src, sl.feat[t])
         else:

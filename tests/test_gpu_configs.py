@@ -157,6 +157,33 @@ def test_config2_rn50_64_actors_fullsize_properties():
     torch.cuda.empty_cache()
 
 
+def test_rn50x16_worker_properties():
+    """[U] ClipResNetPreprocessor's second model type (readme_files/imagenet_vs_objectnav.md:10-11): the RN50x16 tower
+    (width 96, layers (6, 8, 18, 8)) on 224 x 224 frames -> a 3072 x 7 x 7 map per frame, compressor 3072 -> 128 -> 32.
+    Functional path (bench.py --encoder rn50x16): one rollout + GAE + update at 64 actors x rollout 8, the size-independent
+    property set of the other configs, and a frame's features independent of the batch it was encoded in."""
+    from embodied_clip_amd.engine import Worker
+    w = Worker(64, T=8, device="cuda:0", seed=0, encoder="rn50x16")
+    assert (w.S, w.C) == (7, 3072) and w.ns == 2
+    w.collect_rollout()
+    w.compute_returns()
+    torch.cuda.synchronize()
+    assert w.feat.shape == (9, 64, 49, 3072)
+    sl = w.slices[0]
+    b = sl.feat[1][5].float().reshape(-1)
+    rels = []
+    for pidx in range(w.env.pool_steps):
+        alone = sl.enc.forward(w.env.frames[pidx][sl.o + 5:sl.o + 6].contiguous())
+        torch.cuda.synchronize()
+        a = alone[0].float().reshape(-1)
+        rels.append(((a - b).norm() / b.norm()).item())
+    assert min(rels) < 2e-3, rels
+    assert (w.feat >= 0).all()
+    _check_properties(w)
+    del w
+    torch.cuda.empty_cache()
+
+
 def test_sharded_hip_gradients_sum_to_unsharded():
     """Row a18 on the HIP backward: two actor shards (what two ranks own), each pre-scaled by local/global batch,
     summed into one flat bucket == the unsharded HIP gradient (advantages given, so the loss is separable)."""

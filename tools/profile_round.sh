@@ -38,6 +38,7 @@ bash tools/calibrate_fetch.sh $O/fetch_calibration.json > $O/fetch_calibration.l
 python bench.py --steps 3 --warmup 1 > $O/bench_line.json 2> $O/bench.err
 python bench.py --steps 2 --warmup 1 --encoder vit --no-cpu-baseline > $O/bench_vit_line.json 2> $O/bench_vit.err
 python bench.py --steps 2 --warmup 1 --encoder zeroshot --no-cpu-baseline > $O/bench_zeroshot_line.json 2> $O/bench_zs.err
+python bench.py --steps 1 --warmup 1 --encoder rn50x16 --no-cpu-baseline --no-h2d --no-plugin > $O/bench_rn50x16_line.json 2> $O/bench_x16.err
 for A in 128 64 32; do
   python bench.py --steps 3 --warmup 1 --actors $A --no-cpu-baseline --no-h2d --no-plugin > $O/bench_${A}actors_line.json 2> $O/bench$A.err
 done
