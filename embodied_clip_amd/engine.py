@@ -115,7 +115,9 @@ class Worker:
         self.update_repeats, self.gamma, self.tau = update_repeats, gamma, tau
         self.base_lr, self.lr_total_steps = lr, lr_total_steps
         self.encoder = encoder
-        ns = encoder_streams if (encoder_streams > 1 and n_actors >= 64 and n_actors % encoder_streams == 0) else 1
+        # two slices (each with its own act -> encode chain on its own stream) from 48 actors on: measured round 3 at
+        # 32 / 48 / 64 actors, one vs two slices: 26.8 / 29.0 / 35.0 k vs 26.1 / 31.8 / 36.8 k env-frames/s
+        ns = encoder_streams if (encoder_streams > 1 and n_actors >= 48 and n_actors % encoder_streams == 0) else 1
         self.ns = ns
         n = n_actors // ns
         d = self.dev
