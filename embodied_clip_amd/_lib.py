@@ -67,6 +67,10 @@ SIGNATURES = {
     "ec_policy_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int, c_int]),
     "ec_policy_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                   c_void_p, c_size_t, c_int, c_void_p, c_void_p, c_void_p]),
+    "ec_policy_forward2": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                   c_void_p, c_size_t, c_int, c_void_p, c_void_p, c_void_p]),
+    "ec_policy_backward2": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_size_t,
+                                    c_void_p, c_void_p, c_void_p, c_void_p]),
     "ec_policy_set_goal_table": (c_int, [c_void_p, c_void_p]),
     "ec_policy_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_size_t,
                                    c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -93,7 +97,7 @@ SIGNATURES = {
 
 class PolicyCfg(C.Structure):
     _fields_ = [(n, c_int) for n in ("in_channels", "spatial", "hidden", "goal_dims", "num_goals", "num_actions",
-                                     "compress_hid", "compress_out", "comb_hid", "comb_out", "fusion")]
+                                     "compress_hid", "compress_out", "comb_hid", "comb_out", "fusion", "dual")]
 
 _lib = None
 

@@ -39,23 +39,27 @@ __global__ void goal_to_i32_kernel(const long long* g, int* o, int n) {
 }
 
 // x[b, c*S + p] = x4[(b*S + p)*Cc + c]   (channel-major flatten of the combiner output)
-__global__ void to_cmajor_kernel(const float* __restrict__ x4, float* __restrict__ x, int S, int Cc, long total) {
+// (ldx / xcol: row pitch and first column of this stream's block inside x -- the dual RGB + depth encoder concatenates
+//  its two streams' channel-major blocks, [U] ResnetDualTensorGoalEncoder: torch.cat([rgb_x, depth_x], dim=1) then flatten)
+__global__ void to_cmajor_kernel(const float* __restrict__ x4, float* __restrict__ x, int S, int Cc, long total, int ldx,
+                                 int xcol) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const int per = S * Cc;
     const long b = i / per;
     const int r = (int)(i - b * per);
     const int c = r / S, p = r - c * S;
-    x[i] = x4[(b * S + p) * Cc + c];
+    x[b * ldx + xcol + r] = x4[(b * S + p) * Cc + c];
 }
-__global__ void from_cmajor_kernel(const float* __restrict__ dx, float* __restrict__ dx4, int S, int Cc, long total) {
+__global__ void from_cmajor_kernel(const float* __restrict__ dx, float* __restrict__ dx4, int S, int Cc, long total, int ldx,
+                                   int xcol) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const int per = S * Cc;
     const long b = i / per;
     const int r = (int)(i - b * per);
     const int p = r / Cc, c = r - p * Cc;
-    dx4[i] = dx[b * per + c * S + p];
+    dx4[i] = dx[b * ldx + xcol + c * S + p];
 }
 
 // EC_WIH_PERM (learn pass): instead of re-ordering the [T*N x 1568] activations between the combiner's pixel-major rows and
@@ -1159,7 +1163,10 @@ __global__ __launch_bounds__(256) void tail_bwd_reduce_kernel(const float* __res
 
 inline size_t al(size_t v) { return (v + 255) / 256 * 256; }
 
-enum { P_EMB, P_W1, P_B1, P_W2, P_B2, P_W3, P_B3, P_W4, P_B4, P_WIH, P_WHH, P_BIH, P_BHH, P_WA, P_BA, P_WC, P_BC, P_COUNT };
+enum { P_EMB, P_W1, P_B1, P_W2, P_B2, P_W3, P_B3, P_W4, P_B4, P_WIH, P_WHH, P_BIH, P_BHH, P_WA, P_BA, P_WC, P_BC,
+       // dual (RGB + depth) encoder: the depth stream's compressor / combiner, same shapes as P_W1 .. P_B4
+       P_W1D, P_B1D, P_W2D, P_B2D, P_W3D, P_B3D, P_W4D, P_B4D, P_COUNT };
+constexpr int P_COUNT_SINGLE = P_BC + 1;
 
 }  // namespace
 
@@ -1173,13 +1180,15 @@ namespace {
 
 struct Ws {   // float offsets into the workspace
     size_t E1, c1, c2, m1, x4, x, gi, gh, gates, hn, hp, hs, goal32, w1p;
+    size_t E1d, c1d, c2d, m1d, x4d;   // the depth stream's copies (dual encoder)
     size_t dhs, dhc, dgi, dghb, dx, dx4, dm1, dc2, dc1, dE1, tpart, tpartE, whhT, wihP, gwihP, end;
 };
 
 Ws layout(const ec_policy* h, int T, int N, bool bwd) {
     const ec_policy_cfg& c = h->c;
     const size_t B = (size_t)T * N, S = (size_t)c.spatial * c.spatial, M49 = c.fusion ? 0 : B * S, H = c.hidden;
-    const size_t flat = c.fusion ? (size_t)c.in_channels : (size_t)c.comb_out * S;
+    const size_t nstream = (c.dual && !c.fusion) ? 2 : 1;
+    const size_t flat = c.fusion ? (size_t)c.in_channels : nstream * c.comb_out * S;
     Ws w; size_t o = 0;
     auto take = [&](size_t n) { size_t r = o; o += al(n * 4) / 4; return r; };
     w.E1 = take((size_t)c.num_goals * c.comb_hid);
@@ -1189,6 +1198,14 @@ Ws layout(const ec_policy* h, int T, int N, bool bwd) {
     w.c2 = take(M49 * c.compress_out);
     w.m1 = take(M49 * c.comb_hid);
     w.x4 = take(M49 * c.comb_out);
+    w.E1d = w.c1d = w.c2d = w.m1d = w.x4d = o;
+    if (nstream == 2) {
+        w.E1d = take((size_t)c.num_goals * c.comb_hid);
+        w.c1d = take(M49 * c.compress_hid * parts);
+        w.c2d = take(M49 * c.compress_out);
+        w.m1d = take(M49 * c.comb_hid);
+        w.x4d = take(M49 * c.comb_out);
+    }
     w.x = take(B * flat);
     w.gi = take(B * 3 * H * parts);
     w.gh = take((size_t)N * 3 * H);
@@ -1299,6 +1316,8 @@ extern "C" int ec_policy_create(ec_policy_t** out, const ec_policy_cfg* cfg) {
     if (!out || !cfg) return EC_ERR_ARG;
     const ec_policy_cfg& c = *cfg;
     if (c.fusion != 0 && c.fusion != 1) return EC_ERR_ARG;
+    if (c.dual != 0 && c.dual != 1) return EC_ERR_ARG;
+    if (c.dual && c.fusion) return EC_ERR_ARG;
     if (c.in_channels <= 0 || c.spatial <= 0 || c.hidden <= 0 || c.num_goals <= 0 || c.num_actions <= 0) return EC_ERR_SHAPE;
     if ((c.in_channels & 3) || (c.hidden & 3)) return EC_ERR_SHAPE;
     if (c.fusion) {
@@ -1313,16 +1332,18 @@ extern "C" int ec_policy_create(ec_policy_t** out, const ec_policy_cfg* cfg) {
     if (!h) return EC_ERR_ALLOC;
     h->c = c;
     const size_t S = (size_t)c.spatial * c.spatial, H = c.hidden;
-    const size_t flat = c.fusion ? (size_t)c.in_channels : (size_t)c.comb_out * S;
+    const size_t flat = c.fusion ? (size_t)c.in_channels : (size_t)(c.dual ? 2 : 1) * c.comb_out * S;
     size_t n[P_COUNT] = {(size_t)c.num_goals * c.goal_dims,
                                (size_t)c.compress_hid * c.in_channels, (size_t)c.compress_hid,
                                (size_t)c.compress_out * c.compress_hid, (size_t)c.compress_out,
                                (size_t)c.comb_hid * (c.compress_out + c.goal_dims), (size_t)c.comb_hid,
                                (size_t)c.comb_out * c.comb_hid, (size_t)c.comb_out,
                                3 * H * flat, 3 * H * H, 3 * H, 3 * H,
-                               (size_t)c.num_actions * H, (size_t)c.num_actions, H, 1};
+                               (size_t)c.num_actions * H, (size_t)c.num_actions, H, 1, 0, 0, 0, 0, 0, 0, 0, 0};
     if (c.fusion)
         for (int i = P_EMB; i <= P_B4; ++i) n[i] = 0;      // no goal embedding / compressor / combiner: GRU + heads only
+    if (c.dual)
+        for (int i = P_W1; i <= P_B4; ++i) n[i + (P_W1D - P_W1)] = n[i];
     size_t o = 0;
     for (int i = 0; i < P_COUNT; ++i) { h->off[i] = o; h->num[i] = n[i]; o += (n[i] + 3) / 4 * 4; }   // 16-B aligned
     h->total = o;
@@ -1335,7 +1356,7 @@ extern "C" int ec_policy_set_goal_table(ec_policy_t* h, const float* table) {
     h->goal_table = table;
     return EC_OK;
 }
-extern "C" int ec_policy_num_param_tensors(const ec_policy_t*) { return P_COUNT; }
+extern "C" int ec_policy_num_param_tensors(const ec_policy_t* h) { return (h && h->c.dual) ? P_COUNT : P_COUNT_SINGLE; }
 extern "C" size_t ec_policy_flat_size(const ec_policy_t* h) { return h ? h->total : 0; }
 extern "C" int ec_policy_param_offset(const ec_policy_t* h, int idx, size_t* off, size_t* numel) {
     if (!h || idx < 0 || idx >= P_COUNT || !off || !numel) return EC_ERR_ARG;
@@ -1351,7 +1372,16 @@ extern "C" int ec_policy_forward(const ec_policy_t* h, const float* params, cons
                                  const int64_t* goal, const float* h0, const float* masks, int T, int N,
                                  void* workspace, size_t ws_bytes, int for_backward, float* hv, float* h_final,
                                  ec_stream_t stream) {
+    return ec_policy_forward2(h, params, feat, nullptr, feat_bf16, goal, h0, masks, T, N, workspace, ws_bytes, for_backward, hv,
+                              h_final, stream);
+}
+
+extern "C" int ec_policy_forward2(const ec_policy_t* h, const float* params, const void* feat, const void* feat2, int feat_bf16,
+                                  const int64_t* goal, const float* h0, const float* masks, int T, int N,
+                                  void* workspace, size_t ws_bytes, int for_backward, float* hv, float* h_final,
+                                  ec_stream_t stream) {
     if (!h || !params || !feat || !goal || !h0 || !masks || !workspace || !hv) return EC_ERR_ARG;
+    if (h->c.dual && !feat2) return EC_ERR_ARG;
     if (T <= 0 || N <= 0) return EC_ERR_SHAPE;
     const ec_policy_cfg& c = h->c;
     const Ws w = layout(h, T, N, false);
@@ -1361,7 +1391,8 @@ extern "C" int ec_policy_forward(const ec_policy_t* h, const float* params, cons
     hipStream_t s = (hipStream_t)stream;
     const int B = T * N, S = c.spatial * c.spatial, H = c.hidden, A1 = c.num_actions + 1;
     const int M49 = B * S, C = c.in_channels, cat = c.compress_out + c.goal_dims;
-    const int flat = c.fusion ? c.in_channels : c.comb_out * S;
+    const int nstream = (c.dual && !c.fusion) ? 2 : 1, flat1 = c.comb_out * S;
+    const int flat = c.fusion ? c.in_channels : nstream * flat1;
     const float* P = params;
     auto W = [&](int i) { return P + h->off[i]; };
     int* goal32 = (int*)(ws + w.goal32);
@@ -1374,7 +1405,7 @@ extern "C" int ec_policy_forward(const ec_policy_t* h, const float* params, cons
     const bool reuse_tables = for_backward == EC_POLICY_INFER_REUSE;
     // learn pass: the GRU's input projection reads the combiner output where it lies (pixel-major rows) against a re-ordered
     // weight_ih (permute_row_kernel) -- no activation transposes in either direction
-    const bool wih_perm = ec_config().wih_perm && !infer_only && !c.fusion && (size_t)c.comb_out * S * 4 <= 64 * 1024;
+    const bool wih_perm = ec_config().wih_perm && !infer_only && !c.fusion && !c.dual && (size_t)c.comb_out * S * 4 <= 64 * 1024;
     const Ws wb = layout(h, T, N, !infer_only);
     const bool small = !c.fusion && M49 > 0 && M49 <= ACT_MAX_ROWS;            // (== the condition in layout())
     const size_t tail_lds_ = ((size_t)2 * 32 * TL_P128 + 128 * TL_P32 + (size_t)c.num_goals * 128 + 64 +
@@ -1398,27 +1429,32 @@ extern "C" int ec_policy_forward(const ec_policy_t* h, const float* params, cons
             hipLaunchKernelGGL(fuse_goal_kernel<false>, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s, feat, h->goal_table,
                                goal32, ws + w.x, (long)B, flat, c.num_goals);
     } else {
+    for (int sidx = 0; sidx < nstream; ++sidx) {   // dual encoder: the RGB stream, then the depth stream (own weights, own activations)
+    const void* featS = sidx ? feat2 : feat;
+    auto WS = [&](int i) { return P + h->off[(sidx && i >= P_W1 && i <= P_B4) ? i + (P_W1D - P_W1) : i]; };
+    const size_t o_E1 = sidx ? w.E1d : w.E1, o_c1 = sidx ? w.c1d : w.c1, o_c2 = sidx ? w.c2d : w.c2, o_m1 = sidx ? w.m1d : w.m1,
+                 o_x4 = sidx ? w.x4d : w.x4;
     // E1 = embed_class @ W3[:, co:]^T + b3
     if (!reuse_tables)
-    RC(ec_gemm_f32(W(P_EMB), W(P_W3) + c.compress_out, ws + w.E1, c.num_goals, c.comb_hid, c.goal_dims, c.goal_dims, 1,
-                   1, cat, c.comb_hid, 0, W(P_B3), nullptr, nullptr, 0, nullptr, nullptr, 1, stream));
+    RC(ec_gemm_f32(WS(P_EMB), WS(P_W3) + c.compress_out, ws + o_E1, c.num_goals, c.comb_hid, c.goal_dims, c.goal_dims, 1,
+                   1, cat, c.comb_hid, 0, WS(P_B3), nullptr, nullptr, 0, nullptr, nullptr, 1, stream));
     // resnet_compressor
     // EC_C1_PINGPONG (default 1): bf16 features x fp32 W1 as three bf16 planes on the 8-wave ping-pong kernel
     // (conv_igemm8, X3 mode) once there are enough 256-row tiles to fill the chip; else the generic x3 GEMM
     const int c1_pp = ec_config().c1_pingpong;
     if (c1_pp && feat_bf16 && c.compress_hid % 128 == 0 && C % 64 == 0 && M49 >= 256 * 128) {
-        RC(ec_split3_bf16(W(P_W1), ws + w.w1p, c.compress_hid, C, stream));
-        RC(ec_gemm_bf16a_x3(feat, ws + w.w1p, W(P_B1), ws + w.c1, M49, c.compress_hid, C, 1 /* EC_ACT_RELU */, stream));
+        RC(ec_split3_bf16(WS(P_W1), ws + w.w1p, c.compress_hid, C, stream));
+        RC(ec_gemm_bf16a_x3(featS, ws + w.w1p, WS(P_B1), ws + o_c1, M49, c.compress_hid, C, 1 /* EC_ACT_RELU */, stream));
     } else if (act_split) {
         // act step: K = C is long and M small (196 workgroups walking 64 K-steps each): four K slices write four
         // partial matrices, tail_fwd_kernel folds them (+ b1, ReLU) in a fixed order -- no atomics, bit-reproducible,
         // and independent of how the actors are sliced
-        RC(ec_gemm_f32(feat, W(P_W1), ws + w.c1, M49, c.compress_hid, C, C, 1, 1, C, c.compress_hid,
+        RC(ec_gemm_f32(featS, WS(P_W1), ws + o_c1, M49, c.compress_hid, C, C, 1, 1, C, c.compress_hid,
                        EC_GEMM_SPLIT_PARTS | (feat_bf16 ? EC_GEMM_A_BF16 : 0), nullptr, nullptr, nullptr, 0, nullptr, nullptr,
                        ACT_PARTS, stream));
     } else
-    RC(ec_gemm_f32(feat, W(P_W1), ws + w.c1, M49, c.compress_hid, C, C, 1, 1, C, c.compress_hid,
-                   EC_GEMM_RELU | (feat_bf16 ? EC_GEMM_A_BF16 : 0), W(P_B1), nullptr, nullptr, 0, nullptr, nullptr, 1,
+    RC(ec_gemm_f32(featS, WS(P_W1), ws + o_c1, M49, c.compress_hid, C, C, 1, 1, C, c.compress_hid,
+                   EC_GEMM_RELU | (feat_bf16 ? EC_GEMM_A_BF16 : 0), WS(P_B1), nullptr, nullptr, 0, nullptr, nullptr, 1,
                    stream));
     // EC_TAIL_FUSED (default 1): c2 / m1 / x4 in one pass over c1 for the reference's widths
     const int tail_fused = ec_config().tail_fused;
@@ -1433,27 +1469,28 @@ extern "C" int ec_policy_forward(const ec_policy_t* h, const float* params, cons
         const long ntiles = ((long)M49 + 31) / 32;
         long nwg = (ntiles + 3) / 4;
         if (nwg > 512) nwg = 512;
-        hipLaunchKernelGGL(tail_fwd_kernel, dim3((unsigned)nwg), dim3(256), tail_lds, s, ws + w.c1, W(P_W2), W(P_B2), W(P_W3), cat,
-                           ws + w.E1, goal32, S, c.num_goals, W(P_W4), W(P_B4), ws + w.c2, ws + w.m1, ws + w.x4, (long)M49,
-                           act_split ? ACT_PARTS : 1, (long)M49 * c.compress_hid, W(P_B1));
+        hipLaunchKernelGGL(tail_fwd_kernel, dim3((unsigned)nwg), dim3(256), tail_lds, s, ws + o_c1, WS(P_W2), WS(P_B2), WS(P_W3), cat,
+                           ws + o_E1, goal32, S, c.num_goals, WS(P_W4), WS(P_B4), ws + o_c2, ws + o_m1, ws + o_x4, (long)M49,
+                           act_split ? ACT_PARTS : 1, (long)M49 * c.compress_hid, WS(P_B1));
     } else {
-    RC(ec_gemm_f32(ws + w.c1, W(P_W2), ws + w.c2, M49, c.compress_out, c.compress_hid, c.compress_hid, 1, 1,
-                   c.compress_hid, c.compress_out, EC_GEMM_RELU, W(P_B2), nullptr, nullptr, 0, nullptr, nullptr, 1,
+    RC(ec_gemm_f32(ws + o_c1, WS(P_W2), ws + o_c2, M49, c.compress_out, c.compress_hid, c.compress_hid, 1, 1,
+                   c.compress_hid, c.compress_out, EC_GEMM_RELU, WS(P_B2), nullptr, nullptr, 0, nullptr, nullptr, 1,
                    stream));
     // target_obs_combiner (goal half folded into the row-group bias E1[goal])
-    RC(ec_gemm_f32(ws + w.c2, W(P_W3), ws + w.m1, M49, c.comb_hid, c.compress_out, c.compress_out, 1, 1, cat,
-                   c.comb_hid, EC_GEMM_RELU, nullptr, ws + w.E1, goal32, S, nullptr, nullptr, 1, stream));
-    RC(ec_gemm_f32(ws + w.m1, W(P_W4), ws + w.x4, M49, c.comb_out, c.comb_hid, c.comb_hid, 1, 1, c.comb_hid,
-                   c.comb_out, 0, W(P_B4), nullptr, nullptr, 0, nullptr, nullptr, 1, stream));
+    RC(ec_gemm_f32(ws + o_c2, WS(P_W3), ws + o_m1, M49, c.comb_hid, c.compress_out, c.compress_out, 1, 1, cat,
+                   c.comb_hid, EC_GEMM_RELU, nullptr, ws + o_E1, goal32, S, nullptr, nullptr, 1, stream));
+    RC(ec_gemm_f32(ws + o_m1, WS(P_W4), ws + o_x4, M49, c.comb_out, c.comb_hid, c.comb_hid, 1, 1, c.comb_hid,
+                   c.comb_out, 0, WS(P_B4), nullptr, nullptr, 0, nullptr, nullptr, 1, stream));
     }
     if (wih_perm) {
         hipLaunchKernelGGL(permute_row_kernel, dim3((unsigned)(3 * H)), dim3(256), flat * sizeof(float), s, W(P_WIH),
                            ws + wb.wihP, S, c.comb_out, 0);
     } else {
-        const long total = (long)B * flat;
-        hipLaunchKernelGGL(to_cmajor_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ws + w.x4, ws + w.x,
-                           S, c.comb_out, total);
+        const long total = (long)B * flat1;
+        hipLaunchKernelGGL(to_cmajor_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ws + o_x4, ws + w.x,
+                           S, c.comb_out, total, flat, sidx * flat1);
     }
+    }   // streams
     }   // !fusion
     // GRU: input projection for all T at once, then the sequential recurrence
     // (split-K only as separate partial matrices folded by the step kernel: the act step stays free of float atomics, so
@@ -1526,7 +1563,14 @@ extern "C" int ec_policy_forward(const ec_policy_t* h, const float* params, cons
 extern "C" int ec_policy_backward(const ec_policy_t* h, const float* params, const void* feat, int feat_bf16,
                                   const float* masks, int T, int N, void* workspace, size_t ws_bytes, const float* dhv,
                                   const float* dh_final, float* grads, ec_stream_t stream) {
+    return ec_policy_backward2(h, params, feat, nullptr, feat_bf16, masks, T, N, workspace, ws_bytes, dhv, dh_final, grads, stream);
+}
+
+extern "C" int ec_policy_backward2(const ec_policy_t* h, const float* params, const void* feat, const void* feat2, int feat_bf16,
+                                   const float* masks, int T, int N, void* workspace, size_t ws_bytes, const float* dhv,
+                                   const float* dh_final, float* grads, ec_stream_t stream) {
     if (!h || !params || !feat || !masks || !workspace || !dhv || !grads) return EC_ERR_ARG;
+    if (h->c.dual && !feat2) return EC_ERR_ARG;
     if (T <= 0 || N <= 0) return EC_ERR_SHAPE;
     const ec_policy_cfg& c = h->c;
     const Ws w = layout(h, T, N, true);
@@ -1535,7 +1579,8 @@ extern "C" int ec_policy_backward(const ec_policy_t* h, const float* params, con
     hipStream_t s = (hipStream_t)stream;
     const int B = T * N, S = c.spatial * c.spatial, H = c.hidden, A = c.num_actions, A1 = A + 1;
     const int M49 = B * S, C = c.in_channels, cat = c.compress_out + c.goal_dims;
-    const int flat = c.fusion ? c.in_channels : c.comb_out * S;
+    const int nstream = (c.dual && !c.fusion) ? 2 : 1, flat1 = c.comb_out * S;
+    const int flat = c.fusion ? c.in_channels : nstream * flat1;
     auto W = [&](int i) { return params + h->off[i]; };
     auto G = [&](int i) { return grads + h->off[i]; };
     const int* goal32 = (const int*)(ws + w.goal32);
@@ -1618,7 +1663,7 @@ extern "C" int ec_policy_backward(const ec_policy_t* h, const float* params, con
     };
     RC(tn(ws + w.dghb, 3 * H, ws + w.hp, H, 0, G(P_WHH), 3 * H, H, B, H));
     colsum(ws + w.dghb, G(P_BHH), B, 3 * H, 3 * H);
-    const bool wih_perm = ec_config().wih_perm && !c.fusion && (size_t)c.comb_out * S * 4 <= 64 * 1024;   // (== ec_policy_forward's)
+    const bool wih_perm = ec_config().wih_perm && !c.fusion && !c.dual && (size_t)c.comb_out * S * 4 <= 64 * 1024;   // (== ec_policy_forward's)
     if (wih_perm) {   // gradient in the re-ordered weight's column order, then added back in the parameter's order
         (void)hipMemsetAsync(ws + w.gwihP, 0, (size_t)3 * H * flat * 4, s);
         RC(tn(ws + w.dgi, 3 * H, ws + w.x4, flat, 0, ws + w.gwihP, 3 * H, flat, B, flat));
@@ -1635,12 +1680,18 @@ extern "C" int ec_policy_backward(const ec_policy_t* h, const float* params, con
     if (wih_perm)   // dx4 = dgi @ (re-ordered weight_ih): already pixel-major
         RC(ec_gemm_f32(ws + w.dgi, ws + w.wihP, ws + w.dx4, B, flat, 3 * H, 3 * H, 1, flat, 1, flat, 0, nullptr, nullptr,
                        nullptr, 0, nullptr, nullptr, 1, stream));
-    else {
+    else
         RC(ec_gemm_f32(ws + w.dgi, W(P_WIH), ws + w.dx, B, flat, 3 * H, 3 * H, 1, flat, 1, flat, 0, nullptr, nullptr, nullptr,
                        0, nullptr, nullptr, 1, stream));
-        const long total = (long)B * flat;
+    for (int sidx = 0; sidx < nstream; ++sidx) {   // dual encoder: the depth stream re-uses the gradient temporaries (one HIP stream)
+    const void* featS = sidx ? feat2 : feat;
+    auto WS = [&](int i) { return params + h->off[(sidx && i >= P_W1 && i <= P_B4) ? i + (P_W1D - P_W1) : i]; };
+    auto GS = [&](int i) { return grads + h->off[(sidx && i >= P_W1 && i <= P_B4) ? i + (P_W1D - P_W1) : i]; };
+    const size_t o_c1 = sidx ? w.c1d : w.c1, o_c2 = sidx ? w.c2d : w.c2, o_m1 = sidx ? w.m1d : w.m1;
+    if (!wih_perm) {
+        const long total = (long)B * flat1;
         hipLaunchKernelGGL(from_cmajor_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ws + w.dx,
-                           ws + w.dx4, S, c.comb_out, total);
+                           ws + w.dx4, S, c.comb_out, total, flat, sidx * flat1);
     }
     const int tail_fused = ec_config().tail_fused;
     const size_t tb_lds = ((size_t)2 * 128 * TL_P32 + 32 * TL_P128 + (size_t)c.num_goals * 128 +
@@ -1661,41 +1712,42 @@ extern "C" int ec_policy_backward(const ec_policy_t* h, const float* params, con
         const long ntiles = ((long)M49 + 31) / 32;
         long nwg = (ntiles + 3) / 4;
         if (nwg > TB_MAX_WG) nwg = TB_MAX_WG;
-        hipLaunchKernelGGL(tail_bwd_kernel, dim3((unsigned)nwg), dim3(256), tb_lds, s, ws + w.dx4, ws + w.m1, ws + w.c2, ws + w.c1,
-                           W(P_W2), W(P_W3), cat, W(P_W4), goal32, S, c.num_goals, ws + w.dc1,
+        hipLaunchKernelGGL(tail_bwd_kernel, dim3((unsigned)nwg), dim3(256), tb_lds, s, ws + w.dx4, ws + o_m1, ws + o_c2, ws + o_c1,
+                           WS(P_W2), WS(P_W3), cat, WS(P_W4), goal32, S, c.num_goals, ws + w.dc1,
                            dw1_planes ? (uint16_t*)(ws + w.dc1) : nullptr, ws + w.tpart, ws + w.tpartE,
                            (long)M49);
         const int ne = TB_PART + c.num_goals * 128;
         hipLaunchKernelGGL(tail_bwd_reduce_kernel, dim3((unsigned)((ne + 255) / 256), 8), dim3(256), 0, s, ws + w.tpart,
-                           (int)nwg * 4, ws + w.tpartE, (int)nwg, c.num_goals, G(P_W4), G(P_W3), cat, G(P_W2), G(P_B4), G(P_B2),
-                           G(P_B1), ws + w.dE1);
+                           (int)nwg * 4, ws + w.tpartE, (int)nwg, c.num_goals, GS(P_W4), GS(P_W3), cat, GS(P_W2), GS(P_B4), GS(P_B2),
+                           GS(P_B1), ws + w.dE1);
     } else {
     // ---- target_obs_combiner ----
-    RC(tn(ws + w.dx4, c.comb_out, ws + w.m1, c.comb_hid, 0, G(P_W4), c.comb_out, c.comb_hid, M49, c.comb_hid));
-    colsum(ws + w.dx4, G(P_B4), M49, c.comb_out, c.comb_out);
-    RC(ec_gemm_f32(ws + w.dx4, W(P_W4), ws + w.dm1, M49, c.comb_hid, c.comb_out, c.comb_out, 1, c.comb_hid, 1, c.comb_hid,
-                   0, nullptr, nullptr, nullptr, 0, ws + w.m1, nullptr, 1, stream));
-    RC(tn(ws + w.dm1, c.comb_hid, ws + w.c2, c.compress_out, 0, G(P_W3), c.comb_hid, c.compress_out, M49, cat));
+    RC(tn(ws + w.dx4, c.comb_out, ws + o_m1, c.comb_hid, 0, GS(P_W4), c.comb_out, c.comb_hid, M49, c.comb_hid));
+    colsum(ws + w.dx4, GS(P_B4), M49, c.comb_out, c.comb_out);
+    RC(ec_gemm_f32(ws + w.dx4, WS(P_W4), ws + w.dm1, M49, c.comb_hid, c.comb_out, c.comb_out, 1, c.comb_hid, 1, c.comb_hid,
+                   0, nullptr, nullptr, nullptr, 0, ws + o_m1, nullptr, 1, stream));
+    RC(tn(ws + w.dm1, c.comb_hid, ws + o_c2, c.compress_out, 0, GS(P_W3), c.comb_hid, c.compress_out, M49, cat));
     hipLaunchKernelGGL(group_sum_scatter_kernel, dim3((unsigned)B), dim3(128), 0, s, ws + w.dm1, goal32, ws + w.dE1, S,
                        c.comb_hid, (long)B);
     // ---- resnet_compressor ----
-    RC(ec_gemm_f32(ws + w.dm1, W(P_W3), ws + w.dc2, M49, c.compress_out, c.comb_hid, c.comb_hid, 1, cat, 1,
-                   c.compress_out, 0, nullptr, nullptr, nullptr, 0, ws + w.c2, nullptr, 1, stream));
-    RC(tn(ws + w.dc2, c.compress_out, ws + w.c1, c.compress_hid, 0, G(P_W2), c.compress_out, c.compress_hid, M49,
+    RC(ec_gemm_f32(ws + w.dm1, WS(P_W3), ws + w.dc2, M49, c.compress_out, c.comb_hid, c.comb_hid, 1, cat, 1,
+                   c.compress_out, 0, nullptr, nullptr, nullptr, 0, ws + o_c2, nullptr, 1, stream));
+    RC(tn(ws + w.dc2, c.compress_out, ws + o_c1, c.compress_hid, 0, GS(P_W2), c.compress_out, c.compress_hid, M49,
           c.compress_hid));
-    colsum(ws + w.dc2, G(P_B2), M49, c.compress_out, c.compress_out);
-    RC(ec_gemm_f32(ws + w.dc2, W(P_W2), ws + w.dc1, M49, c.compress_hid, c.compress_out, c.compress_out, 1,
-                   c.compress_hid, 1, c.compress_hid, 0, nullptr, nullptr, nullptr, 0, ws + w.c1, nullptr, 1, stream));
-    colsum(ws + w.dc1, G(P_B1), M49, c.compress_hid, c.compress_hid);
+    colsum(ws + w.dc2, GS(P_B2), M49, c.compress_out, c.compress_out);
+    RC(ec_gemm_f32(ws + w.dc2, WS(P_W2), ws + w.dc1, M49, c.compress_hid, c.compress_out, c.compress_out, 1,
+                   c.compress_hid, 1, c.compress_hid, 0, nullptr, nullptr, nullptr, 0, ws + o_c1, nullptr, 1, stream));
+    colsum(ws + w.dc1, GS(P_B1), M49, c.compress_hid, c.compress_hid);
     }
     // goal half of target_obs_combiner.0 (dE1 = row-group sums of dm1 scattered by goal id)
-    colsum(ws + w.dE1, G(P_B3), c.num_goals, c.comb_hid, c.comb_hid);
-    RC(tn(ws + w.dE1, c.comb_hid, W(P_EMB), c.goal_dims, 0, G(P_W3) + c.compress_out, c.comb_hid, c.goal_dims,
+    colsum(ws + w.dE1, GS(P_B3), c.num_goals, c.comb_hid, c.comb_hid);
+    RC(tn(ws + w.dE1, c.comb_hid, WS(P_EMB), c.goal_dims, 0, GS(P_W3) + c.compress_out, c.comb_hid, c.goal_dims,
           c.num_goals, cat));
-    RC(ec_gemm_f32(ws + w.dE1, W(P_W3) + c.compress_out, G(P_EMB), c.num_goals, c.goal_dims, c.comb_hid, c.comb_hid, 1,
+    RC(ec_gemm_f32(ws + w.dE1, WS(P_W3) + c.compress_out, GS(P_EMB), c.num_goals, c.goal_dims, c.comb_hid, c.comb_hid, 1,
                    cat, 1, c.goal_dims, EC_GEMM_ACCUMULATE, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 1, stream));
-    if (dw1_planes) RC(ec_dw_tn_x3(ws + w.dc1, feat, ws + w.tpart, G(P_W1), M49, C, stream));   // (tpart: free again after the reducer)
-    else RC(tn(ws + w.dc1, c.compress_hid, feat, C, feat_bf16, G(P_W1), c.compress_hid, C, M49, C));
+    if (dw1_planes) RC(ec_dw_tn_x3(ws + w.dc1, featS, ws + w.tpart, GS(P_W1), M49, C, stream));   // (tpart: free again after the reducer)
+    else RC(tn(ws + w.dc1, c.compress_hid, featS, C, feat_bf16, GS(P_W1), c.compress_hid, C, M49, C));
+    }   // streams
     EC_CHECK_LAUNCH();
     return EC_OK;
 }

@@ -27,7 +27,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib, spaces
-from .synthetic import POLICY_PARAM_ORDER, policy_param_shapes
+from .synthetic import POLICY_PARAM_ORDER, policy_param_order, policy_param_shapes
 
 
 # ---- AllenAct base abstractions (the real ones when allenact is importable) ----------------------
@@ -42,8 +42,9 @@ class PolicyHandle:
     def __init__(self, **cfg: int):
         self.lib = _lib.load()
         self.cfg = dict(in_channels=2048, spatial=7, hidden=512, goal_dims=32, num_goals=12, num_actions=6,
-                        compress_hid=128, compress_out=32, comb_hid=128, comb_out=32, fusion=0)
+                        compress_hid=128, compress_out=32, comb_hid=128, comb_out=32, fusion=0, dual=0)
         self.cfg.update(cfg)
+        self.param_order = policy_param_order(self.cfg["dual"])
         c = _lib.PolicyCfg(**self.cfg)
         h = C.c_void_p()
         _lib.check(self.lib.ec_policy_create(C.byref(h), C.byref(c)), "ec_policy_create")
@@ -51,8 +52,8 @@ class PolicyHandle:
         self.flat_size = self.lib.ec_policy_flat_size(h)
         self.shapes = policy_param_shapes(**self.cfg)
         self.offsets: "OrderedDict[str, Tuple[int, int]]" = OrderedDict()
-        assert self.lib.ec_policy_num_param_tensors(h) == len(POLICY_PARAM_ORDER)
-        for i, name in enumerate(POLICY_PARAM_ORDER):
+        assert self.lib.ec_policy_num_param_tensors(h) == len(self.param_order)
+        for i, name in enumerate(self.param_order):
             off, num = C.c_size_t(), C.c_size_t()
             _lib.check(self.lib.ec_policy_param_offset(h, i, C.byref(off), C.byref(num)))
             n = 1
@@ -97,7 +98,7 @@ class PolicyHandle:
         return OrderedDict((n, flat[o:o + k].view(self.shapes[n])) for n, (o, k) in self.offsets.items())
 
     def forward(self, flat_params, feat, goal, h0, masks, T, N, ws, hv=None, h_final=None, for_backward: bool = True,
-                reuse_tables: bool = False):
+                reuse_tables: bool = False, feat2=None):
         """feat: bf16 or fp32 NHWC rows [T*N, S*S, C]; returns (hv [T*N, A+1], h_final [N,H]).
         ``for_backward=True`` (default) keeps every activation ``backward`` needs and wants a workspace of
         ``workspace_bytes(T, N, True)``; ``False`` is the inference-only act step (``workspace_bytes(T, N, False)``).
@@ -108,28 +109,32 @@ class PolicyHandle:
         dev = flat_params.device
         with _lib.tensor_guard(flat_params):
             mode = 1 if for_backward else (2 if reuse_tables else 0)
-            return self._forward(flat_params, feat, goal, h0, masks, T, N, ws, hv, h_final, dev, mode)
+            return self._forward(flat_params, feat, goal, h0, masks, T, N, ws, hv, h_final, dev, mode, feat2)
 
-    def _forward(self, flat_params, feat, goal, h0, masks, T, N, ws, hv, h_final, dev, for_backward=True):
+    def _forward(self, flat_params, feat, goal, h0, masks, T, N, ws, hv, h_final, dev, for_backward=True, feat2=None):
         if hv is None:
             hv = torch.empty((T * N, self.A + 1), dtype=torch.float32, device=dev)
         if h_final is None:
             h_final = torch.empty((N, self.H), dtype=torch.float32, device=dev)
-        _lib.check(self.lib.ec_policy_forward(
-            self.h, flat_params.data_ptr(), feat.data_ptr(), int(feat.dtype == torch.bfloat16), goal.data_ptr(),
+        if self.cfg["dual"]:       # RGB + depth: feat = the RGB features, feat2 = the depth features (same shape / dtype)
+            assert feat2 is not None and feat2.is_contiguous() and feat2.dtype == feat.dtype and feat2.shape == feat.shape
+        _lib.check(self.lib.ec_policy_forward2(
+            self.h, flat_params.data_ptr(), feat.data_ptr(), _lib.ptr(feat2), int(feat.dtype == torch.bfloat16), goal.data_ptr(),
             h0.data_ptr(), masks.data_ptr(), T, N, ws.data_ptr(), ws.numel() * ws.element_size(), int(for_backward),
-            hv.data_ptr(), h_final.data_ptr(), _lib.stream_ptr()), "ec_policy_forward")
+            hv.data_ptr(), h_final.data_ptr(), _lib.stream_ptr()), "ec_policy_forward2")
         return hv, h_final
 
-    def backward(self, flat_params, feat, masks, T, N, ws, dhv, dh_final, flat_grads):
+    def backward(self, flat_params, feat, masks, T, N, ws, dhv, dh_final, flat_grads, feat2=None):
         with _lib.tensor_guard(flat_params):
-            return self._backward(flat_params, feat, masks, T, N, ws, dhv, dh_final, flat_grads)
+            return self._backward(flat_params, feat, masks, T, N, ws, dhv, dh_final, flat_grads, feat2)
 
-    def _backward(self, flat_params, feat, masks, T, N, ws, dhv, dh_final, flat_grads):
-        _lib.check(self.lib.ec_policy_backward(
-            self.h, flat_params.data_ptr(), feat.data_ptr(), int(feat.dtype == torch.bfloat16), masks.data_ptr(), T, N,
-            ws.data_ptr(), ws.numel() * ws.element_size(), dhv.data_ptr(), _lib.ptr(dh_final), flat_grads.data_ptr(),
-            _lib.stream_ptr()), "ec_policy_backward")
+    def _backward(self, flat_params, feat, masks, T, N, ws, dhv, dh_final, flat_grads, feat2=None):
+        if self.cfg["dual"]:
+            assert feat2 is not None and feat2.is_contiguous() and feat2.dtype == feat.dtype and feat2.shape == feat.shape
+        _lib.check(self.lib.ec_policy_backward2(
+            self.h, flat_params.data_ptr(), feat.data_ptr(), _lib.ptr(feat2), int(feat.dtype == torch.bfloat16), masks.data_ptr(),
+            T, N, ws.data_ptr(), ws.numel() * ws.element_size(), dhv.data_ptr(), _lib.ptr(dh_final), flat_grads.data_ptr(),
+            _lib.stream_ptr()), "ec_policy_backward2")
         return flat_grads
 
 
@@ -141,12 +146,13 @@ class _PolicyFn(torch.autograd.Function):
     backward is stated explicitly (``for_backward=need_grad``), so an act step always takes the act-step kernel plan."""
 
     @staticmethod
-    def forward(ctx, handle: PolicyHandle, owner, flat, feat, goal, h0, masks, T, N, *params):
+    def forward(ctx, handle: PolicyHandle, owner, flat, feat, feat2, goal, h0, masks, T, N, *params):
         need_grad = any(ctx.needs_input_grad)   # (grad mode is always off inside Function.forward)
         ws = torch.empty(handle.workspace_bytes(T, N, need_grad), dtype=torch.uint8, device=flat.device)
-        hv, h_final = handle.forward(flat, feat, goal, h0, masks, T, N, ws, for_backward=need_grad)
+        hv, h_final = handle.forward(flat, feat, goal, h0, masks, T, N, ws, for_backward=need_grad, feat2=feat2)
         if need_grad:
             ctx.handle, ctx.owner, ctx.T, ctx.N = handle, owner, T, N
+            ctx.feat2 = feat2                    # (the depth stream's features of the dual encoder, or None: frozen input)
             ctx.save_for_backward(flat, feat, masks, ws)
         return hv, h_final
 
@@ -166,9 +172,9 @@ class _PolicyFn(torch.autograd.Function):
             g = torch.zeros_like(flat)
         dhv = dhv.contiguous() if dhv is not None else torch.zeros((ctx.T * ctx.N, h.A + 1), device=flat.device)
         dhf = dh_final.contiguous() if dh_final is not None else None
-        h.backward(flat, feat, masks, ctx.T, ctx.N, ws, dhv, dhf, g)
+        h.backward(flat, feat, masks, ctx.T, ctx.N, ws, dhv, dhf, g, feat2=ctx.feat2)
         grads = tuple(g[o:o + k].view(h.shapes[n]) for n, (o, k) in h.offsets.items())
-        return (None,) * 9 + grads
+        return (None,) * 10 + grads
 
 
 class _Holder(nn.Module):
@@ -193,7 +199,10 @@ class ResnetTensorObjectNavActorCritic(ActorCriticModel):
 
     Exactly one of the two preprocessor uuids selects the single-tower ``ResnetTensorGoalEncoder`` (RGB for the CLIP
     configs of the reference; a depth-only tower is the same arithmetic on the depth features).  Both at once is
-    upstream's ``ResnetDualTensorGoalEncoder`` (RGB-D), which none of the reference's CLIP configs use: not built.
+    upstream's ``ResnetDualTensorGoalEncoder`` (RGB-D: readme_files/baselines_habitat.md:75 "replace rgb with rgbd"):
+    each stream has its own compressor and combiner (parameter names ``goal_visual_encoder.{rgb,depth}_resnet_compressor.*``
+    / ``{rgb,depth}_target_obs_combiner.*``), the goal embedding is shared, and ``cat([rgb_x, depth_x], dim=1)`` is
+    flattened into the GRU (``ec_policy_cfg.dual``).
     """
 
     def __init__(self, action_space, observation_space, goal_sensor_uuid: str,
@@ -202,25 +211,29 @@ class ResnetTensorObjectNavActorCritic(ActorCriticModel):
                  combiner_hidden_out_dims=(128, 32), state_dict: Optional[Dict[str, torch.Tensor]] = None,
                  device="cuda"):
         super().__init__(action_space=action_space, observation_space=observation_space)
-        if rgb_resnet_preprocessor_uuid is not None and depth_resnet_preprocessor_uuid is not None:
-            raise NotImplementedError("RGB-D (ResnetDualTensorGoalEncoder) is not built: the reference's CLIP configs "
-                                      "are single-tower")
         if rgb_resnet_preprocessor_uuid is None and depth_resnet_preprocessor_uuid is None:
             raise ValueError("one of rgb_resnet_preprocessor_uuid / depth_resnet_preprocessor_uuid is required")
         self.goal_uuid = goal_sensor_uuid
+        self.dual = rgb_resnet_preprocessor_uuid is not None and depth_resnet_preprocessor_uuid is not None
         self.resnet_uuid = (rgb_resnet_preprocessor_uuid if rgb_resnet_preprocessor_uuid is not None
                             else depth_resnet_preprocessor_uuid)
+        self.depth_uuid = depth_resnet_preprocessor_uuid if self.dual else None
         self._hidden_size = hidden_size
         self._g_scratch: Optional[torch.Tensor] = None
         if self.resnet_uuid not in observation_space.spaces:
             raise NotImplementedError("blind agent (no visual tensor in the observation space) is not built")
+        if self.dual and self.depth_uuid not in observation_space.spaces:
+            raise ValueError(f"{self.depth_uuid!r} is not in the observation space")
         rs = observation_space.spaces[self.resnet_uuid].shape        # (C, S, S)
+        if self.dual and tuple(observation_space.spaces[self.depth_uuid].shape) != tuple(rs):
+            raise ValueError("the RGB and depth feature tensors must have the same shape")
         num_goals = getattr(observation_space.spaces[self.goal_uuid], "n", 12)
         self.handle = PolicyHandle(in_channels=rs[0], spatial=rs[1], hidden=hidden_size, goal_dims=goal_dims,
                                    num_goals=num_goals, num_actions=action_space.n,
                                    compress_hid=resnet_compressor_hidden_out_dims[0],
                                    compress_out=resnet_compressor_hidden_out_dims[1],
-                                   comb_hid=combiner_hidden_out_dims[0], comb_out=combiner_hidden_out_dims[1])
+                                   comb_hid=combiner_hidden_out_dims[0], comb_out=combiner_hidden_out_dims[1],
+                                   dual=int(self.dual))
         dev = torch.device(device)
         if state_dict is None:
             from .synthetic import policy_state_dict
@@ -234,7 +247,7 @@ class ResnetTensorObjectNavActorCritic(ActorCriticModel):
     # -- flat bucket maintenance -----------------------------------------------------------------
     def _named(self):
         d = dict(self.named_parameters())
-        return [(n, d[n]) for n in POLICY_PARAM_ORDER]
+        return [(n, d[n]) for n in self.handle.param_order]
 
     def _bind_grads(self):
         """(Re)bind every ``p.grad`` to its view of the flat gradient bucket.  ``optimizer.zero_grad()`` of recent
@@ -296,21 +309,28 @@ class ResnetTensorObjectNavActorCritic(ActorCriticModel):
         ``ClipResNetPreprocessor.process_bf16_nhwc``); observations[goal_uuid]: [T,N] int;
         memory 'rnn': [1,N,H]; masks: [T,N,1].  -> (ActorCriticOutput, Memory)."""
         self.ensure_flat()
-        feat = observations[self.resnet_uuid]
         goal = observations[self.goal_uuid]
         T, N = masks.shape[:2]
         c = self.handle.cfg
-        if feat.shape[-1] == c["in_channels"] and feat.shape[-2] == c["spatial"]:
-            rows = feat.reshape(T * N, c["spatial"] ** 2, c["in_channels"]).contiguous()
-        else:   # the reference's NCHW layout -> NHWC rows (lossless re-layout)
-            rows = feat.reshape(T * N, c["in_channels"], -1).transpose(1, 2).contiguous()
-        if rows.dtype not in (torch.bfloat16, torch.float32):
-            rows = rows.float()
+
+        def to_rows(feat):
+            if feat.shape[-1] == c["in_channels"] and feat.shape[-2] == c["spatial"]:
+                rows = feat.reshape(T * N, c["spatial"] ** 2, c["in_channels"]).contiguous()
+            else:   # the reference's NCHW layout -> NHWC rows (lossless re-layout)
+                rows = feat.reshape(T * N, c["in_channels"], -1).transpose(1, 2).contiguous()
+            return rows if rows.dtype in (torch.bfloat16, torch.float32) else rows.float()
+
+        rows = to_rows(observations[self.resnet_uuid])
+        rows2 = None
+        if self.dual:
+            rows2 = to_rows(observations[self.depth_uuid])
+            if rows2.dtype != rows.dtype:
+                rows, rows2 = rows.float(), rows2.float()
         goal = goal.reshape(T * N).to(torch.int64).contiguous()
         h0 = memory.tensor("rnn").reshape(N, self._hidden_size).to(torch.float32).contiguous()
         m = masks.reshape(T * N).to(torch.float32).contiguous()
         params = [p for _, p in self._named()]
-        hv, h_final = _PolicyFn.apply(self.handle, self, self._flat, rows, goal, h0, m, T, N, *params)
+        hv, h_final = _PolicyFn.apply(self.handle, self, self._flat, rows, rows2, goal, h0, m, T, N, *params)
         A = self.handle.A
         hv = hv.view(T, N, A + 1)
         out = ActorCriticOutput(distributions=CategoricalDistr(logits=hv[..., :A]), values=hv[..., A:], extras={})

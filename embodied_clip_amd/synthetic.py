@@ -252,11 +252,35 @@ POLICY_PARAM_ORDER: Tuple[str, ...] = (
 )
 
 
+# [U] ResnetDualTensorGoalEncoder (RGB + depth, ``dual=1``): the same flat layout with the RGB stream's compressor /
+# combiner in the single encoder's slots and the depth stream's eight tensors appended after the heads
+_DUAL_RGB = {k: k.replace("resnet_compressor", "rgb_resnet_compressor").replace("target_obs_combiner", "rgb_target_obs_combiner")
+             for k in POLICY_PARAM_ORDER[1:9]}
+POLICY_PARAM_ORDER_DUAL: Tuple[str, ...] = tuple(_DUAL_RGB.get(k, k) for k in POLICY_PARAM_ORDER) + tuple(
+    k.replace("resnet_compressor", "depth_resnet_compressor").replace("target_obs_combiner", "depth_target_obs_combiner")
+    for k in POLICY_PARAM_ORDER[1:9])
+
+
+def policy_param_order(dual: int = 0) -> Tuple[str, ...]:
+    return POLICY_PARAM_ORDER_DUAL if dual else POLICY_PARAM_ORDER
+
+
 def policy_param_shapes(in_channels: int = 2048, spatial: int = 7, hidden: int = 512, goal_dims: int = 32,
                         num_goals: int = 12, num_actions: int = 6, compress_hid: int = 128,
-                        compress_out: int = 32, comb_hid: int = 128, comb_out: int = 32, fusion: int = 0):
+                        compress_out: int = 32, comb_hid: int = 128, comb_out: int = 32, fusion: int = 0, dual: int = 0):
     """``fusion=1`` (zero-shot dual-encoder policy): the goal-embedding / compressor / combiner tensors have zero
-    elements and the GRU reads the ``in_channels``-wide fused embedding."""
+    elements and the GRU reads the ``in_channels``-wide fused embedding.  ``dual=1``: RGB + depth streams (25 tensors,
+    GRU input 2 * comb_out * spatial^2)."""
+    if dual:
+        assert not fusion
+        one = policy_param_shapes(in_channels, spatial, hidden, goal_dims, num_goals, num_actions, compress_hid, compress_out,
+                                  comb_hid, comb_out)
+        vals = list(one.values())
+        out = OrderedDict(zip(POLICY_PARAM_ORDER_DUAL[:17], vals))
+        out["state_encoder.rnn.weight_ih_l0"] = (3 * hidden, 2 * comb_out * spatial * spatial)
+        for k, v in zip(POLICY_PARAM_ORDER_DUAL[17:], vals[1:9]):
+            out[k] = v
+        return out
     flat = comb_out * spatial * spatial
     if fusion:
         z = (0,)

@@ -236,6 +236,11 @@ typedef struct {
                         *    image embeddings, goal_table = frozen CLIP text embeddings (ec_policy_set_goal_table);
                         *    spatial must be 1, the compressor/combiner fields are ignored and those nine parameter
                         *    tensors have zero elements (the trainable part is GRU + heads) */
+    int dual;          /* 1: RGB + depth, [U] ResnetDualTensorGoalEncoder (readme_files/baselines_habitat.md:75 "replace rgb
+                        *    with rgbd"): two feature tensors, each with its own compressor / combiner (the goal embedding is
+                        *    shared), rgb_x and depth_x concatenated along channels before nn.Flatten -> GRU input
+                        *    2 * comb_out * spatial^2.  Eight more parameter tensors (the depth stream's, after the 17 of
+                        *    the single encoder); use ec_policy_forward2 / ec_policy_backward2.  Not combinable with fusion */
 } ec_policy_cfg;
 typedef struct ec_policy ec_policy_t;
 
@@ -260,11 +265,19 @@ enum { EC_POLICY_INFER = 0, EC_POLICY_LEARN = 1, EC_POLICY_INFER_REUSE = 2 };
 int ec_policy_forward(const ec_policy_t* h, const float* params, const void* feat, int feat_bf16,
                       const int64_t* goal, const float* h0, const float* masks, int T, int N,
                       void* workspace, size_t ws_bytes, int for_backward, float* hv, float* h_final, ec_stream_t stream);
+/* dual == 1: feat = the RGB preprocessor's features, feat2 = the depth preprocessor's (same shape and dtype); with
+ * dual == 0 feat2 is ignored (ec_policy_forward == ec_policy_forward2 with feat2 = NULL). */
+int ec_policy_forward2(const ec_policy_t* h, const float* params, const void* feat, const void* feat2, int feat_bf16,
+                       const int64_t* goal, const float* h0, const float* masks, int T, int N,
+                       void* workspace, size_t ws_bytes, int for_backward, float* hv, float* h_final, ec_stream_t stream);
 /* dhv f32 [T*N, A+1] = dLoss/dhv; dh_final [N,H] or NULL; grads += dLoss/dparams.
  * `workspace` must be the one the matching ec_policy_forward filled (for_backward size). */
 int ec_policy_backward(const ec_policy_t* h, const float* params, const void* feat, int feat_bf16,
                        const float* masks, int T, int N, void* workspace, size_t ws_bytes, const float* dhv,
                        const float* dh_final, float* grads, ec_stream_t stream);
+int ec_policy_backward2(const ec_policy_t* h, const float* params, const void* feat, const void* feat2, int feat_bf16,
+                        const float* masks, int T, int N, void* workspace, size_t ws_bytes, const float* dhv,
+                        const float* dh_final, float* grads, ec_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Rollout post-processing and the PPO update ([U] allenact onpolicy_sync:

@@ -41,6 +41,26 @@ def goal_encoder(feat: torch.Tensor, goal: torch.Tensor, sd: Dict[str, torch.Ten
     return x.reshape(x.shape[0], -1)
 
 
+def dual_goal_encoder(rgb: torch.Tensor, depth: torch.Tensor, goal: torch.Tensor, sd: Dict[str, torch.Tensor]) -> torch.Tensor:
+    """``ResnetDualTensorGoalEncoder.forward`` (same upstream file; the RGB-D variant the reference's Habitat readme
+    names: ``readme_files/baselines_habitat.md:75``): each stream runs its OWN compressor (``rgb_resnet_compressor`` /
+    ``depth_resnet_compressor``) and combiner (``rgb_target_obs_combiner`` / ``depth_target_obs_combiner``) on
+    ``cat([compressed, distribute_target(goal)], dim=1)`` with ONE shared ``embed_class``; the result is
+    ``cat([rgb_x, depth_x], dim=1)`` flattened C-major -> 2 * 32 * H * W.  Restated from the published source like the
+    single-tower encoder (parity unpinned).  rgb, depth: [B, C, H, W]; goal: [B] -> [B, 64*H*W]."""
+    emb = F.embedding(goal, sd[P + "embed_class.weight"])
+    outs = []
+    for tag, feat in (("rgb_", rgb), ("depth_", depth)):
+        x = F.relu(F.conv2d(feat, sd[P + tag + "resnet_compressor.0.weight"], sd[P + tag + "resnet_compressor.0.bias"]))
+        x = F.relu(F.conv2d(x, sd[P + tag + "resnet_compressor.2.weight"], sd[P + tag + "resnet_compressor.2.bias"]))
+        e = emb.view(emb.shape[0], emb.shape[1], 1, 1).expand(-1, -1, x.shape[-2], x.shape[-1])
+        x = torch.cat([x, e], dim=1)
+        x = F.relu(F.conv2d(x, sd[P + tag + "target_obs_combiner.0.weight"], sd[P + tag + "target_obs_combiner.0.bias"]))
+        outs.append(F.conv2d(x, sd[P + tag + "target_obs_combiner.2.weight"], sd[P + tag + "target_obs_combiner.2.bias"]))
+    x = torch.cat(outs, dim=1)
+    return x.reshape(x.shape[0], -1)
+
+
 def gru_cell(x, h, w_ih, w_hh, b_ih, b_hh):
     """torch.nn.GRU cell, gate order (r, z, n):
     r = s(W_ir x + b_ir + W_hr h + b_hr); z likewise;
@@ -75,8 +95,14 @@ def actor_critic_forward(feat: torch.Tensor, goal: torch.Tensor, h0: torch.Tenso
     """``ResnetTensorObjectNavActorCritic.forward``.
     feat: [T, N, C, H, W] fp32; goal: [T, N] int64; h0: [1, N, hidden];
     masks: [T, N, 1].  Returns (logits [T,N,A], values [T,N,1], h [1,N,hidden])."""
-    T, N = feat.shape[:2]
-    x = goal_encoder(feat.reshape(T * N, *feat.shape[2:]), goal.reshape(T * N), sd).view(T, N, -1)
+    if isinstance(feat, (tuple, list)):           # RGB-D: (rgb features, depth features) -> ResnetDualTensorGoalEncoder
+        rgb, depth = feat
+        T, N = rgb.shape[:2]
+        x = dual_goal_encoder(rgb.reshape(T * N, *rgb.shape[2:]), depth.reshape(T * N, *depth.shape[2:]),
+                              goal.reshape(T * N), sd).view(T, N, -1)
+    else:
+        T, N = feat.shape[:2]
+        x = goal_encoder(feat.reshape(T * N, *feat.shape[2:]), goal.reshape(T * N), sd).view(T, N, -1)
     out, h = rnn_state_encoder(x, h0, masks, sd)
     logits = F.linear(out, sd["actor.linear.weight"], sd["actor.linear.bias"])
     values = F.linear(out, sd["critic.fc.weight"], sd["critic.fc.bias"])

@@ -87,7 +87,7 @@ def test_constructor_contracts_without_a_gpu():
     assert max(abs(a - b) for a, b in zip(p.CLIP_RGB_MEANS, (0.48145466, 0.4578275, 0.40821073))) < 1e-8
     assert issubclass(ResnetTensorObjectNavActorCritic, ActorCriticModel) and issubclass(PPO, AbstractActorCriticLoss)
     obs = spaces.Dict({"rgb_clip_resnet": spaces.Box(-1, 1, (2048, 7, 7)), "goal": spaces.Discrete(12)})
-    with pytest.raises(NotImplementedError):     # RGB-D dual tower: not built, and it says so
+    with pytest.raises(ValueError):              # RGB-D dual tower: its depth tensor must be in the observation space
         ResnetTensorObjectNavActorCritic(spaces.Discrete(6), obs, "goal", "rgb_clip_resnet", "depth_clip_resnet")
     with pytest.raises(ValueError):
         ResnetTensorObjectNavActorCritic(spaces.Discrete(6), obs, "goal")

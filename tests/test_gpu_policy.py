@@ -323,6 +323,45 @@ def test_actor_critic_module_autograd_surface(dev):
     assert model.flat_grads.abs().sum() > 0          # grads landed in the single flat bucket
 
 
+def test_dual_rgbd_actor_critic_module_surface(dev):
+    """The drop-in module with BOTH preprocessor uuids = [U] ResnetDualTensorGoalEncoder: upstream's parameter names,
+    fp32 NCHW observations of both towers, autograd-visible forward, gradients vs the oracle."""
+    from embodied_clip_amd import spaces
+    from embodied_clip_amd.policy import Memory, ResnetTensorObjectNavActorCritic
+    from embodied_clip_amd.ppo import PPO
+    T, N, C, S, H = 3, 4, 64, 3, 32
+    sd = syn.policy_state_dict(21, in_channels=C, spatial=S, hidden=H, dual=1)
+    g = torch.Generator().manual_seed(22)
+    rgb, depth = torch.randn(T, N, C, S, S, generator=g).abs(), torch.randn(T, N, C, S, S, generator=g).abs()
+    goal = syn.synthetic_goals(23, (T, N))
+    h0 = torch.randn(1, N, H, generator=g) * 0.5
+    masks = syn.synthetic_masks(24, T, N, p_reset=0.2)
+    obs_space = spaces.Dict({"rgb_clip_resnet": spaces.Box(-1e9, 1e9, (C, S, S)), "depth_clip_resnet": spaces.Box(-1e9, 1e9, (C, S, S)),
+                             "goal": spaces.Discrete(12)})
+    model = ResnetTensorObjectNavActorCritic(spaces.Discrete(6), obs_space, "goal", "rgb_clip_resnet", "depth_clip_resnet",
+                                             hidden_size=H, state_dict=sd, device=dev)
+    names = [n for n, _ in model.named_parameters()]
+    assert sorted(names) == sorted(syn.POLICY_PARAM_ORDER_DUAL) and len(names) == 25
+    assert "goal_visual_encoder.depth_target_obs_combiner.2.bias" in names and "goal_visual_encoder.rgb_resnet_compressor.0.weight" in names
+    mem = Memory().check_append("rnn", h0.to(dev), 1)
+    out, mem2 = model({"rgb_clip_resnet": rgb.to(dev), "depth_clip_resnet": depth.to(dev), "goal": goal.to(dev)}, mem, None,
+                      masks.to(dev))
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    lg, vv, hf = opol.actor_critic_forward((rgb, depth), goal, h0, masks, leaves)
+    assert _rel(out.distributions.logits, torch.log_softmax(lg, -1)) < 2e-5 and _rel(out.values, vv) < 2e-5
+    assert _rel(mem2.tensor("rnn"), hf) < 2e-5
+    actions, old_lp, old_v, returns, nadv = _loss_inputs(T, N, 25)
+    batch = dict(actions=actions.to(dev), old_action_log_probs=old_lp.to(dev), values=old_v.to(dev),
+                 returns=returns.to(dev), norm_adv_targ=nadv.to(dev), adv_targ=nadv.to(dev))
+    total, _ = PPO().loss(0, batch, out)
+    total.backward()
+    tref, _ = oppo.ppo_loss(lg, vv, actions, old_lp, old_v, returns, nadv)
+    tref.backward()
+    assert abs(float(total.detach()) - float(tref.detach())) < 1e-5
+    for n, p in model.named_parameters():
+        assert p.grad is not None and _rel(p.grad, leaves[n].grad) < 2e-4, n
+
+
 def test_ppo_variants_unclipped_value_loss_clip_decay_and_bad_actions(dev):
     """PPO options behind the reference's configs ([U] losses/ppo.py): use_clipped_value_loss=False,
     clip_param * clip_decay(step_count), and loud failure on an out-of-range action id."""
@@ -434,3 +473,64 @@ def test_allenact_engine_call_sequence(dev):
     for n, p in model.named_parameters():
         upd, upd_ref = p.detach().cpu() - sd[n], sd_ref[n] - sd[n]
         assert (upd - upd_ref).abs().max() < 0.15 * 2 * 3e-4 + 1e-7, n
+
+
+@pytest.mark.parametrize("T,N,bf16,S,C,H", [(5, 3, False, 3, 64, 32), (3, 5, True, 7, 64, 32), (4, 19, True, 7, 256, 512),
+                                            (1, 6, True, 7, 64, 32)])
+def test_dual_rgbd_policy_forward_backward_update_match_oracle(dev, T, N, bf16, S, C, H):
+    """[U] ResnetDualTensorGoalEncoder (RGB + depth; readme_files/baselines_habitat.md:75): ec_policy_cfg.dual = 1 --
+    two feature tensors, each stream with its own compressor / combiner, shared goal embedding, cat(rgb_x, depth_x)
+    flattened into the GRU.  Act step (inference plan), learn forward, PPO loss, backward, clip + Adam vs the oracle's
+    dual_goal_encoder through torch-CPU autograd; 25 parameter tensors."""
+    from embodied_clip_amd import ppo
+    from embodied_clip_amd.policy import PolicyHandle
+    cfg = dict(in_channels=C, spatial=S, hidden=H, dual=1)
+    sd = syn.policy_state_dict(11, **cfg)
+    assert len(sd) == 25 and sd["state_encoder.rnn.weight_ih_l0"].shape == (3 * H, 2 * 32 * S * S)
+    g = torch.Generator().manual_seed(12)
+    rgb = torch.randn(T, N, C, S, S, generator=g).abs()
+    depth = torch.randn(T, N, C, S, S, generator=g).abs() * 0.7
+    if bf16:
+        rgb, depth = rgb.to(torch.bfloat16).float(), depth.to(torch.bfloat16).float()
+    goal = syn.synthetic_goals(13, (T, N))
+    h0 = torch.randn(1, N, H, generator=g) * 0.5
+    masks = syn.synthetic_masks(14, T, N, p_reset=0.2)
+    actions, old_lp, old_v, returns, nadv = _loss_inputs(T, N, 15)
+    with torch.no_grad():
+        lg, vv, hf_ref = opol.actor_critic_forward((rgb, depth), goal, h0, masks, sd)
+        old_lp = opol.categorical_log_prob(lg, actions).unsqueeze(-1) + 0.2 * torch.randn(T, N, 1)
+        old_v = vv + 0.2 * torch.randn(T, N, 1)
+    h = PolicyHandle(**cfg)
+    assert len(h.offsets) == 25
+    flat = h.flatten(sd, dev)
+    to_rows = lambda f: (lambda r: (r.to(torch.bfloat16) if bf16 else r).to(dev))(
+        f.permute(0, 1, 3, 4, 2).reshape(T * N, S * S, C).contiguous())
+    r1, r2 = to_rows(rgb), to_rows(depth)
+    m = masks.reshape(-1).to(dev)
+    gl, h0d = goal.reshape(-1).to(dev), h0[0].contiguous().to(dev)
+    # inference plan (the act step's kernels)
+    wsi = torch.empty(h.workspace_bytes(T, N, False), dtype=torch.uint8, device=dev)
+    hv_i, hf_i = h.forward(flat, r1, gl, h0d, m, T, N, wsi, for_backward=False, feat2=r2)
+    torch.cuda.synchronize()
+    assert _rel(hv_i.view(T, N, -1)[..., :6], lg) < 2e-5 and _rel(hv_i.view(T, N, -1)[..., 6:], vv) < 2e-5
+    assert _rel(hf_i, hf_ref[0]) < 2e-5
+    # learn pass + one optimiser step
+    sd_ref = {k: v.clone() for k, v in sd.items()}
+    batch = dict(feat=(rgb, depth), goal=goal, h0=h0, masks=masks, actions=actions, old_log_probs=old_lp, old_values=old_v,
+                 returns=returns, norm_adv=nadv)
+    info, ref_grads = oppo.ppo_update_step(sd_ref, batch, {}, lr=3e-4, max_grad_norm=0.5)
+    ws = torch.empty(h.workspace_bytes(T, N, True), dtype=torch.uint8, device=dev)
+    hv, _ = h.forward(flat, r1, gl, h0d, m, T, N, ws, feat2=r2)
+    f = lambda t: t.reshape(-1).contiguous().to(dev)
+    dhv, sums = ppo.ppo_loss_raw(hv, f(actions), f(old_lp), f(old_v), f(returns), f(nadv), 6)
+    grads = torch.zeros_like(flat)
+    h.backward(flat, r1, m, T, N, ws, dhv, None, grads, feat2=r2)
+    torch.cuda.synchronize()
+    assert torch.equal(hv, hv_i) or _rel(hv, hv_i) < 1e-5         # (the two plans sum K in different orders)
+    total = ((sums[0] + 0.5 * sums[1] + 0.01 * sums[2]) / (T * N)).item()
+    assert abs(total - info["ppo_total"]) < 1e-5 * max(1.0, abs(info["ppo_total"]))
+    gv = h.views(grads)
+    for name, gref in ref_grads.items():
+        assert _rel(gv[name], gref) < 2e-4, (name, _rel(gv[name], gref))
+    with pytest.raises(Exception):                                 # the depth features are mandatory for a dual handle
+        h.forward(flat, r1, gl, h0d, m, T, N, ws)

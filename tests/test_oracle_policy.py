@@ -90,3 +90,29 @@ def test_recurrent_minibatch_ranges_restates_allenact_generator():
         got = oppo.recurrent_minibatch_ranges(N, M, random.Random(11))
         assert got == want
         assert sorted(got)[0][0] == 0 and sorted(got)[-1][1] == N and sum(b - a for a, b in got) == N
+
+
+def test_dual_goal_encoder_is_two_single_towers_sharing_the_goal_embedding():
+    """oracle.dual_goal_encoder ([U] ResnetDualTensorGoalEncoder): cat(rgb_x, depth_x) of two goal_encoder passes whose
+    compressor / combiner weights are the dual state dict's rgb_* / depth_* entries; parameter order and count of the
+    dual layout (25 tensors, GRU input 2 * 32 * S * S)."""
+    import torch
+    from embodied_clip_amd import synthetic as syn
+    from oracle import policy as opol
+    C, S, H = 16, 3, 8
+    sd = syn.policy_state_dict(3, in_channels=C, spatial=S, hidden=H, dual=1)
+    assert tuple(sd.keys()) == syn.POLICY_PARAM_ORDER_DUAL and len(sd) == 25
+    assert sd["state_encoder.rnn.weight_ih_l0"].shape == (3 * H, 2 * 32 * S * S)
+    g = torch.Generator().manual_seed(4)
+    rgb, depth = torch.randn(5, C, S, S, generator=g), torch.randn(5, C, S, S, generator=g)
+    goal = torch.randint(0, 12, (5,), generator=g)
+    x = opol.dual_goal_encoder(rgb, depth, goal, sd)
+    P = "goal_visual_encoder."
+    parts = []
+    for tag, feat in (("rgb_", rgb), ("depth_", depth)):
+        one = {P + "embed_class.weight": sd[P + "embed_class.weight"]}
+        for k in ("resnet_compressor.0", "resnet_compressor.2", "target_obs_combiner.0", "target_obs_combiner.2"):
+            for wb in ("weight", "bias"):
+                one[P + k + "." + wb] = sd[P + tag + k + "." + wb]
+        parts.append(opol.goal_encoder(feat, goal, one).view(5, 32, S * S))
+    assert torch.equal(x, torch.cat(parts, dim=1).reshape(5, -1))
