@@ -32,6 +32,7 @@ SIGNATURES = {
     "ec_stem_conv1": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
     "ec_avgpool2_bf16": (c_int, [c_void_p] * 2 + [c_int] * 4 + [c_void_p]),
     "ec_nhwc_bf16_to_nchw_f32": (c_int, [c_void_p] * 2 + [c_int] * 3 + [c_void_p]),
+    "ec_nchw_f32_to_nhwc_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ec_spatial_mean_bf16": (c_int, [c_void_p] * 2 + [c_int] * 3 + [c_void_p]),
     "ec_rn50_create": (c_int, [C.POINTER(c_void_p), c_int, C.POINTER(c_int), c_int, c_void_p, c_void_p, c_size_t,
                                c_void_p, c_size_t]),

@@ -302,6 +302,43 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const uint16_t* __res
     }
 }
 
+// The inverse, for the drop-in policy module's learn pass: fp32 [B, C, HW] (the reference's tensor contract) -> bf16 [B, HW, C]
+// rows, the operand format of the fast compressor kernels -- used ONLY when every value is exactly a bf16 (what
+// ClipResNetPreprocessor.process returns: the trunk's bf16 output widened), which this kernel checks while it converts:
+// *inexact is OR-ed with 1 as soon as one element does not survive the round trip (the caller then keeps the fp32 path).
+__global__ __launch_bounds__(256) void nchw_to_nhwc_bf16_kernel(const float* __restrict__ in, uint16_t* __restrict__ out,
+                                                               int HW, int C, int* __restrict__ inexact) {
+    extern __shared__ float tile[];   // [HW][TC+1]
+    const int slabs = C / TC;
+    const int b = blockIdx.x / slabs, c0 = (blockIdx.x % slabs) * TC;
+    const float* src = in + ((long)b * C + c0) * HW;          // the slab's [TC][HW] floats are contiguous
+    int bad = 0;
+    for (int e = threadIdx.x; e < HW * TC; e += 256) {
+        const int c = e / HW, hw = e % HW;
+        const float v = src[e];
+        bad |= (ec_bf2f(ec_f2bf(v)) != v) && (v == v);         // (NaNs are left to the consumer)
+        tile[hw * (TC + 1) + c] = v;
+    }
+    __syncthreads();
+    uint16_t* dst = out + (long)b * HW * C + c0;
+    for (int e = threadIdx.x; e < HW * TC; e += 256) {
+        const int hw = e / TC, c = e % TC;
+        dst[(long)hw * C + c] = ec_f2bf(tile[hw * (TC + 1) + c]);
+    }
+    if (__builtin_amdgcn_ballot_w64(bad != 0) != 0 && (threadIdx.x & 63) == 0) atomicOr(inexact, 1);
+}
+
+extern "C" int ec_nchw_f32_to_nhwc_bf16(const float* in, void* out, int B, int HW, int C, int* inexact, ec_stream_t stream) {
+    if (!in || !out || !inexact) return EC_ERR_ARG;
+    if (B <= 0 || HW <= 0 || C % TC != 0) return EC_ERR_SHAPE;
+    const size_t lds = (size_t)HW * (TC + 1) * sizeof(float);
+    if (lds > 64 * 1024) return EC_ERR_SHAPE;
+    hipLaunchKernelGGL(nchw_to_nhwc_bf16_kernel, dim3((unsigned)(B * (C / TC))), dim3(256), lds, (hipStream_t)stream, in,
+                       (uint16_t*)out, HW, C, inexact);
+    EC_CHECK_LAUNCH();
+    return EC_OK;
+}
+
 // mean over HW of bf16 [B, HW, C] -> fp32 [B, C]
 __global__ __launch_bounds__(256) void spatial_mean_kernel(const uint16_t* __restrict__ in, float* __restrict__ out,
                                                           int HW, int C, long total) {

@@ -285,6 +285,37 @@ class ResnetTensorObjectNavActorCritic(ActorCriticModel):
         self.ensure_flat()
         return self._flat_grad
 
+    # -- learn-pass feature rows ------------------------------------------------------------------
+    def _bf16_rows(self, feat: torch.Tensor, T: int, N: int, slot: int = 0):
+        """Learn pass over the reference's fp32 NCHW rollout storage: ``ClipResNetPreprocessor.process`` returns the
+        trunk's bf16 features widened to fp32, so the storage holds values that ARE bf16 -- for such a tensor the rows
+        go to the kernels as bf16 NHWC (half the bytes, the 8-wave compressor kernel and the transpose-read weight-gradient
+        kernel instead of the generic fp32-operand GEMMs; the products are the same numbers).  ``ec_nchw_f32_to_nhwc_bf16``
+        checks exactness while it converts; anything else keeps the fp32 path (returns None).  The converted rows are kept
+        while the SAME storage (base tensor, view geometry, version counter) comes back: the update epochs of a rollout."""
+        import weakref
+        if (feat.dtype != torch.float32 or not feat.is_cuda or not feat.is_contiguous() or feat.requires_grad
+                or feat.dim() != 5 or self.handle.cfg["in_channels"] % 64 != 0):
+            return None
+        base = feat._base if feat._base is not None else feat
+        key = (feat.data_ptr(), tuple(feat.shape), tuple(feat.stride()), base._version)
+        cache = getattr(self, "_rows_cache", None)
+        if cache is None:
+            cache = self._rows_cache = {}
+        hit = cache.get(slot)
+        if hit is not None and hit[0]() is base and hit[1] == key:
+            return hit[2]
+        c = self.handle.cfg
+        rows = torch.empty((T * N, c["spatial"] ** 2, c["in_channels"]), dtype=torch.bfloat16, device=feat.device)
+        flag = torch.zeros(1, dtype=torch.int32, device=feat.device)
+        with _lib.tensor_guard(feat):
+            _lib.check(self.handle.lib.ec_nchw_f32_to_nhwc_bf16(feat.data_ptr(), rows.data_ptr(), T * N, c["spatial"] ** 2,
+                                                               c["in_channels"], flag.data_ptr(), _lib.stream_ptr()),
+                       "ec_nchw_f32_to_nhwc_bf16")
+        out = rows if int(flag.item()) == 0 else None          # (one host sync per rollout storage version)
+        cache[slot] = (weakref.ref(base), key, out)
+        return out
+
     # -- ActorCriticModel surface ----------------------------------------------------------------
     @property
     def recurrent_hidden_state_size(self) -> int:
@@ -313,17 +344,20 @@ class ResnetTensorObjectNavActorCritic(ActorCriticModel):
         T, N = masks.shape[:2]
         c = self.handle.cfg
 
-        def to_rows(feat):
+        def to_rows(feat, slot=0):
             if feat.shape[-1] == c["in_channels"] and feat.shape[-2] == c["spatial"]:
                 rows = feat.reshape(T * N, c["spatial"] ** 2, c["in_channels"]).contiguous()
             else:   # the reference's NCHW layout -> NHWC rows (lossless re-layout)
+                fast = self._bf16_rows(feat, T, N, slot) if (T > 1 and torch.is_grad_enabled()) else None
+                if fast is not None:
+                    return fast
                 rows = feat.reshape(T * N, c["in_channels"], -1).transpose(1, 2).contiguous()
             return rows if rows.dtype in (torch.bfloat16, torch.float32) else rows.float()
 
         rows = to_rows(observations[self.resnet_uuid])
         rows2 = None
         if self.dual:
-            rows2 = to_rows(observations[self.depth_uuid])
+            rows2 = to_rows(observations[self.depth_uuid], 1)
             if rows2.dtype != rows.dtype:
                 rows, rows2 = rows.float(), rows2.float()
         goal = goal.reshape(T * N).to(torch.int64).contiguous()

@@ -141,6 +141,10 @@ int ec_avgpool2_bf16(const void* in, void* out, int B, int H, int W, int C, ec_s
 /* bf16 NHWC [B,HW,C] -> fp32 NCHW [B,C,HW]: the `.float()` + layout the
  * reference exposes (thor_image_features.py:111; observation_space (2048,7,7)). */
 int ec_nhwc_bf16_to_nchw_f32(const void* in, float* out, int B, int HW, int C, ec_stream_t stream);
+/* The inverse for a consumer that holds the reference's fp32 NCHW tensors ([U] ResnetTensorObjectNavActorCritic.forward's
+ * observations): fp32 [B,C,HW] -> bf16 [B,HW,C]; *inexact (device int, zeroed by the caller) is OR-ed with 1 when some
+ * value is not exactly representable in bf16 -- the caller then keeps its fp32 path.  C % 64 == 0. */
+int ec_nchw_f32_to_nhwc_bf16(const float* in, void* out, int B, int HW, int C, int* inexact, ec_stream_t stream);
 
 /* AdaptiveAvgPool2d(1)+Flatten on the fp32-cast features
  * (thor_image_features.py:63-66,113; preprocessor pool=True). bf16 [B,HW,C] -> f32 [B,C]. */

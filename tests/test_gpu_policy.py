@@ -362,6 +362,45 @@ def test_dual_rgbd_actor_critic_module_surface(dev):
         assert p.grad is not None and _rel(p.grad, leaves[n].grad) < 2e-4, n
 
 
+def test_module_learn_pass_uses_bf16_rows_only_when_the_fp32_storage_holds_bf16_values(dev):
+    """The reference's tensor contract hands the policy fp32 NCHW features; ClipResNetPreprocessor's are bf16 values
+    widened to fp32.  In the learn pass (T > 1, grad enabled) the module converts such a storage ONCE per version to bf16
+    NHWC rows (ec_nchw_f32_to_nhwc_bf16 checks exactness while converting) and re-uses them for the following epochs; a
+    storage with any other value keeps the fp32 path.  Results match the oracle either way."""
+    from embodied_clip_amd import spaces
+    from embodied_clip_amd.policy import Memory, ResnetTensorObjectNavActorCritic
+    T, N = 4, 3
+    cfg, sd, feat, goal, h0, masks = _policy_case(T, N, C=64, S=3, H=32, seed=31, bf16=True)   # bf16-exact fp32 values
+    obs_space = spaces.Dict({"rgb_clip_resnet": spaces.Box(-1e9, 1e9, (64, 3, 3)), "goal": spaces.Discrete(12)})
+    model = ResnetTensorObjectNavActorCritic(spaces.Discrete(6), obs_space, "goal", "rgb_clip_resnet", hidden_size=32,
+                                             state_dict=sd, device=dev)
+    storage = torch.zeros(T + 1, N, 64, 3, 3, device=dev)
+    storage[:T] = feat.to(dev)
+    fresh = lambda: Memory().check_append("rnn", h0.to(dev), 1)      # (Memory.set_tensor updates the object it is given)
+    ref_logits, ref_values, _ = opol.actor_critic_forward(feat, goal, h0, masks, sd)
+
+    def run():
+        out, _ = model({"rgb_clip_resnet": storage[:T], "goal": goal.to(dev)}, fresh(), None, masks.to(dev))
+        assert _rel(out.distributions.logits, torch.log_softmax(ref_logits, -1)) < 2e-5 and _rel(out.values, ref_values) < 2e-5
+        return out
+
+    run()
+    first = model._rows_cache[0][2]
+    assert first is not None and first.dtype == torch.bfloat16 and first.shape == (T * N, 9, 64)
+    out = run()                                            # second epoch: the same storage version -> the same rows
+    assert model._rows_cache[0][2] is first
+    out.values.sum().backward()                            # (the bf16 rows feed the backward too)
+    assert all(p.grad is not None for p in model.parameters())
+    with torch.no_grad():                                  # act steps never take this path
+        model({"rgb_clip_resnet": storage[:1], "goal": goal[:1].to(dev)}, fresh(), None, masks[:1].to(dev))
+    assert model._rows_cache[0][2] is first
+    storage[0, 0, 0, 0, 0] += 1e-3                         # not a bf16 any more (and a new storage version)
+    feat2 = storage[:T].cpu()
+    ref_logits, ref_values, _ = opol.actor_critic_forward(feat2, goal, h0, masks, sd)
+    run()
+    assert model._rows_cache[0][2] is None                 # fp32 path
+
+
 def test_ppo_variants_unclipped_value_loss_clip_decay_and_bad_actions(dev):
     """PPO options behind the reference's configs ([U] losses/ppo.py): use_clipped_value_loss=False,
     clip_param * clip_decay(step_count), and loud failure on an out-of-range action id."""
