@@ -236,14 +236,16 @@ def test_gae_matches_oracle(dev):
 
 @pytest.mark.parametrize("T,N,bf16,S,C,H", [(6, 4, False, 3, 64, 32), (8, 4, True, 3, 64, 32), (3, 5, False, 7, 64, 32),
                                             (4, 37, True, 7, 64, 32), (3, 19, True, 7, 256, 32),
-                                            (4, 19, True, 7, 64, 512), (3, 33, False, 3, 64, 512), (2, 16, True, 7, 64, 512)])
+                                            (4, 19, True, 7, 64, 512), (3, 33, False, 3, 64, 512), (2, 16, True, 7, 64, 512),
+                                            (64, 16, True, 3, 64, 512)])
 def test_policy_backward_and_update_step_match_oracle(dev, T, N, bf16, S, C, H):
     """One full optimiser step of HOT LOOP B: forward, PPO loss, backward, clip, Adam.
     S = 7 is the reference's 7x7 feature map: the fused tail kernels (tail_fwd_kernel / tail_bwd_kernel) run there, with
     ragged last tiles (T*N*49 not a multiple of 32) and row groups straddling tiles; S = 3 keeps the GEMM path covered.
     C = 256 with bf16 features additionally takes dW1 through the transpose-read kernel (dc1 as bf16 planes).
     H = 512 (the reference's hidden size) runs the learn pass's recurrences on the 16 x 16-tile step kernels
-    (gru_step_fwd512_kernel / gru_step_bwd512_kernel): N = 19 / 33 leave ragged last actor tiles, N = 16 exactly one."""
+    (gru_step_fwd512_kernel / gru_step_bwd512_kernel): N = 19 / 33 leave ragged last actor tiles, N = 16 exactly one;
+    T * N = 1024 rows additionally takes the GRU's bias gradients through the 16-B column-sum kernel (colsum4_kernel)."""
     from embodied_clip_amd import ppo
     from embodied_clip_amd.policy import PolicyHandle
     cfg, sd, feat, goal, h0, masks = _policy_case(T, N, C=C, S=S, H=H, seed=7, bf16=bf16)
