@@ -143,6 +143,7 @@ struct EcConfig {
     int rn50_fuse;        // EC_RN50_FUSE     (1)   fused layer-1 / layer-2 block boundaries in the trunk plan
     int wih_perm;         // EC_WIH_PERM      (1)   learn pass: re-ordered weight_ih instead of activation transposes
     int conv8_dirb;       // EC_CONV8_DIRB    (0)   conv_igemm8: weight fragments global -> VGPR (only the im2col operand through LDS)
+    int conv8_longseg;    // EC_CONV8_LONGSEG (1)   conv_igemm8, 128-wide tiles: two segments per K-tile, three LDS stages
 };
 const EcConfig& ec_config();          // api.hip
 // conv_igemm.hip (internal): ec_conv_bf16 with an optional fragment-order copy of the weights (ec_pack_wfrag)

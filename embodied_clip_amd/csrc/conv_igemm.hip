@@ -602,6 +602,14 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
     constexpr int A_IT = BM / LR, B_IT = BN / LR;
     constexpr int A_BYTES = BM * ROW_BYTES, B_BYTES = BN * ROW_BYTES, STAGE = A_BYTES + B_BYTES;
     static_assert(FN >= 1 && B_IT >= 1, "BN must be 128 or 256");
+    // ABL bit 512 (production variant of the 128-wide tiles): LONG SEGMENTS -- a wave reads the fragments of a WHOLE K-tile
+    // in one memory segment and issues its 4 FM FN MFMAs in one compute segment: two barrier-separated segments per K-tile
+    // instead of four.  Every segment costs ~350 clk of barrier skew / waits / issue on top of its MFMAs (measured: period =
+    // 4 x (512 + 350) clk with 256-wide tiles, 4 x (256 + 350) with 128-wide ones), so the 128-wide tile, whose segments
+    // are only 8 MFMAs long, pays the most.  Needs three LDS stages (K-tile kt + 2 is fetched while kt computes: with two
+    // segments per K-tile a distance-1 prefetch would have to be waited for in the segment that issues it) and twice the
+    // fragment registers -- which only the 128-wide tile (64 accumulator registers) has.
+    constexpr bool LS = (ABL & 512) != 0 && BN == 128;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const unsigned long long t_entry = (ABL & 32) ? __builtin_amdgcn_s_memtime() : 0ull;   // profiling only
@@ -663,7 +671,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
     // piece q of K-tile kt into stage buf: q < A_IT -> 8 pixel rows per wave, else 8 weight rows
     int g_toff = 0; unsigned g_tapbit = 1u; int g_kb = 0;
     unsigned char* g_sa = smem; unsigned char* g_sb = smem; bool g_issue_a = true;
-    auto glds_begin = [&](int kt, int buf) {
+    auto glds_begin = [&](int kt, int buf) {            // buf: LDS stage of K-tile kt (kt & 1; kt % 3 with long segments)
         g_sa = smem + buf * STAGE + wave_lds;
         g_sb = g_sa + A_BYTES;
         g_kb = kt * (BK * 2);
@@ -677,7 +685,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
             g_toff = ch * (BK * 2);
             g_kb = (pl * p.K + ch * BK) * 2;
             g_sa = smem + (ch & 1) * A_BYTES + wave_lds;
-            g_sb = smem + 2 * A_BYTES + (kt & 1) * B_BYTES + wave_lds;
+            g_sb = smem + 2 * A_BYTES + (LS ? buf : (kt & 1)) * B_BYTES + wave_lds;
             g_issue_a = (kt == 3 * ch);
         }
         if (KS == 3) {
@@ -748,23 +756,24 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
     for (int j = 0; j < FN; ++j) fb_base[j] = A_BYTES + (wn * TN + j * 32 + frow) * ROW_BYTES;
     const int fsw = (frow >> 1) & 7;
 
-    s16x8_t fa[2][FM], fb[2][FN];
-    auto read_half = [&](int kt, auto hc) {             // fragments of k-steps 2h, 2h+1 of K-tile kt
+    s16x8_t fa[LS ? 4 : 2][FM], fb[LS ? 4 : 2][FN];     // (long segments: the four k-steps of a K-tile at once)
+    auto read_half = [&](int kt, int stg, auto hc) {    // fragments of k-steps 2h, 2h+1 of K-tile kt (LDS stage stg)
         constexpr int h = decltype(hc)::value;
-        const unsigned char* sta = smem + (kt & 1) * STAGE;
+        constexpr int fo = LS ? 2 * h : 0;
+        const unsigned char* sta = smem + stg * STAGE;
         const unsigned char* stb = sta;
         if (X3) {                                       // (fb_base carries + A_BYTES: see the LDS map in glds_begin)
             sta = smem + ((kt / 3) & 1) * A_BYTES;
-            stb = smem + A_BYTES + (kt & 1) * B_BYTES;
+            stb = smem + A_BYTES + stg * B_BYTES;
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int c = ((h * 2 + u) * 2 + fhalf) ^ fsw;
 #pragma unroll
-            for (int i = 0; i < FM; ++i) fa[u][i] = *reinterpret_cast<const s16x8_t*>(sta + fa_base[i] + (c << 4));
+            for (int i = 0; i < FM; ++i) fa[fo + u][i] = *reinterpret_cast<const s16x8_t*>(sta + fa_base[i] + (c << 4));
             if constexpr (!DB) {
 #pragma unroll
-                for (int j = 0; j < FN; ++j) fb[u][j] = *reinterpret_cast<const s16x8_t*>(stb + fb_base[j] + (c << 4));
+                for (int j = 0; j < FN; ++j) fb[fo + u][j] = *reinterpret_cast<const s16x8_t*>(stb + fb_base[j] + (c << 4));
             }
         }
     };
@@ -815,19 +824,21 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
     auto mfma16 = [&](auto issue_c, auto hc, int kt) {
         constexpr bool ISSUE = decltype(issue_c)::value;
         [[maybe_unused]] constexpr int H = decltype(hc)::value;
+        constexpr int fo = LS ? 2 * H : 0;              // fragment set; long segments: half of the pieces per call
+        constexpr int PN = LS ? (NPIECE + 1 - H) / 2 : NPIECE, PBASE = LS ? (H ? (NPIECE + 1) / 2 : 0) : 0;
         [&]<int... Q>(std::integer_sequence<int, Q...>) {
             ([&] {
                 constexpr int u = Q / (FM * FN), r = Q % (FM * FN), i = r / FN, j = r % FN;
                 if constexpr (!(ABL & 2))
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                        __builtin_bit_cast(bf16x8_t, DB ? fbd[H][u][j] : fb[u][j]), __builtin_bit_cast(bf16x8_t, fa[u][i]), acc[i][j], 0, 0, 0);
+                        __builtin_bit_cast(bf16x8_t, DB ? fbd[H][u][j] : fb[fo + u][j]), __builtin_bit_cast(bf16x8_t, fa[fo + u][i]), acc[i][j], 0, 0, 0);
                 if constexpr (DB && r == FM * FN - 1) {          // k-step u of this half is consumed: refill it for K-tile kt + 1
                     bload(kt + 1, H, u);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                constexpr int NP = NPIECE, EVERY = (2 * FM * FN) / NP;
-                if constexpr (ISSUE && Q % EVERY == EVERY - 1 && Q / EVERY < NP) {
-                    piece_pre(std::integral_constant<int, Q / EVERY>{});
+                constexpr int NP = PN, EVERY = (2 * FM * FN) / (NP > 0 ? NP : 1);
+                if constexpr (ISSUE && NP > 0 && Q % EVERY == EVERY - 1 && Q / EVERY < NP) {
+                    piece_pre(std::integral_constant<int, PBASE + Q / EVERY>{});
                     // keep one piece per EVERY MFMAs: left alone the scheduler clusters all of them behind the first MFMAs
                     // (measured: 64.6 vs 60.1 us on 3x3 256->256 @14x14, piece segment 1060 vs 852 clk)
                     __builtin_amdgcn_sched_barrier(0);
@@ -837,6 +848,11 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
     };
     using BT = std::true_type;
     using BF = std::false_type;
+    if constexpr (LS) {
+        // long segments: K-tile 1 is fetched by EVERY wave before the loop (K-tile kt + 2 is what a wave fetches during kt)
+        if (nk > 1) issue_all(1, 1);
+        if (grp) __builtin_amdgcn_s_barrier();          // stagger: group 1 runs one segment behind group 0
+    } else
     if (grp) {                                          // stagger: group 1 runs one segment behind group 0 ...
         if (nk > 1 && !(ABL & 1)) issue_all(1, 1);      // ... and uses the slot to fetch K-tile 1 (its "CMP1(-1)")
         if constexpr (!(ABL & 16)) __builtin_amdgcn_s_barrier();
@@ -855,7 +871,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
         constexpr bool ISSUE = decltype(ic)::value;
         const int cur = kt & 1;
         // ---- MEM0 ---- (group 0 also prepares the offsets of the pieces it issues in CMP0: K-tile kt+1 -> stage cur^1)
-        if constexpr (!(abl & 4)) read_half(kt, I0{});
+        if constexpr (!(abl & 4)) read_half(kt, cur, I0{});
         if constexpr (G == 0 && ISSUE) prep(kt + 1, cur ^ 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
@@ -871,7 +887,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
         if constexpr (!(abl & 16)) __builtin_amdgcn_s_barrier();
         stamp();
         // ---- MEM1 ---- (group 1 prepares the pieces of its CMP1: K-tile kt+2 -> stage cur)
-        if constexpr (!(abl & 4)) read_half(kt, I1{});
+        if constexpr (!(abl & 4)) read_half(kt, cur, I1{});
         if constexpr (G == 1 && ISSUE) prep(kt + 2, cur);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         // (DIRECT-B: the 2 FN fragment loads of the CMP segment in between are younger than the pieces and stay in flight)
@@ -902,8 +918,44 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
     // (a static s_setprio 1 for group 1 instead of the per-segment flips: -2..-5 % on single launches, but -4 % END TO END --
     //  a wave that stays at raised priority through its memory segments also wins arbitration against the OTHER stream's
     //  kernels; measured round 3, not kept)
+    // ---- long segments: [MEM(kt): all fragments of K-tile kt | wait for the pieces issued during K-tile kt - 1] barrier
+    //      [CMP(kt): 4 FM FN MFMAs, the wave's pieces of K-tile kt + 2 in their shadow] barrier.  Group 0 runs MEM(kt) in global
+    //      segment 2 kt, group 1 in 2 kt + 1.  RAW: a wave waits (vmcnt(0) at the end of MEM(kt)) for the pieces of K-tile
+    //      kt + 1 it issued in CMP(kt - 1); both groups have passed that wait and a barrier before group 0's MEM(kt + 1) at
+    //      2 kt + 2.  WAR: K-tile kt + 2 goes into the stage of kt - 1, last read in segment 2 kt - 1 (group 1's MEM(kt - 1));
+    //      the earliest issue is group 0's CMP(kt) at 2 kt + 1.  Same K walk, same accumulation order as the 4-segment loop.
+    auto ktile_ls = [&](int kt, int stg, int stg2, auto ic) {
+        constexpr bool ISSUE = decltype(ic)::value;
+        read_half(kt, stg, I0{});
+        read_half(kt, stg, I1{});
+        if constexpr (ISSUE) prep(kt + 2, stg2);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_setprio(1);
+        mfma16(std::bool_constant<ISSUE>{}, I0{}, kt);
+        mfma16(std::bool_constant<ISSUE>{}, I1{}, kt);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    };
+    if constexpr (LS) {
+        int stg = 0, stg2 = 2, kt = 0;                  // stages of K-tiles kt and kt + 2
+        for (; kt < nk - 2; ++kt) {
+            ktile_ls(kt, stg, stg2, BT{});
+            stg = (stg == 2) ? 0 : stg + 1;
+            stg2 = (stg2 == 2) ? 0 : stg2 + 1;
+        }
+        for (; kt < nk; ++kt) {
+            ktile_ls(kt, stg, stg2, BF{});
+            stg = (stg == 2) ? 0 : stg + 1;
+        }
+        if (!grp) __builtin_amdgcn_s_barrier();         // matches group 1's extra entry barrier
+    } else {
     if (grp) kloop(I1{}); else kloop(I0{});
     if (!grp && !(ABL & 16)) __builtin_amdgcn_s_barrier();   // matches group 1's extra entry barrier
+    }
     __syncthreads();                                    // every wave is done with the stages: LDS becomes the epilogue image
     const unsigned long long t_loop_end = (ABL & 32) ? __builtin_amdgcn_s_memtime() : 0ull;
     if constexpr ((abl & 32) != 0) if (dbg) {
@@ -998,7 +1050,10 @@ int launch8(const ConvArgs& a, hipStream_t s) {
     p.ntiles = ((a.M + 255) / 256) * p.ntn;
     const int ablate = ec_config().conv_ablate;
     p.ablate = ablate;
-    const size_t stages = 2 * (size_t)(256 + BN) * ROW_BYTES;
+    const bool ls = BN == 128 && ec_config().conv8_longseg;
+    // (long segments: three stages; X3: two A chunks + three plane tiles)
+    const size_t stages = ls ? (X3 ? (size_t)(2 * 256 + 3 * BN) * ROW_BYTES : 3 * (size_t)(256 + BN) * ROW_BYTES)
+                             : 2 * (size_t)(256 + BN) * ROW_BYTES;
     const size_t epi = X3 ? (size_t)128 * (BN * 4 + 16) : (size_t)(POOL ? 64 : 256) * (BN * 2 + 16);
     const size_t lds = (stages > epi ? stages : epi) + 4096;   // + stamp area (profiling)
     auto go = [&](auto kern) {
@@ -1035,6 +1090,13 @@ int launch8(const ConvArgs& a, hipStream_t s) {
     if constexpr (!X3 && BN == 256) {
         if (ec_config().conv8_dirb && a.wf) {
             go(conv_igemm8_kernel<BN, KS, POOL, 256, X3>);
+            EC_CHECK_LAUNCH();
+            return EC_OK;
+        }
+    }
+    if constexpr (BN == 128) {
+        if (ls) {
+            go(conv_igemm8_kernel<BN, KS, POOL, 512, X3>);
             EC_CHECK_LAUNCH();
             return EC_OK;
         }

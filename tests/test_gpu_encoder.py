@@ -520,3 +520,15 @@ def test_direct_b_variant_of_the_8wave_kernel_is_bit_identical(dev, tmp_path):
     got = torch.load(out)
     assert got["hash"] != base.plan_hash()              # the switch is part of the plan hash
     assert torch.equal(got["feat"], ref)
+
+
+def test_long_segment_variant_of_the_128_wide_8wave_tiles_is_bit_identical(dev, tmp_path):
+    """EC_CONV8_LONGSEG (default 1, round 3): the 128-wide tiles of conv_igemm8 run two barrier-separated segments per
+    K-tile (all fragments of a K-tile read at once, 16 MFMAs in one segment) out of three LDS stages instead of four
+    segments out of two -- a schedule change only: same K walk, same accumulation order, bit-identical outputs."""
+    cases = [(100, 28, 128, 128, 3, 0),    # layer-2 3x3 conv: 128-wide tiles, 18 K-tiles
+             (104, 56, 128, 128, 3, 1)]    # ... with the fused 2x2 average pool (layer 2, block 0)
+    new = _conv_in_child({}, cases, tmp_path, "ls1")
+    old = _conv_in_child({"EC_CONV8_LONGSEG": "0"}, cases, tmp_path, "ls0")
+    for c, a, b in zip(cases, new, old):
+        assert torch.equal(a, b), c
