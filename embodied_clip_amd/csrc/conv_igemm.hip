@@ -1128,6 +1128,10 @@ int dispatch_tile(const ConvArgs& a, hipStream_t s) {
         // sharing all of them (same-box A/B at 2 x 128 frames: +0.4..1.5 % RN50, +3.5 % ViT-B/32 end to end; at 2 x 64: -1.1 %)
         const long mint_env = ec_config().conv8_min_tiles;
         const long mint = mint_env > 0 ? mint_env : (long)ec_tls_conv8_min_tiles;
+        // 3x3 launches whose 256-wide tiles would fill only a fraction of the chip take 128-wide ones (twice the tiles; with
+        // long segments, EC_CONV8_LONGSEG, a 128-wide K-tile costs half a 256-wide one): EC_CONV8_LOWFILL = tile-count limit
+        if (KS == 3 && !POOL && a.Cout % 256 == 0 && a.K >= 2304 && nt256 >= mint && nt256 < ec_config().conv8_lowfill && nt128 >= mint)
+            return launch8<128, KS, POOL>(a, s);
         if (KS == 3 && a.Cout % 256 == 0 && nt256 >= mint) return launch8<256, KS, POOL>(a, s);
         // 3x3 convs with too few 256-wide tiles (layer 4 @7x7 in a single 256-frame launch: 98) but enough 128-wide ones:
         // 196 tiles x 72 K-tiles, 84.7 -> 64.6 us (tools/bench_shapes.py, B = 256)
