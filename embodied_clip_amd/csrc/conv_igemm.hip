@@ -1147,7 +1147,7 @@ int dispatch_tile(const ConvArgs& a, hipStream_t s) {
         // out_proj 768->768 + residual is slower (31 -> 35) and keeps the 4-wave kernel
         // long-K 1x1 launches that would fill less than ~40 % of the chip with 256-wide tiles take 128-wide ones (twice the
         // tiles, same per-tile efficiency): ViT-B/32 c_proj at 6,400 tokens is 75 tiles x 48 K-tiles (same-box A/B: +2.4 % on the ViT config, +0.4 % RN50)
-        if (KS == 1 && !POOL && ec_config().conv8_bn128 >= 0 && a.K >= 2048 && a.Cout % 256 == 0 && nt256 >= mint && nt256 < 100 &&
+        if (KS == 1 && !POOL && ec_config().conv8_bn128 >= 0 && a.K >= ec_config().conv8_lowfill_k && a.Cout % 256 == 0 && nt256 >= mint && nt256 < 100 &&
             nt128 >= mint)
             return launch8<128, KS, POOL>(a, s);
         if (KS == 1 && !POOL && ((!a.res && a.K >= 768) || (a.res && (a.K >= 2048 || (a.K >= 512 && nt256 >= 150))))) {   // (residual, K = 512: 49.5 -> 45.7 us on 512 -> 2048 @7x7; ViT out_proj, 75 tiles x 12 K-tiles, stays on the 4-wave kernel: 19.8 vs 23.3 us)
