@@ -3,7 +3,7 @@
 
 #include "common.h"
 
-extern "C" int ec_version(void) { return 306; }   // 0.3.0 (bump whenever a kernel or a launch plan changes: keys profiles/*traffic*.json)
+extern "C" int ec_version(void) { return 307; }   // 0.3.0 (bump whenever a kernel or a launch plan changes: keys profiles/*traffic*.json)
 
 extern "C" const char* ec_strerror(int code) {
     switch (code) {
@@ -52,6 +52,7 @@ EcConfig read_config() {
     c.conv8_longseg = env_int("EC_CONV8_LONGSEG", 1);
     c.conv8_lowfill = env_int("EC_CONV8_LOWFILL", 100);
     c.conv8_lowfill_k = env_int("EC_CONV8_LOWFILL_K", 1024);
+    c.conv8_res128 = env_int("EC_CONV8_RES128", 1);
     return c;
 }
 }  // namespace
@@ -71,6 +72,6 @@ uint64_t ec_config_hash() {
     mix(c.conv_narrow); mix(c.conv_rowsn); mix(c.rows_dbg); mix(c.conv_nbuf); mix(c.conv_ablate); mix(c.conv_wgs);
     mix(c.conv_waves); mix(c.conv_big); mix(c.conv8_min_tiles); mix(c.conv8_bn128); mix(c.conv_t224); mix(c.conv_t64);
     mix(c.conv_ring); mix(c.conv_regw); mix(c.conv_regw_wide); mix(c.gemm_no_x3); mix(c.act_split); mix(c.tail_fused);
-    mix(c.gru_fused); mix(c.c1_pingpong); mix(c.dw1_tr); mix(c.rn50_fuse); mix(c.wih_perm); mix(c.conv8_dirb); mix(c.conv8_longseg); mix(c.conv8_lowfill); mix(c.conv8_lowfill_k);
+    mix(c.gru_fused); mix(c.c1_pingpong); mix(c.dw1_tr); mix(c.rn50_fuse); mix(c.wih_perm); mix(c.conv8_dirb); mix(c.conv8_longseg); mix(c.conv8_lowfill); mix(c.conv8_lowfill_k); mix(c.conv8_res128);
     return x;
 }

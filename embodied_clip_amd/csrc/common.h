@@ -144,6 +144,7 @@ struct EcConfig {
     int wih_perm;         // EC_WIH_PERM      (1)   learn pass: re-ordered weight_ih instead of activation transposes
     int conv8_dirb;       // EC_CONV8_DIRB    (0)   conv_igemm8: weight fragments global -> VGPR (only the im2col operand through LDS)
     int conv8_longseg;    // EC_CONV8_LONGSEG (1)   conv_igemm8, 128-wide tiles: two segments per K-tile, three LDS stages
+    int conv8_res128;     // EC_CONV8_RES128  (1)   residual 1x1 launches, K 512..2047, < 100 256-wide tiles: 128-wide 8-wave tiles
     int conv8_lowfill_k;  // EC_CONV8_LOWFILL_K (1024) shortest K of a low-fill 1x1 launch that takes 128-wide 8-wave tiles
     int conv8_lowfill;    // EC_CONV8_LOWFILL (100) 3x3 launches with fewer 256-wide tiles than this take 128-wide ones
 };

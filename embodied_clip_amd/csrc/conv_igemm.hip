@@ -1150,6 +1150,12 @@ int dispatch_tile(const ConvArgs& a, hipStream_t s) {
         if (KS == 1 && !POOL && ec_config().conv8_bn128 >= 0 && a.K >= ec_config().conv8_lowfill_k && a.Cout % 256 == 0 && nt256 >= mint && nt256 < 100 &&
             nt128 >= mint)
             return launch8<128, KS, POOL>(a, s);
+        // residual 1x1 launches with K = 512 .. 2047 that would fill less than ~40 % of the chip with 256-wide tiles (ViT-B/32
+        // out_proj at 6,400 tokens: 75 tiles x 12 K-tiles) on the long-segment 128-wide tiles: same-box A/B 74.9 -> 76.3 k
+        // env-frames/s on the ViT config, forward 2.10 -> 2.05 ms; with the limit at 150 tiles the rule also caught layer 4's
+        // conv3 at 2 x 64 frames (104 tiles) and cost the RN50 config 0.4-1.3 % there.  EC_CONV8_RES128 = 0: off
+        if (KS == 1 && !POOL && a.res && ec_config().conv8_res128 && a.K >= 512 && a.K < 2048 && a.Cout % 128 == 0 && nt256 < 100 && nt128 >= mint)
+            return launch8<128, KS, POOL>(a, s);
         if (KS == 1 && !POOL && ((!a.res && a.K >= 768) || (a.res && (a.K >= 2048 || (a.K >= 512 && nt256 >= 150))))) {   // (residual, K = 512: 49.5 -> 45.7 us on 512 -> 2048 @7x7; ViT out_proj, 75 tiles x 12 K-tiles, stays on the 4-wave kernel: 19.8 vs 23.3 us)
             if (a.Cout % 256 == 0 && nt256 >= mint) return launch8<256, KS, POOL>(a, s);
             if (!a.res && a.K >= 1024 && a.Cout % 128 == 0 && nt256 < mint && nt128 >= mint) return launch8<128, KS, POOL>(a, s);
