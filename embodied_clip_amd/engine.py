@@ -206,8 +206,10 @@ class Worker:
             self.slices.append(sl)
         self.encode_frames = n                    # frames per timed encoder launch
         # two launches in flight with >= 128 frames each: the 8-wave conv kernel from 50 tiles on -- a property of THIS
-        # worker's encoder handles (ec_rn50/vit_set_conv8_min_tiles), not of the process
-        self._conv8_min_tiles = 50 if (ns == 2 and n >= 128) else 0
+        # worker's encoder handles (ec_rn50/vit_set_conv8_min_tiles), not of the process.  With 64..127 frames per slice:
+        # from 75 tiles on (round 3, after the long-segment 128-wide tiles: 128 actors 46.6-47.2 k with the default 150,
+        # 48.2 k with 50, 49.2-49.3 k with 60 / 75 / 90; two slices of 32 frames keep the default: 39.1 vs 37.6 k)
+        self._conv8_min_tiles = (50 if n >= 128 else (75 if n >= 64 else 0)) if ns == 2 else 0
         for e in encs:
             e.set_conv8_min_tiles(self._conv8_min_tiles)
         self.seed = seed + 7919 * rank
