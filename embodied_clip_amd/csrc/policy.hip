@@ -700,7 +700,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                                                          const float* __restrict__ W4, const float* __restrict__ b4,
                                                          float* __restrict__ c2, float* __restrict__ m1,
                                                          float* __restrict__ x4, long M, int c1_parts, long c1_pstride,
-                                                         const float* __restrict__ b1) {
+                                                         const float* __restrict__ b1, int gstride) {
     extern __shared__ __attribute__((aligned(16))) float tsm[];
     float* sW2 = tsm;                            // [32][132]
     float* sW3 = sW2 + 32 * TL_P128;             // [128][36]
@@ -829,7 +829,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
             // row group (actor-step) of this row in 32-bit arithmetic: a 64-bit division per element would cost more than the MFMAs
             const unsigned trow = min((unsigned)(grp_rem + row), (unsigned)(grp_rem + last_row));
-            int g = goal[grp_base + (long)(trow / (unsigned)S)];
+            int g = goal[(grp_base + (long)(trow / (unsigned)S)) * gstride];   // (gstride 2: the low words of the caller's int64 ids)
             g = g < 0 ? 0 : (g >= num_goals ? num_goals - 1 : g);
             const float* e = sE1 + g * 128 + i;
 #pragma unroll
@@ -1181,6 +1181,7 @@ namespace {
 struct Ws {   // float offsets into the workspace
     size_t E1, c1, c2, m1, x4, x, gi, gh, gates, hn, hp, hs, goal32, w1p;
     size_t E1d, c1d, c2d, m1d, x4d;   // the depth stream's copies (dual encoder)
+    size_t wihA;                      // act step: weight_ih in pixel-major column order (valid while E1 is)
     size_t dhs, dhc, dgi, dghb, dx, dx4, dm1, dc2, dc1, dE1, tpart, tpartE, whhT, wihP, gwihP, end;
 };
 
@@ -1215,6 +1216,7 @@ Ws layout(const ec_policy* h, int T, int N, bool bwd) {
     w.hs = take(B * H);
     w.goal32 = take(B);
     w.w1p = take(c.fusion ? 0 : ((size_t)c.compress_hid * 3 * c.in_channels + 1) / 2);   // W1 as three bf16 planes
+    w.wihA = take((c.fusion || c.dual) ? 0 : 3 * H * flat);
     w.dhs = w.dhc = w.dgi = w.dghb = w.dx = w.dx4 = w.dm1 = w.dc2 = w.dc1 = w.dE1 = w.tpart = w.tpartE = w.whhT = w.wihP = w.gwihP = o;
     if (bwd) {
         w.dhs = take(B * H);
@@ -1419,6 +1421,12 @@ extern "C" int ec_policy_forward2(const ec_policy_t* h, const float* params, con
     const bool step_ok = gru_fused_ && (H % 32) == 0 && gru_lds_ <= 160 * 1024;
     const bool act_split = act_parts_on && infer_only && small && tail_ok && (C % 32) == 0 && C / 32 >= ACT_PARTS;
     const bool gi_split = act_parts_on && infer_only && small && step_ok && (flat + 31) / 32 >= ACT_PARTS;
+    // act step: the fused tail reads the low words of the int64 goal ids itself (== the conversion kernel's truncation): one
+    // launch less on the act step's chain; and its GRU input projection runs against the re-ordered weight_ih (built by the
+    // first act step after a parameter update, kept in the workspace like E1), so the channel-major transpose goes too
+    const bool goal_direct = infer_only && !c.fusion && tail_ok;
+    const bool wih_act = infer_only && !c.fusion && !c.dual && tail_ok && ec_config().wih_perm && (size_t)c.comb_out * S * 4 <= 64 * 1024;
+    if (!goal_direct)
     hipLaunchKernelGGL(goal_to_i32_kernel, dim3((B + 255) / 256), dim3(256), 0, s, (const long long*)goal, goal32, B);
     if (c.fusion) {
         if (!h->goal_table) return EC_ERR_ARG;
@@ -1470,8 +1478,8 @@ extern "C" int ec_policy_forward2(const ec_policy_t* h, const float* params, con
         long nwg = (ntiles + 3) / 4;
         if (nwg > 512) nwg = 512;
         hipLaunchKernelGGL(tail_fwd_kernel, dim3((unsigned)nwg), dim3(256), tail_lds, s, ws + o_c1, WS(P_W2), WS(P_B2), WS(P_W3), cat,
-                           ws + o_E1, goal32, S, c.num_goals, WS(P_W4), WS(P_B4), ws + o_c2, ws + o_m1, ws + o_x4, (long)M49,
-                           act_split ? ACT_PARTS : 1, (long)M49 * c.compress_hid, WS(P_B1));
+                           ws + o_E1, goal_direct ? (const int*)goal : goal32, S, c.num_goals, WS(P_W4), WS(P_B4), ws + o_c2, ws + o_m1, ws + o_x4, (long)M49,
+                           act_split ? ACT_PARTS : 1, (long)M49 * c.compress_hid, WS(P_B1), goal_direct ? 2 : 1);
     } else {
     RC(ec_gemm_f32(ws + o_c1, WS(P_W2), ws + o_c2, M49, c.compress_out, c.compress_hid, c.compress_hid, 1, 1,
                    c.compress_hid, c.compress_out, EC_GEMM_RELU, WS(P_B2), nullptr, nullptr, 0, nullptr, nullptr, 1,
@@ -1485,6 +1493,10 @@ extern "C" int ec_policy_forward2(const ec_policy_t* h, const float* params, con
     if (wih_perm) {
         hipLaunchKernelGGL(permute_row_kernel, dim3((unsigned)(3 * H)), dim3(256), flat * sizeof(float), s, W(P_WIH),
                            ws + wb.wihP, S, c.comb_out, 0);
+    } else if (wih_act) {
+        if (!reuse_tables)
+            hipLaunchKernelGGL(permute_row_kernel, dim3((unsigned)(3 * H)), dim3(256), flat * sizeof(float), s, W(P_WIH),
+                               ws + w.wihA, S, c.comb_out, 0);
     } else {
         const long total = (long)B * flat1;
         hipLaunchKernelGGL(to_cmajor_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ws + o_x4, ws + w.x,
@@ -1495,7 +1507,7 @@ extern "C" int ec_policy_forward2(const ec_policy_t* h, const float* params, con
     // GRU: input projection for all T at once, then the sequential recurrence
     // (split-K only as separate partial matrices folded by the step kernel: the act step stays free of float atomics, so
     //  rollouts are bit-reproducible)
-    RC(ec_gemm_f32(wih_perm ? ws + w.x4 : ws + w.x, wih_perm ? ws + wb.wihP : W(P_WIH), ws + w.gi, B, 3 * H, flat, flat, 1, 1, flat, 3 * H,
+    RC(ec_gemm_f32((wih_perm || wih_act) ? ws + w.x4 : ws + w.x, wih_perm ? ws + wb.wihP : (wih_act ? ws + w.wihA : W(P_WIH)), ws + w.gi, B, 3 * H, flat, flat, 1, 1, flat, 3 * H,
                    gi_split ? EC_GEMM_SPLIT_PARTS : 0, W(P_BIH), nullptr, nullptr, 0, nullptr, nullptr, gi_split ? ACT_PARTS : 1,
                    stream));
     // EC_GRU_FUSED (default 1): one fused launch per step where the geometry allows (H % 32 == 0, tiles fit the LDS)
