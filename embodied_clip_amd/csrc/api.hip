@@ -48,6 +48,7 @@ EcConfig read_config() {
     c.dw1_tr = env_int("EC_DW1_TR", 1);
     c.rn50_fuse = env_int("EC_RN50_FUSE", 1);
     c.wih_perm = env_int("EC_WIH_PERM", 1);
+    c.dw_transposed = env_int("EC_DW_TRANSPOSED", 1);
     c.conv8_dirb = env_int("EC_CONV8_DIRB", 0);
     c.conv8_longseg = env_int("EC_CONV8_LONGSEG", 1);
     c.conv8_lowfill = env_int("EC_CONV8_LOWFILL", 100);
@@ -72,6 +73,6 @@ uint64_t ec_config_hash() {
     mix(c.conv_narrow); mix(c.conv_rowsn); mix(c.rows_dbg); mix(c.conv_nbuf); mix(c.conv_ablate); mix(c.conv_wgs);
     mix(c.conv_waves); mix(c.conv_big); mix(c.conv8_min_tiles); mix(c.conv8_bn128); mix(c.conv_t224); mix(c.conv_t64);
     mix(c.conv_ring); mix(c.conv_regw); mix(c.conv_regw_wide); mix(c.gemm_no_x3); mix(c.act_split); mix(c.tail_fused);
-    mix(c.gru_fused); mix(c.c1_pingpong); mix(c.dw1_tr); mix(c.rn50_fuse); mix(c.wih_perm); mix(c.conv8_dirb); mix(c.conv8_longseg); mix(c.conv8_lowfill); mix(c.conv8_lowfill_k); mix(c.conv8_res128);
+    mix(c.gru_fused); mix(c.c1_pingpong); mix(c.dw1_tr); mix(c.rn50_fuse); mix(c.wih_perm); mix(c.dw_transposed); mix(c.conv8_dirb); mix(c.conv8_longseg); mix(c.conv8_lowfill); mix(c.conv8_lowfill_k); mix(c.conv8_res128);
     return x;
 }

@@ -142,6 +142,7 @@ struct EcConfig {
     int dw1_tr;           // EC_DW1_TR        (1)   dW1 on the transpose-read kernel
     int rn50_fuse;        // EC_RN50_FUSE     (1)   fused layer-1 / layer-2 block boundaries in the trunk plan
     int wih_perm;         // EC_WIH_PERM      (1)   learn pass: re-ordered weight_ih instead of activation transposes
+    int dw_transposed;    // EC_DW_TRANSPOSED (1)   GRU weight-gradient GEMMs on transposed (K-contiguous) operands
     int conv8_dirb;       // EC_CONV8_DIRB    (0)   conv_igemm8: weight fragments global -> VGPR (only the im2col operand through LDS)
     int conv8_longseg;    // EC_CONV8_LONGSEG (1)   conv_igemm8, 128-wide tiles: two segments per K-tile, three LDS stages
     int conv8_res128;     // EC_CONV8_RES128  (1)   residual 1x1 launches, K 512..2047, < 100 256-wide tiles: 128-wide 8-wave tiles

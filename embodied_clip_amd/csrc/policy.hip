@@ -1182,7 +1182,7 @@ struct Ws {   // float offsets into the workspace
     size_t E1, c1, c2, m1, x4, x, gi, gh, gates, hn, hp, hs, goal32, w1p;
     size_t E1d, c1d, c2d, m1d, x4d;   // the depth stream's copies (dual encoder)
     size_t wihA;                      // act step: weight_ih in pixel-major column order (valid while E1 is)
-    size_t dhs, dhc, dgi, dghb, dx, dx4, dm1, dc2, dc1, dE1, tpart, tpartE, whhT, wihP, gwihP, end;
+    size_t dhs, dhc, dgi, dghb, dx, dx4, dm1, dc2, dc1, dE1, tpart, tpartE, whhT, wihP, gwihP, tA, tB, end;
 };
 
 Ws layout(const ec_policy* h, int T, int N, bool bwd) {
@@ -1217,7 +1217,7 @@ Ws layout(const ec_policy* h, int T, int N, bool bwd) {
     w.goal32 = take(B);
     w.w1p = take(c.fusion ? 0 : ((size_t)c.compress_hid * 3 * c.in_channels + 1) / 2);   // W1 as three bf16 planes
     w.wihA = take((c.fusion || c.dual) ? 0 : 3 * H * flat);
-    w.dhs = w.dhc = w.dgi = w.dghb = w.dx = w.dx4 = w.dm1 = w.dc2 = w.dc1 = w.dE1 = w.tpart = w.tpartE = w.whhT = w.wihP = w.gwihP = o;
+    w.dhs = w.dhc = w.dgi = w.dghb = w.dx = w.dx4 = w.dm1 = w.dc2 = w.dc1 = w.dE1 = w.tpart = w.tpartE = w.whhT = w.wihP = w.gwihP = w.tA = w.tB = o;
     if (bwd) {
         w.dhs = take(B * H);
         w.dhc = take((size_t)N * H);
@@ -1234,6 +1234,8 @@ Ws layout(const ec_policy* h, int T, int N, bool bwd) {
         w.whhT = take(H * 3 * H);                                                       // W_hh^T (fused backward step)
         w.wihP = take(c.fusion ? 0 : 3 * H * flat);                                     // weight_ih in pixel-major column order (EC_WIH_PERM)
         w.gwihP = take(c.fusion ? 0 : 3 * H * flat);                                    // ... and its gradient
+        w.tA = take(B * 3 * H);                                                         // transposed operands of the GRU's weight-gradient GEMMs
+        w.tB = take(B * (flat > H ? flat : H));
     }
     w.end = o;
     return w;
@@ -1673,15 +1675,33 @@ extern "C" int ec_policy_backward2(const ec_policy_t* h, const float* params, co
                            EC_GEMM_ACCUMULATE | (x_bf16 ? EC_GEMM_B_BF16 : 0), nullptr, nullptr, nullptr, 0, nullptr,
                            nullptr, sk, stream);
     };
+    // EC_DW_TRANSPOSED (default 1): the GRU's two weight-gradient GEMMs contract over the T*N rows, i.e. BOTH operands are
+    // strided in K -- the slowest staging of gemm_x3 (1.02 ms for dW_ih at 128 actors against 0.49 ms for the same-size input
+    // projection).  Transposing both operands first (two bandwidth-bound passes, ~0.1 ms) makes it the K-contiguous case.
+    const bool dw_t = ec_config().dw_transposed && B >= 1024;
+    auto tn_t = [&](const float* dY, const float* X, float* dW, int Mo, int No, long K, int ldc) {   // ld(dY) == Mo, ld(X) == No
+        hipLaunchKernelGGL(transpose_f32_kernel, dim3((unsigned)((Mo + 31) / 32), (unsigned)((K + 31) / 32)), dim3(256), 0, s, dY,
+                           ws + w.tA, (int)K, Mo);
+        hipLaunchKernelGGL(transpose_f32_kernel, dim3((unsigned)((No + 31) / 32), (unsigned)((K + 31) / 32)), dim3(256), 0, s, X,
+                           ws + w.tB, (int)K, No);
+        return ec_gemm_f32(ws + w.tA, ws + w.tB, dW, Mo, No, (int)K, K, 1, 1, K, ldc, EC_GEMM_ACCUMULATE, nullptr, nullptr, nullptr,
+                           0, nullptr, nullptr, pick_splitk(Mo, No, K), stream);
+    };
+    if (dw_t) RC(tn_t(ws + w.dghb, ws + w.hp, G(P_WHH), 3 * H, H, B, H));
+    else
     RC(tn(ws + w.dghb, 3 * H, ws + w.hp, H, 0, G(P_WHH), 3 * H, H, B, H));
     colsum(ws + w.dghb, G(P_BHH), B, 3 * H, 3 * H);
     const bool wih_perm = ec_config().wih_perm && !c.fusion && !c.dual && (size_t)c.comb_out * S * 4 <= 64 * 1024;   // (== ec_policy_forward's)
     if (wih_perm) {   // gradient in the re-ordered weight's column order, then added back in the parameter's order
         (void)hipMemsetAsync(ws + w.gwihP, 0, (size_t)3 * H * flat * 4, s);
+        if (dw_t) RC(tn_t(ws + w.dgi, ws + w.x4, ws + w.gwihP, 3 * H, flat, B, flat));
+        else
         RC(tn(ws + w.dgi, 3 * H, ws + w.x4, flat, 0, ws + w.gwihP, 3 * H, flat, B, flat));
         hipLaunchKernelGGL(permute_row_kernel, dim3((unsigned)(3 * H)), dim3(256), flat * sizeof(float), s, ws + w.gwihP,
                            G(P_WIH), S, c.comb_out, 1);
     } else
+    if (dw_t) RC(tn_t(ws + w.dgi, ws + w.x, G(P_WIH), 3 * H, flat, B, flat));
+    else
     RC(tn(ws + w.dgi, 3 * H, ws + w.x, flat, 0, G(P_WIH), 3 * H, flat, B, flat));
     colsum(ws + w.dgi, G(P_BIH), B, 3 * H, 3 * H);
     if (c.fusion) {   // the image embedding and the goal table are frozen: nothing trainable upstream of the GRU
@@ -1689,9 +1709,14 @@ extern "C" int ec_policy_backward2(const ec_policy_t* h, const float* params, co
         return EC_OK;
     }
     // dx = dgi @ W_ih
-    if (wih_perm)   // dx4 = dgi @ (re-ordered weight_ih): already pixel-major
-        RC(ec_gemm_f32(ws + w.dgi, ws + w.wihP, ws + w.dx4, B, flat, 3 * H, 3 * H, 1, flat, 1, flat, 0, nullptr, nullptr,
+    if (wih_perm) { // dx4 = dgi @ (re-ordered weight_ih): already pixel-major.  The weight is transposed first (9.6 MB, into
+                    // the gradient staging buffer, free again by now) so that BOTH operands are K-contiguous: the GEMM's
+                    // strided-B staging runs at half the rate (263 vs ~130 us at 32 actors, 770 vs ~540 at 128)
+        hipLaunchKernelGGL(transpose_f32_kernel, dim3((unsigned)((flat + 31) / 32), (unsigned)(3 * H / 32)), dim3(256), 0, s,
+                           ws + w.wihP, ws + w.gwihP, 3 * H, flat);
+        RC(ec_gemm_f32(ws + w.dgi, ws + w.gwihP, ws + w.dx4, B, flat, 3 * H, 3 * H, 1, 1, 3 * H, flat, 0, nullptr, nullptr,
                        nullptr, 0, nullptr, nullptr, 1, stream));
+    }
     else
         RC(ec_gemm_f32(ws + w.dgi, W(P_WIH), ws + w.dx, B, flat, 3 * H, 3 * H, 1, flat, 1, flat, 0, nullptr, nullptr, nullptr,
                        0, nullptr, nullptr, 1, stream));
