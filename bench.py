@@ -43,6 +43,7 @@ POLICY_UPDATE_MAC = 150_775_808              # 4 x (fwd + bwd)
 ZS_POLICY_ACT_MAC = 1536 * 1024 + 1536 * 512 + 7 * 512            # zero-shot policy: GRU (1024 -> 512) + heads
 ZS_POLICY_UPDATE_MAC = 4 * (ZS_POLICY_ACT_MAC + 1536 * 1024 + 2 * 1536 * 512 + 2 * 7 * 512)
 MFMA_BF16_PEAK_TFLOPS = 2500.0               # MI355X_MICROARCH.md: dense bf16 MFMA
+HBM_ACHIEVABLE_TBS = 6.29                    # MI355X_MICROARCH.md chip table: achievable HBM3E bandwidth (8.0 TB/s spec)
 POLICY_FLAT_PARAMS = 3_480_775
 # PMC-measured HBM bytes per encoder launch: written by tools/pmc_summary.py from separate rocprofv3 --pmc passes
 # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), keyed by the library's launch-plan hash
@@ -136,6 +137,49 @@ def measured_traffic(encoder: str, plan_hash, frames_per_launch: int):
         "layer by layer"), rec
 
 
+def _soft(name, fn, agree=None):
+    """Run a SECONDARY measurement; a Python-level failure becomes `{"error": ...}` under its key instead of costing
+    the headline line.  `agree` (world > 1): all ranks exchange an ok-flag afterwards, so that a rank whose leg failed
+    does not leave the others' result standing alone (the leg is reported failed on every rank)."""
+    try:
+        out, ok = fn(), 1.0
+    except Exception as e:   # noqa: BLE001 -- by design: nothing a secondary leg raises may kill the headline
+        import traceback
+        traceback.print_exc()
+        out, ok = {"error": f"{name}: {type(e).__name__}: {e}"[:300]}, 0.0
+    if agree is not None:
+        try:
+            if agree(ok) < 1.0 and ok:
+                out = {"error": f"{name}: failed on another rank"}
+        except Exception as e:   # noqa: BLE001
+            out = {"error": f"{name}: status exchange failed: {type(e).__name__}: {e}"[:300]}
+    return out
+
+
+class _Watchdog:
+    """The secondary legs run under a wall-clock budget: when it expires, rank 0 prints the line with what has been
+    measured so far (the unfinished leg carries `{"error": "timeout"}`) and every rank leaves with os._exit -- a hung
+    collective in a secondary leg cannot cost the headline number."""
+
+    def __init__(self, seconds: float, emit):
+        import threading
+        self._t = threading.Timer(seconds, self._fire)
+        self._t.daemon = True
+        self._emit = emit
+        self.leg = "?"
+        self._t.start()
+
+    def _fire(self):
+        try:
+            self._emit(self.leg)
+        finally:
+            sys.stdout.flush()
+            os._exit(0)
+
+    def cancel(self):
+        self._t.cancel()
+
+
 def _time_iterations(w, steps, warmup, barrier):
     for _ in range(warmup):
         w.iteration()
@@ -171,7 +215,8 @@ def run_rank(a, rank: int, local_rank: int, world: int, init_method=None):
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback for the product path)"
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
-    if world > 1:
+    use_dist = world > 1 or a.force_dist        # --force-dist: RCCL initialised and used also at world size 1
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", init_method=init_method, rank=rank, world_size=world,
@@ -187,30 +232,38 @@ def run_rank(a, rank: int, local_rank: int, world: int, init_method=None):
         per_gpu = total
     wkw = dict(T=a.rollout, device=dev, seed=0, rank=rank, world=world, update_repeats=a.update_repeats,
                encoder_chunk=a.encoder_chunk, encoder=a.encoder, encoder_streams=a.encoder_streams,
-               frames_u8=a.frames_u8, num_mini_batch=a.num_mini_batch)
+               frames_u8=a.frames_u8, num_mini_batch=a.num_mini_batch, force_allreduce=a.force_dist)
     if a.encoder == "zeroshot":
         wkw.update(encoder="rn50", zeroshot=True)
-    w = Worker(per_gpu, frames_host=a.frames_host, **wkw)
+    w = Worker(per_gpu, frames_host=a.frames_host, sync_actions=a.sync_actions, **wkw)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     def maxreduce(x: float) -> float:
-        if world == 1:
+        if not use_dist:
             return x
         tt = torch.tensor([x], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt.item())
 
+    def agree(ok: float) -> float:      # MIN over ranks of a leg's ok-flag (see _soft)
+        if not use_dist:
+            return ok
+        tt = torch.tensor([ok], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MIN)
+        return float(tt.item())
+
+    # ---- the headline measurement -----------------------------------------------------------------------------------
     dt = maxreduce(_time_iterations(w, a.steps, a.warmup, barrier))
     # dominant kernel family: the RN50 trunk's MFMA implicit-GEMM convs, one ec_rn50_forward per env step
     trunk_ms = [e0.elapsed_time(e1) for e0, e1 in w.trunk_events]
     avg_trunk_ms = sum(trunk_ms) / max(1, len(trunk_ms))
-    # The encoder launches of one env step run concurrently, one per HIP stream.  The chip-level rate is therefore
-    # taken over the UNION of their [start, end] intervals (first start -> last end of the step's launches), which
-    # stays correct whether the launches overlap fully, partly, or (under a serialising profiler) not at all.
+    # The encoder launches of one env step run concurrently, one per HIP stream.  The chip-level rate of the encoder
+    # alone is therefore taken over the UNION of their [start, end] intervals (first start -> last end of the step's
+    # launches): `frac_union`.  The line's `frac` is the whole iteration's algorithmic flop over the timed wall clock.
     n_conc = max(1, per_gpu // max(1, w.encode_frames))
     union_ms = []
     if w.trunk_events:
@@ -222,92 +275,41 @@ def run_rank(a, rank: int, local_rank: int, world: int, init_method=None):
     info = w.loss_info()
     plan_hash = w.slices[0].enc.plan_hash() if hasattr(w.slices[0].enc, "plan_hash") else None
     enc_frames = w.encode_frames
+    rccl_ranks = dist.get_world_size() if use_dist else 1
 
-    phases = None
-    if a.phase_times:
-        torch.cuda.synchronize(); p0 = time.perf_counter()
-        w.collect_rollout(); torch.cuda.synchronize(); p1 = time.perf_counter()
-        w.compute_returns(); torch.cuda.synchronize(); p2 = time.perf_counter()
-        w.update(); w.after_update(); torch.cuda.synchronize(); p3 = time.perf_counter()
-        phases = {"rollout_ms": round((p1 - p0) * 1e3, 1), "gae_ms": round((p2 - p1) * 1e3, 2),
-                  "update_ms": round((p3 - p2) * 1e3, 1)}
-
-    # the single exchange step, timed alone on every rank (HIP events on the current stream, 20 calls)
-    ar_ms = None
-    if world > 1:
-        from embodied_clip_amd.dist import allreduce_flat
-        for _ in range(3):
-            allreduce_flat(w.grads)
-        barrier()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(20):
-            allreduce_flat(w.grads)
-        e1.record(); torch.cuda.synchronize()
-        mine = torch.tensor([e0.elapsed_time(e1) / 20], dtype=torch.float64, device=dev)
-        allv = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allv, mine)
-        ar_ms = [round(float(v.item()), 4) for v in allv]
-    rccl_ranks = dist.get_world_size() if world > 1 else 1
-
-    # secondary measurements (rank-synchronous, so every rank runs them)
-    h2d = None
-    if not a.no_h2d and not a.frames_host:
-        w = None             # free the first worker's ~11 GB before building the next
-        gc.collect(); torch.cuda.empty_cache()
-        u8 = a.encoder != "vit"          # (the ViT patch-embed kernel takes the sensor's fp32 frames only)
-        wh = Worker(per_gpu, frames_host=True, **{**wkw, "frames_u8": u8})
-        dth = maxreduce(_time_iterations(wh, a.h2d_steps, 1, barrier))
-        h2d = {"value": round(a.rollout * per_gpu * world * a.h2d_steps / dth, 1), "unit": "env-frames/s", "steps": a.h2d_steps,
-               "frames": ("uint8 HWC" if u8 else "fp32 normalised HWC") + " in PINNED HOST memory, copied per slice on its "
-                         "own copy stream (double-buffered) while the other slice computes" +
-                         ("; /255 + CLIP mean/std fused into the stem kernel" if u8 else ""),
-               "h2d_bytes_per_env_step": per_gpu * 224 * 224 * 3 * (1 if u8 else 4)}
-        del wh
-        torch.cuda.empty_cache()
-    weak = None
-    if world > 1 and a.scaling == "strong" and not a.no_weak:
-        w = None
-        gc.collect(); torch.cuda.empty_cache()
-        ww = Worker(total, frames_host=a.frames_host, **wkw)
-        dtw = maxreduce(_time_iterations(ww, a.steps, a.warmup, barrier))
-        weak = {"value": round(a.rollout * total * world * a.steps / dtw, 1), "unit": "env-frames/s",
-                "actors_per_gpu": total, "global_actors": total * world, "ms_per_step": round(dtw / a.steps * 1e3, 2)}
-        del ww
-
-    plugin = None
-    if world == 1 and a.encoder == "rn50" and not a.no_plugin:
-        w = None
-        gc.collect(); torch.cuda.empty_cache()
-        from embodied_clip_amd.plugin_path import time_plugin_path
-        plugin = time_plugin_path(per_gpu, a.rollout, dev, steps=a.plugin_steps, warmup=1, update_repeats=a.update_repeats)
-        gc.collect(); torch.cuda.empty_cache()
-
+    frames = a.rollout * per_gpu * world * a.steps
+    value = frames / dt
+    enc_mac = {"rn50": TRUNK_MAC_PER_FRAME, "vit": VIT_MAC_PER_FRAME, "rn50x16": RN50X16_MAC_PER_FRAME,
+               "zeroshot": TRUNK_MAC_PER_FRAME + ATTNPOOL_MAC_PER_FRAME}[a.encoder]
+    flop_per_frame = 2 * (enc_mac + (ZS_POLICY_ACT_MAC + ZS_POLICY_UPDATE_MAC if a.encoder == "zeroshot"
+                                     else POLICY_ACT_MAC + POLICY_UPDATE_MAC +
+                                     # RN50x16: 3072 input channels of the compressor's first conv
+                                     (9 * 49 * 1024 * 128 if a.encoder == "rn50x16" else 0)))
+    out = None
     if rank == 0:
-        frames = a.rollout * per_gpu * world * a.steps
-        value = frames / dt
-        enc_mac = {"rn50": TRUNK_MAC_PER_FRAME, "vit": VIT_MAC_PER_FRAME, "rn50x16": RN50X16_MAC_PER_FRAME,
-                   "zeroshot": TRUNK_MAC_PER_FRAME + ATTNPOOL_MAC_PER_FRAME}[a.encoder]
         # flop of what one timed launch covers (zero-shot: the events bracket trunk + AttentionPool2d)
-        trunk_mac = {"rn50": TRUNK_MAC_PER_FRAME, "vit": VIT_MAC_PER_FRAME, "rn50x16": RN50X16_MAC_PER_FRAME,
-                     "zeroshot": TRUNK_MAC_PER_FRAME + ATTNPOOL_MAC_PER_FRAME}[a.encoder]
-        flops_call = 2.0 * trunk_mac * enc_frames          # one timed launch = one (slice of the) encoder forward
+        flops_call = 2.0 * enc_mac * enc_frames            # one timed launch = one (slice of the) encoder forward
         achieved_launch = flops_call / (avg_trunk_ms * 1e-3) / 1e12
-        achieved = flops_call * n_conc / (avg_union_ms * 1e-3) / 1e12
+        achieved_union = flops_call * n_conc / (avg_union_ms * 1e-3) / 1e12
+        # THE fraction of the line: algorithmic flop of the whole iteration (encoder + act + update) over the
+        # driver-visible wall clock, per GPU -- recomputable from `value` / `ms_per_step` alone
+        achieved_iter = value * flop_per_frame / world / 1e12
         if a.encoder == "rn50x16":
             traffic, tnote, trec = None, "no PMC summary for the RN50x16 trunk (functional, not tuned)", None
         else:
             traffic, tnote, trec = (None, "--no-traffic", None) if a.no_traffic else measured_traffic(
                 "vit" if a.encoder == "vit" else "rn50", plan_hash, enc_frames)
-        # the same fraction from the COMMITTED profile alone (reproducible from profiles/): algorithmic flop of the
+        # the encoder's fraction from the COMMITTED profile alone (reproducible from profiles/): algorithmic flop of the
         # profiled single launch / its summed kernel time (rocprofv3 kernel trace)
         frac_profiles = frac_profiles_256 = None
         if trec and trec.get("kernel_time_us") and trec.get("plan_hash") in (None, "", plan_hash):
-            frac_profiles = round(2.0 * trunk_mac * trec["frames_per_launch"] / (trec["kernel_time_us"] * 1e-6) / 1e12
+            frac_profiles = round(2.0 * enc_mac * trec["frames_per_launch"] / (trec["kernel_time_us"] * 1e-6) / 1e12
                                   / MFMA_BF16_PEAK_TFLOPS, 4)
             if trec.get("single_launch_256"):
-                frac_profiles_256 = round(2.0 * trunk_mac * 256 / (trec["single_launch_256"]["kernel_time_us"] * 1e-6) / 1e12
+                frac_profiles_256 = round(2.0 * enc_mac * 256 / (trec["single_launch_256"]["kernel_time_us"] * 1e-6) / 1e12
                                           / MFMA_BF16_PEAK_TFLOPS, 4)
+        # the second roof: L2-miss bytes of the concurrent launches of an env step over their union, against achievable HBM
+        hbm_tbs = (traffic * n_conc / (avg_union_ms * 1e-3) / 1e12) if traffic else None
         workload = {"rn50": "RoboTHOR ObjectNav: frozen CLIP-RN50 encoder",
                     "vit": "RoboTHOR ObjectNav: frozen CLIP ViT-B/32 encoder (11 blocks)",
                     "rn50x16": "RoboTHOR ObjectNav: frozen CLIP-RN50x16 encoder (width 96, layers 6/8/18/8, 3072 x 7 x 7 features; "
@@ -325,23 +327,30 @@ def run_rank(a, rank: int, local_rank: int, world: int, init_method=None):
                        "update_repeats": a.update_repeats, "num_mini_batch": a.num_mini_batch, "encoder_streams": a.encoder_streams,
                        "frames": ("pinned host -> H2D per step, " if a.frames_host else "resident in HBM, ") +
                                  ("uint8 HWC (normalisation fused)" if a.frames_u8 else "fp32 normalised HWC"),
+                       "env_order": ("action-synchronous: the sampled actions are copied to the host every env step before the "
+                                     "next observation is served" if a.sync_actions else
+                                     "free-running: the synthetic env does not read the actions (SURVEY.md 8d); see `sync_actions`"),
                        "parallelism": f"dp{world} (actors sharded; one flat 13.9 MB grad all-reduce per optimiser step)",
-                       "flop_per_frame": 2 * (enc_mac + (ZS_POLICY_ACT_MAC + ZS_POLICY_UPDATE_MAC if a.encoder == "zeroshot"
-                                                         else POLICY_ACT_MAC + POLICY_UPDATE_MAC +
-                                                         # RN50x16: 3072 input channels of the compressor's first conv
-                                                         (9 * 49 * 1024 * 128 if a.encoder == "rn50x16" else 0)))},
-            "rccl_ranks": rccl_ranks, "allreduce_ms_per_rank": ar_ms,
+                       "flop_per_frame": flop_per_frame},
+            "rccl_ranks": rccl_ranks, "allreduce_ms_per_rank": None,
             "roofline": {"bound": "mfma",
                          "kernel": ("ec_rn50_forward (conv_igemm / conv_pair / conv3x3_narrow MFMA kernels)"
                                     if a.encoder != "vit" else "ec_vit_forward (conv_igemm GEMMs + mha/layernorm kernels)"),
-                         "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
+                         "achieved": round(achieved_iter, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved_iter / MFMA_BF16_PEAK_TFLOPS, 4),
+                         "frac_union": round(achieved_union / MFMA_BF16_PEAK_TFLOPS, 4), "achieved_union": round(achieved_union, 1),
                          "frac_profiles": frac_profiles, "frac_profiles_single_256_launch": frac_profiles_256,
-                         "frac_note": "frac = live HIP-event UNION of the concurrent encoder launches of an env step; "
-                                      "frac_profiles = the committed rocprofv3 kernel trace of ONE engine launch (the plan "
-                                      "with this hash) running ALONE on the chip, frac_profiles_single_256_launch = one "
-                                      "256-frame launch (profiles/*_hbm_traffic.json kernel_time_us): both reproducible "
-                                      "from profiles/ alone",
+                         "hbm_frac": round(hbm_tbs / HBM_ACHIEVABLE_TBS, 4) if hbm_tbs else None,
+                         "hbm_achieved_tbs": round(hbm_tbs, 3) if hbm_tbs else None, "hbm_peak_tbs": HBM_ACHIEVABLE_TBS,
+                         "frac_note": "frac = value x config.flop_per_frame / n_gpus / peak: the WHOLE iteration's algorithmic flop "
+                                      "(encoder + act step + 4 update epochs) over the timed wall clock, recomputable from "
+                                      "value alone; frac_union = the encoder's flop over the live HIP-event UNION of the concurrent "
+                                      "encoder launches of an env step (moves +-4 % between runs at equal throughput); "
+                                      "frac_profiles = the committed rocprofv3 kernel trace of ONE engine launch (the plan with "
+                                      "this hash) running ALONE on the chip, frac_profiles_single_256_launch = one 256-frame "
+                                      "launch (profiles/*_hbm_traffic.json kernel_time_us): both reproducible from profiles/ "
+                                      "alone; hbm_frac = traffic x concurrent_launches / avg_step_union_ms / 6.29 TB/s (the "
+                                      "path is co-bound: both roofs are shown)",
                          "traffic": traffic, "traffic_kind": "L2-miss (fabric-side) bytes, Infinity-Cache hits included",
                          "traffic_note": tnote, "plan_hash": plan_hash,
                          "avg_launch_ms": round(avg_trunk_ms, 3), "avg_step_union_ms": round(avg_union_ms, 3),
@@ -350,18 +359,122 @@ def run_rank(a, rank: int, local_rank: int, world: int, init_method=None):
                          "algorithmic_flop_per_launch": flops_call,
                          "encoder_share_of_step": round(sum(trunk_ms) / (dt * 1e3) / max(1, n_conc), 3)},
             "loss": {k: round(v, 6) for k, v in info.items()},
-            **({"phases": phases} if phases else {}),
-            **({"h2d_inclusive": h2d} if h2d else {}),
-            **({"plugin_path": {**plugin, "fraction_of_engine": round(plugin["value"] / value, 3)}} if plugin else {}),
-            **({"weak": weak} if weak else {}),
         }
-        if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a.cpu_actors, a.cpu_rollout, a.update_repeats)
-            out["cpu_baseline"]["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+
+    # ---- secondary measurements: each fails SOFT (its key carries {"error": ...}) and the whole block runs under a watchdog
+    def emit(timeout_leg=None):
+        if rank == 0 and out is not None:
+            if timeout_leg is not None:
+                out.setdefault(timeout_leg, {"error": f"timeout: secondary legs exceeded {a.secondary_budget_s} s"})
+            print(json.dumps(out), flush=True)
+
+    dog = _Watchdog(a.secondary_budget_s, emit)
+
+    def put(key, val):
+        if out is not None and val is not None:
+            out[key] = val
+
+    if a.phase_times:
+        def leg_phases():
+            torch.cuda.synchronize(); p0 = time.perf_counter()
+            w.collect_rollout(); torch.cuda.synchronize(); p1 = time.perf_counter()
+            w.compute_returns(); torch.cuda.synchronize(); p2 = time.perf_counter()
+            w.update(); w.after_update(); torch.cuda.synchronize(); p3 = time.perf_counter()
+            return {"rollout_ms": round((p1 - p0) * 1e3, 1), "gae_ms": round((p2 - p1) * 1e3, 2),
+                    "update_ms": round((p3 - p2) * 1e3, 1)}
+        dog.leg = "phases"
+        put("phases", _soft("phases", leg_phases, agree))
+
+    # the single exchange step, timed alone on every rank (HIP events on the current stream, 20 calls)
+    if use_dist:
+        def leg_allreduce():
+            from embodied_clip_amd.dist import allreduce_flat
+            for _ in range(3):
+                allreduce_flat(w.grads, force=True)
+            barrier()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                allreduce_flat(w.grads, force=True)
+            e1.record(); torch.cuda.synchronize()
+            mine = torch.tensor([e0.elapsed_time(e1) / 20], dtype=torch.float64, device=dev)
+            allv = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allv, mine)
+            return [round(float(v.item()), 4) for v in allv]
+        dog.leg = "allreduce_ms_per_rank"
+        put("allreduce_ms_per_rank", _soft("allreduce_ms_per_rank", leg_allreduce, agree))
+
+    def free_worker():
+        nonlocal w
+        w = None             # free the previous worker's ~11 GB before building the next
+        gc.collect(); torch.cuda.empty_cache()
+
+    if not a.no_sync_actions and not a.sync_actions and not a.frames_host:
+        def leg_sync():
+            free_worker()
+            ws_ = Worker(per_gpu, frames_host=False, sync_actions=True, **wkw)
+            dts = maxreduce(_time_iterations(ws_, a.sync_steps, 1, barrier))
+            r = {"value": round(a.rollout * per_gpu * world * a.sync_steps / dts, 1), "unit": "env-frames/s", "steps": a.sync_steps,
+                 "order": "per env step: act(t) on every slice -> the sampled actions of all actors copied D2H and waited for "
+                          "(what VectorSampledTasks.step(actions) forces) -> observe() -> encode(t+1); the free-running "
+                          "headline lets the host issue arbitrarily far ahead"}
+            del ws_
+            return r
+        dog.leg = "sync_actions"
+        put("sync_actions", _soft("sync_actions", leg_sync, agree))
+        gc.collect(); torch.cuda.empty_cache()
+    if not a.no_h2d and not a.frames_host:
+        def leg_h2d():
+            free_worker()
+            u8 = a.encoder != "vit"          # (the ViT patch-embed kernel takes the sensor's fp32 frames only)
+            wh = Worker(per_gpu, frames_host=True, **{**wkw, "frames_u8": u8})
+            dth = maxreduce(_time_iterations(wh, a.h2d_steps, 1, barrier))
+            r = {"value": round(a.rollout * per_gpu * world * a.h2d_steps / dth, 1), "unit": "env-frames/s", "steps": a.h2d_steps,
+                 "frames": ("uint8 HWC" if u8 else "fp32 normalised HWC") + " in PINNED HOST memory, copied per slice on its "
+                           "own copy stream (double-buffered) while the other slice computes" +
+                           ("; /255 + CLIP mean/std fused into the stem kernel" if u8 else ""),
+                 "h2d_bytes_per_env_step": per_gpu * 224 * 224 * 3 * (1 if u8 else 4)}
+            del wh
+            return r
+        dog.leg = "h2d_inclusive"
+        put("h2d_inclusive", _soft("h2d_inclusive", leg_h2d, agree))
+        gc.collect(); torch.cuda.empty_cache()
+    if world > 1 and a.scaling == "strong" and not a.no_weak:
+        def leg_weak():
+            free_worker()
+            ww = Worker(total, frames_host=a.frames_host, **wkw)
+            dtw = maxreduce(_time_iterations(ww, a.steps, a.warmup, barrier))
+            r = {"value": round(a.rollout * total * world * a.steps / dtw, 1), "unit": "env-frames/s",
+                 "actors_per_gpu": total, "global_actors": total * world, "ms_per_step": round(dtw / a.steps * 1e3, 2)}
+            del ww
+            return r
+        dog.leg = "weak"
+        put("weak", _soft("weak", leg_weak, agree))
+        gc.collect(); torch.cuda.empty_cache()
+    if world == 1 and a.encoder == "rn50" and not a.no_plugin:
+        def leg_plugin():
+            free_worker()
+            from embodied_clip_amd.plugin_path import time_plugin_path
+            r = time_plugin_path(per_gpu, a.rollout, dev, steps=a.plugin_steps, warmup=1, update_repeats=a.update_repeats)
+            return {**r, "fraction_of_engine": round(r["value"] / value, 3)}
+        dog.leg = "plugin_path"
+        put("plugin_path", _soft("plugin_path", leg_plugin))
+        gc.collect(); torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        def leg_cpu():
+            r = cpu_baseline(a.cpu_actors, a.cpu_rollout, a.update_repeats)
+            r["gpu_over_cpu"] = round(value / r["value"], 1)
+            return r
+        dog.leg = "cpu_baseline"
+        put("cpu_baseline", _soft("cpu_baseline", leg_cpu))
+    dog.cancel()
+    emit()
+    if use_dist:
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception:   # noqa: BLE001 -- the line is out; a teardown hiccup must not turn into a non-zero exit
+            pass
     return 0
 
 
@@ -398,6 +511,17 @@ def parse_args(argv=None):
                          "classes with the reference's tensor contracts (embodied_clip_amd/plugin_path.py)")
     ap.add_argument("--plugin-steps", type=int, default=1)
     ap.add_argument("--h2d-steps", type=int, default=5, help="timed iterations of the h2d_inclusive measurement")
+    ap.add_argument("--sync-actions", action="store_true",
+                    help="HEADLINE run in the action-synchronous order: every env step the sampled actions are copied D2H and "
+                         "waited for before the next observation is served (what VectorSampledTasks.step(actions) forces); "
+                         "by default this order is a secondary key of the line (`sync_actions`)")
+    ap.add_argument("--no-sync-actions", action="store_true", help="skip the secondary `sync_actions` measurement")
+    ap.add_argument("--sync-steps", type=int, default=3, help="timed iterations of the sync_actions measurement")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise RCCL (backend nccl) and run the flat-bucket all-reduce also at world size 1 -- the "
+                         "first-contact check of the N > 1 path on a 1-GPU box (tests/test_gpu_multi.py)")
+    ap.add_argument("--secondary-budget-s", type=float, default=1500.0,
+                    help="wall-clock budget of ALL secondary legs together; on expiry the line is printed with what is there")
     ap.add_argument("--no-traffic", action="store_true", help="do not read profiles/*_hbm_traffic.json")
     ap.add_argument("--phase-times", action="store_true", help="extra untimed iteration with per-phase sync timing")
     ap.add_argument("--cpu-actors", type=int, default=32)
@@ -416,7 +540,7 @@ def main(argv=None):
         if a.gpus != world:
             raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
         return run_rank(a, rank, int(os.environ.get("LOCAL_RANK", str(rank))), world, None)
-    if a.gpus > 1:                                      # self-launch: one spawned rank per GPU, file-store rendezvous
+    if a.gpus > 1 or a.force_dist:                      # self-launch: one spawned rank per GPU, file-store rendezvous
         import torch.multiprocessing as mp
         fd, store = tempfile.mkstemp(prefix="ec_bench_store_")
         os.close(fd); os.unlink(store)

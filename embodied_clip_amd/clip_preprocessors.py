@@ -76,6 +76,7 @@ class _PreprocessorBase(Preprocessor):
         self.device = torch.device(device)
         self._model = None   # rebuilt lazily on the new device
         self._twin = None
+        self._streams = self._copy_stream = None      # (streams belong to the old device)
         return self
 
 
@@ -127,9 +128,13 @@ class ClipResNetPreprocessor(_PreprocessorBase):
         trunk = self.resnet
         if getattr(self, "_twin", None) is None:
             self._twin = RN50Trunk(None, device=self.device, chunk=self._chunk, weights_from=trunk)
+            self._twin.set_conv8_min_tiles(50)    # (the twin only ever runs beside the primary trunk)
+        if getattr(self, "_streams", None) is None:
             self._streams = [torch.cuda.Stream(device=self.device) for _ in range(2)]
-            for t in (trunk, self._twin):
-                t.set_conv8_min_tiles(50)         # two launches in flight (see ec_rn50_set_conv8_min_tiles)
+        # two launches in flight: the lower 8-wave dispatch threshold (see ec_rn50_set_conv8_min_tiles) -- on the PRIMARY
+        # trunk only while this call issues its launches (the handle's value is read at issue time); a later batch that runs
+        # alone takes the default again
+        trunk.set_conv8_min_tiles(50)
         N = x.shape[0]
         h = N // 2
         out = torch.empty((N, trunk.out_channels, trunk.out_spatial, trunk.out_spatial), dtype=torch.float32, device=self.device)
@@ -159,6 +164,10 @@ class ClipResNetPreprocessor(_PreprocessorBase):
             out.record_stream(st)          # (allocated on the caller's stream, written on this one)
         for st in self._streams:
             cur.wait_stream(st)
+        trunk.set_conv8_min_tiles(0)
+        # the copies were asynchronous (pinned source): the caller may refill `x` for the next env step as soon as this
+        # returns, so wait for the LAST copy here (the encoder launches keep running behind it)
+        copied[-1].synchronize()
         return out
 
     def process(self, obs: Dict[str, Any], *args: Any, **kwargs: Any) -> torch.Tensor:

@@ -29,8 +29,27 @@ def grad_scale(local_bsize: int, global_bsize: int) -> float:
     return float(local_bsize) / float(global_bsize)
 
 
-def allreduce_flat(flat_grads: torch.Tensor, group=None) -> torch.Tensor:
-    """In-place SUM over ranks of the flat gradient bucket (no-op when not initialised / world 1)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+def allreduce_flat(flat_grads: torch.Tensor, group=None, force: bool = False) -> torch.Tensor:
+    """In-place SUM over ranks of the flat gradient bucket (no-op when not initialised / world 1).
+    ``force``: issue the collective also at world size 1 (an identity, but RCCL's communicator set-up and its kernel
+    run -- the first-contact check of the N > 1 path on a 1-GPU box)."""
+    if dist.is_available() and dist.is_initialized() and (force or dist.get_world_size(group) > 1):
         dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=group)
     return flat_grads
+
+
+def check_job_seed(seed: int, world: int, group=None) -> None:
+    """The minibatch shuffle stream must be IDENTICAL on every rank (every rank visits the same sampler range at the same
+    optimiser step; only then is the SUM all-reduce with the fixed 1/world scale the global minibatch mean when
+    N % num_mini_batch != 0).  With a process group up, the ranks compare their seeds (MIN == MAX) and a launcher that
+    passed per-rank seeds fails here instead of training on silently inconsistent gradients."""
+    if world <= 1 or not (dist.is_available() and dist.is_initialized()):
+        return
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    lo = torch.tensor([float(seed)], dtype=torch.float64, device=dev)
+    hi = lo.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    if float(lo.item()) != float(hi.item()):
+        raise ValueError(f"Worker(seed=...) must be the JOB seed, identical on every rank (got {int(lo.item())}..{int(hi.item())}); "
+                         "per-rank randomness is derived from it internally (seed + 7919 * rank)")

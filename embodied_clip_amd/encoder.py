@@ -231,6 +231,10 @@ class RN50Trunk:
         assert o.is_contiguous() and o.dtype == torch.float32 and o.numel() == B * Cc * S * S
         _lib.check(self.lib.ec_nhwc_bf16_to_nchw_f32(feat.data_ptr(), o.data_ptr(), B, S * S, Cc, _lib.stream_ptr()),
                    "ec_nhwc_bf16_to_nchw_f32")
+        if out is not None and not torch.is_inference(o):
+            # the kernel wrote through the raw pointer: bump the tensor's version counter (a zero-element in-place op, no
+            # launch), so that caches keyed on it (policy._bf16_rows) see the storage as changed
+            o.view(-1)[:0].zero_()
         return o
 
     @_lib.on_device

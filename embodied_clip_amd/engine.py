@@ -31,7 +31,7 @@ import torch
 
 from . import _lib
 from . import synthetic as syn
-from .dist import allreduce_flat
+from .dist import allreduce_flat, check_job_seed
 from .encoder import AttentionPool, ClipTextEncoder, RN50Trunk, ViTEmbedder
 from .policy import PolicyHandle
 from .ppo import FlatAdam, linear_decay_lr, ppo_loss_raw
@@ -66,7 +66,9 @@ class SyntheticEnv:
         self.rewards = syn.synthetic_rewards(seed + 3, masks[1:]).reshape(T, n_actors).to(device).contiguous()
         self._k = 0
 
-    def observe(self) -> torch.Tensor:
+    def observe(self, actions_host: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Next batch of frames.  ``actions_host`` (the sampled actions, on the host) is what a simulator would consume;
+        the synthetic env only requires that it has arrived."""
         f = self.frames[self._k % self.pool_steps]
         self._k += 1
         return f
@@ -89,12 +91,18 @@ class Worker:
                  tau: float = 0.95, encoder_sd=None, policy_sd=None, lr_total_steps: int = 300_000_000,
                  encoder_chunk: int = 0, encoder: str = "rn50", encoder_streams: int = 2, frames_u8: bool = False,
                  frames_host: bool = False, zeroshot: bool = False, text_sd=None, goal_tokens=None,
-                 num_mini_batch: int = 1):
+                 num_mini_batch: int = 1, sync_actions: bool = False, force_allreduce: bool = False):
         """``zeroshot=True`` (BASELINE config 5, readme_files/zeroshot_objectnav.md): the observation is the CLIP image
         EMBEDDING (RN50 trunk + AttentionPool2d, 1024-d), the goal is the frozen CLIP text embedding of its prompt
         (text tower run once -> [12, 1024] table) and the policy is the fusion=1 variant (GRU + heads trainable)."""
         self.lib = _lib.load()
         self.zeroshot, self._text_sd, self._goal_tokens = zeroshot, text_sd, goal_tokens
+        # sync_actions: the action-synchronous order of a real vectorised env ([U] VectorSampledTasks.step(actions)): every
+        # env step the sampled actions of ALL actors are copied to the host and waited for before observe() serves the next
+        # frames.  Default off: the synthetic env does not read the actions (SURVEY.md 8d) and the host issues ahead.
+        self.sync_actions = sync_actions
+        # force_allreduce: run the flat-bucket collective also at world size 1 (RCCL first-contact check on a 1-GPU box)
+        self.force_allreduce = force_allreduce
         # [U] allenact RolloutStorage.recurrent_generator(num_mini_batch): contiguous sampler ranges, shuffled order
         assert 1 <= num_mini_batch <= n_actors, "num_mini_batch must not exceed the number of samplers"
         self.num_mini_batch = num_mini_batch
@@ -102,6 +110,7 @@ class Worker:
         # SUM all-reduce with the fixed 1/world scale is the global minibatch mean also when N % num_mini_batch != 0
         # (ranges of different sizes) -- with per-rank streams it would be a mean of differently-sized means
         self._mb_rng = random.Random(seed)                  # (`seed` is the job's seed: identical on every rank)
+        check_job_seed(seed, world)                         # ... which is ENFORCED when a process group is up
         self.dev = self.device = torch.device(device)
         if self.dev.index is None:
             self.dev = self.device = torch.device("cuda", torch.cuda.current_device())
@@ -306,6 +315,8 @@ class Worker:
         T = self.T
         self.h_start.copy_(self.h)
         self._fork()
+        if self.sync_actions:
+            return self._collect_rollout_sync()
         for t in range(T):
             rgb = self.env.observe()      # env.step(actions[t]) happens here in the real system (fp32 NHWC frames)
             for sl in self.slices:
@@ -318,6 +329,43 @@ class Worker:
         self._join()
         if (T & 1) == 1:   # after an odd number of advancing steps the live memory sits in h_next
             self.h, self.h_next = self.h_next, self.h
+
+    def _collect_rollout_sync(self):
+        """The action-synchronous order: act(t) on every slice -> actions[t] D2H, WAITED FOR -> env.step -> encode(t+1).
+        One host round trip per env step sits between act(t) and encode(t+1), as in the real engine."""
+        T = self.T
+        if getattr(self, "_actions_host", None) is None:
+            self._actions_host = torch.empty((self.N,), dtype=torch.int64).pin_memory()
+        for t in range(T):
+            for sl in self.slices:
+                with self._on(sl):
+                    self._act_slice(sl, t)
+                    self._actions_host[sl.o:sl.o + sl.n].copy_(self.actions[t][sl.o:sl.o + sl.n], non_blocking=True)
+            for sl in self.slices:
+                (sl.stream if sl.stream is not None else torch.cuda.current_stream()).synchronize()
+            rgb = self.env.observe(self._actions_host)          # env.step(actions[t])
+            for sl in self.slices:
+                with self._on(sl):
+                    self._encode_slice(sl, rgb, t + 1)
+        for sl in self.slices:
+            with self._on(sl):
+                self._act_slice(sl, T, sample=False)
+        self._join()
+        if (T & 1) == 1:
+            self.h, self.h_next = self.h_next, self.h
+
+    # ---- parameters ---------------------------------------------------------------------------
+    def invalidate_act_tables(self):
+        """The act workspaces cache weight-derived tables (the goal-embedding table E1, the re-ordered weight_ih).  Call
+        this after ANY write to ``self.params`` that does not go through ``update()`` (checkpoint restore, parameter
+        broadcast, an external optimiser)."""
+        for sl in self.slices:
+            sl.act_tables_valid = False
+
+    def set_params(self, flat: torch.Tensor):
+        """Replace the flat parameter vector (e.g. a restored checkpoint) and drop everything derived from it."""
+        self.params.copy_(flat.to(self.params.device, self.params.dtype).view_as(self.params))
+        self.invalidate_act_tables()
 
     @_lib.on_device
     def compute_returns(self):
@@ -414,11 +462,10 @@ class Worker:
                         torch.add(parts[0][0].grads, parts[1][0].grads, out=self.grads)
                         for (sl, _, _) in parts[2:]:
                             self.grads.add_(sl.grads)
-                if self.world > 1:
-                    allreduce_flat(self.grads)                   # one flat 13.9 MB bucket over RCCL/xGMI
+                if self.world > 1 or self.force_allreduce:
+                    allreduce_flat(self.grads, force=self.force_allreduce)   # one flat 13.9 MB bucket over RCCL/xGMI
                 self.opt.step(self.grads, lr=linear_decay_lr(self.base_lr, self.total_steps, self.lr_total_steps))
-                for sl in self.slices:
-                    sl.act_tables_valid = False
+                self.invalidate_act_tables()
 
     @_lib.on_device
     def after_update(self):

@@ -297,21 +297,32 @@ class ResnetTensorObjectNavActorCritic(ActorCriticModel):
         if (feat.dtype != torch.float32 or not feat.is_cuda or not feat.is_contiguous() or feat.requires_grad
                 or feat.dim() != 5 or self.handle.cfg["in_channels"] % 64 != 0):
             return None
+        c = self.handle.cfg
+        if c["spatial"] ** 2 * 65 * 4 > 64 * 1024:       # the conversion kernel's LDS tile (EC_ERR_SHAPE beyond): fp32 path
+            return None
         base = feat._base if feat._base is not None else feat
-        key = (feat.data_ptr(), tuple(feat.shape), tuple(feat.stride()), base._version)
+        try:                                             # (inference-mode tensors have no version counter)
+            version = base._version
+        except RuntimeError:
+            return None
+        # NOTE the cache key relies on the storage's VERSION COUNTER: the storage must be filled through torch ops (or through
+        # RN50Trunk.to_nchw_f32(out=...), which bumps the counter itself) -- a raw-pointer write from foreign code would
+        # leave stale rows here
+        key = (feat.data_ptr(), tuple(feat.shape), tuple(feat.stride()), version)
         cache = getattr(self, "_rows_cache", None)
         if cache is None:
             cache = self._rows_cache = {}
         hit = cache.get(slot)
         if hit is not None and hit[0]() is base and hit[1] == key:
             return hit[2]
-        c = self.handle.cfg
         rows = torch.empty((T * N, c["spatial"] ** 2, c["in_channels"]), dtype=torch.bfloat16, device=feat.device)
         flag = torch.zeros(1, dtype=torch.int32, device=feat.device)
         with _lib.tensor_guard(feat):
-            _lib.check(self.handle.lib.ec_nchw_f32_to_nhwc_bf16(feat.data_ptr(), rows.data_ptr(), T * N, c["spatial"] ** 2,
-                                                               c["in_channels"], flag.data_ptr(), _lib.stream_ptr()),
-                       "ec_nchw_f32_to_nhwc_bf16")
+            rc = self.handle.lib.ec_nchw_f32_to_nhwc_bf16(feat.data_ptr(), rows.data_ptr(), T * N, c["spatial"] ** 2,
+                                                          c["in_channels"], flag.data_ptr(), _lib.stream_ptr())
+        if rc != 0:                                            # a geometry the fast path does not take: the fp32 path serves it
+            cache[slot] = (weakref.ref(base), key, None)
+            return None
         out = rows if int(flag.item()) == 0 else None          # (one host sync per rollout storage version)
         cache[slot] = (weakref.ref(base), key, out)
         return out

@@ -44,3 +44,24 @@ def test_bench_defaults_are_the_metric_configuration():
     assert (a.gpus, a.actors, a.rollout, a.update_repeats, a.scaling, a.encoder) == (1, 256, 128, 4, "strong", "rn50")
     a = bench.parse_args(["--gpus", "8", "--actors-total", "512"])
     assert a.actors_total == 512 and a.scaling == "strong"       # config 4: 64 actors per GPU
+
+
+def test_secondary_legs_fail_soft_and_under_a_watchdog():
+    """nothing a secondary leg raises may cost the headline line, and a hung leg is cut off by the
+    watchdog, which prints the line with what is there."""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench._soft("weak", lambda: {"value": 1.0}) == {"value": 1.0}
+    r = bench._soft("weak", lambda: 1 / 0)
+    assert set(r) == {"error"} and "ZeroDivisionError" in r["error"]
+    # another rank failed (agree = MIN over ranks of the ok flags): this rank's result is withdrawn
+    assert "another rank" in bench._soft("weak", lambda: {"value": 1.0}, agree=lambda ok: 0.0)["error"]
+    code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "out = {'value': 1.0}\n"
+            "def emit(leg=None):\n"
+            "    if leg: out.setdefault(leg, {'error': 'timeout'})\n"
+            "    print(__import__('json').dumps(out), flush=True)\n"
+            "d = bench._Watchdog(0.5, emit); d.leg = 'weak'; time.sleep(30); print('not reached')\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "not reached" not in r.stdout
+    assert _last_json(r.stdout) == {"value": 1.0, "weak": {"error": "timeout"}}

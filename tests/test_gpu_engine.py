@@ -138,3 +138,40 @@ def test_two_stream_encode_is_bit_identical():
     # the policy update is run-to-run non-deterministic at rounding level (split-K fp32 atomics) and Adam's first
     # step maps a near-zero gradient to +-lr, so parameters can only be compared to within two steps of lr = 3e-4
     assert (w1.params - w2.params).abs().max().item() <= 2 * 3e-4 + 1e-7
+
+
+def test_action_synchronous_order_gives_the_same_rollout():
+    """``Worker(sync_actions=True)``: the order a real vectorised env forces (actions D2H and waited for every env step,
+    [U] VectorSampledTasks.step(actions)) changes the schedule only -- features, actions, log-probs, values and the
+    parameters after the update are those of the free-running order, bit for bit."""
+    from embodied_clip_amd.engine import Worker
+    T, N = 4, 64                                        # two slices of 32
+    enc_sd, pol_sd = syn.rn50_visual_state_dict(0), syn.policy_state_dict(0)
+    ws = [Worker(N, T=T, device="cuda:0", seed=5, update_repeats=1, encoder_sd=enc_sd, policy_sd=pol_sd, sync_actions=s)
+          for s in (False, True)]
+    for w in ws:
+        w.iteration()
+    torch.cuda.synchronize()
+    a, b = ws
+    assert b.ns == 2 and b._actions_host.shape == (N,)
+    assert torch.equal(a.actions, b.actions) and torch.equal(a.logp, b.logp) and torch.equal(a.values, b.values)
+    assert torch.equal(a.feat, b.feat) and torch.equal(a.params, b.params)
+    assert torch.equal(b._actions_host, b.actions[T - 1].cpu())          # the host copy of the last step's actions
+
+
+def test_set_params_invalidates_the_act_tables():
+    """the act workspaces cache weight-derived tables; `set_params` / `invalidate_act_tables` drop them, so a
+    parameter write outside `update()` cannot leave the act steps on stale goal-embedding / W_ih tables."""
+    from embodied_clip_amd.engine import Worker
+    T, N = 2, 4
+    enc_sd = syn.rn50_visual_state_dict(0)
+    sd_a, sd_b = syn.policy_state_dict(0), syn.policy_state_dict(1)
+    wa = Worker(N, T=T, device="cuda:0", seed=5, update_repeats=1, encoder_sd=enc_sd, policy_sd=sd_a)
+    wb = Worker(N, T=T, device="cuda:0", seed=5, update_repeats=1, encoder_sd=enc_sd, policy_sd=sd_b)
+    wa.collect_rollout()                               # tables of sd_a are now cached in wa's act workspaces
+    wa.set_params(wb.params)
+    assert not any(sl.act_tables_valid for sl in wa.slices)
+    wa.h.zero_(); wa.h_next.zero_(); wa.env._k = wb.env._k = 1; wa.iter = wb.iter = 0
+    wa.collect_rollout(); wb.collect_rollout()
+    torch.cuda.synchronize()
+    assert torch.equal(wa.values, wb.values) and torch.equal(wa.logp, wb.logp)

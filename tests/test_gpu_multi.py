@@ -24,6 +24,24 @@ def _bench(*flags, timeout=1500):
     return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
 
 
+def test_rccl_first_contact_at_world_size_1():
+    """the N > 1 path's plumbing on the driver's 1-GPU box -- `bench.py --gpus 1 --force-dist` goes through
+    the SPAWN launcher (`_spawned_entry`, file-store rendezvous), `init_process_group("nccl", device_id=...)` (RCCL
+    communicator set-up), and runs `allreduce_flat` on the device gradient bucket inside every optimiser step and in the
+    timed all-reduce leg.  At world size 1 the collective is an identity, so the loss must be that of the plain run."""
+    kw = ("--actors", "32", "--rollout", "8", "--steps", "1", "--warmup", "1", "--no-plugin", "--no-sync-actions")
+    line = _bench("--gpus", "1", "--force-dist", *kw, timeout=900)
+    assert line["n_gpus"] == 1 and line["rccl_ranks"] == 1
+    assert isinstance(line["allreduce_ms_per_rank"], list) and len(line["allreduce_ms_per_rank"]) == 1
+    assert 0 < line["allreduce_ms_per_rank"][0] < 50
+    plain = _bench("--gpus", "1", *kw, timeout=900)
+    assert plain["allreduce_ms_per_rank"] is None
+    assert line["loss"] == plain["loss"], (line["loss"], plain["loss"])
+    # the reproducible fraction of the line: value x flop_per_frame / peak
+    r = line["roofline"]
+    assert abs(r["frac"] - line["value"] * line["config"]["flop_per_frame"] / 1e12 / r["peak"]) < 2e-4
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs")
 def test_bench_two_ranks_over_rccl():
     line = _bench("--gpus", "2", "--actors", "64", "--rollout", "8", "--steps", "1", "--warmup", "1", timeout=900)
