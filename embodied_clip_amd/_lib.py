@@ -20,6 +20,8 @@ SIGNATURES = {
     "ec_version": (c_int, []),
     "ec_strerror": (C.c_char_p, [c_int]),
     "ec_conv_bf16": (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p]),
+    "ec_conv_splitk_workspace_bytes": (c_size_t, [c_int] * 6),
+    "ec_conv_bf16_ws": (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p, c_size_t, c_void_p]),
     "ec_clip_resize_table_ints": (c_size_t, [c_int, c_int, c_int]),
     "ec_clip_resize_table": (c_int, [c_int, c_int, c_int, c_void_p, c_size_t]),
     "ec_clip_resize_crop_u8": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

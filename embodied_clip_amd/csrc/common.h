@@ -91,6 +91,19 @@ struct ec_min_tiles_scope {
     ~ec_min_tiles_scope() { ec_tls_conv8_min_tiles = prev; }
 };
 
+// Partial-sum workspace of the K-sliced conv launches (conv_igemm.hip dispatch_split): borrowed from the caller's workspace
+// for the duration of one call (ec_rn50_forward, ec_conv_bf16_ws); without it no launch is K-sliced.
+extern thread_local float* ec_tls_splitk_ws;
+extern thread_local size_t ec_tls_splitk_bytes;
+struct ec_splitk_scope {
+    float* prev; size_t prev_bytes;
+    ec_splitk_scope(void* ws, size_t bytes) : prev(ec_tls_splitk_ws), prev_bytes(ec_tls_splitk_bytes) {
+        ec_tls_splitk_ws = (float*)ws; ec_tls_splitk_bytes = ws ? bytes : 0;
+    }
+    ec_splitk_scope(const ec_splitk_scope&) = delete;
+    ~ec_splitk_scope() { ec_tls_splitk_ws = prev; ec_tls_splitk_bytes = prev_bytes; }
+};
+
 // Once-per-workgroup staging loops (weights -> LDS).  Written as `for (idx = tid; ...) lds[f(idx)] = global[g(idx)]` hipcc
 // emits load -> s_waitcnt vmcnt(0) -> ds_write per iteration: TOTAL / NT serial L2 round trips at the head of EVERY
 // launch (18 of them, ~15 us, in the narrow 3x3 kernels -- round-3 EC_ROWS_DBG ablation).  Here all of a thread's loads
@@ -148,6 +161,14 @@ struct EcConfig {
     int conv8_res128;     // EC_CONV8_RES128  (1)   residual 1x1 launches, K 512..2047, < 100 256-wide tiles: 128-wide 8-wave tiles
     int conv8_lowfill_k;  // EC_CONV8_LOWFILL_K (1024) shortest K of a low-fill 1x1 launch that takes 128-wide 8-wave tiles
     int conv8_lowfill;    // EC_CONV8_LOWFILL (100) 3x3 launches with fewer 256-wide tiles than this take 128-wide ones
+    int conv_ring_ilv;    // EC_CONV_RING_ILV (1)   ring-mode launches issue their LDS-DMA pieces between the MFMAs of the running K-tile
+    int conv_ring_w8;     // EC_CONV_RING_W8  (0)   128x128 ring launches on 8 waves (2 x 4) instead of 4
+    int rn50_side;        // EC_RN50_SIDE     (0)   launches of at most this many frames run the stride-2 blocks' downsample branch on a side stream (0: never; measured: slower)
+    int conv_splitk;      // EC_CONV_SPLITK   (1)   fixed K partition for low-tile-count launches: 0 off, 1 rule, 2..8 forced slice count
+    int conv_splitk_tiles;  // EC_CONV_SPLITK_TILES (200) the rule applies below this many 128x128 tiles
+    int conv_splitk_target; // EC_CONV_SPLITK_TARGET (400) slices = ceil(target / tiles): workgroups the K-sliced launch aims at
+    int conv_splitk_ns;   // EC_CONV_SPLITK_NS (2)  LDS stages of the K-sliced launches (2: double buffer, 2 workgroups per CU; 3: ring)
+    int conv_splitk_tile; // EC_CONV_SPLITK_TILE (128) output tile of the K-sliced launches (64: 64x64 tiles, 4-stage ring)
 };
 const EcConfig& ec_config();          // api.hip
 // conv_igemm.hip (internal): ec_conv_bf16 with an optional fragment-order copy of the weights (ec_pack_wfrag)

@@ -51,6 +51,8 @@
 #include "common.h"
 
 thread_local int ec_tls_conv8_min_tiles = EC_CONV8_MIN_TILES_DEFAULT;   // common.h: set per call from the encoder handle
+thread_local float* ec_tls_splitk_ws = nullptr;                         // common.h (ec_splitk_scope): partial-sum workspace
+thread_local size_t ec_tls_splitk_bytes = 0;
 
 namespace {
 
@@ -73,6 +75,11 @@ struct ConvArgs {
     unsigned res_bytes;           // ... of the residual tensor (= output extent)
     int ablate;                   // profiling only (EC_CONV_ABLATE): 1 no global loads, 2 no MFMA, 4 no LDS stores, 8 no epilogue
     const uint16_t* wf = nullptr; // the weights in MFMA-fragment order (ec_pack_wfrag), or null: conv_igemm8's DIRECT-B variant
+    // fixed K partition (SPLIT instances of conv_igemm_kernel): ksplit slices of the K-tile range, slice z writes its raw fp32
+    // accumulators to part + z * part_stride ([M][Cout] each); splitk_reduce_kernel folds them in slice order
+    int ksplit = 1;
+    float* part = nullptr;
+    long part_stride = 0;
 };
 
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
@@ -223,7 +230,17 @@ __device__ __forceinline__ void fr_step(FragRing<R>& ring, AddrFn& addr, MmaFn& 
 // waves.  The K walk and the per-element summation order are those of the other modes (bit-identical results); what changes
 // is that a K-tile no longer costs a full L2 round trip: measured (round 3, rocprofv3) a 64x64 tile of the single-stage mode
 // takes ~750 ns per K-tile with one workgroup per CU -- 128 clk of MFMA issue per wave.
-template <int BM, int BN, int WM, int WN, int KS, bool POOL, bool PF, int MV, int NS>
+// SPLIT: the launch covers ntiles x ksplit VIRTUAL tiles; virtual tile vt = (K slice z = vt / ntiles, output tile vt % ntiles)
+// walks K-tiles [z nk / S, (z + 1) nk / S) only and leaves its accumulators as raw fp32 in the slice's partial matrix --
+// a FIXED partition of the K walk (decided by the dispatch from the layer's shape and the launch's tile count), folded in
+// slice order by splitk_reduce_kernel: deterministic, no atomics.  For launches with fewer output tiles than CUs (small
+// per-GPU batches: the 14x14 / 7x7 maps at 32-64 frames) every workgroup is otherwise one serial chain of 16-72 K-tiles.
+// ILV (ring mode only): the LDS-DMA pieces of K-tile kt + NS - 1 are issued INSIDE the MFMA stream of K-tile kt (a share of
+// them after every k-step) instead of in front of it.  A CU's L2 -> LDS path moves ~30 B/clk (round 2/3 measurements): the
+// 32 KB of a 128 x 128 K-tile keep the issuing waves blocked for ~1,100 clk, and with ONE workgroup per CU (the ring
+// launches of small per-GPU batches) all four waves sit in that phase together, then in the MFMA phase together -- the two
+// add up (~2,000 clk per K-tile measured at 32 frames).  Issued between MFMAs, the pieces drain while the matrix pipe works.
+template <int BM, int BN, int WM, int WN, int KS, bool POOL, bool PF, int MV, int NS, bool SPLIT = false, bool ILV = false>
 __global__ __launch_bounds__(WM * WN * 64, (BM > 192) ? 2 : ((WM * WN == 8) ? 4 : (NS >= 3 ? 2 : 3))) void conv_igemm_kernel(ConvArgs p) {
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int FM = TM / 32, FN = TN / 32;
@@ -244,8 +261,13 @@ __global__ __launch_bounds__(WM * WN * 64, (BM > 192) ? 2 : ((WM * WN == 8) ? 4 
     // tiles in flight at any moment are neighbours and each XCD owns a contiguous run of them).
     const unsigned grid = gridDim.x;
     const unsigned lb = ec_xcd_remap(blockIdx.x, grid);
-    int tile = (int)lb;
-    if (tile >= p.ntiles) return;
+    static_assert(!SPLIT || (!PF && MV == BM), "K-sliced instances: no residual prefetch, no padded tiles");
+    static_assert(!ILV || (NS >= 3 && !PF && FM + FN <= 4), "interleaved pieces: ring mode with the inline-asm fragment stream");
+    const int nvt = SPLIT ? p.ntiles * p.ksplit : p.ntiles;     // virtual tiles of the launch
+    int vt = (int)lb;
+    if (vt >= nvt) return;
+    int kz = SPLIT ? vt / p.ntiles : 0;                         // K slice of this virtual tile
+    int tile = SPLIT ? vt - kz * p.ntiles : vt;
     static_assert(MV <= BM && (MV == BM || !POOL), "padded tiles: non-pooled only");
     int m0 = (tile / p.ntn) * MV;
     int n0 = (tile % p.ntn) * BN;
@@ -306,6 +328,16 @@ __global__ __launch_bounds__(WM * WN * 64, (BM > 192) ? 2 : ((WM * WN == 8) ? 4 
 #endif
     const int wave_lds = wave * 1024;                       // 64 lanes x 16 B
     // per-K-tile addressing state shared by the pieces of one tile
+    const int nk = (p.K + BK - 1) / BK;
+    int kt0 = 0, kt1 = nk, k_lim = p.K;         // this virtual tile's K-tile range; k >= k_lim reads as zeros
+    auto krange = [&]() {
+        if constexpr (SPLIT) {
+            kt0 = (int)((long)kz * nk / p.ksplit);
+            kt1 = (int)((long)(kz + 1) * nk / p.ksplit);
+            k_lim = kt1 * BK < p.K ? kt1 * BK : p.K;
+        }
+    };
+    krange();
     int g_toff = 0; unsigned g_tapbit = 0; bool g_kin = false; int g_kt = 0;
     unsigned char* g_sa = smem; unsigned char* g_sb = smem;
     auto glds_begin = [&](int kt, int buf) {
@@ -326,7 +358,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM > 192) ? 2 : ((WM * WN == 8) ? 4 
             const int ky = (tap * 11) >> 5;   // tap / 3 for tap in 0..8
             g_toff = (((ky - 1) * p.W + (tap - ky * 3 - 1)) * p.Cin + ci) * 2;
         }
-        g_kin = k < p.K;
+        g_kin = k < k_lim;
         g_tapbit = g_kin ? (1u << tap) : 0u;
         g_kt = kt;
     };
@@ -364,7 +396,6 @@ __global__ __launch_bounds__(WM * WN * 64, (BM > 192) ? 2 : ((WM * WN == 8) ? 4 
     constexpr bool PREFETCH = PF && !POOL && (NPASS <= 8);   // PF: short-K (bandwidth-bound) launches only
     uint4 rres[PREFETCH ? NPASS : 1];
 
-    const int nk = (p.K + BK - 1) / BK;
     const int frow = lane & 31;
     const int fhalf = lane >> 5;
     auto compute = [&](int buf) {
@@ -412,6 +443,13 @@ __global__ __launch_bounds__(WM * WN * 64, (BM > 192) ? 2 : ((WM * WN == 8) ? 4 
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                         __builtin_bit_cast(bf16x8_t, rg.f[(ks * G + FM + j) % R]), __builtin_bit_cast(bf16x8_t, rg.f[(ks * G + i) % R]),
                         acc[i][j], 0, 0, 0);
+            if constexpr (ILV) {   // this k-step's share of the next ring tile's pieces, pinned behind its MFMAs
+                constexpr int P = A_IT + B_IT, lo = ks * P / NKS, hi = (ks + 1) * P / NKS;
+                __builtin_amdgcn_sched_barrier(0);
+                [&]<int... Q>(std::integer_sequence<int, Q...>) { (glds_piece(std::integral_constant<int, lo + Q>{}), ...); }
+                (std::make_integer_sequence<int, hi - lo>{});
+                __builtin_amdgcn_sched_barrier(0);
+            }
         };
         [&]<int... Q>(std::integer_sequence<int, Q...>) { (fr_issue<Q, R>(ring, addr), ...); }(std::make_integer_sequence<int, G>{});
         fr_step<0, NKS, G, R>(ring, addr, mma);
@@ -445,49 +483,83 @@ __global__ __launch_bounds__(WM * WN * 64, (BM > 192) ? 2 : ((WM * WN == 8) ? 4 
             // K-tiles past the end are all out-of-range offsets (zeros into a free stage): every K-tile then has exactly
             // PIECES younger-by-one-tile instructions behind it and the counted wait needs no tail cases
 #pragma unroll
-            for (int t = 0; t < NS - 1; ++t) glds_tile(t, t);
+            for (int t = 0; t < NS - 1; ++t) glds_tile(kt0 + t, t);
             int st_c = 0, st_l = NS - 1;                        // stage of the K-tile computed / loaded next
-            for (int kt = 0; kt < nk; ++kt) {
+            for (int kt = kt0; kt < kt1; ++kt) {
                 asm volatile("s_waitcnt vmcnt(%0)" : : "n"((NS - 2) * PIECES) : "memory");   // own pieces of K-tile kt
                 __builtin_amdgcn_s_barrier();                   // everyone's landed; everyone is done with K-tile kt-1
+                if constexpr (ILV) {
+                    glds_begin(kt + NS - 1, st_l);              // addresses now, the pieces from inside compute()
+                    compute(st_c);
+                } else {
                 if (!(p.ablate & 1)) glds_tile(kt + NS - 1, st_l);   // into the stage K-tile kt-1 just left
                 if (!(p.ablate & 2)) compute(st_c);
+                }
                 st_c = (st_c + 1 == NS) ? 0 : st_c + 1;
                 st_l = (st_l + 1 == NS) ? 0 : st_l + 1;
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the zero-filled tail tiles too: LDS becomes the epilogue image
             __syncthreads();
         } else {
-        glds_tile(0, 0);
+        glds_tile(kt0, 0);
         __syncthreads();
         if (p.nbuf == 1) {
             // single LDS stage, two barriers per K-tile: smallest footprint (3 workgroups per CU); the load
             // latency of one workgroup is covered by the MFMAs of the other two
-            for (int kt = 0; kt < nk; ++kt) {
+            for (int kt = kt0; kt < kt1; ++kt) {
                 if (!(p.ablate & 2)) compute(0);
-                if (kt + 1 < nk) {
+                if (kt + 1 < kt1) {
                     __syncthreads();
                     if (!(p.ablate & 1)) glds_tile(kt + 1, 0);
                 }
                 __syncthreads();
             }
         } else {
-            for (int kt = 0; kt < nk; ++kt) {
-                const int cur = kt & 1;
-                const bool more = (kt + 1) < nk;
+            for (int kt = kt0; kt < kt1; ++kt) {
+                const int cur = (kt - kt0) & 1;
+                const bool more = (kt + 1) < kt1;
                 if (more && !(p.ablate & 1)) glds_tile(kt + 1, cur ^ 1);
                 if (!(p.ablate & 2)) compute(cur);
                 __syncthreads();
             }
         }
         }   // NS < 3
-        tile += (int)grid;
-        const bool has_next = tile < p.ntiles;
+        const int e_kz = kz;
+        vt += (int)grid;
+        const bool has_next = vt < nvt;
         if (has_next) {
+            kz = SPLIT ? vt / p.ntiles : 0;
+            tile = SPLIT ? vt - kz * p.ntiles : vt;
             m0 = (tile / p.ntn) * MV;
             n0 = (tile % p.ntn) * BN;
             decode();
+            krange();
         }
+        if constexpr (SPLIT) {
+            // raw fp32 accumulators -> LDS image (swapped operands: a lane owns one pixel and, per 4 registers, 4 consecutive
+            // channels = one 16-byte slot) -> the slice's partial matrix as coalesced 16-byte row chunks
+            constexpr int PITCH4 = BN * 4 + 16, CH4 = BN / 4, RPP4 = NT / CH4;
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int i = 0; i < FM; ++i) {
+                        const int lrow_px = wm * TM + i * 32 + frow, lcol = wn * TN + j * 32 + 8 * g + 4 * fhalf;
+                        *reinterpret_cast<float4*>(smem + lrow_px * PITCH4 + lcol * 4) =
+                            make_float4(acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+                    }
+            __syncthreads();
+            float* dst = p.part + (long)e_kz * p.part_stride;
+            const int srow4 = tid / CH4, sch4 = tid % CH4;
+#pragma unroll
+            for (int r0 = 0; r0 < BM; r0 += RPP4) {
+                const int row = r0 + srow4;
+                if (e_m0 + row < p.M)
+                    *reinterpret_cast<float4*>(dst + (long)(e_m0 + row) * p.Cout + e_n0 + sch4 * 4) =
+                        *reinterpret_cast<const float4*>(smem + row * PITCH4 + sch4 * 16);
+            }
+        } else
         if (!(p.ablate & 8)) {
     // ---- epilogue: staged through LDS so every global access is a coalesced 16-B chunk ----
     //   1. prefetched residual tile -> LDS                [only with a residual]
@@ -528,7 +600,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM > 192) ? 2 : ((WM * WN == 8) ? 4 
     }
 }
 
-template <int BM, int BN, int WM, int WN, int KS, bool POOL, bool PF = false, int MV = BM, int NS = 0>
+template <int BM, int BN, int WM, int WN, int KS, bool POOL, bool PF = false, int MV = BM, int NS = 0, bool ILV = false>
 int launch(const ConvArgs& a, hipStream_t s) {
     ConvArgs p = a;
     p.ntn = a.Cout / BN;
@@ -542,7 +614,7 @@ int launch(const ConvArgs& a, hipStream_t s) {
     p.ablate = ablate;
     size_t lds = (size_t)(NS >= 3 ? NS : p.nbuf) * (BM + BN) * ROW_BYTES;
     if (lds < epi) lds = epi;
-    auto kern = conv_igemm_kernel<BM, BN, WM, WN, KS, POOL, PF, MV, NS>;
+    auto kern = conv_igemm_kernel<BM, BN, WM, WN, KS, POOL, PF, MV, NS, false, ILV>;
     static std::atomic<uint64_t> attr_done{0};
     if (auto attr_g_ = ec_attr_needed(attr_done)) {
         const size_t want = NS >= 3 ? lds : (lds_max > epi ? lds_max : epi);
@@ -555,6 +627,89 @@ int launch(const ConvArgs& a, hipStream_t s) {
     const int cap = NS >= 3 ? 256 * ring_per_cu : ((BM * BN >= 256 * 256) ? 256 : wg_cap);      // 8-wave 256x256 tiles: one workgroup per CU
     const int nwg = p.ntiles < cap ? p.ntiles : cap;
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(WM * WN * 64), lds, s, p);
+    EC_CHECK_LAUNCH();
+    return EC_OK;
+}
+
+
+// ---- fixed K partition for launches with fewer output tiles than CUs (round 4) --------------------------------------
+// out[m][n] = act(sum_z part[z][m][n] + bias[n] (+ res[m][n])) -> bf16, slices folded in index order (deterministic).
+// POOL: rows are ordered m = 4 q + (dy 2 + dx) (conv_igemm_kernel's POOL decode): out[q] = mean_s relu(...), summed as
+// (s0 + s1) + (s2 + s3) like the fused epilogue's two DPP adds.  One thread = 8 consecutive channels of one output row.
+template <bool POOL>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, long stride, int S,
+                                                            const float* __restrict__ bias, const uint16_t* __restrict__ res,
+                                                            uint16_t* __restrict__ out, int Mout, int Cout, int relu) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int c8 = Cout >> 3;
+    const long row = idx / c8;
+    if (row >= Mout) return;
+    const int col = (int)(idx - row * c8) * 8;
+    float b[8];
+    {
+        const float4 b0 = bias ? *reinterpret_cast<const float4*>(bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 b1 = bias ? *reinterpret_cast<const float4*>(bias + col + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        b[0] = b0.x; b[1] = b0.y; b[2] = b0.z; b[3] = b0.w; b[4] = b1.x; b[5] = b1.y; b[6] = b1.z; b[7] = b1.w;
+    }
+    constexpr int R = POOL ? 4 : 1;
+    float v[R][8];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const float* src = part + ((long)row * R + r) * Cout + col;
+        float4 a0 = *reinterpret_cast<const float4*>(src), a1 = *reinterpret_cast<const float4*>(src + 4);
+        for (int z = 1; z < S; ++z) {
+            const float4 c0 = *reinterpret_cast<const float4*>(src + z * stride), c1 = *reinterpret_cast<const float4*>(src + z * stride + 4);
+            a0.x += c0.x; a0.y += c0.y; a0.z += c0.z; a0.w += c0.w;
+            a1.x += c1.x; a1.y += c1.y; a1.z += c1.z; a1.w += c1.w;
+        }
+        v[r][0] = a0.x + b[0]; v[r][1] = a0.y + b[1]; v[r][2] = a0.z + b[2]; v[r][3] = a0.w + b[3];
+        v[r][4] = a1.x + b[4]; v[r][5] = a1.y + b[5]; v[r][6] = a1.z + b[6]; v[r][7] = a1.w + b[7];
+    }
+    float o[8];
+    if constexpr (POOL) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            o[c] = 0.25f * ((ec_relu(v[0][c]) + ec_relu(v[1][c])) + (ec_relu(v[2][c]) + ec_relu(v[3][c])));
+    } else {
+        if (res) {
+            const uint4 rr = *reinterpret_cast<const uint4*>(res + row * Cout + col);
+            v[0][0] += ec_lo(rr.x); v[0][1] += ec_hi(rr.x); v[0][2] += ec_lo(rr.y); v[0][3] += ec_hi(rr.y);
+            v[0][4] += ec_lo(rr.z); v[0][5] += ec_hi(rr.z); v[0][6] += ec_lo(rr.w); v[0][7] += ec_hi(rr.w);
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) o[c] = relu ? ec_relu(v[0][c]) : v[0][c];
+    }
+    uint4 w;
+    w.x = ec_pack2(o[0], o[1]); w.y = ec_pack2(o[2], o[3]); w.z = ec_pack2(o[4], o[5]); w.w = ec_pack2(o[6], o[7]);
+    *reinterpret_cast<uint4*>(out + row * Cout + col) = w;
+}
+
+// NS: LDS stages of the K-sliced launch (>= 3: ring mode; 2: plain double buffer, 64 KB for 128x128 tiles = 2 workgroups per CU)
+template <int BM, int BN, int WM, int WN, int KS, bool POOL, int NS>
+int launch_split(const ConvArgs& a, int S, float* part, hipStream_t s) {
+    ConvArgs p = a;
+    p.ntn = a.Cout / BN;
+    p.ntiles = ((a.M + BM - 1) / BM) * p.ntn;
+    p.ksplit = S;
+    p.part = part;
+    p.part_stride = (long)a.M * a.Cout;
+    p.nbuf = 2;
+    p.ablate = 0;
+    size_t lds = (size_t)(NS >= 3 ? NS : 2) * (BM + BN) * ROW_BYTES;
+    const size_t raw = (size_t)BM * (BN * 4 + 16);
+    if (lds < raw) lds = raw;
+    auto kern = conv_igemm_kernel<BM, BN, WM, WN, KS, POOL, false, BM, (NS >= 3 ? NS : 0), true>;
+    static std::atomic<uint64_t> attr_done{0};
+    if (auto attr_g_ = ec_attr_needed(attr_done))
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int per_cu = (int)std::min<size_t>(NS >= 3 ? 2 : 3, (160 * 1024) / lds);
+    const int nvt = p.ntiles * S, cap = 256 * per_cu;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(nvt < cap ? nvt : cap)), dim3(WM * WN * 64), lds, s, p);
+    EC_CHECK_LAUNCH();
+    const int Mout = POOL ? a.M / 4 : a.M;
+    const long threads = (long)Mout * (a.Cout / 8);
+    hipLaunchKernelGGL(splitk_reduce_kernel<POOL>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, part, p.part_stride, S,
+                       a.bias, POOL ? nullptr : a.res, a.out, Mout, a.Cout, a.act == EC_ACT_RELU ? 1 : 0);
     EC_CHECK_LAUNCH();
     return EC_OK;
 }
@@ -1107,8 +1262,41 @@ int launch8(const ConvArgs& a, hipStream_t s) {
 }
 
 
+// Fixed K partition (round 4): launches with too few output tiles to fill the chip -- the 14x14 / 7x7 maps of layers 3-4 at
+// 32-64 frames per launch.  The slice count is a function of the layer's shape and the launch's tile count only, so a
+// given launch shape always sums in the same order (run-to-run determinism, bit-identity for a fixed launch shape);
+// ACROSS launch shapes results agree to fp32-accumulation rounding (tests: rel-L2 <= 1e-3 on the bf16 features).
+// EC_CONV_SPLITK: 0 off; 1 (default) the rule below; 2..8: force that many slices wherever the preconditions hold (tests).
+// Needs the caller's partial-sum workspace (ec_splitk_scope: set by ec_rn50_forward / ec_conv_bf16_ws).
+template <int KS, bool POOL>
+int dispatch_split(const ConvArgs& a, hipStream_t s) {
+    const int mode = ec_config().conv_splitk;
+    if (mode == 0 || !ec_tls_splitk_ws || a.Cout % 128 != 0 || a.Cin % 8 != 0 || a.act == EC_ACT_QUICKGELU) return EC_ERR_SHAPE;
+    if (POOL && (a.M % 4) != 0) return EC_ERR_SHAPE;
+    const int nk = (a.K + BK - 1) / BK;
+    const long t128 = (long)((a.M + 127) / 128) * (a.Cout / 128);
+    int S;
+    if (mode >= 2) S = mode;
+    else {
+        // the rule: fewer 128x128 tiles than ~3/4 of the CUs and a K walk of >= 16 tiles: as many slices as bring the
+        // launch to ~1.5-2 workgroups per CU, each slice keeping >= 4 K-tiles
+        if (t128 >= ec_config().conv_splitk_tiles || nk < 16) return EC_ERR_SHAPE;
+        S = (int)((ec_config().conv_splitk_target + t128 - 1) / t128);
+        if (S > 8) S = 8;
+    }
+    while (S > 1 && nk / S < 4) --S;
+    if (S < 2) return EC_ERR_SHAPE;
+    if ((size_t)S * (size_t)a.M * (size_t)a.Cout * 4 > ec_tls_splitk_bytes) return EC_ERR_SHAPE;
+    if constexpr (!POOL) {
+        if (ec_config().conv_splitk_tile == 64) return launch_split<64, 64, 2, 2, KS, POOL, 4>(a, S, ec_tls_splitk_ws, s);
+    }
+    if (ec_config().conv_splitk_ns >= 3) return launch_split<128, 128, 2, 2, KS, POOL, 3>(a, S, ec_tls_splitk_ws, s);
+    return launch_split<128, 128, 2, 2, KS, POOL, 2>(a, S, ec_tls_splitk_ws, s);
+}
+
 template <int KS, bool POOL>
 int dispatch_tile(const ConvArgs& a, hipStream_t s) {
+    if (dispatch_split<KS, POOL>(a, s) == EC_OK) return EC_OK;
     const int force = ec_config().conv_waves;
     // Tile choice: 128x128 wherever Cout allows; 256-row tiles for the narrow early layers.
     // (Fatter 128x256 / 256x128 tiles were measured: no gain, and they spill once loads run two tiles ahead.)
@@ -1198,13 +1386,22 @@ int dispatch_tile(const ConvArgs& a, hipStream_t s) {
                 // (deeper rings -- 6 / 8 stages for launches with at most one workgroup per CU, 4 stages for the 128x128 ring --
                 //  measured round 3: 0.944 -> 0.95-0.96 ms at 32 frames, 1.50 -> 1.50-1.51 at 64: stages in flight are not
                 //  what bounds these launches any more; what is left per K-tile is barrier + piece issue)
-                return ring ? launch<64, 64, 2, 2, KS, POOL, false, 64, 4>(a, s) : launch<64, 64, 2, 2, KS, POOL>(a, s);
+                return ring ? (ec_config().conv_ring_ilv ? launch<64, 64, 2, 2, KS, POOL, false, 64, 4, true>(a, s)
+                                                          : launch<64, 64, 2, 2, KS, POOL, false, 64, 4>(a, s))
+                            : launch<64, 64, 2, 2, KS, POOL>(a, s);
         }
         {
             const long t128 = (long)((a.M + 127) / 128) * (a.Cout / 128);
             const bool pf = (KS == 1 && !POOL && a.res && a.K <= 256);
-            if (force != 8 && !pf && a.K >= 512 && ((ring == 1 && t128 <= 256) || ring == 2))
-                return launch<128, 128, 2, 2, KS, POOL, false, 128, 3>(a, s);
+            if (force != 8 && !pf && a.K >= 512 && ((ring == 1 && t128 <= 256) || ring == 2)) {
+                // EC_CONV_RING_W8: the one-workgroup-per-CU ring launches on 8 waves (2 x 4, wave tile 64 x 32): two waves
+                // per SIMD, so one wave's fragment reads / piece issue run beside the other's MFMAs
+                if (ec_config().conv_ring_w8)
+                    return ec_config().conv_ring_ilv ? launch<128, 128, 2, 4, KS, POOL, false, 128, 3, true>(a, s)
+                                                     : launch<128, 128, 2, 4, KS, POOL, false, 128, 3>(a, s);
+                return ec_config().conv_ring_ilv ? launch<128, 128, 2, 2, KS, POOL, false, 128, 3, true>(a, s)
+                                                 : launch<128, 128, 2, 2, KS, POOL, false, 128, 3>(a, s);
+            }
         }
         // residual register prefetch only for the short-K, bandwidth-bound expanding 1x1 convs
         if (force != 8) {
@@ -1258,6 +1455,23 @@ int ec_pack_wfrag(const void* w, void* wf, int Cout, int K, hipStream_t s) {
 
 extern "C" int ec_conv_bf16(const void* in, const void* w, const float* bias, const void* res, void* out, int B,
                             int H, int W, int Cin, int Cout, int ksize, int pool, int act, ec_stream_t stream) {
+    return ec_conv_bf16_wf(in, w, nullptr, bias, res, out, B, H, W, Cin, Cout, ksize, pool, act, stream);
+}
+
+// ... with a caller-owned fp32 workspace for the K-sliced launches (dispatch_split); without one (ec_conv_bf16) no launch
+// is K-sliced.  ec_conv_splitk_workspace_bytes: the most such a launch of this shape can use (0: never K-sliced).
+extern "C" size_t ec_conv_splitk_workspace_bytes(int B, int H, int W, int Cin, int Cout, int ksize) {
+    const long M = (long)B * H * W, K = (long)ksize * ksize * Cin;
+    if (B <= 0 || Cout % 128 != 0 || K < 16 * BK) return 0;
+    const long t128 = ((M + 127) / 128) * (Cout / 128);
+    const int mode = ec_config().conv_splitk;
+    if (mode == 0 || (mode == 1 && t128 >= ec_config().conv_splitk_tiles)) return 0;
+    return (size_t)8 * (size_t)M * (size_t)Cout * 4;
+}
+extern "C" int ec_conv_bf16_ws(const void* in, const void* w, const float* bias, const void* res, void* out, int B,
+                               int H, int W, int Cin, int Cout, int ksize, int pool, int act, void* workspace,
+                               size_t ws_bytes, ec_stream_t stream) {
+    const ec_splitk_scope scope(workspace, ws_bytes);
     return ec_conv_bf16_wf(in, w, nullptr, bias, res, out, B, H, W, Cin, Cout, ksize, pool, act, stream);
 }
 

@@ -32,6 +32,10 @@ struct Op {
     int src1 = -1, dst2 = -1, N2 = 0;
     int dst3 = -1;           // OP_PAIR at the layer-1 -> layer-2 boundary: AvgPool2d(2)(y) for the downsample path
     size_t w1_off = 0, b1_off = 0, w2_off = 0, b2_off = 0;
+    // side branch (small batches): the downsample path of a stride-2 block (AvgPool2d + 1x1 conv) is independent of the
+    // block's conv1 -> conv2 chain; group g > 0: `fork` on the op before which the branch may start (conv1), `side` on the
+    // branch's ops, `join` on the op that consumes its result (conv3)
+    int fork = 0, side = 0, join = 0;
 };
 
 }  // namespace
@@ -46,7 +50,18 @@ struct ec_rn50 {
     size_t n_w, n_b;
     int conv8_min_tiles = 0;      // 0 = library default (ec_rn50_set_conv8_min_tiles)
     uint16_t* wfrag = nullptr;    // EC_CONV8_DIRB: fragment-order copies of the 256-multiple-Cout convs' weights (same offsets as w)
-    ~ec_rn50() { if (wfrag) (void)hipFree(wfrag); }
+    // side branch of the stride-2 blocks (EC_RN50_SIDE): the handle's own non-blocking stream + fork / join events per group
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_fork[4] = {nullptr, nullptr, nullptr, nullptr}, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
+    int n_side = 0;
+    ~ec_rn50() {
+        if (wfrag) (void)hipFree(wfrag);
+        for (int i = 0; i < 4; ++i) {
+            if (ev_fork[i]) (void)hipEventDestroy(ev_fork[i]);
+            if (ev_join[i]) (void)hipEventDestroy(ev_join[i]);
+        }
+        if (side_stream) (void)hipStreamDestroy(side_stream);
+    }
 };
 
 namespace {
@@ -143,6 +158,7 @@ extern "C" int ec_rn50_create(ec_rn50_t** out, int width, const int* layers4, in
                 inplanes = planes * 4;
                 continue;
             }
+            int side_grp = 0;
             if (ds) {
                 int dsrc = x, ddst = 3;
                 if (stride > 1 && pooled_in >= 0) {   // pooled input came with the previous boundary launch (buffer 3);
@@ -150,12 +166,22 @@ extern "C" int ec_rn50_create(ec_rn50_t** out, int width, const int* layers4, in
                     ddst = 1;
                     pooled_in = -1;
                 } else if (stride > 1) {
-                    Op o{OP_POOL, x, 1, -1, R, R, inplanes, inplanes, 0, 0, 0, 0, 0};
+                    // the pooled block input goes to the block's OUTPUT buffer y (free until conv3 writes it), not to the
+                    // conv1 / conv2 temporaries: the downsample branch then shares no buffer with the conv1 -> conv2 chain
+                    // and can run beside it (rn50_run, EC_RN50_SIDE)
+                    Op o{OP_POOL, x, y, -1, R, R, inplanes, inplanes, 0, 0, 0, 0, 0};
+                    if (h->n_side < 4 && h->ops.size() >= 2 && h->ops[h->ops.size() - 2].kind == OP_CONV &&
+                        h->ops[h->ops.size() - 2].src == x) {
+                        side_grp = ++h->n_side;
+                        h->ops[h->ops.size() - 2].fork = side_grp;      // this block's conv1
+                        o.side = side_grp;
+                    }
                     h->ops.push_back(o);
                     track(Ro, Ro, inplanes);
-                    dsrc = 1;
+                    dsrc = y;
                 }
                 conv(dsrc, ddst, -1, Ro, Ro, inplanes, planes * 4, 1, 0, EC_ACT_NONE);
+                h->ops.back().side = side_grp;
                 idt = ddst;
             }
             // Layer-2 block boundaries (28x28, 128 -> 512 -> 128): conv3 + identity + ReLU and the next block's conv1 in
@@ -172,6 +198,7 @@ extern "C" int ec_rn50_create(ec_rn50_t** out, int width, const int* layers4, in
                 c1_buf = o.dst2;
             } else {
                 Op o{OP_CONV, 2, y, idt, Ro, Ro, planes, planes * 4, 1, 0, EC_ACT_RELU, w_c3, b_c3};
+                o.join = side_grp;
                 h->ops.push_back(o);
                 track(Ro, Ro, planes * 4);
             }
@@ -185,6 +212,13 @@ extern "C" int ec_rn50_create(ec_rn50_t** out, int width, const int* layers4, in
     h->max_elems_per_frame = mx;
     h->n_w = wo; h->n_b = bo;
     if (n_w != wo || n_bias != bo) { delete h; return EC_ERR_SHAPE; }
+    if (h->n_side > 0 && ec_config().rn50_side > 0) {
+        bool ok = hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking) == hipSuccess;
+        for (int i = 0; i < h->n_side && ok; ++i)
+            ok = hipEventCreateWithFlags(&h->ev_fork[i], hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming) == hipSuccess;
+        if (!ok) { delete h; return EC_ERR_LAUNCH; }
+    }
     if (ec_config().conv8_dirb) {   // fragment-order weights of every conv the 8-wave kernel's direct-B variant can take
         if (hipMalloc(&h->wfrag, wo * sizeof(uint16_t)) != hipSuccess) { h->wfrag = nullptr; delete h; return EC_ERR_LAUNCH; }
         for (const Op& o : h->ops)
@@ -213,7 +247,7 @@ extern "C" uint64_t ec_rn50_plan_hash(const ec_rn50_t* h) {
     mix(h->width); mix(h->res); mix(h->conv8_min_tiles);
     for (const Op& o : h->ops) {
         mix(o.kind); mix(o.src); mix(o.dst); mix(o.res); mix(o.H); mix(o.W); mix(o.Cin); mix(o.Cout); mix(o.ks);
-        mix(o.pool); mix(o.act); mix(o.src1); mix(o.dst2); mix(o.N2); mix(o.dst3);
+        mix(o.pool); mix(o.act); mix(o.src1); mix(o.dst2); mix(o.N2); mix(o.dst3); mix(o.side);
     }
     return x;
 }
@@ -224,9 +258,20 @@ extern "C" int ec_rn50_set_conv8_min_tiles(ec_rn50_t* h, int n) {
     return EC_OK;
 }
 
+extern "C" size_t ec_conv_splitk_workspace_bytes(int B, int H, int W, int Cin, int Cout, int ksize);
+namespace {
+// fp32 partial-sum region for the K-sliced launches of small batches (conv_igemm.hip dispatch_split), behind the five
+// activation buffers: the largest any conv of the plan can use at this batch (0 at large batches: nothing is K-sliced)
+size_t rn50_splitk_bytes(const ec_rn50_t* h, int batch) {
+    size_t mx = 0;
+    for (const Op& o : h->ops)
+        if (o.kind == OP_CONV) mx = std::max(mx, ec_conv_splitk_workspace_bytes(batch, o.H, o.W, o.Cin, o.Cout, o.ks));
+    return align_up(mx, 256);
+}
+}  // namespace
 extern "C" size_t ec_rn50_workspace_bytes(const ec_rn50_t* h, int batch) {
     if (!h || batch <= 0) return 0;
-    return NBUF * align_up(h->max_elems_per_frame * 2 * (size_t)batch, 256);
+    return NBUF * align_up(h->max_elems_per_frame * 2 * (size_t)batch, 256) + rn50_splitk_bytes(h, batch);
 }
 
 extern "C" int ec_stem_conv1_u8(const uint8_t* rgb_u8, const float* mean3, const float* std3, const float* w,
@@ -251,7 +296,7 @@ extern "C" int ec_rn50_forward_u8(const ec_rn50_t* h, const uint8_t* rgb_u8, con
 
 namespace {
 int rn50_run(const ec_rn50_t* h, const void* rgb, bool u8, const float* mean3, const float* std3, int batch,
-             void* workspace, size_t ws_bytes, void* feat, int chunk, ec_stream_t stream) {
+             void* workspace, size_t ws_bytes, void* feat, int chunk, ec_stream_t stream_main) {
     if (!h || !rgb || !workspace || !feat) return EC_ERR_ARG;
     if (batch <= 0) return EC_ERR_SHAPE;
     if (chunk <= 0 || chunk > batch) chunk = batch;
@@ -263,6 +308,7 @@ int rn50_run(const ec_rn50_t* h, const void* rgb, bool u8, const float* mean3, c
     const ec_min_tiles_scope mint_scope(h->conv8_min_tiles);   // this handle's dispatch threshold, for this call only
     const size_t bufsz = align_up(h->max_elems_per_frame * 2 * (size_t)chunk, 256);
     unsigned char* base = (unsigned char*)workspace;
+    const ec_splitk_scope splitk_scope(base + NBUF * bufsz, rn50_splitk_bytes(h, chunk));   // (the region behind the buffers)
     const size_t rgb_stride = (size_t)h->res * h->res * 3;
     const size_t out_stride = (size_t)h->out_sp * h->out_sp * h->out_c;
     for (int b0 = 0; b0 < batch; b0 += chunk) {
@@ -271,8 +317,25 @@ int rn50_run(const ec_rn50_t* h, const void* rgb, bool u8, const float* mean3, c
             if (id == -3) return (uint16_t*)feat + (size_t)b0 * out_stride;
             return base + (size_t)id * bufsz;
         };
+        // EC_RN50_SIDE = n (default 0 = off): in launches of at most n frames -- where no single conv fills the chip -- the
+        // downsample branch of the stride-2 blocks (AvgPool2d + 1x1 conv) runs on the handle's side stream beside the
+        // block's conv1 -> conv2 chain: forked before conv1, joined before conv3.  MEASURED (round 4): 0.929 -> 0.963 ms at
+        // 32 frames, neutral at 64, and 36.7 -> 26.4 k env-frames/s with two 32-frame slices in flight (four streams
+        // contending: the event hand-offs serialise the slices) -- kept as an experiment switch only.
+        const bool side_on = h->side_stream && nb <= ec_config().rn50_side;
         for (const Op& o : h->ops) {
             int rc;
+            hipStream_t stream = (hipStream_t)stream_main;
+            if (side_on) {
+                if (o.fork) { if (hipEventRecord(h->ev_fork[o.fork - 1], (hipStream_t)stream_main) != hipSuccess) return EC_ERR_LAUNCH; }
+                if (o.join) { if (hipStreamWaitEvent((hipStream_t)stream_main, h->ev_join[o.join - 1], 0) != hipSuccess) return EC_ERR_LAUNCH; }
+                if (o.side) {
+                    stream = h->side_stream;
+                    if (o.kind == OP_POOL && hipStreamWaitEvent(h->side_stream, h->ev_fork[o.side - 1], 0) != hipSuccess) return EC_ERR_LAUNCH;
+                }
+            }
+            const ec_splitk_scope side_nosplit(o.side && side_on ? nullptr : (void*)ec_tls_splitk_ws,
+                                               o.side && side_on ? 0 : ec_tls_splitk_bytes);   // (one partial-sum region: main stream only)
             switch (o.kind) {
                 case OP_STEM1:
                     if (u8)
@@ -313,6 +376,8 @@ int rn50_run(const ec_rn50_t* h, const void* rgb, bool u8, const float* mean3, c
                                          buf(o.dst), nb, o.H, o.W, o.Cin, o.Cout, o.ks, o.pool, o.act, stream);
             }
             if (rc != EC_OK) return rc;
+            if (side_on && o.side && o.kind == OP_CONV &&
+                hipEventRecord(h->ev_join[o.side - 1], h->side_stream) != hipSuccess) return EC_ERR_LAUNCH;
         }
     }
     return EC_OK;

@@ -400,16 +400,31 @@ def _guard_first(fn):
 
 
 @_guard_first
-def conv_bf16(x, w, bias, res=None, ksize=1, pool=False, act=1):
-    """x bf16 [B,H,W,Cin]; w bf16 [Cout, k*k*Cin]; bias f32 [Cout] -> bf16 [B,H',W',Cout]."""
+def conv_bf16(x, w, bias, res=None, ksize=1, pool=False, act=1, workspace=None, out=None):
+    """x bf16 [B,H,W,Cin]; w bf16 [Cout, k*k*Cin]; bias f32 [Cout] -> bf16 [B,H',W',Cout].
+    ``workspace`` (a uint8 device tensor, e.g. ``conv_splitk_workspace(...)``): lets low-tile-count launches run as a fixed
+    K partition (``ec_conv_bf16_ws``)."""
     lib = _lib.load()
     B, H, W, Cin = x.shape
     Cout = w.shape[0]
     Ho, Wo = (H // 2, W // 2) if pool else (H, W)
-    out = torch.empty((B, Ho, Wo, Cout), dtype=torch.bfloat16, device=x.device)
+    if out is None:
+        out = torch.empty((B, Ho, Wo, Cout), dtype=torch.bfloat16, device=x.device)
+    if workspace is not None:
+        _lib.check(lib.ec_conv_bf16_ws(x.data_ptr(), w.data_ptr(), _lib.ptr(bias), _lib.ptr(res), out.data_ptr(), B, H, W,
+                                       Cin, Cout, ksize, int(pool), act, workspace.data_ptr(), workspace.numel(),
+                                       _lib.stream_ptr()), "ec_conv_bf16_ws")
+        return out
     _lib.check(lib.ec_conv_bf16(x.data_ptr(), w.data_ptr(), _lib.ptr(bias), _lib.ptr(res), out.data_ptr(), B, H, W,
                                 Cin, Cout, ksize, int(pool), act, _lib.stream_ptr()), "ec_conv_bf16")
     return out
+
+
+def conv_splitk_workspace(x, w, ksize=1):
+    """The fp32 partial-sum workspace ``conv_bf16(..., workspace=)`` can use for this shape (None: never K-sliced)."""
+    B, H, W, Cin = x.shape
+    n = _lib.load().ec_conv_splitk_workspace_bytes(B, H, W, Cin, w.shape[0], ksize)
+    return torch.empty(n, dtype=torch.uint8, device=x.device) if n else None
 
 
 @_guard_first

@@ -64,6 +64,17 @@ const char* ec_strerror(int code);
 int ec_conv_bf16(const void* in, const void* w, const float* bias, const void* res, void* out,
                  int B, int H, int W, int Cin, int Cout, int ksize, int pool, int act,
                  ec_stream_t stream);
+/* The same conv with a caller-owned fp32 workspace: launches with fewer 128x128 output tiles than CUs and a K walk of
+ * >= 16 tiles (the 14x14 / 7x7 maps of layers 3-4 at 32-64 frames per launch: the strong-scaling operating points of
+ * readme_files/baselines_habitat.md:63-73, NUM_GPUS=8) run as a FIXED K partition -- 2..8 slices of the K-tile range,
+ * each slice's fp32 partial sums in the workspace, folded in slice order (+ bias / residual / ReLU / AvgPool2d, one
+ * rounding to bf16) by a second small launch: deterministic, no atomics; the slice count depends on the layer's shape
+ * and the launch's tile count only.  Without a workspace (ec_conv_bf16) no launch is K-sliced.
+ * ec_conv_splitk_workspace_bytes: the most a launch of this shape can use (0 = never K-sliced). */
+size_t ec_conv_splitk_workspace_bytes(int B, int H, int W, int Cin, int Cout, int ksize);
+int ec_conv_bf16_ws(const void* in, const void* w, const float* bias, const void* res, void* out,
+                    int B, int H, int W, int Cin, int Cout, int ksize, int pool, int act,
+                    void* workspace, size_t ws_bytes, ec_stream_t stream);
 
 /* Plain GEMM view of the same kernel: out[M,N] = act(A[M,K] W[N,K]^T + bias (+res)).
  * Replaces nn.Linear / nn.MultiheadAttention projections of [U] clip/model.py

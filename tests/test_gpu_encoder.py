@@ -199,10 +199,11 @@ def test_rn50_trunk_matches_oracle(dev, width, layers, res):
     assert _rel(got, ref_fp32) < 2e-2, _rel(got, ref_fp32)
     cos = F.cosine_similarity(got.flatten(1), ref_fp32.flatten(1)).min().item()
     assert cos > 0.999, cos
-    # sub-batch chunking is a pure scheduling choice: identical bits
+    # sub-batch chunking changes the launch shapes (3 frames vs 2 + 1): the same features up to fp32-accumulation
+    # rounding (the K partition of the small layer-3/4 launches depends on the launch's tile count: tests/test_gpu_splitk.py)
     trunk.chunk = 2
     feat2 = trunk.forward(rgb.to(dev))
-    assert torch.equal(feat2.cpu(), feat.cpu())
+    assert _rel(feat2.cpu(), feat.cpu()) <= 1e-3
     # pool=True head
     pooled = trunk.spatial_mean(feat).cpu()
     assert torch.allclose(pooled, got.mean((2, 3)), atol=1e-3 * got.abs().max().item())

@@ -124,8 +124,11 @@ def test_worker_iteration_matches_oracle():
     assert torch.equal(w.feat[0], w.feat[T])
 
 
-def test_two_stream_encode_is_bit_identical():
-    """Encoding the two halves of the actor batch on two HIP streams is a pure scheduling choice."""
+def test_two_stream_encode_matches_one_stream():
+    """Encoding the two halves of the actor batch on two HIP streams is a scheduling choice: launches of 32 instead of 64
+    frames, i.e. the same features up to fp32-accumulation rounding (the K partition of the small layer-3/4 launches
+    follows the launch shape, tests/test_gpu_splitk.py) and, from the near-identical logits, the same sampled actions
+    but for rare ties."""
     from embodied_clip_amd.engine import Worker
     enc_sd = syn.rn50_visual_state_dict(0)
     w1 = Worker(64, T=1, device="cuda:0", seed=3, update_repeats=1, encoder_sd=enc_sd, encoder_streams=1)
@@ -133,8 +136,8 @@ def test_two_stream_encode_is_bit_identical():
     assert not w1.enc_streams and len(w2.enc_streams) == 2
     w1.iteration(); w2.iteration()
     torch.cuda.synchronize()
-    assert torch.equal(w1.feat, w2.feat)
-    assert torch.equal(w1.actions, w2.actions)
+    assert _rel(w1.feat, w2.feat) <= 1e-3
+    assert (w1.actions == w2.actions).float().mean().item() >= 0.98
     # the policy update is run-to-run non-deterministic at rounding level (split-K fp32 atomics) and Adam's first
     # step maps a near-zero gradient to +-lr, so parameters can only be compared to within two steps of lr = 3e-4
     assert (w1.params - w2.params).abs().max().item() <= 2 * 3e-4 + 1e-7
@@ -155,7 +158,10 @@ def test_action_synchronous_order_gives_the_same_rollout():
     a, b = ws
     assert b.ns == 2 and b._actions_host.shape == (N,)
     assert torch.equal(a.actions, b.actions) and torch.equal(a.logp, b.logp) and torch.equal(a.values, b.values)
-    assert torch.equal(a.feat, b.feat) and torch.equal(a.params, b.params)
+    assert torch.equal(a.feat, b.feat)
+    # (the policy update is run-to-run non-deterministic at rounding level -- split-K fp32 atomics in the weight-gradient
+    #  GEMMs -- and Adam's first step maps a near-zero gradient to +-lr: parameters agree to within two steps of lr = 3e-4)
+    assert (a.params - b.params).abs().max().item() <= 2 * 3e-4 + 1e-7
     assert torch.equal(b._actions_host, b.actions[T - 1].cpu())          # the host copy of the last step's actions
 
 

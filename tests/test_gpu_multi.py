@@ -36,7 +36,9 @@ def test_rccl_first_contact_at_world_size_1():
     assert 0 < line["allreduce_ms_per_rank"][0] < 50
     plain = _bench("--gpus", "1", *kw, timeout=900)
     assert plain["allreduce_ms_per_rank"] is None
-    assert line["loss"] == plain["loss"], (line["loss"], plain["loss"])
+    # (the weight-gradient GEMMs of the update use split-K atomics: the gradient norm moves in the 5th digit run to run)
+    for k, v in plain["loss"].items():
+        assert abs(line["loss"][k] - v) <= 1e-3 * max(1.0, abs(v)), (k, line["loss"], plain["loss"])
     # the reproducible fraction of the line: value x flop_per_frame / peak
     r = line["roofline"]
     assert abs(r["frac"] - line["value"] * line["config"]["flop_per_frame"] / 1e12 / r["peak"]) < 2e-4

@@ -30,6 +30,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--B", type=int, default=256)
 ap.add_argument("--set", default="all")
 ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--ws", type=int, default=0, help="1: pass a K-partition workspace (ec_conv_bf16_ws): small launches are K-sliced")
 a = ap.parse_args()
 shapes = {"c3": C3, "k1": K1, "all": C3 + K1}[a.set]
 dev = torch.device("cuda:0")
@@ -41,17 +42,20 @@ for (H, Cin, Cout, ks, pool, res, label) in shapes:
     b = torch.randn(Cout, generator=g).to(dev)
     Ho = H // 2 if pool else H
     r = torch.randn(a.B, Ho, Ho, Cout, generator=g).to(torch.bfloat16).to(dev) if res else None
+    ws = enc.conv_splitk_workspace(x, w, ks) if a.ws else None
+    out = None
     for _ in range(3):
-        enc.conv_bf16(x, w, b, r, ksize=ks, pool=bool(pool), act=1)
+        out = enc.conv_bf16(x, w, b, r, ksize=ks, pool=bool(pool), act=1, workspace=ws, out=out)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(a.iters):
-        enc.conv_bf16(x, w, b, r, ksize=ks, pool=bool(pool), act=1)
+        enc.conv_bf16(x, w, b, r, ksize=ks, pool=bool(pool), act=1, workspace=ws, out=out)
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / a.iters * 1e3
     fl = 2.0 * a.B * H * H * Cout * ks * ks * Cin
     by = 2.0 * (a.B * H * H * Cin + Cout * ks * ks * Cin + a.B * Ho * Ho * Cout * (2 if res else 1))
     tot += us
-    print(f"{label:20s} {ks}x{ks} {Cin:4d}->{Cout:4d} @{H:2d} B={a.B} pool={pool} res={res}: {us:8.1f} us {fl/us/1e6:7.0f} TFLOP/s {by/us/1e3:6.0f} GB/s", flush=True)
+    label = label + (" [ws]" if ws is not None else "")
+    print(f"{label:25s} {ks}x{ks} {Cin:4d}->{Cout:4d} @{H:2d} B={a.B} pool={pool} res={res}: {us:8.1f} us {fl/us/1e6:7.0f} TFLOP/s {by/us/1e3:6.0f} GB/s", flush=True)
 print(f"sum {tot:.1f} us")
