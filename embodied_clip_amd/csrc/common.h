@@ -164,6 +164,7 @@ struct EcConfig {
     int conv_ring_ilv;    // EC_CONV_RING_ILV (1)   ring-mode launches issue their LDS-DMA pieces between the MFMAs of the running K-tile
     int conv_ring_w8;     // EC_CONV_RING_W8  (0)   128x128 ring launches on 8 waves (2 x 4) instead of 4
     int rn50_side;        // EC_RN50_SIDE     (0)   launches of at most this many frames run the stride-2 blocks' downsample branch on a side stream (0: never; measured: slower)
+    int rn50_bneck;       // EC_RN50_BNECK    (128) launches of at least this many frames run layer3.1-5's conv2 + conv3 as ONE fused launch (conv_bneck.hip); 0: never
     int conv_splitk;      // EC_CONV_SPLITK   (1)   fixed K partition for low-tile-count launches: 0 off, 1 rule, 2..8 forced slice count
     int conv_splitk_tiles;  // EC_CONV_SPLITK_TILES (200) the rule applies below this many 128x128 tiles
     int conv_splitk_target; // EC_CONV_SPLITK_TARGET (400) slices = ceil(target / tiles): workgroups the K-sliced launch aims at

@@ -1,0 +1,404 @@
+// Bottleneck-level fusion for the 14x14 stage of the CLIP-RN50 trunk (round 4): conv2 (3x3, C -> C) + bn2 + ReLU and
+// conv3 (1x1, C -> 4C) + bn3 + identity + ReLU of one Bottleneck in ONE launch, ONE WORKGROUP PER IMAGE.
+//
+// Replaces, inside `clip_model(clip_input)` (primitive_probing/generate_data/thor_image_features.py:109; [U] openai/CLIP
+// clip/model.py Bottleneck.forward: `out = relu2(bn2(conv2(out))); out = avgpool(out) [identity here]; out = bn3(conv3(out));
+// out += identity; out = relu3(out)`), the two launches conv_igemm runs for layer3.1 .. layer3.5.
+//
+// Why (VERDICT r3 item 2 / SURVEY.md section 7 "hard parts"): tiled over output pixels, every 128..256-pixel tile of conv2
+// streams its im2col operand AND the weights through the CU's L2 -> LDS path (~30 B/clk/CU under load), and conv3 re-reads
+// conv2's output from HBM/L2 once per N tile; both launches sit at the sum of their MFMA and operand-feed times.  A 14x14x256
+// map is 98 KB: it FITS the LDS.  So a workgroup keeps one image's conv1 output resident (T, 196 rows x 512 B + a zero
+// row), reads the nine taps of the im2col operand straight out of it (a tap is a row shift; out-of-frame taps read the
+// zero row -- no address arithmetic in the K loop beyond nine v_cndmask per M block and tap), overwrites T with conv2's
+// output and runs conv3 out of the same LDS image.  Only the weights (1.7 MB per image, L2-resident) and the residual /
+// output rows move: 2.2 MB per image through L2 -> LDS instead of 3.4 MB, x read once (as the residual), c2 never written.
+//
+// Structure (wave64, v_mfma_f32_32x32x16_bf16, swapped operands D[n][m] as in conv_igemm.hip):
+//   * 8 waves = 1 (M) x 8 (N): wave w owns output channels [32 w, 32 w + 32) of conv2 and, in each of the four conv3
+//     passes, channels [256 q + 32 w, +32); ALL 7 pixel blocks (196 of 224 rows) -> 7 accumulator tiles (112 VGPRs),
+//     8 fragment reads per 7 MFMAs.
+//   * the weight operand is PRIVATE to a wave (its 32 rows of W), so each wave streams its own K-tiles (32 x 32 bf16 =
+//     2 KB, two 1-KB LDS-DMA pieces) through its own 3-stage ring: NO workgroup barrier in either K loop -- a wave waits
+//     for its own pieces with a counted s_waitcnt vmcnt (MI355X_MICROARCH.md: the issuing wave's covering vmcnt orders its
+//     own ds_read behind its LDS-DMA).  T is read-only inside a K loop.  Barriers: after T is loaded, and around the
+//     overwrite of T with conv2's output -- three per image.
+//   * fragment reads are inline asm one k-step ahead of the MFMAs that use them (the compiler would put s_waitcnt
+//     vmcnt(0) in front of every LDS read that follows an LDS-DMA); waits carry the fragment registers.
+//   * conv3's epilogue runs per 32-pixel block through the wave's free ring stage: residual rows in as 16-byte chunks
+//     (64 B contiguous per pixel), out as 16-byte chunks -- bias + identity + ReLU + ONE rounding to bf16 in between.
+//
+// Rounding points are those of the unfused path (bf16 c2, fp32 accumulate, one rounding of y) and each output element sums
+// its K walk in the same order (tap-major, channel-minor; k-steps in order), so results are bit-identical to conv_igemm's.
+#include <stdlib.h>
+
+#include <utility>
+
+#include "common.h"
+
+namespace {
+
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+struct BneckArgs {
+    const uint16_t* c1;    // [B][PIX][C]   conv1 output (bf16, post-ReLU)
+    const uint16_t* w2;    // conv2 weights ([C][9 C], K = (ky, kx, ci)) in STREAMING ORDER (ec_bneck_pack_weights)
+    const float* b2;       // [C]
+    const uint16_t* w3;    // conv3 weights ([4C][C]) in streaming order
+    const float* b3;       // [4C]
+    const uint16_t* xres;  // [B][PIX][4C]  block input (identity)
+    uint16_t* y;           // [B][PIX][4C]
+    int B;
+    unsigned w2_bytes, w3_bytes;
+    unsigned long long* dbg;   // profiling only (ec_bneck_set_debug): workgroup 0 stores {s_memtime, s_memrealtime} at entry / phase ends
+};
+
+__device__ __forceinline__ float bn_relu(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, __builtin_inff()); }
+
+template <int OFF>
+__device__ __forceinline__ void lds_read16(u32x4_t& d, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+__device__ __forceinline__ void tie(u32x4_t& d) { asm volatile("" : "+v"(d)); }
+
+template <int C, int HW>
+__global__ __launch_bounds__(512, 2) void bneck23_kernel(BneckArgs p) {
+    constexpr int PIX = HW * HW, MB = (PIX + 31) / 32;          // 196 pixels, 7 blocks of 32
+    constexpr int PITCH = C * 2 + 16;                            // T row pitch (bytes): +16 staggers the banks between rows
+    constexpr int T_BYTES = (PIX + 1) * PITCH;                   // + the zero row (index PIX)
+    constexpr int BK = 32, NS = 3, STAGE = 32 * BK * 2, RING = NS * STAGE;   // per-wave weight ring: 3 x 2 KB
+    constexpr int K2 = 9 * C, NK2 = K2 / BK, KT_PER_TAP = C / BK;
+    constexpr int K3 = C, NK3 = K3 / BK, NPASS = 4 * C / 256;
+    static_assert(C == 256, "8 waves x 32 channels");
+    static_assert(T_BYTES + 8 * RING <= 160 * 1024, "LDS budget");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* T = smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 31, hh = lane >> 5;
+    unsigned char* ring = smem + T_BYTES + wave * RING;
+    const unsigned ring_lds = (unsigned)(unsigned long)(lds_void_t*)ring;
+    const unsigned t_lds = (unsigned)(unsigned long)(lds_void_t*)T;
+    const int img = blockIdx.x;
+    auto stamp = [&](int slot) {   // profiling only: shader-clock and 100-MHz real-time counters of workgroup 0 / wave 0
+        if (p.dbg && blockIdx.x == 0 && tid == 0) {
+            p.dbg[2 * slot] = __builtin_amdgcn_s_memtime();
+            p.dbg[2 * slot + 1] = __builtin_amdgcn_s_memrealtime();
+        }
+    };
+    stamp(0);
+
+    const __amdgpu_buffer_rsrc_t rs_w2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w2, 0, p.w2_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w3 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w3, 0, p.w3_bytes, 0x00020000);
+
+    // ---- weight ring: K-tile kt of the wave's 32 rows -> stage st (two 1-KB pieces: 16 rows x 64 B each) ----
+    // LDS image of a stage: row r (0..31) x 64 B, 16-byte chunk c stored at c ^ ((r >> 2) & 3) (conflict-free ds_read_b128
+    // over the 16-lane groups); LDS-DMA writes lane-linear, so the swizzle is applied to the SOURCE chunk.
+    // The weights arrive PACKED in this order (ec_bneck_pack_weights): the 2-KB stage image of (32-row slice, K-tile) is one
+    // contiguous block, so a piece is a 1-KB contiguous read (8 full cache lines, consecutive channels of the L2).  Fetched
+    // out of the plain [n][K] layout a piece touched 16 rows x 64 B, 4.6 KB apart: half-used lines on 4 of the 16 L2
+    // channels, the same ones for every wave of every workgroup at the same time (per-image time 64 us alone -> 105 us
+    // with 256 workgroups in flight).
+    const unsigned wsrc2 = (unsigned)(wave * NK2 * STAGE + lane * 16);   // slice `wave`, K-tile 0, piece 0
+    const unsigned wsrc3 = (unsigned)(wave * NK3 * STAGE + lane * 16);   // (+ pass * 8 slices: added per pass)
+    auto issue_w2 = [&](int kt, int st) {                        // (kt >= NK2: out-of-range offsets, zeros into a free stage)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const unsigned off = kt < NK2 ? wsrc2 + (unsigned)kt * STAGE + j * 1024 : 0xFFFFFFF0u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w2, (lds_void_t*)(ring + st * STAGE + j * 1024), 16, off, 0, 0, 0);
+        }
+    };
+    // B fragment of k-step ks (0, 1) of a stage: row frow, chunk 2 ks + hh
+    unsigned boff[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) boff[ks] = (unsigned)(frow * 64 + (((2 * ks + hh) ^ ((frow >> 2) & 3)) << 4));
+
+    issue_w2(0, 0);
+    issue_w2(1, 1);
+
+    // ---- T <- this image's conv1 output (PIX rows x C bf16, 16-byte chunks through registers: the rows are padded) ----
+    {
+        constexpr int CHUNKS = PIX * C / 8, IT = (CHUNKS + 511) / 512;
+        const uint4* src = reinterpret_cast<const uint4*>(p.c1 + (size_t)img * PIX * C);
+        uint4 v[IT];
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            int q = tid + i * 512;
+            q = q < CHUNKS ? q : CHUNKS - 1;
+            v[i] = src[q];
+        }
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int q = tid + i * 512;
+            if (q < CHUNKS) *reinterpret_cast<uint4*>(T + (q / (C / 8)) * PITCH + (q % (C / 8)) * 16) = v[i];
+        }
+        if (tid < PITCH / 16) *reinterpret_cast<uint4*>(T + PIX * PITCH + tid * 16) = make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+    stamp(1);
+
+    // ---- per-lane geometry of the 7 pixel blocks: base address of the lane's pixel row and its 9-bit tap mask ----
+    unsigned pbase[MB], pmask[MB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+        const int px = i * 32 + frow;
+        const int y = px / HW, x = px - y * HW;
+        unsigned m = 0;
+        if (px < PIX) {
+            const unsigned xm = (x > 0 ? 1u : 0u) | 2u | (x < HW - 1 ? 4u : 0u);
+            m = (y > 0 ? xm : 0u) | (xm << 3) | (y < HW - 1 ? (xm << 6) : 0u);
+        }
+        pmask[i] = m;
+        pbase[i] = t_lds + (unsigned)(px < PIX ? px : PIX) * PITCH + hh * 16;
+    }
+    const unsigned zbase = t_lds + PIX * PITCH + hh * 16;
+
+    f32x16_t acc[MB];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    };
+    u32x4_t fa[2][MB], fb[2];                                    // fragment double buffer: [k-step parity]
+    auto mma = [&](int par) {
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fb[par]), __builtin_bit_cast(bf16x8_t, fa[par][i]),
+                                                             acc[i], 0, 0, 0);
+    };
+
+    // =====================================================================================================================
+    // conv2: K = 9 taps x C channels, K-tiles of 32 channels; tap loop at run time, the 8 K-tiles x 2 k-steps of a tap unrolled
+    // =====================================================================================================================
+    zero_acc();
+    int st = 0;                                                  // ring stage of the K-tile being computed
+    for (int tap = 0; tap < 9; ++tap) {
+        const int ky = (tap * 11) >> 5, kx = tap - ky * 3;       // tap / 3, tap % 3
+        const int shift = ((ky - 1) * HW + (kx - 1)) * PITCH;
+        unsigned aaddr[MB];
+#pragma unroll
+        for (int i = 0; i < MB; ++i) aaddr[i] = ((pmask[i] >> tap) & 1u) ? pbase[i] + (unsigned)shift : zbase;
+        // first k-step of the tap: its K-tile's pieces must have landed (the two newest pieces in flight belong to the next tile)
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        {
+            const unsigned bb = ring_lds + st * STAGE + boff[0];
+            [&]<int... I>(std::integer_sequence<int, I...>) { (lds_read16<0>(fa[0][I], aaddr[I]), ...); }(std::make_integer_sequence<int, MB>{});
+            lds_read16<0>(fb[0], bb);
+        }
+        [&]<int... S>(std::integer_sequence<int, S...>) {
+            ([&] {
+                constexpr int s = S, j = s >> 1, ks = s & 1, par = s & 1;            // step s of the tap: K-tile j, k-step ks
+                const int kt = tap * KT_PER_TAP + j;
+                if constexpr (ks == 0) {
+                    int st2 = st + 2; st2 = st2 >= NS ? st2 - NS : st2;
+                    issue_w2(kt + 2, st2);                                            // into the stage K-tile kt - 1 has left
+                }
+                if constexpr (s + 1 < 2 * KT_PER_TAP) {                               // prefetch the next step's fragments
+                    constexpr int s1 = s + 1, j1 = s1 >> 1, ks1 = s1 & 1;
+                    int stn = st;
+                    if constexpr (ks1 == 0) {                                         // ... of the next K-tile: landed?
+                        stn = st + 1; stn = stn >= NS ? stn - NS : stn;
+                        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");              // (all but K-tile kt + 2's two pieces)
+                    }
+                    const unsigned bb = ring_lds + stn * STAGE + boff[ks1];
+                    [&]<int... I>(std::integer_sequence<int, I...>) {
+                        (lds_read16<j1 * 64 + ks1 * 32>(fa[par ^ 1][I], aaddr[I]), ...);
+                    }(std::make_integer_sequence<int, MB>{});
+                    lds_read16<0>(fb[par ^ 1], bb);
+                    asm volatile("s_waitcnt lgkmcnt(%0)" : : "n"(MB + 1));
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)");
+                }
+                [&]<int... I>(std::integer_sequence<int, I...>) { (tie(fa[par][I]), ...); }(std::make_integer_sequence<int, MB>{});
+                tie(fb[par]);
+                mma(par);
+                if constexpr (ks == 1) { st = st + 1; st = st >= NS ? st - NS : st; }
+            }(), ...);
+        }(std::make_integer_sequence<int, 2 * KT_PER_TAP>{});
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the zero-filled tail tiles
+    stamp(2);
+    __syncthreads();                                             // every wave is done reading T as conv1's output
+
+    // ---- T <- c2 = relu(conv2 + b2) in bf16: a lane owns one pixel and, per 4 registers, 4 consecutive channels ----
+    {
+        const int n0 = wave * 32;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 bv = *reinterpret_cast<const float4*>(p.b2 + n0 + 8 * g + 4 * hh);
+#pragma unroll
+            for (int i = 0; i < MB; ++i) {
+                const int px = i * 32 + frow;
+                uint2 o;
+                o.x = ec_pack2(bn_relu(acc[i][4 * g + 0] + bv.x), bn_relu(acc[i][4 * g + 1] + bv.y));
+                o.y = ec_pack2(bn_relu(acc[i][4 * g + 2] + bv.z), bn_relu(acc[i][4 * g + 3] + bv.w));
+                if (px < PIX) *reinterpret_cast<uint2*>(T + px * PITCH + (n0 + 8 * g + 4 * hh) * 2) = o;
+            }
+        }
+    }
+    // conv3's first two K-tiles (pass 0) while the other waves finish their rows
+    auto issue_w3 = [&](int pass, int kt, int stg) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const unsigned off = (pass < NPASS && kt < NK3) ? wsrc3 + (unsigned)pass * (8u * NK3 * STAGE) + (unsigned)kt * STAGE + j * 1024 : 0xFFFFFFF0u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w3, (lds_void_t*)(ring + stg * STAGE + j * 1024), 16, off, 0, 0, 0);
+        }
+    };
+    issue_w3(0, 0, 0);
+    issue_w3(0, 1, 1);
+    __syncthreads();                                             // T now holds c2
+    stamp(3);
+
+    // =====================================================================================================================
+    // conv3: four passes of 256 output channels (32 per wave), K = C; epilogue per 32-pixel block through the free ring stage
+    // =====================================================================================================================
+    const size_t img_off = (size_t)img * PIX * (4 * C);
+    for (int pass = 0; pass < NPASS; ++pass) {
+        zero_acc();
+        // stages at pass start: K-tile 0 in stage 0, K-tile 1 in stage 1 (issued before the previous epilogue).  vmcnt(0), not a
+        // counted wait: the epilogue's global stores share the counter and loads / stores may retire out of order
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        {
+            const unsigned bb = ring_lds + boff[0];
+            [&]<int... I>(std::integer_sequence<int, I...>) { (lds_read16<0>(fa[0][I], pbase[I]), ...); }(std::make_integer_sequence<int, MB>{});
+            lds_read16<0>(fb[0], bb);
+        }
+        [&]<int... S>(std::integer_sequence<int, S...>) {
+            ([&] {
+                constexpr int s = S, kt = s >> 1, ks = s & 1, par = s & 1;
+                constexpr int stc = kt % NS;
+                if constexpr (ks == 0) issue_w3(pass, kt + 2, (kt + 2) % NS);          // (kt + 2 >= NK3: zeros into a free stage)
+                if constexpr (s + 1 < 2 * NK3) {
+                    constexpr int s1 = s + 1, kt1 = s1 >> 1, ks1 = s1 & 1;
+                    if constexpr (ks1 == 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    const unsigned bb = ring_lds + (kt1 % NS) * STAGE + boff[ks1];
+                    [&]<int... I>(std::integer_sequence<int, I...>) {
+                        (lds_read16<kt1 * 64 + ks1 * 32>(fa[par ^ 1][I], pbase[I]), ...);
+                    }(std::make_integer_sequence<int, MB>{});
+                    lds_read16<0>(fb[par ^ 1], bb);
+                    asm volatile("s_waitcnt lgkmcnt(%0)" : : "n"(MB + 1));
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)");
+                }
+                (void)stc;
+                [&]<int... I>(std::integer_sequence<int, I...>) { (tie(fa[par][I]), ...); }(std::make_integer_sequence<int, MB>{});
+                tie(fb[par]);
+                mma(par);
+            }(), ...);
+        }(std::make_integer_sequence<int, 2 * NK3>{});
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // (the two zero tail tiles: stages (NK3) % 3 and (NK3 + 1) % 3)
+        // next pass's first two K-tiles stream in under this pass's epilogue; the epilogue stages through ring stage 2
+        issue_w3(pass + 1, 0, 0);
+        issue_w3(pass + 1, 1, 1);
+        unsigned char* E = ring + 2 * STAGE;                     // [32 px][64 B], chunk c of pixel r at c ^ ((r >> 2) & 3)
+        const int n0 = pass * 256 + wave * 32;
+        float4 bv[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bv[g] = *reinterpret_cast<const float4*>(p.b3 + n0 + 8 * g + 4 * hh);
+        const uint16_t* xr = p.xres + img_off + n0;
+        uint16_t* yo = p.y + img_off + n0;
+        // chunk-order view of a block: lane -> (pixel row er = lane / 4 + 16 h, chunk ec = lane % 4)
+        const int ec = lane & 3;
+        // (native vector registers, plain code: an array captured by a lambda lands in scratch memory)
+        u32x4_t res0, res1;
+        const int er0 = lane >> 2, er1 = (lane >> 2) + 16;
+        const unsigned char* e0p = E + er0 * 64 + ((ec ^ ((er0 >> 2) & 3)) << 4);
+        const unsigned char* e1p = E + er1 * 64 + ((ec ^ ((er1 >> 2) & 3)) << 4);
+#define EC_BNECK_LOAD_RES(I)                                                                                         \
+        {                                                                                                            \
+            int px0 = (I) * 32 + er0, px1 = (I) * 32 + er1;                                                          \
+            px0 = px0 < PIX ? px0 : PIX - 1; px1 = px1 < PIX ? px1 : PIX - 1;                                        \
+            res0 = *reinterpret_cast<const u32x4_t*>(xr + (size_t)px0 * (4 * C) + ec * 8);                           \
+            res1 = *reinterpret_cast<const u32x4_t*>(xr + (size_t)px1 * (4 * C) + ec * 8);                           \
+        }
+        EC_BNECK_LOAD_RES(0)
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+            *reinterpret_cast<u32x4_t*>(const_cast<unsigned char*>(e0p)) = res0;
+            *reinterpret_cast<u32x4_t*>(const_cast<unsigned char*>(e1p)) = res1;
+            if (i + 1 < MB) EC_BNECK_LOAD_RES(i + 1)              // next block's identity rows in flight under this block's math
+            // (wave-private buffer: the wave's own LDS accesses are ordered by the compiler's lgkmcnt waits)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                unsigned char* slot = E + frow * 64 + ((g ^ ((frow >> 2) & 3)) << 4) + hh * 8;
+                const uint2 rr = *reinterpret_cast<const uint2*>(slot);
+                uint2 o;
+                o.x = ec_pack2(bn_relu(acc[i][4 * g + 0] + bv[g].x + ec_lo(rr.x)), bn_relu(acc[i][4 * g + 1] + bv[g].y + ec_hi(rr.x)));
+                o.y = ec_pack2(bn_relu(acc[i][4 * g + 2] + bv[g].z + ec_lo(rr.y)), bn_relu(acc[i][4 * g + 3] + bv[g].w + ec_hi(rr.y)));
+                *reinterpret_cast<uint2*>(slot) = o;
+            }
+            {
+                const u32x4_t v0 = *reinterpret_cast<const u32x4_t*>(e0p), v1 = *reinterpret_cast<const u32x4_t*>(e1p);
+                const int px0 = i * 32 + er0, px1 = i * 32 + er1;
+                if (px0 < PIX) *reinterpret_cast<u32x4_t*>(yo + (size_t)px0 * (4 * C) + ec * 8) = v0;
+                if (px1 < PIX) *reinterpret_cast<u32x4_t*>(yo + (size_t)px1 * (4 * C) + ec * 8) = v1;
+            }
+        }
+#undef EC_BNECK_LOAD_RES
+        stamp(4 + pass);
+    }
+}
+
+// Streaming order of a [N][K] bf16 weight matrix for bneck23_kernel: 16-byte unit ((s * K/32 + kt) * 32 + r) * 4 + pc holds
+// row 32 s + r, k = 32 kt + 8 (pc ^ ((r >> 2) & 3)) .. + 7 -- the swizzled 2-KB LDS image of (slice s, K-tile kt), contiguous.
+__global__ void bneck_pack_kernel(const uint4* __restrict__ w, uint4* __restrict__ out, int N, int K) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long)N * K / 8) return;
+    const int pc = (int)(t & 3), r = (int)((t >> 2) & 31);
+    const long blk = t >> 7;
+    const int nk = K / 32, kt = (int)(blk % nk), sidx = (int)(blk / nk);
+    const int sc = pc ^ ((r >> 2) & 3);
+    out[t] = w[((long)(sidx * 32 + r) * K + kt * 32 + sc * 8) >> 3];
+}
+
+}  // namespace
+
+namespace { unsigned long long* g_bneck_dbg = nullptr; }
+// profiling only: device buffer of 16 x u64 that workgroup 0 of every following fused launch fills with {shader clock,
+// 100-MHz real time} stamps (entry, T loaded, conv2 done, c2 written, after each conv3 pass); nullptr switches it off
+extern "C" void ec_bneck_set_debug(void* dev_u64x16) { g_bneck_dbg = (unsigned long long*)dev_u64x16; }
+
+// Packs conv2's [C][9C] and conv3's [4C][C] bf16 weights into the fused kernel's streaming order: packed holds C * 9C
+// elements of conv2 followed by 4C * C of conv3 (ec_bneck_packed_elems).  Once per set of weights.
+extern "C" size_t ec_bneck_packed_elems(int C) { return C > 0 ? (size_t)C * 9 * C + (size_t)4 * C * C : 0; }
+extern "C" int ec_bneck_pack_weights(const void* w2, const void* w3, void* packed, int C, ec_stream_t stream) {
+    if (!w2 || !w3 || !packed) return EC_ERR_ARG;
+    if (C != 256) return EC_ERR_SHAPE;
+    const long n2 = (long)C * 9 * C / 8, n3 = (long)4 * C * C / 8;
+    hipLaunchKernelGGL(bneck_pack_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint4*)w2,
+                       (uint4*)packed, C, 9 * C);
+    hipLaunchKernelGGL(bneck_pack_kernel, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint4*)w3,
+                       (uint4*)packed + n2, 4 * C, C);
+    EC_CHECK_LAUNCH();
+    return EC_OK;
+}
+
+// y = relu(conv3(relu(conv2(c1) + b2)) + b3 + x): the second and third conv of a stride-1 Bottleneck whose planes are C = 256
+// on a 14 x 14 map (CLIP-RN50 layer3.1 .. layer3.5), BatchNorm folded into (w, b).  c1 bf16 [B,14,14,C] (conv1's output),
+// packed = ec_bneck_pack_weights(w2 [C][3*3*C], w3 [4C][C]), x / y bf16 [B,14,14,4C].  EC_ERR_SHAPE for any other geometry (the
+// caller then runs the two convs separately).
+extern "C" int ec_bneck_conv23_bf16(const void* c1, const void* packed, const float* b2, const float* b3,
+                                    const void* x, void* y, int B, int H, int W, int C, ec_stream_t stream) {
+    const void* w2 = packed;
+    const void* w3 = packed ? (const uint16_t*)packed + (size_t)C * 9 * C : nullptr;
+    if (!c1 || !w2 || !b2 || !w3 || !b3 || !x || !y) return EC_ERR_ARG;
+    if (B <= 0) return EC_ERR_SHAPE;
+    if (H != 14 || W != 14 || C != 256) return EC_ERR_SHAPE;
+    BneckArgs a;
+    a.c1 = (const uint16_t*)c1; a.w2 = (const uint16_t*)w2; a.b2 = b2; a.w3 = (const uint16_t*)w3; a.b3 = b3;
+    a.xres = (const uint16_t*)x; a.y = (uint16_t*)y; a.B = B;
+    a.w2_bytes = (unsigned)((size_t)C * 9 * C * 2);
+    a.w3_bytes = (unsigned)((size_t)4 * C * C * 2);
+    a.dbg = g_bneck_dbg;
+    constexpr int PITCH = 256 * 2 + 16;
+    const size_t lds = (size_t)(196 + 1) * PITCH + 8 * 3 * 2048;
+    auto kern = bneck23_kernel<256, 14>;
+    static std::atomic<uint64_t> attr_done{0};
+    if (auto attr_g_ = ec_attr_needed(attr_done))
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(512), lds, (hipStream_t)stream, a);
+    EC_CHECK_LAUNCH();
+    return EC_OK;
+}

@@ -18,9 +18,11 @@
 
 #include "common.h"
 
+// (common.h includes include/ec_amd.h, which declares the conv_bneck.hip entry points used below)
+
 namespace {
 
-enum OpKind { OP_STEM1, OP_CONV, OP_POOL, OP_PAIR };
+enum OpKind { OP_STEM1, OP_CONV, OP_POOL, OP_PAIR, OP_BNECK };
 
 struct Op {
     OpKind kind;
@@ -50,12 +52,14 @@ struct ec_rn50 {
     size_t n_w, n_b;
     int conv8_min_tiles = 0;      // 0 = library default (ec_rn50_set_conv8_min_tiles)
     uint16_t* wfrag = nullptr;    // EC_CONV8_DIRB: fragment-order copies of the 256-multiple-Cout convs' weights (same offsets as w)
+    uint16_t* wbneck = nullptr;   // streaming-order weights of the fused bottleneck launches (ec_bneck_pack_weights), one block per OP_BNECK
     // side branch of the stride-2 blocks (EC_RN50_SIDE): the handle's own non-blocking stream + fork / join events per group
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork[4] = {nullptr, nullptr, nullptr, nullptr}, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
     int n_side = 0;
     ~ec_rn50() {
         if (wfrag) (void)hipFree(wfrag);
+        if (wbneck) (void)hipFree(wbneck);
         for (int i = 0; i < 4; ++i) {
             if (ev_fork[i]) (void)hipEventDestroy(ev_fork[i]);
             if (ev_join[i]) (void)hipEventDestroy(ev_join[i]);
@@ -196,6 +200,19 @@ extern "C" int ec_rn50_create(ec_rn50_t** out, int width, const int* layers4, in
                 track(Ro, Ro, planes * 4);
                 conv1_done = true;
                 c1_buf = o.dst2;
+            } else if (ec_config().rn50_bneck > 0 && !ds && stride == 1 && planes == 256 && Ro == 14 && !h->ops.empty() &&
+                       h->ops.back().kind == OP_CONV && h->ops.back().ks == 3 && h->ops.back().dst == 2) {
+                // Bottleneck-level fusion (conv_bneck.hip): conv2 + conv3 + identity + ReLU of layer3.1 .. layer3.5 in one
+                // launch, one workgroup per image with the 14 x 14 x 256 map resident in LDS.  The conv2 op just planned
+                // is folded in: src = conv1's output, res = the block input, w / b = conv2's, w1 / b1 = conv3's.
+                // Launches below EC_RN50_BNECK frames run the two convs separately (rn50_run): a workgroup per image
+                // only fills the chip from ~128 images on.
+                const Op c2 = h->ops.back();
+                h->ops.pop_back();
+                Op o{OP_BNECK, c2.src, y, idt, Ro, Ro, planes, planes * 4, 3, 0, EC_ACT_RELU, c2.w_off, c2.b_off};
+                o.w1_off = w_c3; o.b1_off = b_c3;
+                h->ops.push_back(o);
+                track(Ro, Ro, planes * 4);
             } else {
                 Op o{OP_CONV, 2, y, idt, Ro, Ro, planes, planes * 4, 1, 0, EC_ACT_RELU, w_c3, b_c3};
                 o.join = side_grp;
@@ -212,6 +229,20 @@ extern "C" int ec_rn50_create(ec_rn50_t** out, int width, const int* layers4, in
     h->max_elems_per_frame = mx;
     h->n_w = wo; h->n_b = bo;
     if (n_w != wo || n_bias != bo) { delete h; return EC_ERR_SHAPE; }
+    {   // fused bottleneck launches: their conv2 + conv3 weights in streaming order, one packed block per op (w2_off = its offset)
+        size_t tot = 0;
+        for (Op& o : h->ops)
+            if (o.kind == OP_BNECK) { o.w2_off = tot; tot += ec_bneck_packed_elems(o.Cin); }
+        if (tot) {
+            if (hipMalloc(&h->wbneck, tot * sizeof(uint16_t)) != hipSuccess) { h->wbneck = nullptr; delete h; return EC_ERR_LAUNCH; }
+            for (const Op& o : h->ops)
+                if (o.kind == OP_BNECK && ec_bneck_pack_weights(h->w + o.w_off, h->w + o.w1_off, h->wbneck + o.w2_off, o.Cin, nullptr) != EC_OK) {
+                    delete h;
+                    return EC_ERR_LAUNCH;
+                }
+            (void)hipStreamSynchronize(nullptr);
+        }
+    }
     if (h->n_side > 0 && ec_config().rn50_side > 0) {
         bool ok = hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking) == hipSuccess;
         for (int i = 0; i < h->n_side && ok; ++i)
@@ -367,6 +398,18 @@ int rn50_run(const ec_rn50_t* h, const void* rgb, bool u8, const float* mean3, c
                         if (rc == EC_OK)
                             rc = ec_conv_bf16(buf(o.dst), h->w + o.w2_off, h->bias + o.b2_off, nullptr, buf(o.dst2), nb, o.H,
                                               o.W, o.Cout, o.N2, 1, 0, EC_ACT_RELU, stream);
+                    }
+                    break;
+                case OP_BNECK:
+                    if (nb >= ec_config().rn50_bneck)
+                        rc = ec_bneck_conv23_bf16(buf(o.src), h->wbneck + o.w2_off, h->bias + o.b_off, h->bias + o.b1_off,
+                                                  buf(o.res), buf(o.dst), nb, o.H, o.W, o.Cin, stream);
+                    else {   // small launches: the two convs separately (buffer 2 = conv2's output, as in the unfused plan)
+                        rc = ec_conv_bf16_wf(buf(o.src), h->w + o.w_off, nullptr, h->bias + o.b_off, nullptr, buf(2), nb, o.H, o.W,
+                                             o.Cin, o.Cin, 3, 0, EC_ACT_RELU, stream);
+                        if (rc == EC_OK)
+                            rc = ec_conv_bf16_wf(buf(2), h->w + o.w1_off, nullptr, h->bias + o.b1_off, buf(o.res), buf(o.dst), nb, o.H,
+                                                 o.W, o.Cin, o.Cout, 1, 0, EC_ACT_RELU, stream);
                     }
                     break;
                 default:

@@ -420,6 +420,39 @@ def conv_bf16(x, w, bias, res=None, ksize=1, pool=False, act=1, workspace=None, 
     return out
 
 
+@_guard_first
+def bneck_conv23_bf16(c1, w2, b2, w3, b3, x, out=None):
+    """Fused conv2 (3x3) + conv3 (1x1) + identity + ReLU of a stride-1 Bottleneck (``ec_bneck_conv23_bf16``):
+    c1 bf16 [B,14,14,C], w2 bf16 [C, 9C], w3 bf16 [4C, C], x bf16 [B,14,14,4C] -> bf16 [B,14,14,4C]."""
+    lib = _lib.load()
+    B, H, W, C = c1.shape
+    if out is None:
+        out = torch.empty_like(x)
+    packed = bneck_pack_weights(w2, w3)
+    _lib.check(lib.ec_bneck_conv23_bf16(c1.data_ptr(), packed.data_ptr(), b2.data_ptr(), b3.data_ptr(), x.data_ptr(),
+                                        out.data_ptr(), B, H, W, C, _lib.stream_ptr()), "ec_bneck_conv23_bf16")
+    return out
+
+
+_BNECK_PACKED = {}
+
+
+def bneck_pack_weights(w2, w3):
+    """The two weight matrices in the fused kernel's streaming order (``ec_bneck_pack_weights``); cached per tensor pair."""
+    key = (w2.data_ptr(), w3.data_ptr(), w2._version, w3._version)
+    hit = _BNECK_PACKED.get(key)
+    if hit is not None:
+        return hit
+    lib = _lib.load()
+    C = w3.shape[1]
+    packed = torch.empty(lib.ec_bneck_packed_elems(C), dtype=torch.bfloat16, device=w2.device)
+    _lib.check(lib.ec_bneck_pack_weights(w2.data_ptr(), w3.data_ptr(), packed.data_ptr(), C, _lib.stream_ptr()), "ec_bneck_pack_weights")
+    if len(_BNECK_PACKED) > 16:
+        _BNECK_PACKED.clear()
+    _BNECK_PACKED[key] = packed
+    return packed
+
+
 def conv_splitk_workspace(x, w, ksize=1):
     """The fp32 partial-sum workspace ``conv_bf16(..., workspace=)`` can use for this shape (None: never K-sliced)."""
     B, H, W, Cin = x.shape

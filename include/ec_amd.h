@@ -146,6 +146,22 @@ int ec_conv1x1_pair_pool_bf16(const void* a0, const void* w0, const float* b0, c
 int ec_stem_conv1_u8(const uint8_t* rgb_u8_nhwc, const float* h_mean3, const float* h_std3, const float* w,
                      const float* bias, void* out, int B, int H, int W, int Cout, ec_stream_t stream);
 
+/* Bottleneck-level fusion (conv_bneck.hip): conv2 (3x3) + bn2 + ReLU and conv3 (1x1) + bn3 + identity + ReLU of ONE
+ * stride-1 Bottleneck in one launch, one workgroup per image, the image's 14 x 14 x C map resident in LDS -- replaces the
+ * last two convs of [U] clip/model.py Bottleneck.forward for CLIP-RN50 layer3.1 .. layer3.5 (planes C = 256), reached
+ * through `clip_model(clip_input)` (primitive_probing/generate_data/thor_image_features.py:109).
+ * c1 bf16 [B,14,14,C] = relu(bn1(conv1(x))); b2 / b3 f32 (folded BatchNorm); x (identity) and y bf16 [B,14,14,4C].
+ * The weights come in the kernel's streaming order: ec_bneck_pack_weights(w2 bf16 [C][3*3*C], w3 bf16 [4C][C]) ->
+ * packed (ec_bneck_packed_elems(C) bf16 elements, conv2 then conv3; once per set of weights).
+ * Bit-identical to ec_conv_bf16(3x3) followed by ec_conv_bf16(1x1, res = x).  EC_ERR_SHAPE unless H = W = 14, C = 256. */
+size_t ec_bneck_packed_elems(int C);
+int ec_bneck_pack_weights(const void* w2, const void* w3, void* packed, int C, ec_stream_t stream);
+/* profiling only: a device buffer of 16 uint64 that workgroup 0 of every following fused launch fills with {shader clock,
+ * 100-MHz real time} stamps at its phase boundaries (tools/bench_bneck.py --stamps); NULL switches it off */
+void ec_bneck_set_debug(void* dev_u64x16);
+int ec_bneck_conv23_bf16(const void* c1, const void* packed, const float* b2, const float* b3,
+                         const void* x, void* y, int B, int H, int W, int C, ec_stream_t stream);
+
 /* AvgPool2d(2) on bf16 NHWC ([U] Bottleneck downsample "-1"). C multiple of 8. */
 int ec_avgpool2_bf16(const void* in, void* out, int B, int H, int W, int C, ec_stream_t stream);
 

@@ -533,3 +533,62 @@ def test_long_segment_variant_of_the_128_wide_8wave_tiles_is_bit_identical(dev, 
     old = _conv_in_child({"EC_CONV8_LONGSEG": "0"}, cases, tmp_path, "ls0")
     for c, a, b in zip(cases, new, old):
         assert torch.equal(a, b), c
+
+
+def test_fused_bottleneck_launch_matches_reference_and_the_two_conv_launches(dev):
+    """conv_bneck.hip (round 4): conv2 (3x3) + bn2 + ReLU and conv3 (1x1) + bn3 + identity + ReLU of a stride-1
+    Bottleneck ([U] clip/model.py Bottleneck.forward) in one launch, one workgroup per image, the 14 x 14 x 256 map
+    resident in LDS.  Against a torch fp32 reference of the same two ops on the same bf16 operands (with c2 rounded to
+    bf16 where the kernel rounds it), and bit-identical to the two conv_igemm launches it replaces (same rounding
+    points, same K walk per output element).  Frame counts: 1, a ragged 3, and 130 (> one workgroup per CU half)."""
+    from embodied_clip_amd import encoder as enc
+    C, H = 256, 14
+    for B in (1, 3, 130):
+        g = torch.Generator().manual_seed(100 + B)
+        c1 = _bf(torch.randn(B, H, H, C, generator=g).relu())
+        x = _bf(torch.randn(B, H, H, 4 * C, generator=g).relu())
+        w2 = _bf(torch.randn(C, 3, 3, C, generator=g) * (9 * C) ** -0.5)
+        w3 = _bf(torch.randn(4 * C, C, generator=g) * C ** -0.5)
+        b2, b3 = torch.randn(C, generator=g) * 0.1, torch.randn(4 * C, generator=g) * 0.1
+        got = enc.bneck_conv23_bf16(c1.to(dev), w2.reshape(C, -1).to(dev), b2.to(dev), w3.to(dev), b3.to(dev), x.to(dev))
+        c2u = enc.conv_bf16(c1.to(dev), w2.reshape(C, -1).to(dev), b2.to(dev), None, ksize=3, act=1)
+        yu = enc.conv_bf16(c2u, w3.to(dev), b3.to(dev), x.to(dev), ksize=1, act=1)
+        torch.cuda.synchronize()
+        assert torch.equal(got, yu), B
+        c2 = F.relu(F.conv2d(c1.float().permute(0, 3, 1, 2), w2.float().permute(0, 3, 1, 2), b2, padding=1))
+        c2 = c2.to(torch.bfloat16).float()                                     # the kernel's one rounding of conv2's output
+        y = F.relu(F.conv2d(c2, w3.float()[:, :, None, None], b3) + x.float().permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+        assert _rel(got.cpu(), y) < 4e-3, (B, _rel(got.cpu(), y))
+    # unsupported geometry: the caller falls back to the two convs
+    lib = __import__("embodied_clip_amd._lib", fromlist=["load"]).load()
+    assert lib.ec_bneck_conv23_bf16(1, 1, 1, 1, 1, 1, 2, 7, 7, 512, None) == -2
+
+
+def test_trunk_with_fused_bottlenecks_is_bit_identical_to_the_unfused_plan(dev, tmp_path):
+    """EC_RN50_BNECK (default 128: launches of >= 128 frames run layer3.1 .. layer3.5's conv2 + conv3 as one fused launch
+    each): the same features, bit for bit, as the plan without them (child process, EC_RN50_BNECK=0), and fewer ops."""
+    import os
+    import subprocess
+    import sys
+    from embodied_clip_amd.encoder import RN50Trunk
+    sd = syn.rn50_visual_state_dict(0)
+    x = syn.synthetic_rgb(21, 8).repeat(16, 1, 1, 1).roll(2, dims=1)[:128].contiguous().to(dev)
+    base = RN50Trunk(sd, device=dev)
+    ref = base.forward(x).float().cpu()                     # 128 frames: the fused launches run
+    small = base.forward(x[:5].contiguous()).float().cpu()  # 5 frames: the fallback inside the same plan
+    out = str(tmp_path / "nobneck.pt")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, torch; sys.path.insert(0, %r)\n"
+            "from embodied_clip_amd import synthetic as syn\n"
+            "from embodied_clip_amd.encoder import RN50Trunk\n"
+            "t = RN50Trunk(syn.rn50_visual_state_dict(0), device='cuda:0')\n"
+            "x = syn.synthetic_rgb(21, 8).repeat(16, 1, 1, 1).roll(2, dims=1)[:128].contiguous().to('cuda:0')\n"
+            "torch.save({'feat': t.forward(x).float().cpu(), 'small': t.forward(x[:5].contiguous()).float().cpu(),\n"
+            "            'hash': t.plan_hash(), 'ops': t.lib.ec_rn50_num_ops(t.h)}, %r)\n") % (root, out)
+    r = subprocess.run([sys.executable, "-c", code], env={**os.environ, "EC_RN50_BNECK": "0"}, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = torch.load(out)
+    assert got["hash"] != base.plan_hash() and got["ops"] == base.lib.ec_rn50_num_ops(base.h) + 5
+    assert torch.equal(got["feat"], ref)
+    assert torch.equal(got["small"], small)

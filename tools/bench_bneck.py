@@ -1,0 +1,75 @@
+"""Micro-benchmark + check of the fused bottleneck launch (conv_bneck.hip) against the two conv_igemm launches it replaces.
+
+  python tools/bench_bneck.py [--B 128] [--iters 20] [--streams 1|2]
+--streams 2: two launches of B frames in flight on two HIP streams (the engine's two actor slices)."""
+import argparse, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from embodied_clip_amd import encoder as enc
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--B", type=int, default=128)
+ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--streams", type=int, default=1)
+ap.add_argument("--stamps", action="store_true", help="print workgroup 0's phase stamps (shader clocks, us, implied MHz)")
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+g = torch.Generator().manual_seed(0)
+C, H = 256, 14
+mk = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc)
+sets = []
+for _ in range(a.streams):
+    c1 = mk(a.B, H, H, C).relu().to(torch.bfloat16).to(dev)
+    x = mk(a.B, H, H, 4 * C).relu().to(torch.bfloat16).to(dev)
+    w2 = mk(C, 9 * C, sc=(9 * C) ** -0.5).to(torch.bfloat16).to(dev)
+    w3 = mk(4 * C, C, sc=C ** -0.5).to(torch.bfloat16).to(dev)
+    b2, b3 = mk(C, sc=0.1).to(dev), mk(4 * C, sc=0.1).to(dev)
+    sets.append((c1, x, w2, w3, b2, b3, torch.empty_like(x), torch.empty_like(c1), torch.empty_like(x)))
+c1, x, w2, w3, b2, b3, yf, c2u, yu = sets[0]
+
+def unfused(s):
+    c1, x, w2, w3, b2, b3, yf, c2u, yu = s
+    enc.conv_bf16(c1, w2, b2, None, ksize=3, pool=False, act=1, out=c2u)
+    enc.conv_bf16(c2u, w3, b3, x, ksize=1, pool=False, act=1, out=yu)
+
+def fused(s):
+    c1, x, w2, w3, b2, b3, yf, c2u, yu = s
+    enc.bneck_conv23_bf16(c1, w2, b2, w3, b3, x, out=yf)
+
+unfused(sets[0]); fused(sets[0]); torch.cuda.synchronize()
+d = (yf.float() - yu.float())
+print(f"fused vs unfused: equal={torch.equal(yf, yu)} max|d|={d.abs().max().item():.4g} rel={d.norm().item() / yu.float().norm().item():.3g} "
+      f"nonzero={(yf != 0).float().mean().item():.3f}")
+streams = [torch.cuda.Stream() for _ in range(a.streams)]
+for name, fn in (("unfused (3x3 + 1x1+res)", unfused), ("fused bneck23", fused)):
+    for _ in range(3):
+        for s in sets: fn(s)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for st in streams: st.wait_stream(torch.cuda.current_stream())
+    for _ in range(a.iters):
+        for st, s in zip(streams, sets):
+            with torch.cuda.stream(st):
+                fn(s)
+    for st in streams: torch.cuda.current_stream().wait_stream(st)
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / a.iters * 1e3
+    fl = 2.0 * a.B * a.streams * H * H * (C * 9 * C + 4 * C * C)
+    print(f"{name:26s} B={a.B} x {a.streams} stream(s): {us:8.1f} us  {fl / us / 1e6:7.0f} TFLOP/s")
+
+if a.stamps:
+    from embodied_clip_amd import _lib
+    lib = _lib.load()
+    buf = torch.zeros(16, dtype=torch.int64, device=dev)
+    lib.ec_bneck_set_debug(buf.data_ptr())
+    for _ in range(3):
+        for s in sets: fused(s)
+    torch.cuda.synchronize()
+    lib.ec_bneck_set_debug(None)
+    t = buf.cpu().tolist()
+    names = ["entry", "T loaded", "conv2 done", "c2 in T", "pass 0", "pass 1", "pass 2", "pass 3"]
+    for i in range(1, 8):
+        dc, dr = t[2 * i] - t[2 * i - 2], t[2 * i + 1] - t[2 * i - 1]
+        print(f"  {names[i]:12s} +{dc:8d} clk  +{dr / 100.0:7.2f} us  ({dc / max(dr, 1) * 100:.0f} MHz)")
+    print(f"  total {t[14] - t[0]} clk, {(t[15] - t[1]) / 100.0:.2f} us")
