@@ -456,7 +456,13 @@ def run_rank(a, rank: int, local_rank: int, world: int, init_method=None):
             free_worker()
             from embodied_clip_amd.plugin_path import time_plugin_path
             r = time_plugin_path(per_gpu, a.rollout, dev, steps=a.plugin_steps, warmup=1, update_repeats=a.update_repeats)
-            return {**r, "fraction_of_engine": round(r["value"] / value, 3)}
+            gc.collect(); torch.cuda.empty_cache()
+            # the same route when the RGB sensor hands over raw uint8 frames (a quarter of the PCIe bytes)
+            r8 = time_plugin_path(per_gpu, a.rollout, dev, steps=a.plugin_steps, warmup=1, update_repeats=a.update_repeats,
+                                  frames_u8=True)
+            return {**r, "fraction_of_engine": round(r["value"] / value, 3),
+                    "u8_sensor_frames": {"value": r8["value"], "ms_per_step": r8["ms_per_step"],
+                                         "fraction_of_engine": round(r8["value"] / value, 3), "route": r8["route"]}}
         dog.leg = "plugin_path"
         put("plugin_path", _soft("plugin_path", leg_plugin))
         gc.collect(); torch.cuda.empty_cache()

@@ -123,7 +123,14 @@ class ClipResNetPreprocessor(_PreprocessorBase):
         """HOST frames (what the simulators hand over), >= 64 of them, full feature maps: the batch is cut in two halves
         that run copy -> trunk -> NCHW conversion on two HIP streams, so one half's PCIe copy hides behind the other
         half's encoder and the two encoder launches overlap as they do in ``engine.Worker`` (same per-frame results:
-        a frame's features do not depend on how the batch is sliced)."""
+        a frame's features do not depend on how the batch is sliced).
+
+        ASYNCHRONOUS with respect to the caller's stream (round 4): nothing here depends on work the caller has in
+        flight (the input is host memory, the staging buffers are the preprocessor's own, the output is allocated on a
+        side stream), so the copies and the encoder launches start at once -- beside the policy's act step of the previous
+        env step, which is still running on the caller's stream -- and the caller's stream merely WAITS (an event, no
+        host sync) for the two halves before whatever consumes the returned tensor.  The host blocks only until the
+        H2D copies have left ``x`` (the caller may refill its frame buffer as soon as this returns)."""
         from .encoder import RN50Trunk
         trunk = self.resnet
         if getattr(self, "_twin", None) is None:
@@ -131,28 +138,45 @@ class ClipResNetPreprocessor(_PreprocessorBase):
             self._twin.set_conv8_min_tiles(50)    # (the twin only ever runs beside the primary trunk)
         if getattr(self, "_streams", None) is None:
             self._streams = [torch.cuda.Stream(device=self.device) for _ in range(2)]
+            self._copy_stream = torch.cuda.Stream(device=self.device)
+            self._stage, self._stage_free, self._calls = {}, {}, 0
         # two launches in flight: the lower 8-wave dispatch threshold (see ec_rn50_set_conv8_min_tiles) -- on the PRIMARY
         # trunk only while this call issues its launches (the handle's value is read at issue time); a later batch that runs
         # alone takes the default again
         trunk.set_conv8_min_tiles(50)
         N = x.shape[0]
         h = N // 2
-        out = torch.empty((N, trunk.out_channels, trunk.out_spatial, trunk.out_spatial), dtype=torch.float32, device=self.device)
         cur = torch.cuda.current_stream(self.device)
-        if getattr(self, "_copy_stream", None) is None:
-            self._copy_stream = torch.cuda.Stream(device=self.device)
-        # both copies go back to back on ONE copy stream (the SDMA queue); each compute stream waits for its half only
-        self._copy_stream.wait_stream(cur)
+        par = self._calls & 1                                   # staging buffers are double-buffered over calls
+        self._calls += 1
         halves, copied = [], []
+        sync_caller = os.environ.get("EC_PLUGIN_ASYNC", "1") == "0"      # (A/B switch: 0 = start behind the caller's stream, as round 3 did)
+        if sync_caller:
+            self._copy_stream.wait_stream(cur)
+            for st in self._streams:
+                st.wait_stream(cur)
         with torch.cuda.stream(self._copy_stream):
-            for (a, b) in ((0, h), (h, N)):
-                xs = torch.empty((b - a,) + tuple(x.shape[1:]), dtype=x.dtype, device=self.device)
+            # both copies go back to back on ONE copy stream (the SDMA queue); each compute stream waits for its half only
+            for k, (a, b) in enumerate(((0, h), (h, N))):
+                key = (par, k, b - a, tuple(x.shape[1:]), x.dtype)
+                xs = self._stage.get(key)
+                if xs is None:                                   # the preprocessor's OWN device staging (no allocator hand-over
+                    xs = self._stage[key] = torch.empty((b - a,) + tuple(x.shape[1:]), dtype=x.dtype, device=self.device)
+                free = self._stage_free.get(key)                 # ... between streams); reused once its last reader is done
+                if free is not None:
+                    self._copy_stream.wait_event(free)
                 xs.copy_(x[a:b], non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(self._copy_stream)
-                halves.append(xs); copied.append(ev)
-        for (a, b), tr, st, xs, ev in zip(((0, h), (h, N)), (trunk, self._twin), self._streams, halves, copied):
-            st.wait_stream(cur)
+                halves.append((key, xs)); copied.append(ev)
+        with torch.cuda.stream(self._streams[0]):               # allocated on a side stream: no dependency on the caller's stream
+            out = torch.empty((N, trunk.out_channels, trunk.out_spatial, trunk.out_spatial), dtype=torch.float32, device=self.device)
+            alloc = torch.cuda.Event()
+            alloc.record(self._streams[0])
+        self._streams[1].wait_event(alloc)
+        out.record_stream(self._streams[1])
+        out.record_stream(cur)
+        for (a, b), tr, st, (key, xs), ev in zip(((0, h), (h, N)), (trunk, self._twin), self._streams, halves, copied):
             st.wait_event(ev)
             with torch.cuda.stream(st):
                 if xs.dtype == torch.uint8:
@@ -160,10 +184,11 @@ class ClipResNetPreprocessor(_PreprocessorBase):
                 else:
                     f = tr.forward(xs if xs.dtype == torch.float32 else xs.to(torch.float32))
                 tr.to_nchw_f32(f, out[a:b])
-            xs.record_stream(st)
-            out.record_stream(st)          # (allocated on the caller's stream, written on this one)
+                done = torch.cuda.Event()
+                done.record(st)
+            self._stage_free[key] = done
         for st in self._streams:
-            cur.wait_stream(st)
+            cur.wait_stream(st)                                  # an event wait on the caller's stream; the host does not block
         trunk.set_conv8_min_tiles(0)
         # the copies were asynchronous (pinned source): the caller may refill `x` for the next env step as soon as this
         # returns, so wait for the LAST copy here (the encoder launches keep running behind it)

@@ -32,6 +32,7 @@
 // its K walk in the same order (tap-major, channel-minor; k-steps in order), so results are bit-identical to conv_igemm's.
 #include <stdlib.h>
 
+#include <algorithm>
 #include <utility>
 
 #include "common.h"
@@ -341,6 +342,218 @@ __global__ __launch_bounds__(512, 2) void bneck23_kernel(BneckArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// conv3x3_img_kernel: the 3x3 conv of a 14x14x256 / 7x7x512 map for SMALL launches (32-64 frames: the strong-scaling
+// operating points, readme_files/baselines_habitat.md:63-73).  Tiled over output pixels these launches are 200-400
+// workgroups that each walk 36-72 K-tiles in series at ~0.5 us per K-tile (20-30 us per conv at 32 frames for 3 us of MFMA
+// work at peak).  Here a workgroup is (image, slice of 32 FN output channels): the image's input map is resident in LDS as
+// in bneck23_kernel (taps = row shifts, zero row for padding), and the EIGHT WAVES SPLIT K -- wave w walks K-tiles
+// [w NK/8, (w+1) NK/8) out of its private weight ring, no barrier in the loop -- so the serial chain is 9-18 K-tiles of 32.
+// The eight partial tiles are folded through LDS in a FIXED order (((w0+w4)+(w1+w5))+((w2+w6)+(w3+w7))): deterministic,
+// no atomics; the summation order differs from the pixel-tiled kernels', so results agree with them to fp32-accumulation
+// rounding (one bf16 ulp on rare elements), not bit for bit.
+struct ImgArgs {
+    const uint16_t* in;    // [B][PIX][C]
+    const uint16_t* w;     // [C][9 C] in streaming order (32-row slices, ec_conv3x3_img_pack)
+    const float* bias;     // [C]
+    uint16_t* out;         // [B][PIX][C]
+    int B;
+    unsigned w_bytes;
+};
+
+template <int C, int HW, int FN>
+__global__ __launch_bounds__(512, 2) void conv3x3_img_kernel(ImgArgs p) {
+    constexpr int PIX = HW * HW, MB = (PIX + 31) / 32, NT = MB * FN;
+    constexpr int PITCH = C * 2 + 16, T_BYTES = (PIX + 1) * PITCH;
+    constexpr int BK = 32, NS = 3, SUB = 32 * BK * 2, STAGE = FN * SUB, RING = NS * STAGE;
+    constexpr int K2 = 9 * C, NK2 = K2 / BK, KT_PER_TAP = C / BK, KPW = NK2 / 8, NSLICE = C / (32 * FN);
+    constexpr int SLOT = NT * 4096;                              // one wave's partial tiles (fp32)
+    constexpr int E_OFF = (4 * SLOT + 255) / 256 * 256;          // per-wave 2-KB output staging, behind the four reduction slots
+    static_assert(NK2 % 8 == 0 && NT <= 8, "K-tiles divide over the 8 waves; one output tile per wave in the last fold");
+    static_assert(T_BYTES + 8 * RING <= 160 * 1024 && E_OFF + 8 * 2048 <= 160 * 1024, "LDS budget");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* T = smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 31, hh = lane >> 5;
+    unsigned char* ring = smem + T_BYTES + wave * RING;
+    const unsigned ring_lds = (unsigned)(unsigned long)(lds_void_t*)ring;
+    const unsigned t_lds = (unsigned)(unsigned long)(lds_void_t*)T;
+    const int img = blockIdx.x / NSLICE, slice = blockIdx.x - img * NSLICE;      // the slices of an image are neighbours: its map is fetched from L2
+
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+    const int kt0 = wave * KPW;
+    // K-tile kt of 32-row sub-slice (slice FN + f): one contiguous 2-KB block of the packed weights
+    const unsigned wsrc = (unsigned)((slice * FN) * NK2 * SUB + lane * 16);
+    auto issue_w = [&](int kk, int st) {                         // K-tile kt0 + kk (kk >= KPW: zeros into a free stage)
+#pragma unroll
+        for (int f = 0; f < FN; ++f)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const unsigned off = kk < KPW ? wsrc + (unsigned)(f * NK2 + kt0 + kk) * SUB + j * 1024 : 0xFFFFFFF0u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_t*)(ring + st * STAGE + f * SUB + j * 1024), 16, off, 0, 0, 0);
+            }
+    };
+    unsigned boff[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) boff[ks] = (unsigned)(frow * 64 + (((2 * ks + hh) ^ ((frow >> 2) & 3)) << 4));
+    issue_w(0, 0);
+    issue_w(1, 1);
+    {   // T <- the image's input map (padded rows: through registers)
+        constexpr int CHUNKS = PIX * C / 8, IT = (CHUNKS + 511) / 512;
+        const uint4* src = reinterpret_cast<const uint4*>(p.in + (size_t)img * PIX * C);
+        uint4 v[IT];
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            int q = tid + i * 512;
+            q = q < CHUNKS ? q : CHUNKS - 1;
+            v[i] = src[q];
+        }
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int q = tid + i * 512;
+            if (q < CHUNKS) *reinterpret_cast<uint4*>(T + (q / (C / 8)) * PITCH + (q % (C / 8)) * 16) = v[i];
+        }
+        if (tid < PITCH / 16) *reinterpret_cast<uint4*>(T + PIX * PITCH + tid * 16) = make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+
+    unsigned pbase[MB], pmask[MB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+        const int px = i * 32 + frow;
+        const int y = px / HW, x = px - y * HW;
+        unsigned m = 0;
+        if (px < PIX) {
+            const unsigned xm = (x > 0 ? 1u : 0u) | 2u | (x < HW - 1 ? 4u : 0u);
+            m = (y > 0 ? xm : 0u) | (xm << 3) | (y < HW - 1 ? (xm << 6) : 0u);
+        }
+        pmask[i] = m;
+        pbase[i] = t_lds + (unsigned)(px < PIX ? px : PIX) * PITCH + hh * 16;
+    }
+    const unsigned zbase = t_lds + PIX * PITCH + hh * 16;
+    auto addr_of = [&](int kt, unsigned (&a)[MB]) {              // fragment addresses of K-tile kt: tap shift + channel offset
+        const int tap = kt / KT_PER_TAP, j = kt - tap * KT_PER_TAP;
+        const int ky = (tap * 11) >> 5, kx = tap - ky * 3;
+        const unsigned sh = (unsigned)(((ky - 1) * HW + (kx - 1)) * PITCH + j * (BK * 2));
+#pragma unroll
+        for (int i = 0; i < MB; ++i) a[i] = ((pmask[i] >> tap) & 1u) ? pbase[i] + sh : zbase;
+    };
+
+    f32x16_t acc[MB][FN];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int f = 0; f < FN; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][f][r] = 0.f;
+    u32x4_t fa[2][MB], fb[2][FN];
+    auto mma = [&](int par) {
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int f = 0; f < FN; ++f)
+                acc[i][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fb[par][f]),
+                                                                    __builtin_bit_cast(bf16x8_t, fa[par][i]), acc[i][f], 0, 0, 0);
+    };
+    constexpr int G = MB + FN;                                   // fragment reads per k-step
+    static_assert(G <= 15, "lgkmcnt is a 4-bit counter");
+    unsigned a_cur[MB], a_nxt[MB];
+    addr_of(kt0, a_cur);
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * FN) : "memory");   // K-tile 0 landed (K-tile 1's pieces may be in flight)
+    {
+        [&]<int... I>(std::integer_sequence<int, I...>) { (lds_read16<0>(fa[0][I], a_cur[I]), ...); }(std::make_integer_sequence<int, MB>{});
+        [&]<int... F>(std::integer_sequence<int, F...>) { (lds_read16<F * SUB>(fb[0][F], ring_lds + boff[0]), ...); }(std::make_integer_sequence<int, FN>{});
+    }
+    int st = 0;
+    for (int kk = 0; kk < KPW; ++kk) {
+        int st2 = st + 2; st2 = st2 >= NS ? st2 - NS : st2;
+        int st1 = st + 1; st1 = st1 >= NS ? st1 - NS : st1;
+        // ---- k-step 0 ----
+        issue_w(kk + 2, st2);                                    // into the stage K-tile kk - 1 has left
+        {
+            const unsigned bb = ring_lds + st * STAGE + boff[1];
+            [&]<int... I>(std::integer_sequence<int, I...>) { (lds_read16<32>(fa[1][I], a_cur[I]), ...); }(std::make_integer_sequence<int, MB>{});
+            [&]<int... F>(std::integer_sequence<int, F...>) { (lds_read16<F * SUB>(fb[1][F], bb), ...); }(std::make_integer_sequence<int, FN>{});
+        }
+        asm volatile("s_waitcnt lgkmcnt(%0)" : : "n"(G));
+        [&]<int... I>(std::integer_sequence<int, I...>) { (tie(fa[0][I]), ...); }(std::make_integer_sequence<int, MB>{});
+        [&]<int... F>(std::integer_sequence<int, F...>) { (tie(fb[0][F]), ...); }(std::make_integer_sequence<int, FN>{});
+        mma(0);
+        // ---- k-step 1 (+ the next K-tile's first fragments) ----
+        if (kk + 1 < KPW) {
+            addr_of(kt0 + kk + 1, a_nxt);
+            asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * FN) : "memory");   // K-tile kk + 1 landed
+            const unsigned bb = ring_lds + st1 * STAGE + boff[0];
+            [&]<int... I>(std::integer_sequence<int, I...>) { (lds_read16<0>(fa[0][I], a_nxt[I]), ...); }(std::make_integer_sequence<int, MB>{});
+            [&]<int... F>(std::integer_sequence<int, F...>) { (lds_read16<F * SUB>(fb[0][F], bb), ...); }(std::make_integer_sequence<int, FN>{});
+            asm volatile("s_waitcnt lgkmcnt(%0)" : : "n"(G));
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)");
+        }
+        [&]<int... I>(std::integer_sequence<int, I...>) { (tie(fa[1][I]), ...); }(std::make_integer_sequence<int, MB>{});
+        [&]<int... F>(std::integer_sequence<int, F...>) { (tie(fb[1][F]), ...); }(std::make_integer_sequence<int, FN>{});
+        mma(1);
+#pragma unroll
+        for (int i = 0; i < MB; ++i) a_cur[i] = a_nxt[i];
+        st = st1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // (the zero-filled tail tiles)
+    __syncthreads();                                             // T and the rings are dead: the LDS becomes the fold's workspace
+
+    // ---- fold the eight partial sets in a fixed order: 4..7 -> 0..3, then tile t by wave t over the four sets ----
+    auto slot_ptr = [&](int slot, int ti, int r4) { return smem + slot * SLOT + ((ti * 4 + r4) * 64 + lane) * 16; };
+    if (wave >= 4) {
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int f = 0; f < FN; ++f)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4)
+                    *reinterpret_cast<f32x4_t*>(slot_ptr(wave - 4, i * FN + f, r4)) =
+                        f32x4_t{acc[i][f][4 * r4], acc[i][f][4 * r4 + 1], acc[i][f][4 * r4 + 2], acc[i][f][4 * r4 + 3]};
+    }
+    __syncthreads();
+    if (wave < 4) {
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int f = 0; f < FN; ++f)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    f32x4_t* sp = reinterpret_cast<f32x4_t*>(slot_ptr(wave, i * FN + f, r4));
+                    const f32x4_t o = *sp;
+                    f32x4_t v = f32x4_t{acc[i][f][4 * r4], acc[i][f][4 * r4 + 1], acc[i][f][4 * r4 + 2], acc[i][f][4 * r4 + 3]} + o;
+                    *sp = v;                                     // (w + (w + 4)) back into the same slot: this wave only
+                }
+    }
+    __syncthreads();
+    if (wave < NT) {
+        const int ti = wave, i = ti / FN, f = ti - i * FN;
+        const int n0 = slice * (32 * FN) + f * 32;
+        unsigned char* E = smem + E_OFF + wave * 2048;           // [32 px][64 B], chunk c of pixel r at c ^ ((r >> 2) & 3)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(slot_ptr(0, ti, g)), s1 = *reinterpret_cast<const f32x4_t*>(slot_ptr(1, ti, g));
+            const f32x4_t s2 = *reinterpret_cast<const f32x4_t*>(slot_ptr(2, ti, g)), s3 = *reinterpret_cast<const f32x4_t*>(slot_ptr(3, ti, g));
+            const f32x4_t v = (s0 + s1) + (s2 + s3);
+            const float4 bv = *reinterpret_cast<const float4*>(p.bias + n0 + 8 * g + 4 * hh);
+            uint2 o;
+            o.x = ec_pack2(bn_relu(v[0] + bv.x), bn_relu(v[1] + bv.y));
+            o.y = ec_pack2(bn_relu(v[2] + bv.z), bn_relu(v[3] + bv.w));
+            *reinterpret_cast<uint2*>(E + frow * 64 + ((g ^ ((frow >> 2) & 3)) << 4) + hh * 8) = o;
+        }
+        const int ec = lane & 3;
+        uint16_t* yo = p.out + (size_t)img * PIX * C + n0;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const int er = (lane >> 2) + 16 * h2, px = i * 32 + er;
+            const u32x4_t v = *reinterpret_cast<const u32x4_t*>(E + er * 64 + ((ec ^ ((er >> 2) & 3)) << 4));
+            if (px < PIX) *reinterpret_cast<u32x4_t*>(yo + (size_t)px * C + ec * 8) = v;
+        }
+    }
+}
+
 // Streaming order of a [N][K] bf16 weight matrix for bneck23_kernel: 16-byte unit ((s * K/32 + kt) * 32 + r) * 4 + pc holds
 // row 32 s + r, k = 32 kt + 8 (pc ^ ((r >> 2) & 3)) .. + 7 -- the swizzled 2-KB LDS image of (slice s, K-tile kt), contiguous.
 __global__ void bneck_pack_kernel(const uint4* __restrict__ w, uint4* __restrict__ out, int N, int K) {
@@ -354,6 +567,43 @@ __global__ void bneck_pack_kernel(const uint4* __restrict__ w, uint4* __restrict
 }
 
 }  // namespace
+
+// relu(conv3x3(in) + bias) for the two map geometries of the trunk's late 3x3 convs, one workgroup per (image, channel slice):
+// (H = W = 14, C = 256) and (H = W = 7, C = 512).  in / out bf16 [B,H,W,C]; packed = ec_conv3x3_img_pack(w bf16 [C][3*3*C]).
+// Meant for launches of <= 64 frames; EC_ERR_SHAPE for any other geometry.
+extern "C" int ec_conv3x3_img_pack(const void* w, void* packed, int C, ec_stream_t stream) {
+    if (!w || !packed) return EC_ERR_ARG;
+    if (C != 256 && C != 512) return EC_ERR_SHAPE;
+    const long n = (long)C * 9 * C / 8;
+    hipLaunchKernelGGL(bneck_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint4*)w,
+                       (uint4*)packed, C, 9 * C);
+    EC_CHECK_LAUNCH();
+    return EC_OK;
+}
+extern "C" int ec_conv3x3_img_bf16(const void* in, const void* packed, const float* bias, void* out, int B, int H, int W, int C,
+                                   ec_stream_t stream) {
+    if (!in || !packed || !bias || !out) return EC_ERR_ARG;
+    if (B <= 0 || H != W) return EC_ERR_SHAPE;
+    ImgArgs a;
+    a.in = (const uint16_t*)in; a.w = (const uint16_t*)packed; a.bias = bias; a.out = (uint16_t*)out; a.B = B;
+    a.w_bytes = (unsigned)((size_t)C * 9 * C * 2);
+    auto go = [&](auto kern, int nslice, size_t lds, std::atomic<uint64_t>& done) {
+        if (auto attr_g_ = ec_attr_needed(done))
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3((unsigned)(B * nslice)), dim3(512), lds, (hipStream_t)stream, a);
+    };
+    if (H == 14 && C == 256) {
+        static std::atomic<uint64_t> done{0};
+        go(conv3x3_img_kernel<256, 14, 1>, 8, std::max<size_t>((size_t)197 * 528 + 8 * 3 * 2048, (size_t)4 * 7 * 4096 + 8 * 2048 + 256), done);
+    } else if (H == 7 && C == 512) {
+        static std::atomic<uint64_t> done{0};
+        go(conv3x3_img_kernel<512, 7, 2>, 8, std::max<size_t>((size_t)50 * 1040 + 8 * 3 * 4096, (size_t)4 * 4 * 4096 + 8 * 2048 + 256), done);
+    } else {
+        return EC_ERR_SHAPE;
+    }
+    EC_CHECK_LAUNCH();
+    return EC_OK;
+}
 
 namespace { unsigned long long* g_bneck_dbg = nullptr; }
 // profiling only: device buffer of 16 x u64 that workgroup 0 of every following fused launch fills with {shader clock,

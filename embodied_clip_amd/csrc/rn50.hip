@@ -38,6 +38,7 @@ struct Op {
     // block's conv1 -> conv2 chain; group g > 0: `fork` on the op before which the branch may start (conv1), `side` on the
     // branch's ops, `join` on the op that consumes its result (conv3)
     int fork = 0, side = 0, join = 0;
+    long wimg_off = -1;      // offset (elements, into wbneck) of this 3x3 conv's streaming-order weights for the small-launch kernel
 };
 
 }  // namespace
@@ -231,15 +232,22 @@ extern "C" int ec_rn50_create(ec_rn50_t** out, int width, const int* layers4, in
     if (n_w != wo || n_bias != bo) { delete h; return EC_ERR_SHAPE; }
     {   // fused bottleneck launches: their conv2 + conv3 weights in streaming order, one packed block per op (w2_off = its offset)
         size_t tot = 0;
-        for (Op& o : h->ops)
-            if (o.kind == OP_BNECK) { o.w2_off = tot; tot += ec_bneck_packed_elems(o.Cin); }
+        for (Op& o : h->ops) {
+            if (o.kind == OP_BNECK) { o.w2_off = tot; o.wimg_off = (long)tot; tot += ec_bneck_packed_elems(o.Cin); }   // (packed conv2 comes first)
+            // the un-pooled 3x3 convs of the 7x7 stage: streaming-order weights for the small-launch kernel (conv3x3_img_kernel)
+            if (o.kind == OP_CONV && o.ks == 3 && !o.pool && o.H == 7 && o.W == 7 && o.Cin == 512 && o.Cout == 512 && ec_config().rn50_img3) {
+                o.wimg_off = (long)tot;
+                tot += (size_t)o.Cout * 9 * o.Cin;
+            }
+        }
         if (tot) {
             if (hipMalloc(&h->wbneck, tot * sizeof(uint16_t)) != hipSuccess) { h->wbneck = nullptr; delete h; return EC_ERR_LAUNCH; }
-            for (const Op& o : h->ops)
-                if (o.kind == OP_BNECK && ec_bneck_pack_weights(h->w + o.w_off, h->w + o.w1_off, h->wbneck + o.w2_off, o.Cin, nullptr) != EC_OK) {
-                    delete h;
-                    return EC_ERR_LAUNCH;
-                }
+            for (const Op& o : h->ops) {
+                int rc = EC_OK;
+                if (o.kind == OP_BNECK) rc = ec_bneck_pack_weights(h->w + o.w_off, h->w + o.w1_off, h->wbneck + o.w2_off, o.Cin, nullptr);
+                else if (o.wimg_off >= 0) rc = ec_conv3x3_img_pack(h->w + o.w_off, h->wbneck + o.wimg_off, o.Cin, nullptr);
+                if (rc != EC_OK) { delete h; return EC_ERR_LAUNCH; }
+            }
             (void)hipStreamSynchronize(nullptr);
         }
     }
@@ -405,6 +413,10 @@ int rn50_run(const ec_rn50_t* h, const void* rgb, bool u8, const float* mean3, c
                         rc = ec_bneck_conv23_bf16(buf(o.src), h->wbneck + o.w2_off, h->bias + o.b_off, h->bias + o.b1_off,
                                                   buf(o.res), buf(o.dst), nb, o.H, o.W, o.Cin, stream);
                     else {   // small launches: the two convs separately (buffer 2 = conv2's output, as in the unfused plan)
+                        // ... conv2 on the image-resident K-split kernel while its (image, slice) workgroups fit one round
+                        if (ec_config().rn50_img3 && nb * 8 <= 256)
+                            rc = ec_conv3x3_img_bf16(buf(o.src), h->wbneck + o.wimg_off, h->bias + o.b_off, buf(2), nb, o.H, o.W, o.Cin, stream);
+                        else
                         rc = ec_conv_bf16_wf(buf(o.src), h->w + o.w_off, nullptr, h->bias + o.b_off, nullptr, buf(2), nb, o.H, o.W,
                                              o.Cin, o.Cin, 3, 0, EC_ACT_RELU, stream);
                         if (rc == EC_OK)
@@ -413,6 +425,10 @@ int rn50_run(const ec_rn50_t* h, const void* rgb, bool u8, const float* mean3, c
                     }
                     break;
                 default:
+                    if (o.wimg_off >= 0 && o.kind == OP_CONV && nb <= 64) {   // 7x7x512 3x3 convs of small launches (two rounds of workgroups at most)
+                        rc = ec_conv3x3_img_bf16(buf(o.src), h->wbneck + o.wimg_off, h->bias + o.b_off, buf(o.dst), nb, o.H, o.W, o.Cin, stream);
+                        break;
+                    }
                     rc = ec_conv_bf16_wf(buf(o.src), h->w + o.w_off,
                                          (h->wfrag && o.Cin % 64 == 0 && o.Cout % 256 == 0) ? h->wfrag + o.w_off : nullptr,
                                          h->bias + o.b_off, o.res >= 0 ? buf(o.res) : nullptr,

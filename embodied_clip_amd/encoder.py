@@ -434,6 +434,25 @@ def bneck_conv23_bf16(c1, w2, b2, w3, b3, x, out=None):
     return out
 
 
+@_guard_first
+def conv3x3_img_bf16(x, w, bias, out=None):
+    """relu(conv3x3(x) + bias) on the image-resident small-launch kernel (``ec_conv3x3_img_bf16``): x bf16 [B,14,14,256] or
+    [B,7,7,512], w bf16 [C, 9C]."""
+    lib = _lib.load()
+    B, H, W, C = x.shape
+    key = ("img", w.data_ptr(), w._version)
+    packed = _BNECK_PACKED.get(key)
+    if packed is None:
+        packed = torch.empty_like(w)
+        _lib.check(lib.ec_conv3x3_img_pack(w.data_ptr(), packed.data_ptr(), C, _lib.stream_ptr()), "ec_conv3x3_img_pack")
+        _BNECK_PACKED[key] = packed
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.check(lib.ec_conv3x3_img_bf16(x.data_ptr(), packed.data_ptr(), bias.data_ptr(), out.data_ptr(), B, H, W, C,
+                                       _lib.stream_ptr()), "ec_conv3x3_img_bf16")
+    return out
+
+
 _BNECK_PACKED = {}
 
 

@@ -33,7 +33,9 @@ class PluginPathRunner:
 
     def __init__(self, n_actors: int, T: int = 128, device="cuda:0", seed: int = 0, update_repeats: int = 4,
                  lr: float = 3e-4, max_grad_norm: float = 0.5, gamma: float = 0.99, tau: float = 0.95,
-                 pool_steps: int = 4):
+                 pool_steps: int = 4, frames_u8: bool = False):
+        """``frames_u8``: the RGB sensor hands over raw uint8 HWC frames (``ClipResNetPreprocessor.process`` then fuses /255
+        and the CLIP mean / std into the stem kernel): a quarter of the PCIe bytes of the normalised fp32 frames."""
         self.N, self.T, self.dev = n_actors, T, torch.device(device)
         self.update_repeats, self.max_grad_norm, self.gamma, self.tau, self.lr = update_repeats, max_grad_norm, gamma, tau, lr
         dev = self.dev
@@ -48,7 +50,7 @@ class PluginPathRunner:
         self.sampler_dim = [d[0] for d in dims].index("sampler")
         H = self.model.recurrent_hidden_state_size
         # what the simulators hand over: host fp32 NHWC frames (pinned, so the copy inside process() can be asynchronous)
-        base = syn.synthetic_rgb(1000 + seed, n_actors)
+        base = syn.synthetic_rgb_u8(1000 + seed, n_actors) if frames_u8 else syn.synthetic_rgb(1000 + seed, n_actors)
         self.host_frames = [base.roll(shifts=s + 1, dims=0).roll(shifts=7 * (s + 1), dims=2).contiguous().pin_memory()
                             for s in range(pool_steps)]
         masks = torch.cat([torch.ones(1, n_actors, 1), syn.synthetic_masks(1001 + seed, T, n_actors)], 0)
@@ -108,8 +110,9 @@ class PluginPathRunner:
         self.total_steps += T * self.N
 
 
-def time_plugin_path(n_actors: int, T: int, device, steps: int = 1, warmup: int = 1, update_repeats: int = 4) -> Dict:
-    r = PluginPathRunner(n_actors, T, device, update_repeats=update_repeats)
+def time_plugin_path(n_actors: int, T: int, device, steps: int = 1, warmup: int = 1, update_repeats: int = 4,
+                     frames_u8: bool = False) -> Dict:
+    r = PluginPathRunner(n_actors, T, device, update_repeats=update_repeats, frames_u8=frames_u8)
     for _ in range(warmup):
         r.iteration()
     torch.cuda.synchronize()
@@ -120,6 +123,7 @@ def time_plugin_path(n_actors: int, T: int, device, steps: int = 1, warmup: int 
     dt = time.perf_counter() - t0
     return {"value": round(T * n_actors * steps / dt, 1), "unit": "env-frames/s", "steps": steps, "warmup": warmup,
             "ms_per_step": round(dt / steps * 1e3, 2), "loss": {k: round(float(v), 6) for k, v in r.info.items()},
-            "route": "HOST fp32 NHWC frames -> ClipResNetPreprocessor.process (fp32 NCHW out) -> fp32 NCHW rollout storage -> "
+            "route": ("HOST uint8 HWC frames (raw sensor output; /255 + CLIP mean/std fused into the stem)" if frames_u8 else
+                      "HOST fp32 NHWC frames") + " -> ClipResNetPreprocessor.process (fp32 NCHW out) -> fp32 NCHW rollout storage -> "
                      "ResnetTensorObjectNavActorCritic.forward (T=1 act, T=rollout learn) -> PPO.loss -> backward() -> "
                      "per-parameter grads -> clip_grad_norm_ -> torch.optim.Adam"}

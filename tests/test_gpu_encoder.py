@@ -203,7 +203,7 @@ def test_rn50_trunk_matches_oracle(dev, width, layers, res):
     # rounding (the K partition of the small layer-3/4 launches depends on the launch's tile count: tests/test_gpu_splitk.py)
     trunk.chunk = 2
     feat2 = trunk.forward(rgb.to(dev))
-    assert _rel(feat2.cpu(), feat.cpu()) <= 1e-3
+    assert _rel(feat2.cpu(), feat.cpu()) <= 1e-2
     # pool=True head
     pooled = trunk.spatial_mean(feat).cpu()
     assert torch.allclose(pooled, got.mean((2, 3)), atol=1e-3 * got.abs().max().item())
@@ -591,4 +591,30 @@ def test_trunk_with_fused_bottlenecks_is_bit_identical_to_the_unfused_plan(dev, 
     got = torch.load(out)
     assert got["hash"] != base.plan_hash() and got["ops"] == base.lib.ec_rn50_num_ops(base.h) + 5
     assert torch.equal(got["feat"], ref)
-    assert torch.equal(got["small"], small)
+    # 5 frames: the default plan runs layer 3's conv2 on the image-resident K-split kernel (fixed fold order), the child's
+    # unfused plan on conv_igemm: equal up to fp32-accumulation rounding amplified through the rest of the trunk
+    assert _rel(got["small"], small) <= 1e-2, _rel(got["small"], small)
+
+
+@pytest.mark.parametrize("H,C", [(14, 256), (7, 512)])
+def test_small_launch_image_resident_3x3_kernel(dev, H, C):
+    """conv3x3_img_kernel (round 4): the late 3x3 convs of SMALL launches (32-64 frames per GPU: strong scaling's operating
+    points) -- one workgroup per (image, channel slice), the map resident in LDS, K split over the eight waves, partial
+    tiles folded in a fixed order.  vs a torch fp32 reference of the op on the same bf16 operands; deterministic (two runs
+    bit-identical); equal to the pixel-tiled conv_igemm launch up to fp32-accumulation rounding (rare 1-ulp bf16 flips)."""
+    from embodied_clip_amd import encoder as enc
+    for B in (1, 3, 33):
+        g = torch.Generator().manual_seed(7 * B + H)
+        x = _bf(torch.randn(B, H, H, C, generator=g).relu())
+        w = _bf(torch.randn(C, 3, 3, C, generator=g) * (9 * C) ** -0.5)
+        b = torch.randn(C, generator=g) * 0.1
+        xd, wd, bd = x.to(dev), w.reshape(C, -1).to(dev), b.to(dev)
+        a1 = enc.conv3x3_img_bf16(xd, wd, bd).cpu()
+        a2 = enc.conv3x3_img_bf16(xd, wd, bd).cpu()
+        plain = enc.conv_bf16(xd, wd, bd, None, ksize=3, act=1).cpu()
+        ref = F.relu(F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), b, padding=1)).permute(0, 2, 3, 1)
+        assert torch.equal(a1, a2), B
+        assert _rel(a1, ref) < 4e-3, (B, _rel(a1, ref))
+        assert _rel(a1, plain) <= 1e-3 and (a1 != plain).float().mean().item() < 0.01, (B, _rel(a1, plain))
+    lib = __import__("embodied_clip_amd._lib", fromlist=["load"]).load()
+    assert lib.ec_conv3x3_img_bf16(1, 1, 1, 1, 2, 28, 28, 128, None) == -2       # any other geometry: EC_ERR_SHAPE
