@@ -416,8 +416,17 @@ def run_rank(a, rank: int, local_rank: int, world: int, init_method=None):
             dts = maxreduce(_time_iterations(ws_, a.sync_steps, 1, barrier))
             r = {"value": round(a.rollout * per_gpu * world * a.sync_steps / dts, 1), "unit": "env-frames/s", "steps": a.sync_steps,
                  "order": "per env step: act(t) on every slice -> the sampled actions of all actors copied D2H and waited for "
-                          "(what VectorSampledTasks.step(actions) forces) -> observe() -> encode(t+1); the free-running "
-                          "headline lets the host issue arbitrarily far ahead"}
+                          "(what ONE VectorSampledTasks.step(actions) over all samplers forces) -> observe() -> encode(t+1); "
+                          "the free-running headline lets the host issue arbitrarily far ahead"}
+            del ws_
+            gc.collect(); torch.cuda.empty_cache()
+            ws_ = Worker(per_gpu, frames_host=False, sync_actions="slice", **wkw)
+            dts = maxreduce(_time_iterations(ws_, a.sync_steps, 1, barrier))
+            r["per_slice_envs"] = {
+                "value": round(a.rollout * per_gpu * world * a.sync_steps / dts, 1), "unit": "env-frames/s",
+                "order": "one vectorised env per actor slice: the host waits for slice s's actions only, steps that slice's env "
+                         "and issues its encode(t+1) + act(t+1) while the other slice's encoder is still running (same "
+                         "per-actor arithmetic, same round trips per actor)"}
             del ws_
             return r
         dog.leg = "sync_actions"
@@ -517,7 +526,7 @@ def parse_args(argv=None):
                          "classes with the reference's tensor contracts (embodied_clip_amd/plugin_path.py)")
     ap.add_argument("--plugin-steps", type=int, default=1)
     ap.add_argument("--h2d-steps", type=int, default=5, help="timed iterations of the h2d_inclusive measurement")
-    ap.add_argument("--sync-actions", action="store_true",
+    ap.add_argument("--sync-actions", nargs="?", const=True, default=False, choices=[True, "slice"],
                     help="HEADLINE run in the action-synchronous order: every env step the sampled actions are copied D2H and "
                          "waited for before the next observation is served (what VectorSampledTasks.step(actions) forces); "
                          "by default this order is a secondary key of the line (`sync_actions`)")

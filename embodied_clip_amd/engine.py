@@ -73,6 +73,10 @@ class SyntheticEnv:
         self._k += 1
         return f
 
+    def observe_at(self, k: int, actions_host: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The batch ``observe()`` serves as its k-th call (per-slice env stepping: every slice asks for step k itself)."""
+        return self.frames[k % self.pool_steps]
+
 
 class _Slice:
     """Per-slice state: a contiguous group of actors with its own stream, encoder handle and buffers."""
@@ -126,7 +130,8 @@ class Worker:
         self.encoder = encoder
         # two slices (each with its own act -> encode chain on its own stream) from 48 actors on: measured round 3 at
         # 32 / 48 / 64 actors, one vs two slices: 26.8 / 29.0 / 35.0 k vs 26.1 / 31.8 / 36.8 k env-frames/s
-        ns = encoder_streams if (encoder_streams > 1 and n_actors >= 48 and n_actors % encoder_streams == 0) else 1
+        two_min = int(os.environ.get("EC_TWO_SLICE_MIN", "48"))          # (experiment switch for the rule above)
+        ns = encoder_streams if (encoder_streams > 1 and n_actors >= two_min and n_actors % encoder_streams == 0) else 1
         self.ns = ns
         n = n_actors // ns
         d = self.dev
@@ -331,25 +336,60 @@ class Worker:
             self.h, self.h_next = self.h_next, self.h
 
     def _collect_rollout_sync(self):
-        """The action-synchronous order: act(t) on every slice -> actions[t] D2H, WAITED FOR -> env.step -> encode(t+1).
-        One host round trip per env step sits between act(t) and encode(t+1), as in the real engine."""
+        """The action-synchronous orders: one host round trip per env step sits between act(t) and encode(t+1), as in the
+        real engine.
+
+        ``sync_actions=True`` ("all"): ONE vectorised env for all actors ([U] ``VectorSampledTasks.step(actions)``): act(t)
+        on every slice -> actions[t] D2H, WAITED FOR -> env.step -> encode(t+1) on every slice.  The slices then run in
+        lock step and the chip idles over every round trip.
+
+        ``sync_actions="slice"``: one vectorised env PER SLICE (two ``VectorSampledTasks`` groups): the host waits for the
+        actions of slice s only, steps that slice's env and issues its encode(t+1) + act(t+1) -- while the other slice's
+        encoder is still running.  Same per-actor arithmetic and the same number of round trips per actor, but the two
+        slices stay out of phase as they do in the free-running order."""
         T = self.T
         if getattr(self, "_actions_host", None) is None:
             self._actions_host = torch.empty((self.N,), dtype=torch.int64).pin_memory()
-        for t in range(T):
+        k0 = self.env._k
+
+        def d2h(sl, t):
+            self._actions_host[sl.o:sl.o + sl.n].copy_(self.actions[t][sl.o:sl.o + sl.n], non_blocking=True)
+
+        def wait(sl):
+            (sl.stream if sl.stream is not None else torch.cuda.current_stream()).synchronize()
+
+        if self.sync_actions == "slice":
             for sl in self.slices:
                 with self._on(sl):
-                    self._act_slice(sl, t)
-                    self._actions_host[sl.o:sl.o + sl.n].copy_(self.actions[t][sl.o:sl.o + sl.n], non_blocking=True)
-            for sl in self.slices:
-                (sl.stream if sl.stream is not None else torch.cuda.current_stream()).synchronize()
-            rgb = self.env.observe(self._actions_host)          # env.step(actions[t])
+                    self._act_slice(sl, 0)
+                    d2h(sl, 0)
+            for t in range(T):
+                for sl in self.slices:
+                    wait(sl)                                                 # this slice's actions[t] are on the host
+                    rgb = self.env.observe_at(k0 + t, self._actions_host)   # env.step of this slice's samplers
+                    with self._on(sl):
+                        self._encode_slice(sl, rgb, t + 1)
+                        if t + 1 < T:
+                            self._act_slice(sl, t + 1)
+                            d2h(sl, t + 1)
+                        else:
+                            self._act_slice(sl, T, sample=False)
+            self.env._k = k0 + T
+        else:
+            for t in range(T):
+                for sl in self.slices:
+                    with self._on(sl):
+                        self._act_slice(sl, t)
+                        d2h(sl, t)
+                for sl in self.slices:
+                    wait(sl)
+                rgb = self.env.observe(self._actions_host)          # env.step(actions[t])
+                for sl in self.slices:
+                    with self._on(sl):
+                        self._encode_slice(sl, rgb, t + 1)
             for sl in self.slices:
                 with self._on(sl):
-                    self._encode_slice(sl, rgb, t + 1)
-        for sl in self.slices:
-            with self._on(sl):
-                self._act_slice(sl, T, sample=False)
+                    self._act_slice(sl, T, sample=False)
         self._join()
         if (T & 1) == 1:
             self.h, self.h_next = self.h_next, self.h

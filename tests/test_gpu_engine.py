@@ -152,11 +152,14 @@ def test_action_synchronous_order_gives_the_same_rollout():
     T, N = 4, 64                                        # two slices of 32
     enc_sd, pol_sd = syn.rn50_visual_state_dict(0), syn.policy_state_dict(0)
     ws = [Worker(N, T=T, device="cuda:0", seed=5, update_repeats=1, encoder_sd=enc_sd, policy_sd=pol_sd, sync_actions=s)
-          for s in (False, True)]
+          for s in (False, True, "slice")]
     for w in ws:
         w.iteration()
     torch.cuda.synchronize()
-    a, b = ws
+    a, b, c = ws
+    # ... and with one env per slice (the host waits per slice; the slices stay out of phase)
+    assert torch.equal(a.actions, c.actions) and torch.equal(a.logp, c.logp) and torch.equal(a.values, c.values)
+    assert torch.equal(a.feat, c.feat) and c.env._k == a.env._k
     assert b.ns == 2 and b._actions_host.shape == (N,)
     assert torch.equal(a.actions, b.actions) and torch.equal(a.logp, b.logp) and torch.equal(a.values, b.values)
     assert torch.equal(a.feat, b.feat)
