@@ -690,6 +690,56 @@ __global__ __launch_bounds__(256) void fuse_goal_kernel(const void* __restrict__
 // back to the wave's LDS image (bias + ReLU applied) as the next stage's A operand -- and to HBM, because the backward
 // needs c2 and m1.  No workgroup barrier after the weights are staged.  Geometry fixed to the reference's
 // (128, 32, 128, 32); other widths keep the GEMM path.
+// Act step (T = 1): the GRU's input projection gi[N][3H] = x[N][K] W[3H][K]^T + b for a handful of actor rows (N = 32..128),
+// K = 1568.  As a tiled GEMM this is 24-96 workgroups walking K in series behind a split-K fold (18 us at 32 actors);
+// here a workgroup owns a 32 x 32 output tile and its NW waves SPLIT K (224 each for K = 1568 = 7 x 224), fragments straight
+// from global memory as float4 (exact-fp32 MFMA 32x32x2: an operand is one element per lane, so a float4 feeds four MFMAs),
+// the NW partial tiles folded through LDS in wave order + bias: deterministic, no atomics, no partial matrices in HBM.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void gi_act_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                         const float* __restrict__ bias, float* __restrict__ gi, int N, int K,
+                                                         int NO) {
+    __shared__ float part[NW][32][33];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, hh = lane >> 5;
+    const int j0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const int kw = K / NW, k0 = wave * kw;
+    const float* pa = x + (long)min(n0 + i, N - 1) * K + k0 + 4 * hh;        // (rows past N are computed on a clamped row, never stored)
+    const float* pb = W + (long)(j0 + i) * K + k0 + 4 * hh;
+    f32x16_t acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    constexpr int U = 4;                                          // groups of 8 k in flight
+    for (int kb = 0; kb < kw; kb += 8 * U) {
+        f32x4_t a[U], b[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int kk = min(kb + 8 * u, kw - 8);                // (kw is a multiple of 8; a clamped group is skipped below)
+            a[u] = *reinterpret_cast<const f32x4_t*>(pa + kk);
+            b[u] = *reinterpret_cast<const f32x4_t*>(pb + kk);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (kb + 8 * u < kw) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][0], b[u][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][1], b[u][1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][2], b[u][2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][3], b[u][3], acc, 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[wave][(r & 3) + 8 * (r >> 2) + 4 * hh][i] = acc[r];     // C/D layout: row = actor, column = lane & 31
+    __syncthreads();
+    for (int e = tid; e < 32 * 32; e += NW * 64) {
+        const int row = e >> 5, col = e & 31;
+        float v = part[0][row][col];
+#pragma unroll
+        for (int w2 = 1; w2 < NW; ++w2) v += part[w2][row][col];
+        if (n0 + row < N) gi[(long)(n0 + row) * NO + j0 + col] = v + (bias ? bias[j0 + col] : 0.f);
+    }
+}
+
 constexpr int ACT_PARTS = 4, ACT_MAX_ROWS = 16384;   // act step: split-K factor of the two long-K GEMMs / row limit of that path
 constexpr int TL_P128 = 132, TL_P32 = 36;     // LDS row pitches (floats): 16-byte slots of 16 consecutive rows differ
 
@@ -1509,6 +1559,16 @@ extern "C" int ec_policy_forward2(const ec_policy_t* h, const float* params, con
     // GRU: input projection for all T at once, then the sequential recurrence
     // (split-K only as separate partial matrices folded by the step kernel: the act step stays free of float atomics, so
     //  rollouts are bit-reproducible)
+    // act step with a handful of rows: one launch, K split over the waves of a workgroup, folded in-kernel (gi_act_kernel)
+    const int gi_nw = (flat % 56 == 0) ? 7 : ((flat % 64 == 0) ? 8 : 0);
+    const bool gi_small = infer_only && T == 1 && B <= 256 && gi_nw != 0 && (3 * H) % 32 == 0 && ec_config().act_split;
+    if (gi_small) {
+        const float* xin = (wih_perm || wih_act) ? ws + w.x4 : ws + w.x;
+        const float* win = wih_perm ? ws + wb.wihP : (wih_act ? ws + w.wihA : W(P_WIH));
+        const dim3 grid((unsigned)(3 * H / 32), (unsigned)((B + 31) / 32));
+        if (gi_nw == 7) hipLaunchKernelGGL(gi_act_kernel<7>, grid, dim3(448), 0, s, xin, win, W(P_BIH), ws + w.gi, B, flat, 3 * H);
+        else hipLaunchKernelGGL(gi_act_kernel<8>, grid, dim3(512), 0, s, xin, win, W(P_BIH), ws + w.gi, B, flat, 3 * H);
+    } else
     RC(ec_gemm_f32((wih_perm || wih_act) ? ws + w.x4 : ws + w.x, wih_perm ? ws + wb.wihP : (wih_act ? ws + w.wihA : W(P_WIH)), ws + w.gi, B, 3 * H, flat, flat, 1, 1, flat, 3 * H,
                    gi_split ? EC_GEMM_SPLIT_PARTS : 0, W(P_BIH), nullptr, nullptr, 0, nullptr, nullptr, gi_split ? ACT_PARTS : 1,
                    stream));
@@ -1548,7 +1608,7 @@ extern "C" int ec_policy_forward2(const ec_policy_t* h, const float* params, con
         if (fused_step) {
             hipLaunchKernelGGL(gru_step_fwd_kernel, dim3((unsigned)(H / 8), (unsigned)((N + 31) / 32)), dim3(256), gru_lds, s,
                                ws + w.gi + o3, W(P_WHH), W(P_BHH), hprev, masks + (size_t)t * N, hs_base + o1,
-                               ws + w.gates + o3, ws + w.hn + o1, ws + w.hp + o1, N, H, gi_split ? ACT_PARTS : 1,
+                               ws + w.gates + o3, ws + w.hn + o1, ws + w.hp + o1, N, H, (gi_split && !gi_small) ? ACT_PARTS : 1,
                                (long)B * 3 * H);
             continue;
         }

@@ -4,8 +4,8 @@ import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from embodied_clip_amd.engine import Worker
-ap = argparse.ArgumentParser(); ap.add_argument("--actors", type=int, default=256); ap.add_argument("--iters", type=int, default=50)
-a = ap.parse_args()
+ap = argparse.ArgumentParser(); ap.add_argument("actors_pos", nargs="?", type=int); ap.add_argument("--actors", type=int, default=256); ap.add_argument("--iters", type=int, default=50)
+a = ap.parse_args(); a.actors = a.actors_pos or a.actors
 w = Worker(a.actors, T=4, device="cuda:0", encoder_streams=2)
 w.collect_rollout(); torch.cuda.synchronize()
 sl = w.slices[0]
