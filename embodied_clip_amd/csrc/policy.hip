@@ -740,6 +740,57 @@ __global__ __launch_bounds__(NW * 64) void gi_act_kernel(const float* __restrict
     }
 }
 
+// Act step: the compressor's first 1x1 conv over the slice's bf16 feature rows, c1[M][NO] = relu(feat[M][K] W1[NO][K]^T + b1)
+// (M = 49 n rows, K = 2048, NO = 128), exact-fp32 as everywhere in the policy: W1 arrives as three bf16 planes
+// ([NO][3][K], ec_split3_bf16, cached in the act workspace with the other weight-derived tables) and each k-step runs the
+// three plane products, lowest plane first, into one accumulator.  A workgroup owns a 32 x 32 output tile and its eight
+// waves split K (fragments straight from global memory); the partial tiles are folded through LDS in wave order.  Replaces
+// a split-K GEMM whose four partial matrices tail_fwd_kernel had to fold.
+__global__ __launch_bounds__(512) void c1_act_kernel(const uint16_t* __restrict__ feat, const uint16_t* __restrict__ Wp,
+                                                     const float* __restrict__ bias, float* __restrict__ c1, long M, int K, int NO) {
+    constexpr int NW = 8;
+    __shared__ float part[NW][32][33];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, hh = lane >> 5;
+    const int j0 = blockIdx.x * 32;
+    const long m0 = (long)blockIdx.y * 32;
+    const int kw = K / NW, k0 = wave * kw;
+    const uint16_t* pa = feat + min(m0 + i, M - 1) * K + k0 + 8 * hh;
+    const uint16_t* pb = Wp + (long)(j0 + i) * 3 * K + k0 + 8 * hh;
+    f32x16_t acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    constexpr int U = 2;                                          // k-steps (of 16) in flight
+    for (int kb = 0; kb < kw; kb += 16 * U) {
+        s16x8_t a[U], b[U][3];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int kk = min(kb + 16 * u, kw - 16);
+            a[u] = *reinterpret_cast<const s16x8_t*>(pa + kk);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) b[u][pl] = *reinterpret_cast<const s16x8_t*>(pb + (long)pl * K + kk);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (kb + 16 * u < kw) {
+#pragma unroll
+                for (int pl = 2; pl >= 0; --pl)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[u]), __builtin_bit_cast(bf16x8_t, b[u][pl]), acc, 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[wave][(r & 3) + 8 * (r >> 2) + 4 * hh][i] = acc[r];
+    __syncthreads();
+    for (int e = tid; e < 32 * 32; e += NW * 64) {
+        const int row = e >> 5, col = e & 31;
+        float v = part[0][row][col];
+#pragma unroll
+        for (int w2 = 1; w2 < NW; ++w2) v += part[w2][row][col];
+        if (m0 + row < M) c1[(m0 + row) * NO + j0 + col] = fmaxf(v + bias[j0 + col], 0.f);
+    }
+}
+
 constexpr int ACT_PARTS = 4, ACT_MAX_ROWS = 16384;   // act step: split-K factor of the two long-K GEMMs / row limit of that path
 constexpr int TL_P128 = 132, TL_P32 = 36;     // LDS row pitches (floats): 16-byte slots of 16 consecutive rows differ
 
@@ -1502,9 +1553,16 @@ extern "C" int ec_policy_forward2(const ec_policy_t* h, const float* params, con
     // EC_C1_PINGPONG (default 1): bf16 features x fp32 W1 as three bf16 planes on the 8-wave ping-pong kernel
     // (conv_igemm8, X3 mode) once there are enough 256-row tiles to fill the chip; else the generic x3 GEMM
     const int c1_pp = ec_config().c1_pingpong;
+    bool c1_final = false;                                       // c1 already carries bias + ReLU (no partial matrices to fold)
     if (c1_pp && feat_bf16 && c.compress_hid % 128 == 0 && C % 64 == 0 && M49 >= 256 * 128) {
         RC(ec_split3_bf16(WS(P_W1), ws + w.w1p, c.compress_hid, C, stream));
         RC(ec_gemm_bf16a_x3(featS, ws + w.w1p, WS(P_B1), ws + o_c1, M49, c.compress_hid, C, 1 /* EC_ACT_RELU */, stream));
+    } else if (act_split && feat_bf16 && !c.dual && (C % 128) == 0 && (c.compress_hid % 32) == 0) {
+        // act step: one launch, K split over the waves of a workgroup, W1's three bf16 planes cached in the workspace with E1
+        if (!reuse_tables) RC(ec_split3_bf16(WS(P_W1), ws + w.w1p, c.compress_hid, C, stream));
+        hipLaunchKernelGGL(c1_act_kernel, dim3((unsigned)(c.compress_hid / 32), (unsigned)((M49 + 31) / 32)), dim3(512), 0, s,
+                           (const uint16_t*)featS, (const uint16_t*)(ws + w.w1p), WS(P_B1), ws + o_c1, (long)M49, C, c.compress_hid);
+        c1_final = true;
     } else if (act_split) {
         // act step: K = C is long and M small (196 workgroups walking 64 K-steps each): four K slices write four
         // partial matrices, tail_fwd_kernel folds them (+ b1, ReLU) in a fixed order -- no atomics, bit-reproducible,
@@ -1531,7 +1589,7 @@ extern "C" int ec_policy_forward2(const ec_policy_t* h, const float* params, con
         if (nwg > 512) nwg = 512;
         hipLaunchKernelGGL(tail_fwd_kernel, dim3((unsigned)nwg), dim3(256), tail_lds, s, ws + o_c1, WS(P_W2), WS(P_B2), WS(P_W3), cat,
                            ws + o_E1, goal_direct ? (const int*)goal : goal32, S, c.num_goals, WS(P_W4), WS(P_B4), ws + o_c2, ws + o_m1, ws + o_x4, (long)M49,
-                           act_split ? ACT_PARTS : 1, (long)M49 * c.compress_hid, WS(P_B1), goal_direct ? 2 : 1);
+                           (act_split && !c1_final) ? ACT_PARTS : 1, (long)M49 * c.compress_hid, WS(P_B1), goal_direct ? 2 : 1);
     } else {
     RC(ec_gemm_f32(ws + o_c1, WS(P_W2), ws + o_c2, M49, c.compress_out, c.compress_hid, c.compress_hid, 1, 1,
                    c.compress_hid, c.compress_out, EC_GEMM_RELU, WS(P_B2), nullptr, nullptr, 0, nullptr, nullptr, 1,
