@@ -29,3 +29,4 @@ fps = a.batch / ms * 1e3
 print(f"batch={a.batch} chunk={a.chunk} {ms:.3f} ms/forward  {fps:.0f} frames/s  "
       f"{fps * 2 * 5.367226368e9 / 1e12:.1f} TFLOP/s (trunk 5.367 GMAC/frame)")
 print('plan_hash', trunk.plan_hash())
+print('num_ops', trunk.lib.ec_rn50_num_ops(trunk.h))

@@ -32,7 +32,7 @@ def fetch_factor(name):
 root, n_last, frames, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
 plan_hash = sys.argv[5] if len(sys.argv) > 5 else None
 alg_mb = float(sys.argv[6]) if len(sys.argv) > 6 else 45.7
-KEYS = ('conv_igemm', 'stem', 'avgpool', 'conv1x1_pair', 'conv1x1_regw', 'conv3x3_narrow', 'conv3x3_rows', 'layernorm',
+KEYS = ('conv_igemm', 'bneck23', 'conv3x3_img', 'stem', 'avgpool', 'conv1x1_pair', 'conv1x1_regw', 'conv3x3_narrow', 'conv3x3_rows', 'layernorm',
         'mha_', 'patchify', 'assemble', 'attn', 'resize')
 
 

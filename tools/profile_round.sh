@@ -6,11 +6,16 @@ O=gpurun_out/$R; mkdir -p $O
 # the launch the ENGINE issues (bench.py: two slices of 128 frames, dispatch threshold 50): same plan hash as bench.py's handles
 bash tools/pmc_collect.sh trunk_$R tools/bench_trunk.py --batch 128 --min-tiles 50 --iters 1 > $O/pmc_trunk.log 2>&1
 H=$(grep -h plan_hash gpurun_out/pmc_trunk_$R.kt.log | tail -1 | cut -d" " -f2)
-python tools/pmc_summary.py gpurun_out/pmc_trunk_$R 50 128 $O/trunk_b128 $H 45.7 > $O/trunk_summary_tail.txt 2>&1
+NL=$(grep -h num_ops gpurun_out/pmc_trunk_$R.kt.log | tail -1 | cut -d" " -f2)      # launches per forward (>= 128 frames: one per op)
+python tools/pmc_summary.py gpurun_out/pmc_trunk_$R $NL 128 $O/trunk_b128 $H 45.7 > $O/trunk_summary_tail.txt 2>&1
 # ... and the single 256-frame launch (default threshold), the shape rounds 1-2 profiled: per-kernel table for continuity
 bash tools/pmc_collect.sh trunk256_$R tools/bench_trunk.py --batch 256 --iters 1 > $O/pmc_trunk256.log 2>&1
 H2=$(grep -h plan_hash gpurun_out/pmc_trunk256_$R.kt.log | tail -1 | cut -d" " -f2)
-python tools/pmc_summary.py gpurun_out/pmc_trunk256_$R 50 256 $O/trunk_b256 $H2 45.7 > $O/trunk256_summary_tail.txt 2>&1
+python tools/pmc_summary.py gpurun_out/pmc_trunk256_$R $NL 256 $O/trunk_b256 $H2 45.7 > $O/trunk256_summary_tail.txt 2>&1
+# the strong-scaling operating point: one 32-frame launch (the fused layer-3 ops fall back to two launches each: + 5)
+bash tools/pmc_collect.sh trunk32_$R tools/bench_trunk.py --batch 32 --iters 1 > $O/pmc_trunk32.log 2>&1
+H3=$(grep -h plan_hash gpurun_out/pmc_trunk32_$R.kt.log | tail -1 | cut -d" " -f2)
+python tools/pmc_summary.py gpurun_out/pmc_trunk32_$R $((NL + 5)) 32 $O/trunk_b32 $H3 45.7 > $O/trunk32_summary_tail.txt 2>&1
 bash tools/pmc_collect.sh vit_$R tools/bench_vit.py --batch 128 --min-tiles 50 --iters 1 > $O/pmc_vit.log 2>&1
 NV=$(python - <<PY
 import csv,glob
@@ -24,7 +29,7 @@ HV=$(grep -h plan_hash gpurun_out/pmc_vit_$R.kt.log | tail -1 | cut -d" " -f2)
 python tools/pmc_summary.py gpurun_out/pmc_vit_$R $NV 128 $O/vit_b128 "$HV" 23.3 > $O/vit_summary_tail.txt 2>&1
 bash tools/pmc_collect.sh upd_$R tools/bench_update.py --iters 1 > $O/pmc_upd.log 2>&1
 python tools/pmc_by_name.py gpurun_out/pmc_upd_$R 2.0 > $O/update_pmc_by_kernel.txt 2>&1
-rm -rf gpurun_out/pmc_trunk_$R gpurun_out/pmc_trunk256_$R gpurun_out/pmc_vit_$R gpurun_out/pmc_upd_$R    # raw counter CSVs: ~80 MB, summaries are kept
+rm -rf gpurun_out/pmc_trunk32_$R gpurun_out/pmc_trunk_$R gpurun_out/pmc_trunk256_$R gpurun_out/pmc_vit_$R gpurun_out/pmc_upd_$R    # raw counter CSVs: ~80 MB, summaries are kept
 python - <<PY
 import json
 O = "$O"
@@ -70,4 +75,13 @@ cd $GRAFT_REPO_ROOT
 (echo "# rocprofv3 --kernel-trace --stats of tools/bench_update.py --iters 3 (4 updates of 4 epochs incl. warm-up + one 128-step rollout): non-encoder kernels, total ms / calls / avg us / min us"; python tools/stats_noconv.py $(find $O/prof_upd -name "*kernel_stats.csv" | head -1) 0.5; grep "conv_igemm8.*true>" $(find $O/prof_upd -name "*kernel_stats.csv" | head -1) | cut -c1-160; tail -1 $O/update_under_rocprof.log) > $O/update_kernel_stats.txt
 rm -rf $O/prof_upd
 python tools/bench_update.py --iters 3 | tail -1 > $O/update_ms.txt
+# fused bottleneck launch: phase stamps of workgroup 0 (shader clocks, wall time, implied clock) alone / 128 / 256 workgroups
+(for B in 1 128 256; do python tools/bench_bneck.py --B $B --iters 20 --stamps 2>&1 | grep -v "amdgpu.ids\|unfused (3x3"; done) > $O/bneck_stamps.txt
+python tools/bench_img3x3.py 2>&1 | grep -v amdgpu.ids > $O/img3x3_vs_conv_igemm.txt
+for N in 32 128; do python tools/bench_act.py --actors $((2 * N > 48 ? 2 * N : N)) 2>&1 | tail -1; done > $O/act_step_us.txt
+# one env step of the engine at 32 actors per GPU, kernel by kernel
+cd /tmp
+rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$O/tr32 -o t -- python $GRAFT_REPO_ROOT/bench.py --actors 32 --steps 1 --warmup 1 --no-cpu-baseline --no-h2d --no-plugin --no-sync-actions --no-traffic > /dev/null 2>&1
+cd $GRAFT_REPO_ROOT
+python tools/trace_step.py $(find $O/tr32 -name "*kernel_trace.csv" | head -1) 40 > $O/env_step_32actors.txt; rm -rf $O/tr32
 tail -c 600 $O/bench_line.json; echo; tail -3 $O/trunk_summary_tail.txt; tail -2 $O/vit_summary_tail.txt
