@@ -690,6 +690,31 @@ __global__ __launch_bounds__(256) void fuse_goal_kernel(const void* __restrict__
 // back to the wave's LDS image (bias + ReLU applied) as the next stage's A operand -- and to HBM, because the backward
 // needs c2 and m1.  No workgroup barrier after the weights are staged.  Geometry fixed to the reference's
 // (128, 32, 128, 32); other widths keep the GEMM path.
+// Fragment-order copies of the act step's two weight operands (built with the other weight-derived tables, once per
+// parameter update): a fragment = what one MFMA operand load of a wave fetches = 64 lanes x 16 B = ONE contiguous 1-KB unit.
+// Out of the row-major tables a fragment load touched 32 rows x 32 B -- 64 quarter-used sectors per instruction -- and the
+// act kernels ran at the resulting L2 -> L1 rate (gi 16-19 us, c1 19 us at 32 actors).
+//   fp32 [N][K]  (gi):  unit (cb * K/8 + g) * 64 + l  =  row 32 cb + (l & 31), k = 8 g + 4 (l >> 5) .. + 3
+//   bf16 planes [N][3][K] (c1):  unit ((cb * K/16 + ks) * 3 + pl) * 64 + l  =  row 32 cb + (l & 31), plane pl, k = 16 ks + 8 (l >> 5) .. + 7
+__global__ void frag_pack_f32_kernel(const float4* __restrict__ W, float4* __restrict__ F, int N, int K) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long)N * K / 4) return;
+    const int l = (int)(t & 63);
+    const long f = t >> 6;
+    const int G = K / 8, g = (int)(f % G), cb = (int)(f / G);
+    F[t] = W[((long)(cb * 32 + (l & 31)) * K + g * 8 + 4 * (l >> 5)) >> 2];
+}
+__global__ void frag_pack_planes_kernel(const uint4* __restrict__ P, uint4* __restrict__ F, int N, int K) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long)N * 3 * K / 8) return;
+    const int l = (int)(t & 63);
+    const long f = t >> 6;
+    const int pl = (int)(f % 3);
+    const long f2 = f / 3;
+    const int KS = K / 16, ks = (int)(f2 % KS), cb = (int)(f2 / KS);
+    F[t] = P[(((long)(cb * 32 + (l & 31)) * 3 + pl) * K + ks * 16 + 8 * (l >> 5)) >> 3];
+}
+
 // Act step (T = 1): the GRU's input projection gi[N][3H] = x[N][K] W[3H][K]^T + b for a handful of actor rows (N = 32..128),
 // K = 1568.  As a tiled GEMM this is 24-96 workgroups walking K in series behind a split-K fold (18 us at 32 actors);
 // here a workgroup owns a 32 x 32 output tile and its NW waves SPLIT K (224 each for K = 1568 = 7 x 224), fragments straight
@@ -705,18 +730,19 @@ __global__ __launch_bounds__(NW * 64) void gi_act_kernel(const float* __restrict
     const int j0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
     const int kw = K / NW, k0 = wave * kw;
     const float* pa = x + (long)min(n0 + i, N - 1) * K + k0 + 4 * hh;        // (rows past N are computed on a clamped row, never stored)
-    const float* pb = W + (long)(j0 + i) * K + k0 + 4 * hh;
+    // W in fragment order (frag_pack_f32_kernel): group g of column block cb is the contiguous 1-KB unit (cb K/8 + g)
+    const f32x4_t* pbf = reinterpret_cast<const f32x4_t*>(W) + ((long)blockIdx.x * (K / 8) + k0 / 8) * 64 + lane;
     f32x16_t acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    constexpr int U = 4;                                          // groups of 8 k in flight
+    constexpr int U = 7;                                          // groups of 8 k in flight
     for (int kb = 0; kb < kw; kb += 8 * U) {
         f32x4_t a[U], b[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int kk = min(kb + 8 * u, kw - 8);                // (kw is a multiple of 8; a clamped group is skipped below)
             a[u] = *reinterpret_cast<const f32x4_t*>(pa + kk);
-            b[u] = *reinterpret_cast<const f32x4_t*>(pb + kk);
+            b[u] = pbf[(kk >> 3) * 64];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -746,48 +772,64 @@ __global__ __launch_bounds__(NW * 64) void gi_act_kernel(const float* __restrict
 // three plane products, lowest plane first, into one accumulator.  A workgroup owns a 32 x 32 output tile and its eight
 // waves split K (fragments straight from global memory); the partial tiles are folded through LDS in wave order.  Replaces
 // a split-K GEMM whose four partial matrices tail_fwd_kernel had to fold.
+template <int MBLK, int U>
 __global__ __launch_bounds__(512) void c1_act_kernel(const uint16_t* __restrict__ feat, const uint16_t* __restrict__ Wp,
                                                      const float* __restrict__ bias, float* __restrict__ c1, long M, int K, int NO) {
+    // MBLK 32-row blocks per workgroup (the W slice is fetched once per workgroup: taller tiles for larger M), U k-steps of
+    // fragment loads in flight per wave (the loop is L2-latency-bound: few, deep rounds)
     constexpr int NW = 8;
     __shared__ float part[NW][32][33];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, hh = lane >> 5;
     const int j0 = blockIdx.x * 32;
-    const long m0 = (long)blockIdx.y * 32;
+    const long m0 = (long)blockIdx.y * (32 * MBLK);
     const int kw = K / NW, k0 = wave * kw;
-    const uint16_t* pa = feat + min(m0 + i, M - 1) * K + k0 + 8 * hh;
-    const uint16_t* pb = Wp + (long)(j0 + i) * 3 * K + k0 + 8 * hh;
-    f32x16_t acc;
+    const uint16_t* pa[MBLK];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    constexpr int U = 2;                                          // k-steps (of 16) in flight
+    for (int mb = 0; mb < MBLK; ++mb) pa[mb] = feat + min(m0 + mb * 32 + i, M - 1) * K + k0 + 8 * hh;
+    // W1's planes in fragment order (frag_pack_planes_kernel): (k-step ks, plane pl) of column block cb is one 1-KB unit
+    const s16x8_t* pbf = reinterpret_cast<const s16x8_t*>(Wp) + ((long)blockIdx.x * (K / 16) + k0 / 16) * 3 * 64 + lane;
+    f32x16_t acc[MBLK];
+#pragma unroll
+    for (int mb = 0; mb < MBLK; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
     for (int kb = 0; kb < kw; kb += 16 * U) {
-        s16x8_t a[U], b[U][3];
+        s16x8_t a[U][MBLK], b[U][3];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int kk = min(kb + 16 * u, kw - 16);
-            a[u] = *reinterpret_cast<const s16x8_t*>(pa + kk);
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) b[u][pl] = *reinterpret_cast<const s16x8_t*>(pb + (long)pl * K + kk);
+            for (int mb = 0; mb < MBLK; ++mb) a[u][mb] = *reinterpret_cast<const s16x8_t*>(pa[mb] + kk);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) b[u][pl] = pbf[((kk >> 4) * 3 + pl) * 64];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (kb + 16 * u < kw) {
 #pragma unroll
                 for (int pl = 2; pl >= 0; --pl)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[u]), __builtin_bit_cast(bf16x8_t, b[u][pl]), acc, 0, 0, 0);
+#pragma unroll
+                    for (int mb = 0; mb < MBLK; ++mb)
+                        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[u][mb]),
+                                                                          __builtin_bit_cast(bf16x8_t, b[u][pl]), acc[mb], 0, 0, 0);
             }
         }
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) part[wave][(r & 3) + 8 * (r >> 2) + 4 * hh][i] = acc[r];
-    __syncthreads();
-    for (int e = tid; e < 32 * 32; e += NW * 64) {
-        const int row = e >> 5, col = e & 31;
-        float v = part[0][row][col];
+    for (int mb = 0; mb < MBLK; ++mb) {
+        if (mb) __syncthreads();                                  // the previous block's fold is done reading `part`
 #pragma unroll
-        for (int w2 = 1; w2 < NW; ++w2) v += part[w2][row][col];
-        if (m0 + row < M) c1[(m0 + row) * NO + j0 + col] = fmaxf(v + bias[j0 + col], 0.f);
+        for (int r = 0; r < 16; ++r) part[wave][(r & 3) + 8 * (r >> 2) + 4 * hh][i] = acc[mb][r];
+        __syncthreads();
+        for (int e = tid; e < 32 * 32; e += NW * 64) {
+            const int row = e >> 5, col = e & 31;
+            float v = part[0][row][col];
+#pragma unroll
+            for (int w2 = 1; w2 < NW; ++w2) v += part[w2][row][col];
+            const long m = m0 + mb * 32 + row;
+            if (m < M) c1[m * NO + j0 + col] = fmaxf(v + bias[j0 + col], 0.f);
+        }
     }
 }
 
@@ -1283,6 +1325,7 @@ struct Ws {   // float offsets into the workspace
     size_t E1, c1, c2, m1, x4, x, gi, gh, gates, hn, hp, hs, goal32, w1p;
     size_t E1d, c1d, c2d, m1d, x4d;   // the depth stream's copies (dual encoder)
     size_t wihA;                      // act step: weight_ih in pixel-major column order (valid while E1 is)
+    size_t wihF, w1pF;                // ... and the same / W1's planes in MFMA-FRAGMENT order for gi_act_kernel / c1_act_kernel
     size_t dhs, dhc, dgi, dghb, dx, dx4, dm1, dc2, dc1, dE1, tpart, tpartE, whhT, wihP, gwihP, tA, tB, end;
 };
 
@@ -1318,6 +1361,8 @@ Ws layout(const ec_policy* h, int T, int N, bool bwd) {
     w.goal32 = take(B);
     w.w1p = take(c.fusion ? 0 : ((size_t)c.compress_hid * 3 * c.in_channels + 1) / 2);   // W1 as three bf16 planes
     w.wihA = take((c.fusion || c.dual) ? 0 : 3 * H * flat);
+    w.wihF = take((c.fusion || c.dual) ? 0 : 3 * H * flat);
+    w.w1pF = take(c.fusion ? 0 : ((size_t)c.compress_hid * 3 * c.in_channels + 1) / 2);
     w.dhs = w.dhc = w.dgi = w.dghb = w.dx = w.dx4 = w.dm1 = w.dc2 = w.dc1 = w.dE1 = w.tpart = w.tpartE = w.whhT = w.wihP = w.gwihP = w.tA = w.tB = o;
     if (bwd) {
         w.dhs = take(B * H);
@@ -1559,9 +1604,26 @@ extern "C" int ec_policy_forward2(const ec_policy_t* h, const float* params, con
         RC(ec_gemm_bf16a_x3(featS, ws + w.w1p, WS(P_B1), ws + o_c1, M49, c.compress_hid, C, 1 /* EC_ACT_RELU */, stream));
     } else if (act_split && feat_bf16 && !c.dual && (C % 128) == 0 && (c.compress_hid % 32) == 0) {
         // act step: one launch, K split over the waves of a workgroup, W1's three bf16 planes cached in the workspace with E1
-        if (!reuse_tables) RC(ec_split3_bf16(WS(P_W1), ws + w.w1p, c.compress_hid, C, stream));
-        hipLaunchKernelGGL(c1_act_kernel, dim3((unsigned)(c.compress_hid / 32), (unsigned)((M49 + 31) / 32)), dim3(512), 0, s,
-                           (const uint16_t*)featS, (const uint16_t*)(ws + w.w1p), WS(P_B1), ws + o_c1, (long)M49, C, c.compress_hid);
+        if (!reuse_tables) {
+            RC(ec_split3_bf16(WS(P_W1), ws + w.w1p, c.compress_hid, C, stream));
+            const long nu = (long)c.compress_hid * 3 * C / 8;
+            hipLaunchKernelGGL(frag_pack_planes_kernel, dim3((unsigned)((nu + 255) / 256)), dim3(256), 0, s, (const uint4*)(ws + w.w1p),
+                               (uint4*)(ws + w.w1pF), c.compress_hid, C);
+        }
+        {
+            const uint16_t* fa_ = (const uint16_t*)featS;
+            const uint16_t* wp_ = (const uint16_t*)(ws + w.w1pF);
+            const unsigned nx = (unsigned)(c.compress_hid / 32);
+            if (M49 <= 2048)
+                hipLaunchKernelGGL((c1_act_kernel<1, 8>), dim3(nx, (unsigned)((M49 + 31) / 32)), dim3(512), 0, s, fa_, wp_, WS(P_B1),
+                                   ws + o_c1, (long)M49, C, c.compress_hid);
+            else if (M49 <= 4096)
+                hipLaunchKernelGGL((c1_act_kernel<2, 4>), dim3(nx, (unsigned)((M49 + 63) / 64)), dim3(512), 0, s, fa_, wp_, WS(P_B1),
+                                   ws + o_c1, (long)M49, C, c.compress_hid);
+            else
+                hipLaunchKernelGGL((c1_act_kernel<4, 4>), dim3(nx, (unsigned)((M49 + 127) / 128)), dim3(512), 0, s, fa_, wp_, WS(P_B1),
+                                   ws + o_c1, (long)M49, C, c.compress_hid);
+        }
         c1_final = true;
     } else if (act_split) {
         // act step: K = C is long and M small (196 workgroups walking 64 K-steps each): four K slices write four
@@ -1619,10 +1681,15 @@ extern "C" int ec_policy_forward2(const ec_policy_t* h, const float* params, con
     //  rollouts are bit-reproducible)
     // act step with a handful of rows: one launch, K split over the waves of a workgroup, folded in-kernel (gi_act_kernel)
     const int gi_nw = (flat % 56 == 0) ? 7 : ((flat % 64 == 0) ? 8 : 0);
-    const bool gi_small = infer_only && T == 1 && B <= 256 && gi_nw != 0 && (3 * H) % 32 == 0 && ec_config().act_split;
+    const bool gi_small = infer_only && wih_act && T == 1 && B <= 256 && gi_nw != 0 && (3 * H) % 32 == 0 && ec_config().act_split;
     if (gi_small) {
-        const float* xin = (wih_perm || wih_act) ? ws + w.x4 : ws + w.x;
-        const float* win = wih_perm ? ws + wb.wihP : (wih_act ? ws + w.wihA : W(P_WIH));
+        const float* xin = ws + w.x4;
+        const float* win = ws + w.wihF;                              // the re-ordered weight_ih in fragment order
+        if (!reuse_tables) {
+            const long nu = (long)3 * H * flat / 4;
+            hipLaunchKernelGGL(frag_pack_f32_kernel, dim3((unsigned)((nu + 255) / 256)), dim3(256), 0, s, (const float4*)(ws + w.wihA),
+                               (float4*)(ws + w.wihF), 3 * H, flat);
+        }
         const dim3 grid((unsigned)(3 * H / 32), (unsigned)((B + 31) / 32));
         if (gi_nw == 7) hipLaunchKernelGGL(gi_act_kernel<7>, grid, dim3(448), 0, s, xin, win, W(P_BIH), ws + w.gi, B, flat, 3 * H);
         else hipLaunchKernelGGL(gi_act_kernel<8>, grid, dim3(512), 0, s, xin, win, W(P_BIH), ws + w.gi, B, flat, 3 * H);
