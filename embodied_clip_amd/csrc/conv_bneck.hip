@@ -52,6 +52,7 @@ struct BneckArgs {
     uint16_t* y;           // [B][PIX][4C]
     int B;
     unsigned w2_bytes, w3_bytes;
+    int stagger;               // units of 512 clocks by which waves 4-7 enter conv3 late
     unsigned long long* dbg;   // profiling only (ec_bneck_set_debug): workgroup 0 stores {s_memtime, s_memrealtime} at entry / phase ends
 };
 
@@ -251,6 +252,12 @@ __global__ __launch_bounds__(512, 2) void bneck23_kernel(BneckArgs p) {
     issue_w3(0, 1, 1);
     __syncthreads();                                             // T now holds c2
     stamp(3);
+    // Anti-phase the two waves of every SIMD (waves w and w + 4): a conv3 pass is a K loop (3.6 k clocks of MFMA issue per
+    // wave) followed by an epilogue of dependent LDS round trips (~6 k clocks, no MFMAs).  Started together, both waves of a
+    // SIMD share the matrix pipe in the K loop and then leave it idle together (13.3 k clocks per pass); with one of them
+    // started ~one K loop later, each wave's epilogue runs beside the other's K loop.  (EC_BNECK_STAGGER clocks / 64.)
+    if (wave >= 4)
+        for (int q = 0; q < p.stagger; ++q) __builtin_amdgcn_s_sleep(8);      // 8 x 64 clocks per iteration
 
     // =====================================================================================================================
     // conv3: four passes of 256 output channels (32 per wave), K = C; epilogue per 32-pixel block through the free ring stage
@@ -361,16 +368,22 @@ struct ImgArgs {
     unsigned w_bytes;
 };
 
-template <int C, int HW, int FN>
+// NCH > 1: the input map does not fit the LDS (14 x 14 x 512 = 200 KB): it is made resident in NCH channel chunks, one after
+// the other, every chunk's K-tiles again split over the eight waves into the same accumulators.  POOL: CLIP's anti-aliased
+// stride -- ReLU then AvgPool2d(2) of the full-resolution result, through an LDS image of the folded tiles.
+template <int C, int HW, int FN, int NCH = 1, bool POOL = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_img_kernel(ImgArgs p) {
     constexpr int PIX = HW * HW, MB = (PIX + 31) / 32, NT = MB * FN;
-    constexpr int PITCH = C * 2 + 16, T_BYTES = (PIX + 1) * PITCH;
+    constexpr int CT = C / NCH;                                  // input channels resident at a time
+    constexpr int PITCH = CT * 2 + 16, T_BYTES = (PIX + 1) * PITCH;
     constexpr int BK = 32, NS = 3, SUB = 32 * BK * 2, STAGE = FN * SUB, RING = NS * STAGE;
-    constexpr int K2 = 9 * C, NK2 = K2 / BK, KT_PER_TAP = C / BK, KPW = NK2 / 8, NSLICE = C / (32 * FN);
+    constexpr int K2 = 9 * C, NK2 = K2 / BK, KT_PER_TAP = CT / BK, KPW = 9 * KT_PER_TAP / 8, NSLICE = C / (32 * FN);
+    static_assert((9 * KT_PER_TAP) % 8 == 0, "a chunk's K-tiles divide over the 8 waves");
     constexpr int SLOT = NT * 4096;                              // one wave's partial tiles (fp32)
     constexpr int E_OFF = (4 * SLOT + 255) / 256 * 256;          // per-wave 2-KB output staging, behind the four reduction slots
     static_assert(NK2 % 8 == 0 && NT <= 8, "K-tiles divide over the 8 waves; one output tile per wave in the last fold");
     static_assert(T_BYTES + 8 * RING <= 160 * 1024 && E_OFF + 8 * 2048 <= 160 * 1024, "LDS budget");
+    static_assert(!POOL || (FN == 1 && (HW % 2) == 0 && 4 * SLOT + PIX * 32 * 4 <= 160 * 1024), "pooled variant: 32-channel slices");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* T = smem;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -385,37 +398,41 @@ __global__ __launch_bounds__(512, 2) void conv3x3_img_kernel(ImgArgs p) {
     const int kt0 = wave * KPW;
     // K-tile kt of 32-row sub-slice (slice FN + f): one contiguous 2-KB block of the packed weights
     const unsigned wsrc = (unsigned)((slice * FN) * NK2 * SUB + lane * 16);
-    auto issue_w = [&](int kk, int st) {                         // K-tile kt0 + kk (kk >= KPW: zeros into a free stage)
+    int chunk = 0;                                               // input-channel chunk resident in T
+    auto issue_w = [&](int kk, int st) {                         // K-tile kt0 + kk of the chunk (kk >= KPW: zeros into a free stage)
+        const int q = kt0 + kk, tap = q / KT_PER_TAP;
+        const int kts = tap * (C / BK) + chunk * KT_PER_TAP + (q - tap * KT_PER_TAP);   // its index in the [N][9 C] weight matrix
 #pragma unroll
         for (int f = 0; f < FN; ++f)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const unsigned off = kk < KPW ? wsrc + (unsigned)(f * NK2 + kt0 + kk) * SUB + j * 1024 : 0xFFFFFFF0u;
+                const unsigned off = kk < KPW ? wsrc + (unsigned)(f * NK2 + kts) * SUB + j * 1024 : 0xFFFFFFF0u;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_t*)(ring + st * STAGE + f * SUB + j * 1024), 16, off, 0, 0, 0);
             }
     };
     unsigned boff[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) boff[ks] = (unsigned)(frow * 64 + (((2 * ks + hh) ^ ((frow >> 2) & 3)) << 4));
-    issue_w(0, 0);
-    issue_w(1, 1);
-    {   // T <- the image's input map (padded rows: through registers)
-        constexpr int CHUNKS = PIX * C / 8, IT = (CHUNKS + 511) / 512;
-        const uint4* src = reinterpret_cast<const uint4*>(p.in + (size_t)img * PIX * C);
-        uint4 v[IT];
+    auto load_T = [&](int h) {   // T <- channels [h CT, (h + 1) CT) of the image's input map (padded rows: through registers)
+        constexpr int CHUNKS = PIX * CT / 8, IT = (CHUNKS + 511) / 512;
+        const uint4* src = reinterpret_cast<const uint4*>(p.in + (size_t)img * PIX * C + (size_t)h * CT);
+        u32x4_t v[IT];
 #pragma unroll
         for (int i = 0; i < IT; ++i) {
             int q = tid + i * 512;
             q = q < CHUNKS ? q : CHUNKS - 1;
-            v[i] = src[q];
+            v[i] = *reinterpret_cast<const u32x4_t*>(src + (size_t)(q / (CT / 8)) * (C / 8) + (q % (CT / 8)));
         }
 #pragma unroll
         for (int i = 0; i < IT; ++i) {
             const int q = tid + i * 512;
-            if (q < CHUNKS) *reinterpret_cast<uint4*>(T + (q / (C / 8)) * PITCH + (q % (C / 8)) * 16) = v[i];
+            if (q < CHUNKS) *reinterpret_cast<u32x4_t*>(T + (q / (CT / 8)) * PITCH + (q % (CT / 8)) * 16) = v[i];
         }
         if (tid < PITCH / 16) *reinterpret_cast<uint4*>(T + PIX * PITCH + tid * 16) = make_uint4(0, 0, 0, 0);
-    }
+    };
+    issue_w(0, 0);
+    issue_w(1, 1);
+    load_T(0);
     __syncthreads();
 
     unsigned pbase[MB], pmask[MB];
@@ -459,6 +476,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_img_kernel(ImgArgs p) {
     constexpr int G = MB + FN;                                   // fragment reads per k-step
     static_assert(G <= 15, "lgkmcnt is a 4-bit counter");
     unsigned a_cur[MB], a_nxt[MB];
+    for (chunk = 0; chunk < NCH; ++chunk) {
+    if (chunk > 0) {                                             // next input-channel chunk: same accumulators
+        __syncthreads();                                         // every wave is done reading T
+        issue_w(0, 0);
+        issue_w(1, 1);
+        load_T(chunk);
+        __syncthreads();
+    }
     addr_of(kt0, a_cur);
     asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * FN) : "memory");   // K-tile 0 landed (K-tile 1's pieces may be in flight)
     {
@@ -499,6 +524,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_img_kernel(ImgArgs p) {
         st = st1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // (the zero-filled tail tiles)
+    }   // chunks
     __syncthreads();                                             // T and the rings are dead: the LDS becomes the fold's workspace
 
     // ---- fold the eight partial sets in a fixed order: 4..7 -> 0..3, then tile t by wave t over the four sets ----
@@ -528,6 +554,37 @@ __global__ __launch_bounds__(512, 2) void conv3x3_img_kernel(ImgArgs p) {
                 }
     }
     __syncthreads();
+    if constexpr (POOL) {
+        // folded tiles -> relu(+ bias) as fp32 into an LDS image P[px][32] behind the slots -> 2 x 2 average -> bf16 rows out
+        float* P = reinterpret_cast<float*>(smem + 4 * SLOT);
+        const int n0 = slice * 32;
+        if (wave < NT) {
+            const int ti = wave, px = ti * 32 + frow;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(slot_ptr(0, ti, g)), s1 = *reinterpret_cast<const f32x4_t*>(slot_ptr(1, ti, g));
+                const f32x4_t s2 = *reinterpret_cast<const f32x4_t*>(slot_ptr(2, ti, g)), s3 = *reinterpret_cast<const f32x4_t*>(slot_ptr(3, ti, g));
+                const f32x4_t v = (s0 + s1) + (s2 + s3);
+                const float4 bv = *reinterpret_cast<const float4*>(p.bias + n0 + 8 * g + 4 * hh);
+                if (px < PIX)
+                    *reinterpret_cast<f32x4_t*>(P + px * 32 + 8 * g + 4 * hh) =
+                        f32x4_t{bn_relu(v[0] + bv.x), bn_relu(v[1] + bv.y), bn_relu(v[2] + bv.z), bn_relu(v[3] + bv.w)};
+            }
+        }
+        __syncthreads();
+        constexpr int HP = HW / 2, PP = HP * HP;
+        if (tid < PP * 8) {
+            const int q = tid >> 3, c4 = tid & 7, yp = q / HP, xp = q - yp * HP;
+            const float* b00 = P + ((2 * yp) * HW + 2 * xp) * 32 + c4 * 4;
+            const f32x4_t a = *reinterpret_cast<const f32x4_t*>(b00), b = *reinterpret_cast<const f32x4_t*>(b00 + 32);
+            const f32x4_t c = *reinterpret_cast<const f32x4_t*>(b00 + HW * 32), d = *reinterpret_cast<const f32x4_t*>(b00 + HW * 32 + 32);
+            const f32x4_t o = ((a + b) + (c + d)) * 0.25f;       // (the fused epilogue's order: (s0 + s1) + (s2 + s3))
+            uint2 w;
+            w.x = ec_pack2(o[0], o[1]); w.y = ec_pack2(o[2], o[3]);
+            *reinterpret_cast<uint2*>(p.out + ((size_t)img * PP + q) * C + n0 + c4 * 4) = w;
+        }
+        return;
+    }
     if (wave < NT) {
         const int ti = wave, i = ti / FN, f = ti - i * FN;
         const int n0 = slice * (32 * FN) + f * 32;
@@ -569,7 +626,8 @@ __global__ void bneck_pack_kernel(const uint4* __restrict__ w, uint4* __restrict
 }  // namespace
 
 // relu(conv3x3(in) + bias) for the two map geometries of the trunk's late 3x3 convs, one workgroup per (image, channel slice):
-// (H = W = 14, C = 256) and (H = W = 7, C = 512).  in / out bf16 [B,H,W,C]; packed = ec_conv3x3_img_pack(w bf16 [C][3*3*C]).
+// (H = W = 14, C = 256), (H = W = 7, C = 512) and, with pool = 1 (ReLU then AvgPool2d(2): out is [B,7,7,C]), (H = W = 14,
+// C = 512).  in / out bf16 [B,H,W,C]; packed = ec_conv3x3_img_pack(w bf16 [C][3*3*C]).
 // Meant for launches of <= 64 frames; EC_ERR_SHAPE for any other geometry.
 extern "C" int ec_conv3x3_img_pack(const void* w, void* packed, int C, ec_stream_t stream) {
     if (!w || !packed) return EC_ERR_ARG;
@@ -581,7 +639,7 @@ extern "C" int ec_conv3x3_img_pack(const void* w, void* packed, int C, ec_stream
     return EC_OK;
 }
 extern "C" int ec_conv3x3_img_bf16(const void* in, const void* packed, const float* bias, void* out, int B, int H, int W, int C,
-                                   ec_stream_t stream) {
+                                   int pool, ec_stream_t stream) {
     if (!in || !packed || !bias || !out) return EC_ERR_ARG;
     if (B <= 0 || H != W) return EC_ERR_SHAPE;
     ImgArgs a;
@@ -592,12 +650,15 @@ extern "C" int ec_conv3x3_img_bf16(const void* in, const void* packed, const flo
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kern, dim3((unsigned)(B * nslice)), dim3(512), lds, (hipStream_t)stream, a);
     };
-    if (H == 14 && C == 256) {
+    if (H == 14 && C == 256 && !pool) {
         static std::atomic<uint64_t> done{0};
         go(conv3x3_img_kernel<256, 14, 1>, 8, std::max<size_t>((size_t)197 * 528 + 8 * 3 * 2048, (size_t)4 * 7 * 4096 + 8 * 2048 + 256), done);
-    } else if (H == 7 && C == 512) {
+    } else if (H == 7 && C == 512 && !pool) {
         static std::atomic<uint64_t> done{0};
         go(conv3x3_img_kernel<512, 7, 2>, 8, std::max<size_t>((size_t)50 * 1040 + 8 * 3 * 4096, (size_t)4 * 4 * 4096 + 8 * 2048 + 256), done);
+    } else if (H == 14 && C == 512 && pool) {   // layer4.0 conv2 + AvgPool2d(2): the 200-KB map resident in two channel chunks
+        static std::atomic<uint64_t> done{0};
+        go(conv3x3_img_kernel<512, 14, 1, 2, true>, 16, std::max<size_t>((size_t)197 * 528 + 8 * 3 * 2048, (size_t)4 * 7 * 4096 + 196 * 32 * 4 + 8 * 2048 + 256), done);
     } else {
         return EC_ERR_SHAPE;
     }
@@ -642,6 +703,7 @@ extern "C" int ec_bneck_conv23_bf16(const void* c1, const void* packed, const fl
     a.w2_bytes = (unsigned)((size_t)C * 9 * C * 2);
     a.w3_bytes = (unsigned)((size_t)4 * C * C * 2);
     a.dbg = g_bneck_dbg;
+    a.stagger = ec_config().bneck_stagger;
     constexpr int PITCH = 256 * 2 + 16;
     const size_t lds = (size_t)(196 + 1) * PITCH + 8 * 3 * 2048;
     auto kern = bneck23_kernel<256, 14>;

@@ -235,7 +235,8 @@ extern "C" int ec_rn50_create(ec_rn50_t** out, int width, const int* layers4, in
         for (Op& o : h->ops) {
             if (o.kind == OP_BNECK) { o.w2_off = tot; o.wimg_off = (long)tot; tot += ec_bneck_packed_elems(o.Cin); }   // (packed conv2 comes first)
             // the un-pooled 3x3 convs of the 7x7 stage: streaming-order weights for the small-launch kernel (conv3x3_img_kernel)
-            if (o.kind == OP_CONV && o.ks == 3 && !o.pool && o.H == 7 && o.W == 7 && o.Cin == 512 && o.Cout == 512 && ec_config().rn50_img3) {
+            if (o.kind == OP_CONV && o.ks == 3 && o.Cin == 512 && o.Cout == 512 && ec_config().rn50_img3 &&
+                ((!o.pool && o.H == 7 && o.W == 7) || (o.pool && o.H == 14 && o.W == 14))) {   // (layer4.0's conv2 + AvgPool2d: the chunked variant)
                 o.wimg_off = (long)tot;
                 tot += (size_t)o.Cout * 9 * o.Cin;
             }
@@ -415,7 +416,7 @@ int rn50_run(const ec_rn50_t* h, const void* rgb, bool u8, const float* mean3, c
                     else {   // small launches: the two convs separately (buffer 2 = conv2's output, as in the unfused plan)
                         // ... conv2 on the image-resident K-split kernel while its (image, slice) workgroups fit one round
                         if (ec_config().rn50_img3 && nb * 8 <= 256)
-                            rc = ec_conv3x3_img_bf16(buf(o.src), h->wbneck + o.wimg_off, h->bias + o.b_off, buf(2), nb, o.H, o.W, o.Cin, stream);
+                            rc = ec_conv3x3_img_bf16(buf(o.src), h->wbneck + o.wimg_off, h->bias + o.b_off, buf(2), nb, o.H, o.W, o.Cin, 0, stream);
                         else
                         rc = ec_conv_bf16_wf(buf(o.src), h->w + o.w_off, nullptr, h->bias + o.b_off, nullptr, buf(2), nb, o.H, o.W,
                                              o.Cin, o.Cin, 3, 0, EC_ACT_RELU, stream);
@@ -425,8 +426,9 @@ int rn50_run(const ec_rn50_t* h, const void* rgb, bool u8, const float* mean3, c
                     }
                     break;
                 default:
-                    if (o.wimg_off >= 0 && o.kind == OP_CONV && nb <= 64) {   // 7x7x512 3x3 convs of small launches (two rounds of workgroups at most)
-                        rc = ec_conv3x3_img_bf16(buf(o.src), h->wbneck + o.wimg_off, h->bias + o.b_off, buf(o.dst), nb, o.H, o.W, o.Cin, stream);
+                    if (o.wimg_off >= 0 && o.kind == OP_CONV && nb <= (o.pool ? 16 : 64)) {   // 7x7x512 3x3 convs of small launches (two rounds of
+                        // workgroups at most); layer4.0's pooled 14x14x512 conv2 (two channel chunks, 16 slices per image: one round of workgroups) up to 16 frames -- at 32 it ties with conv_igemm (47.6 vs 46.6 us)
+                        rc = ec_conv3x3_img_bf16(buf(o.src), h->wbneck + o.wimg_off, h->bias + o.b_off, buf(o.dst), nb, o.H, o.W, o.Cin, o.pool, stream);
                         break;
                     }
                     rc = ec_conv_bf16_wf(buf(o.src), h->w + o.w_off,

@@ -435,20 +435,19 @@ def bneck_conv23_bf16(c1, w2, b2, w3, b3, x, out=None):
 
 
 @_guard_first
-def conv3x3_img_bf16(x, w, bias, out=None):
+def conv3x3_img_bf16(x, w, bias, out=None, pool=False):
     """relu(conv3x3(x) + bias) on the image-resident small-launch kernel (``ec_conv3x3_img_bf16``): x bf16 [B,14,14,256] or
-    [B,7,7,512], w bf16 [C, 9C]."""
+    [B,7,7,512], w bf16 [C, 9C]; ``pool``: [B,14,14,512] -> AvgPool2d(2) of the result, [B,7,7,512]."""
     lib = _lib.load()
     B, H, W, C = x.shape
-    key = ("img", w.data_ptr(), w._version)
-    packed = _BNECK_PACKED.get(key)
+    packed = _packed_lookup("img", (w,))
     if packed is None:
         packed = torch.empty_like(w)
         _lib.check(lib.ec_conv3x3_img_pack(w.data_ptr(), packed.data_ptr(), C, _lib.stream_ptr()), "ec_conv3x3_img_pack")
-        _BNECK_PACKED[key] = packed
+        _packed_store("img", (w,), packed)
     if out is None:
-        out = torch.empty_like(x)
-    _lib.check(lib.ec_conv3x3_img_bf16(x.data_ptr(), packed.data_ptr(), bias.data_ptr(), out.data_ptr(), B, H, W, C,
+        out = torch.empty((B, H // 2, W // 2, C), dtype=x.dtype, device=x.device) if pool else torch.empty_like(x)
+    _lib.check(lib.ec_conv3x3_img_bf16(x.data_ptr(), packed.data_ptr(), bias.data_ptr(), out.data_ptr(), B, H, W, C, int(pool),
                                        _lib.stream_ptr()), "ec_conv3x3_img_bf16")
     return out
 
@@ -456,19 +455,37 @@ def conv3x3_img_bf16(x, w, bias, out=None):
 _BNECK_PACKED = {}
 
 
+def _packed_lookup(tag, tensors):
+    """Packed-weight cache keyed by the IDENTITY of the source tensors (weak references: a freed tensor's address can be
+    handed to another one) and their version counters."""
+    import weakref  # noqa: F401
+    hit = _BNECK_PACKED.get((tag,) + tuple(id(t) for t in tensors))
+    if hit is None:
+        return None
+    refs, versions, packed = hit
+    if all(r() is t for r, t in zip(refs, tensors)) and versions == tuple(t._version for t in tensors):
+        return packed
+    return None
+
+
+def _packed_store(tag, tensors, packed):
+    import weakref
+    if len(_BNECK_PACKED) > 32:
+        _BNECK_PACKED.clear()
+    _BNECK_PACKED[(tag,) + tuple(id(t) for t in tensors)] = (tuple(weakref.ref(t) for t in tensors),
+                                                           tuple(t._version for t in tensors), packed)
+
+
 def bneck_pack_weights(w2, w3):
     """The two weight matrices in the fused kernel's streaming order (``ec_bneck_pack_weights``); cached per tensor pair."""
-    key = (w2.data_ptr(), w3.data_ptr(), w2._version, w3._version)
-    hit = _BNECK_PACKED.get(key)
+    hit = _packed_lookup("bneck", (w2, w3))
     if hit is not None:
         return hit
     lib = _lib.load()
     C = w3.shape[1]
     packed = torch.empty(lib.ec_bneck_packed_elems(C), dtype=torch.bfloat16, device=w2.device)
     _lib.check(lib.ec_bneck_pack_weights(w2.data_ptr(), w3.data_ptr(), packed.data_ptr(), C, _lib.stream_ptr()), "ec_bneck_pack_weights")
-    if len(_BNECK_PACKED) > 16:
-        _BNECK_PACKED.clear()
-    _BNECK_PACKED[key] = packed
+    _packed_store("bneck", (w2, w3), packed)
     return packed
 
 

@@ -165,11 +165,13 @@ int ec_bneck_conv23_bf16(const void* c1, const void* packed, const float* b2, co
 /* relu(bn2(conv2(x))) of a late Bottleneck for SMALL launches (<= 64 frames: the per-GPU batches of strong scaling,
  * readme_files/baselines_habitat.md:63-73): one workgroup per (image, 32/64-channel slice), the image's map resident in
  * LDS, the eight waves split K and their partial tiles are folded through LDS in a fixed order (deterministic; equal to
- * ec_conv_bf16 up to fp32-accumulation rounding).  Geometries: (H = W = 14, C = 256) and (H = W = 7, C = 512); else
- * EC_ERR_SHAPE.  in / out bf16 [B,H,W,C]; packed = ec_conv3x3_img_pack(w bf16 [C][3*3*C]) (C * 9C elements). */
+ * ec_conv_bf16 up to fp32-accumulation rounding).  Geometries: (H = W = 14, C = 256), (H = W = 7, C = 512) and, with
+ * pool = 1 (CLIP's anti-aliased stride: ReLU then AvgPool2d(2), out [B,7,7,C]; the 200-KB map resident in two channel
+ * chunks), (H = W = 14, C = 512); else EC_ERR_SHAPE.  in / out bf16 [B,H,W,C]; packed = ec_conv3x3_img_pack(w bf16
+ * [C][3*3*C]) (C * 9C elements). */
 int ec_conv3x3_img_pack(const void* w, void* packed, int C, ec_stream_t stream);
 int ec_conv3x3_img_bf16(const void* in, const void* packed, const float* bias, void* out, int B, int H, int W, int C,
-                        ec_stream_t stream);
+                        int pool, ec_stream_t stream);
 
 /* AvgPool2d(2) on bf16 NHWC ([U] Bottleneck downsample "-1"). C multiple of 8. */
 int ec_avgpool2_bf16(const void* in, void* out, int B, int H, int W, int C, ec_stream_t stream);

@@ -617,4 +617,25 @@ def test_small_launch_image_resident_3x3_kernel(dev, H, C):
         assert _rel(a1, ref) < 4e-3, (B, _rel(a1, ref))
         assert _rel(a1, plain) <= 1e-3 and (a1 != plain).float().mean().item() < 0.01, (B, _rel(a1, plain))
     lib = __import__("embodied_clip_amd._lib", fromlist=["load"]).load()
-    assert lib.ec_conv3x3_img_bf16(1, 1, 1, 1, 2, 28, 28, 128, None) == -2       # any other geometry: EC_ERR_SHAPE
+    assert lib.ec_conv3x3_img_bf16(1, 1, 1, 1, 2, 28, 28, 128, 0, None) == -2    # any other geometry: EC_ERR_SHAPE
+
+
+def test_small_launch_image_resident_pooled_3x3_kernel(dev):
+    """layer4.0's conv2 + CLIP's anti-aliased stride (ReLU, AvgPool2d(2)) at small launches: the 14 x 14 x 512 map (200 KB)
+    is made resident in two channel chunks, each chunk's K-tiles split over the eight waves into the same accumulators,
+    the fold's tiles pooled through an LDS image.  vs the torch reference, vs conv_igemm's fused-pool launch, deterministic."""
+    from embodied_clip_amd import encoder as enc
+    C, H = 512, 14
+    for B in (1, 3, 33):
+        g = torch.Generator().manual_seed(900 + B)
+        x = _bf(torch.randn(B, H, H, C, generator=g).relu())
+        w = _bf(torch.randn(C, 3, 3, C, generator=g) * (9 * C) ** -0.5)
+        b = torch.randn(C, generator=g) * 0.1
+        xd, wd, bd = x.to(dev), w.reshape(C, -1).to(dev), b.to(dev)
+        a1 = enc.conv3x3_img_bf16(xd, wd, bd, pool=True).cpu()
+        a2 = enc.conv3x3_img_bf16(xd, wd, bd, pool=True).cpu()
+        plain = enc.conv_bf16(xd, wd, bd, None, ksize=3, pool=True, act=1).cpu()
+        ref = F.avg_pool2d(F.relu(F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), b, padding=1)), 2).permute(0, 2, 3, 1)
+        assert a1.shape == (B, 7, 7, C) and torch.equal(a1, a2), B
+        assert _rel(a1, ref) < 4e-3, (B, _rel(a1, ref))
+        assert _rel(a1, plain) <= 1e-3, (B, _rel(a1, plain))
