@@ -145,7 +145,9 @@ class ClipResNetPreprocessor(_PreprocessorBase):
         # alone takes the default again
         trunk.set_conv8_min_tiles(50)
         N = x.shape[0]
-        h = N // 2
+        nck = max(2, int(os.environ.get("EC_PLUGIN_CHUNKS", "2")))   # pieces of the batch (alternating over the two streams)
+        cuts = [round(i * N / nck) for i in range(nck + 1)]
+        spans = [(cuts[i], cuts[i + 1]) for i in range(nck) if cuts[i + 1] > cuts[i]]
         cur = torch.cuda.current_stream(self.device)
         par = self._calls & 1                                   # staging buffers are double-buffered over calls
         self._calls += 1
@@ -157,7 +159,7 @@ class ClipResNetPreprocessor(_PreprocessorBase):
                 st.wait_stream(cur)
         with torch.cuda.stream(self._copy_stream):
             # both copies go back to back on ONE copy stream (the SDMA queue); each compute stream waits for its half only
-            for k, (a, b) in enumerate(((0, h), (h, N))):
+            for k, (a, b) in enumerate(spans):
                 key = (par, k, b - a, tuple(x.shape[1:]), x.dtype)
                 xs = self._stage.get(key)
                 if xs is None:                                   # the preprocessor's OWN device staging (no allocator hand-over
@@ -176,7 +178,8 @@ class ClipResNetPreprocessor(_PreprocessorBase):
         self._streams[1].wait_event(alloc)
         out.record_stream(self._streams[1])
         out.record_stream(cur)
-        for (a, b), tr, st, (key, xs), ev in zip(((0, h), (h, N)), (trunk, self._twin), self._streams, halves, copied):
+        for k, ((a, b), (key, xs), ev) in enumerate(zip(spans, halves, copied)):
+            tr, st = (trunk, self._twin)[k & 1], self._streams[k & 1]
             st.wait_event(ev)
             with torch.cuda.stream(st):
                 if xs.dtype == torch.uint8:
