@@ -535,7 +535,7 @@ def parse_args(argv=None):
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL (backend nccl) and run the flat-bucket all-reduce also at world size 1 -- the "
                          "first-contact check of the N > 1 path on a 1-GPU box (tests/test_gpu_multi.py)")
-    ap.add_argument("--secondary-budget-s", type=float, default=1500.0,
+    ap.add_argument("--secondary-budget-s", type=float, default=420.0,
                     help="wall-clock budget of ALL secondary legs together; on expiry the line is printed with what is there")
     ap.add_argument("--no-traffic", action="store_true", help="do not read profiles/*_hbm_traffic.json")
     ap.add_argument("--phase-times", action="store_true", help="extra untimed iteration with per-phase sync timing")
