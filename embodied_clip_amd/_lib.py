@@ -23,6 +23,9 @@ SIGNATURES = {
     "ec_conv_splitk_workspace_bytes": (c_size_t, [c_int] * 6),
     "ec_conv3x3_img_pack": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "ec_conv3x3_img_bf16": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
+    "ec_bneck3_packed_elems": (c_size_t, [c_int]),
+    "ec_bneck3_pack_weights": (c_int, [c_void_p] * 4 + [c_int, c_void_p]),
+    "ec_bneck_conv123_bf16": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_void_p]),
     "ec_bneck_set_debug": (None, [c_void_p]),
     "ec_bneck_packed_elems": (c_size_t, [c_int]),
     "ec_bneck_pack_weights": (c_int, [c_void_p] * 3 + [c_int, c_void_p]),

@@ -48,10 +48,12 @@ struct BneckArgs {
     const float* b2;       // [C]
     const uint16_t* w3;    // conv3 weights ([4C][C]) in streaming order
     const float* b3;       // [4C]
-    const uint16_t* xres;  // [B][PIX][4C]  block input (identity)
+    const uint16_t* xres;  // [B][PIX][4C]  block input (identity; with F1 also conv1's input)
     uint16_t* y;           // [B][PIX][4C]
+    const uint16_t* w1;    // F1: conv1 weights ([C][4C]) in streaming order
+    const float* b1;       // F1: [C]
     int B;
-    unsigned w2_bytes, w3_bytes;
+    unsigned w2_bytes, w3_bytes, w1_bytes;
     int stagger;               // units of 512 clocks by which waves 4-7 enter conv3 late
     unsigned long long* dbg;   // profiling only (ec_bneck_set_debug): workgroup 0 stores {s_memtime, s_memrealtime} at entry / phase ends
 };
@@ -64,7 +66,12 @@ __device__ __forceinline__ void lds_read16(u32x4_t& d, unsigned addr) {
 }
 __device__ __forceinline__ void tie(u32x4_t& d) { asm volatile("" : "+v"(d)); }
 
-template <int C, int HW>
+// F1: conv1 (1x1, 4C -> C) + bn1 + ReLU runs in the same launch, in front: the whole Bottleneck is one launch, c1 never
+// exists in HBM.  Its im2col operand is the block input x (196 x 1024: does not fit), so x streams through a SHARED 3-stage
+// ring of 16-KB K-tiles (256 rows x 32 k, inside T's still unused area; every wave issues two of a K-tile's sixteen 1-KB pieces
+// next to its two private weight pieces: four per wave and K-tile, so the counted vmcnt stays uniform) with ONE raw barrier per
+// K-tile (ring mode of conv_igemm: own pieces landed -> barrier -> issue K-tile kt + 2 -> fragments + MFMAs).
+template <int C, int HW, bool F1 = false>
 __global__ __launch_bounds__(512, 2) void bneck23_kernel(BneckArgs p) {
     constexpr int PIX = HW * HW, MB = (PIX + 31) / 32;          // 196 pixels, 7 blocks of 32
     constexpr int PITCH = C * 2 + 16;                            // T row pitch (bytes): +16 staggers the banks between rows
@@ -116,11 +123,13 @@ __global__ __launch_bounds__(512, 2) void bneck23_kernel(BneckArgs p) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) boff[ks] = (unsigned)(frow * 64 + (((2 * ks + hh) ^ ((frow >> 2) & 3)) << 4));
 
+    if constexpr (F1) {
+        if (tid < PITCH / 16) *reinterpret_cast<uint4*>(T + PIX * PITCH + tid * 16) = make_uint4(0, 0, 0, 0);   // T's zero row
+    } else {
     issue_w2(0, 0);
     issue_w2(1, 1);
 
     // ---- T <- this image's conv1 output (PIX rows x C bf16, 16-byte chunks through registers: the rows are padded) ----
-    {
         constexpr int CHUNKS = PIX * C / 8, IT = (CHUNKS + 511) / 512;
         const uint4* src = reinterpret_cast<const uint4*>(p.c1 + (size_t)img * PIX * C);
         uint4 v[IT];
@@ -170,6 +179,79 @@ __global__ __launch_bounds__(512, 2) void bneck23_kernel(BneckArgs p) {
             acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fb[par]), __builtin_bit_cast(bf16x8_t, fa[par][i]),
                                                              acc[i], 0, 0, 0);
     };
+
+    if constexpr (F1) {
+        // =================================================================================================================
+        // conv1: c1 = relu(x W1^T + b1), K = 4C; x through the shared ring in T's area, W1 through the private rings
+        // =================================================================================================================
+        constexpr int K1 = 4 * C, NK1 = K1 / BK, XSTAGE = 256 * BK * 2;      // 16 KB: 256 rows x 64 B (rows >= PIX read as zeros)
+        static_assert(NS * XSTAGE <= PIX * PITCH, "the x ring lives below T's zero row");
+        const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(p.xres + (size_t)img * PIX * K1), 0,
+                                                                              (unsigned)(PIX * K1 * 2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_w1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w1, 0, p.w1_bytes, 0x00020000);
+        unsigned xsrc[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {                            // piece (2 wave + j): rows 16 (2 wave + j) + lane / 4, swizzled source chunk
+            const int r = (2 * wave + j) * 16 + (lane >> 2), sc = (lane & 3) ^ ((r >> 2) & 3);
+            xsrc[j] = r < PIX ? (unsigned)(r * (K1 * 2) + sc * 16) : 0xFFFFFFF0u;
+        }
+        const unsigned wsrc1 = (unsigned)(wave * NK1 * STAGE + lane * 16);
+        auto issue1 = [&](int kt, int stg) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const unsigned xo = (kt < NK1 && xsrc[j] != 0xFFFFFFF0u) ? xsrc[j] + (unsigned)kt * (BK * 2) : 0xFFFFFFF0u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_t*)(T + stg * XSTAGE + (2 * wave + j) * 1024), 16, xo, 0, 0, 0);
+                const unsigned wo = kt < NK1 ? wsrc1 + (unsigned)kt * STAGE + j * 1024 : 0xFFFFFFF0u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w1, (lds_void_t*)(ring + stg * STAGE + j * 1024), 16, wo, 0, 0, 0);
+            }
+        };
+        issue1(0, 0);
+        issue1(1, 1);
+        zero_acc();
+        int s1 = 0;
+        for (int kt = 0; kt < NK1; ++kt) {
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // this wave's four pieces of K-tile kt (kt + 1's may be in flight)
+            __builtin_amdgcn_s_barrier();                        // everyone's landed; everyone is done reading K-tile kt - 1
+            int s2 = s1 + 2; s2 = s2 >= NS ? s2 - NS : s2;
+            issue1(kt + 2, s2);                                  // into the stages K-tile kt - 1 has left
+            const unsigned xa0 = t_lds + s1 * XSTAGE + boff[0], xa1 = t_lds + s1 * XSTAGE + boff[1];   // (row swizzle depends on frow only)
+            const unsigned wb = ring_lds + s1 * STAGE;
+            [&]<int... I>(std::integer_sequence<int, I...>) { (lds_read16<I * 2048>(fa[0][I], xa0), ...); }(std::make_integer_sequence<int, MB>{});
+            lds_read16<0>(fb[0], wb + boff[0]);
+            [&]<int... I>(std::integer_sequence<int, I...>) { (lds_read16<I * 2048>(fa[1][I], xa1), ...); }(std::make_integer_sequence<int, MB>{});
+            lds_read16<0>(fb[1], wb + boff[1]);
+            asm volatile("s_waitcnt lgkmcnt(%0)" : : "n"(MB + 1));
+            [&]<int... I>(std::integer_sequence<int, I...>) { (tie(fa[0][I]), ...); }(std::make_integer_sequence<int, MB>{});
+            tie(fb[0]);
+            mma(0);
+            asm volatile("s_waitcnt lgkmcnt(0)");
+            [&]<int... I>(std::integer_sequence<int, I...>) { (tie(fa[1][I]), ...); }(std::make_integer_sequence<int, MB>{});
+            tie(fb[1]);
+            mma(1);
+            s1 = s1 + 1 == NS ? 0 : s1 + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // (the zero-filled tail tiles)
+        issue_w2(0, 0);                                          // conv2's first K-tiles under the c1 write
+        issue_w2(1, 1);
+        __syncthreads();                                         // every wave is done reading the x ring: T becomes c1
+        {
+            const int n0 = wave * 32;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 bv = *reinterpret_cast<const float4*>(p.b1 + n0 + 8 * g + 4 * hh);
+#pragma unroll
+                for (int i = 0; i < MB; ++i) {
+                    const int px = i * 32 + frow;
+                    uint2 o;
+                    o.x = ec_pack2(bn_relu(acc[i][4 * g + 0] + bv.x), bn_relu(acc[i][4 * g + 1] + bv.y));
+                    o.y = ec_pack2(bn_relu(acc[i][4 * g + 2] + bv.z), bn_relu(acc[i][4 * g + 3] + bv.w));
+                    if (px < PIX) *reinterpret_cast<uint2*>(T + px * PITCH + (n0 + 8 * g + 4 * hh) * 2) = o;
+                }
+            }
+        }
+        __syncthreads();                                         // T holds c1
+        stamp(1);
+    }
 
     // =====================================================================================================================
     // conv2: K = 9 taps x C channels, K-tiles of 32 channels; tap loop at run time, the 8 K-tiles x 2 k-steps of a tap unrolled
@@ -690,27 +772,54 @@ extern "C" int ec_bneck_pack_weights(const void* w2, const void* w3, void* packe
 // on a 14 x 14 map (CLIP-RN50 layer3.1 .. layer3.5), BatchNorm folded into (w, b).  c1 bf16 [B,14,14,C] (conv1's output),
 // packed = ec_bneck_pack_weights(w2 [C][3*3*C], w3 [4C][C]), x / y bf16 [B,14,14,4C].  EC_ERR_SHAPE for any other geometry (the
 // caller then runs the two convs separately).
-extern "C" int ec_bneck_conv23_bf16(const void* c1, const void* packed, const float* b2, const float* b3,
-                                    const void* x, void* y, int B, int H, int W, int C, ec_stream_t stream) {
-    const void* w2 = packed;
-    const void* w3 = packed ? (const uint16_t*)packed + (size_t)C * 9 * C : nullptr;
-    if (!c1 || !w2 || !b2 || !w3 || !b3 || !x || !y) return EC_ERR_ARG;
+namespace {
+template <bool F1>
+int launch_bneck(const void* c1, const void* packed, const float* b1, const float* b2, const float* b3, const void* x, void* y,
+                 int B, int H, int W, int C, ec_stream_t stream) {
+    if (!packed || !b2 || !b3 || !x || !y || (F1 ? !b1 : !c1)) return EC_ERR_ARG;
     if (B <= 0) return EC_ERR_SHAPE;
     if (H != 14 || W != 14 || C != 256) return EC_ERR_SHAPE;
     BneckArgs a;
-    a.c1 = (const uint16_t*)c1; a.w2 = (const uint16_t*)w2; a.b2 = b2; a.w3 = (const uint16_t*)w3; a.b3 = b3;
+    a.c1 = (const uint16_t*)c1; a.w2 = (const uint16_t*)packed; a.b2 = b2;
+    a.w3 = (const uint16_t*)packed + (size_t)C * 9 * C; a.b3 = b3;
+    a.w1 = (const uint16_t*)packed + (size_t)C * 9 * C + (size_t)4 * C * C; a.b1 = b1;
     a.xres = (const uint16_t*)x; a.y = (uint16_t*)y; a.B = B;
     a.w2_bytes = (unsigned)((size_t)C * 9 * C * 2);
     a.w3_bytes = (unsigned)((size_t)4 * C * C * 2);
+    a.w1_bytes = (unsigned)((size_t)C * 4 * C * 2);
     a.dbg = g_bneck_dbg;
     a.stagger = ec_config().bneck_stagger;
     constexpr int PITCH = 256 * 2 + 16;
     const size_t lds = (size_t)(196 + 1) * PITCH + 8 * 3 * 2048;
-    auto kern = bneck23_kernel<256, 14>;
+    auto kern = bneck23_kernel<256, 14, F1>;
     static std::atomic<uint64_t> attr_done{0};
     if (auto attr_g_ = ec_attr_needed(attr_done))
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(512), lds, (hipStream_t)stream, a);
     EC_CHECK_LAUNCH();
     return EC_OK;
+}
+}  // namespace
+
+extern "C" int ec_bneck_conv23_bf16(const void* c1, const void* packed, const float* b2, const float* b3,
+                                    const void* x, void* y, int B, int H, int W, int C, ec_stream_t stream) {
+    return launch_bneck<false>(c1, packed, nullptr, b2, b3, x, y, B, H, W, C, stream);
+}
+
+// The WHOLE Bottleneck in one launch: y = relu(conv3(relu(conv2(relu(conv1(x) + b1)) + b2)) + b3 + x).  packed =
+// ec_bneck3_pack_weights(w1 [C][4C], w2 [C][3*3*C], w3 [4C][C]) (ec_bneck3_packed_elems(C) elements: conv2, conv3, conv1).
+extern "C" size_t ec_bneck3_packed_elems(int C) { return C > 0 ? ec_bneck_packed_elems(C) + (size_t)C * 4 * C : 0; }
+extern "C" int ec_bneck3_pack_weights(const void* w1, const void* w2, const void* w3, void* packed, int C, ec_stream_t stream) {
+    if (!w1) return EC_ERR_ARG;
+    const int rc = ec_bneck_pack_weights(w2, w3, packed, C, stream);
+    if (rc != EC_OK) return rc;
+    const long n1 = (long)C * 4 * C / 8;
+    hipLaunchKernelGGL(bneck_pack_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint4*)w1,
+                       (uint4*)((uint16_t*)packed + ec_bneck_packed_elems(C)), C, 4 * C);
+    EC_CHECK_LAUNCH();
+    return EC_OK;
+}
+extern "C" int ec_bneck_conv123_bf16(const void* x, const void* packed, const float* b1, const float* b2, const float* b3,
+                                     void* y, int B, int H, int W, int C, ec_stream_t stream) {
+    return launch_bneck<true>(nullptr, packed, b1, b2, b3, x, y, B, H, W, C, stream);
 }

@@ -38,6 +38,7 @@ struct Op {
     // block's conv1 -> conv2 chain; group g > 0: `fork` on the op before which the branch may start (conv1), `side` on the
     // branch's ops, `join` on the op that consumes its result (conv3)
     int fork = 0, side = 0, join = 0;
+    long wc1_off = -1, bc1_off = -1;   // OP_BNECK with conv1 folded in (whole block in one launch): conv1's weight / bias offsets; its input is `res`
     long wimg_off = -1;      // offset (elements, into wbneck) of this 3x3 conv's streaming-order weights for the small-launch kernel
 };
 
@@ -212,6 +213,13 @@ extern "C" int ec_rn50_create(ec_rn50_t** out, int width, const int* layers4, in
                 h->ops.pop_back();
                 Op o{OP_BNECK, c2.src, y, idt, Ro, Ro, planes, planes * 4, 3, 0, EC_ACT_RELU, c2.w_off, c2.b_off};
                 o.w1_off = w_c3; o.b1_off = b_c3;
+                // EC_RN50_BNECK3 (default 1): conv1 too -- the whole Bottleneck is ONE launch (bneck23_kernel<.., F1>): the op
+                // just before conv2 is this block's conv1 (x -> buffer 1); it is folded in and its output never leaves the LDS
+                if (ec_config().rn50_bneck3 && !h->ops.empty() && h->ops.back().kind == OP_CONV && h->ops.back().ks == 1 &&
+                    h->ops.back().src == idt && h->ops.back().dst == c2.src && h->ops.back().Cin == planes * 4 && h->ops.back().Cout == planes) {
+                    o.wc1_off = (long)h->ops.back().w_off; o.bc1_off = (long)h->ops.back().b_off;
+                    h->ops.pop_back();
+                }
                 h->ops.push_back(o);
                 track(Ro, Ro, planes * 4);
             } else {
@@ -233,7 +241,7 @@ extern "C" int ec_rn50_create(ec_rn50_t** out, int width, const int* layers4, in
     {   // fused bottleneck launches: their conv2 + conv3 weights in streaming order, one packed block per op (w2_off = its offset)
         size_t tot = 0;
         for (Op& o : h->ops) {
-            if (o.kind == OP_BNECK) { o.w2_off = tot; o.wimg_off = (long)tot; tot += ec_bneck_packed_elems(o.Cin); }   // (packed conv2 comes first)
+            if (o.kind == OP_BNECK) { o.w2_off = tot; o.wimg_off = (long)tot; tot += ec_bneck3_packed_elems(o.Cin); }   // (packed conv2 comes first; room for conv1 too)
             // the un-pooled 3x3 convs of the 7x7 stage: streaming-order weights for the small-launch kernel (conv3x3_img_kernel)
             if (o.kind == OP_CONV && o.ks == 3 && o.Cin == 512 && o.Cout == 512 && ec_config().rn50_img3 &&
                 ((!o.pool && o.H == 7 && o.W == 7) || (o.pool && o.H == 14 && o.W == 14))) {   // (layer4.0's conv2 + AvgPool2d: the chunked variant)
@@ -245,7 +253,9 @@ extern "C" int ec_rn50_create(ec_rn50_t** out, int width, const int* layers4, in
             if (hipMalloc(&h->wbneck, tot * sizeof(uint16_t)) != hipSuccess) { h->wbneck = nullptr; delete h; return EC_ERR_LAUNCH; }
             for (const Op& o : h->ops) {
                 int rc = EC_OK;
-                if (o.kind == OP_BNECK) rc = ec_bneck_pack_weights(h->w + o.w_off, h->w + o.w1_off, h->wbneck + o.w2_off, o.Cin, nullptr);
+                if (o.kind == OP_BNECK)
+                    rc = o.wc1_off >= 0 ? ec_bneck3_pack_weights(h->w + o.wc1_off, h->w + o.w_off, h->w + o.w1_off, h->wbneck + o.w2_off, o.Cin, nullptr)
+                                        : ec_bneck_pack_weights(h->w + o.w_off, h->w + o.w1_off, h->wbneck + o.w2_off, o.Cin, nullptr);
                 else if (o.wimg_off >= 0) rc = ec_conv3x3_img_pack(h->w + o.w_off, h->wbneck + o.wimg_off, o.Cin, nullptr);
                 if (rc != EC_OK) { delete h; return EC_ERR_LAUNCH; }
             }
@@ -287,7 +297,7 @@ extern "C" uint64_t ec_rn50_plan_hash(const ec_rn50_t* h) {
     mix(h->width); mix(h->res); mix(h->conv8_min_tiles);
     for (const Op& o : h->ops) {
         mix(o.kind); mix(o.src); mix(o.dst); mix(o.res); mix(o.H); mix(o.W); mix(o.Cin); mix(o.Cout); mix(o.ks);
-        mix(o.pool); mix(o.act); mix(o.src1); mix(o.dst2); mix(o.N2); mix(o.dst3); mix(o.side);
+        mix(o.pool); mix(o.act); mix(o.src1); mix(o.dst2); mix(o.N2); mix(o.dst3); mix(o.side); mix(o.wc1_off >= 0);
     }
     return x;
 }
@@ -410,10 +420,18 @@ int rn50_run(const ec_rn50_t* h, const void* rgb, bool u8, const float* mean3, c
                     }
                     break;
                 case OP_BNECK:
-                    if (nb >= ec_config().rn50_bneck)
+                    if (nb >= ec_config().rn50_bneck && o.wc1_off >= 0)
+                        rc = ec_bneck_conv123_bf16(buf(o.res), h->wbneck + o.w2_off, h->bias + o.bc1_off, h->bias + o.b_off, h->bias + o.b1_off,
+                                                   buf(o.dst), nb, o.H, o.W, o.Cin, stream);
+                    else if (nb >= ec_config().rn50_bneck)
                         rc = ec_bneck_conv23_bf16(buf(o.src), h->wbneck + o.w2_off, h->bias + o.b_off, h->bias + o.b1_off,
                                                   buf(o.res), buf(o.dst), nb, o.H, o.W, o.Cin, stream);
-                    else {   // small launches: the two convs separately (buffer 2 = conv2's output, as in the unfused plan)
+                    else {   // small launches: the convs separately (buffer 1 = conv1's, buffer 2 = conv2's output, as in the unfused plan)
+                        if (o.wc1_off >= 0) {
+                            rc = ec_conv_bf16_wf(buf(o.res), h->w + o.wc1_off, nullptr, h->bias + o.bc1_off, nullptr, buf(o.src), nb, o.H, o.W,
+                                                 o.Cout, o.Cin, 1, 0, EC_ACT_RELU, stream);
+                            if (rc != EC_OK) return rc;
+                        }
                         // ... conv2 on the image-resident K-split kernel while its (image, slice) workgroups fit one round
                         if (ec_config().rn50_img3 && nb * 8 <= 256)
                             rc = ec_conv3x3_img_bf16(buf(o.src), h->wbneck + o.wimg_off, h->bias + o.b_off, buf(2), nb, o.H, o.W, o.Cin, 0, stream);

@@ -452,6 +452,26 @@ def conv3x3_img_bf16(x, w, bias, out=None, pool=False):
     return out
 
 
+@_guard_first
+def bneck_conv123_bf16(x, w1, b1, w2, b2, w3, b3, out=None):
+    """The whole stride-1 Bottleneck in one launch (``ec_bneck_conv123_bf16``): x bf16 [B,14,14,4C], w1 bf16 [C,4C], w2 bf16
+    [C,9C], w3 bf16 [4C,C] -> bf16 [B,14,14,4C]."""
+    lib = _lib.load()
+    B, H, W, C4 = x.shape
+    C = C4 // 4
+    packed = _packed_lookup("bneck3", (w1, w2, w3))
+    if packed is None:
+        packed = torch.empty(lib.ec_bneck3_packed_elems(C), dtype=torch.bfloat16, device=x.device)
+        _lib.check(lib.ec_bneck3_pack_weights(w1.data_ptr(), w2.data_ptr(), w3.data_ptr(), packed.data_ptr(), C, _lib.stream_ptr()),
+                   "ec_bneck3_pack_weights")
+        _packed_store("bneck3", (w1, w2, w3), packed)
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.check(lib.ec_bneck_conv123_bf16(x.data_ptr(), packed.data_ptr(), b1.data_ptr(), b2.data_ptr(), b3.data_ptr(), out.data_ptr(),
+                                         B, H, W, C, _lib.stream_ptr()), "ec_bneck_conv123_bf16")
+    return out
+
+
 _BNECK_PACKED = {}
 
 

@@ -162,6 +162,15 @@ void ec_bneck_set_debug(void* dev_u64x16);
 int ec_bneck_conv23_bf16(const void* c1, const void* packed, const float* b2, const float* b3,
                          const void* x, void* y, int B, int H, int W, int C, ec_stream_t stream);
 
+/* The WHOLE stride-1 Bottleneck in one launch (conv1 + bn1 + ReLU in front of the two above; c1 never exists in HBM: the
+ * block input x streams through a shared LDS ring): y = relu(conv3(relu(conv2(relu(conv1(x)))) + x).  packed =
+ * ec_bneck3_pack_weights(w1 bf16 [C][4C], w2, w3) (ec_bneck3_packed_elems(C) elements).  Bit-identical to the three ec_conv_bf16
+ * calls.  Same geometry restriction. */
+size_t ec_bneck3_packed_elems(int C);
+int ec_bneck3_pack_weights(const void* w1, const void* w2, const void* w3, void* packed, int C, ec_stream_t stream);
+int ec_bneck_conv123_bf16(const void* x, const void* packed, const float* b1, const float* b2, const float* b3,
+                          void* y, int B, int H, int W, int C, ec_stream_t stream);
+
 /* relu(bn2(conv2(x))) of a late Bottleneck for SMALL launches (<= 64 frames: the per-GPU batches of strong scaling,
  * readme_files/baselines_habitat.md:63-73): one workgroup per (image, 32/64-channel slice), the image's map resident in
  * LDS, the eight waves split K and their partial tiles are folded through LDS in a fixed order (deterministic; equal to

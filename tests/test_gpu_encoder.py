@@ -535,6 +535,34 @@ def test_long_segment_variant_of_the_128_wide_8wave_tiles_is_bit_identical(dev, 
         assert torch.equal(a, b), c
 
 
+def test_whole_bottleneck_launch_is_bit_identical_to_the_three_conv_launches(dev):
+    """bneck23_kernel<.., F1> (round 4): conv1 + bn1 + ReLU in front of the fused conv2 / conv3 launch -- the whole stride-1
+    Bottleneck ([U] clip/model.py Bottleneck.forward) in ONE launch, the block input streaming through a shared LDS ring,
+    c1 and c2 never in HBM.  Same rounding points and K walks as the three conv_igemm launches: bit-identical; and against a
+    torch fp32 reference with c1 / c2 rounded to bf16 where the kernels round them."""
+    from embodied_clip_amd import encoder as enc
+    C, H = 256, 14
+    for B in (1, 3, 130):
+        g = torch.Generator().manual_seed(300 + B)
+        x = _bf(torch.randn(B, H, H, 4 * C, generator=g).relu())
+        w1 = _bf(torch.randn(C, 4 * C, generator=g) * (4 * C) ** -0.5)
+        w2 = _bf(torch.randn(C, 3, 3, C, generator=g) * (9 * C) ** -0.5)
+        w3 = _bf(torch.randn(4 * C, C, generator=g) * C ** -0.5)
+        b1, b2, b3 = (torch.randn(n, generator=g) * 0.1 for n in (C, C, 4 * C))
+        d = lambda t: t.to(dev)
+        got = enc.bneck_conv123_bf16(d(x), d(w1), d(b1), d(w2.reshape(C, -1)), d(b2), d(w3), d(b3))
+        c1u = enc.conv_bf16(d(x), d(w1), d(b1), None, ksize=1, act=1)
+        c2u = enc.conv_bf16(c1u, d(w2.reshape(C, -1)), d(b2), None, ksize=3, act=1)
+        yu = enc.conv_bf16(c2u, d(w3), d(b3), d(x), ksize=1, act=1)
+        torch.cuda.synchronize()
+        assert torch.equal(got, yu), B
+        xf = x.float().permute(0, 3, 1, 2)
+        c1 = F.relu(F.conv2d(xf, w1.float()[:, :, None, None], b1)).to(torch.bfloat16).float()
+        c2 = F.relu(F.conv2d(c1, w2.float().permute(0, 3, 1, 2), b2, padding=1)).to(torch.bfloat16).float()
+        y = F.relu(F.conv2d(c2, w3.float()[:, :, None, None], b3) + xf).permute(0, 2, 3, 1)
+        assert _rel(got.cpu(), y) < 6e-3, (B, _rel(got.cpu(), y))
+
+
 def test_fused_bottleneck_launch_matches_reference_and_the_two_conv_launches(dev):
     """conv_bneck.hip (round 4): conv2 (3x3) + bn2 + ReLU and conv3 (1x1) + bn3 + identity + ReLU of a stride-1
     Bottleneck ([U] clip/model.py Bottleneck.forward) in one launch, one workgroup per image, the 14 x 14 x 256 map
@@ -589,7 +617,7 @@ def test_trunk_with_fused_bottlenecks_is_bit_identical_to_the_unfused_plan(dev, 
                        timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     got = torch.load(out)
-    assert got["hash"] != base.plan_hash() and got["ops"] == base.lib.ec_rn50_num_ops(base.h) + 5
+    assert got["hash"] != base.plan_hash() and got["ops"] == base.lib.ec_rn50_num_ops(base.h) + 10    # (conv1 + conv2 + conv3 -> 1 op, five times)
     assert torch.equal(got["feat"], ref)
     # 5 frames: the default plan runs layer 3's conv2 on the image-resident K-split kernel (fixed fold order), the child's
     # unfused plan on conv_igemm: equal up to fp32-accumulation rounding amplified through the rest of the trunk

@@ -24,24 +24,43 @@ for _ in range(a.streams):
     w2 = mk(C, 9 * C, sc=(9 * C) ** -0.5).to(torch.bfloat16).to(dev)
     w3 = mk(4 * C, C, sc=C ** -0.5).to(torch.bfloat16).to(dev)
     b2, b3 = mk(C, sc=0.1).to(dev), mk(4 * C, sc=0.1).to(dev)
-    sets.append((c1, x, w2, w3, b2, b3, torch.empty_like(x), torch.empty_like(c1), torch.empty_like(x)))
-c1, x, w2, w3, b2, b3, yf, c2u, yu = sets[0]
+    w1 = mk(C, 4 * C, sc=(4 * C) ** -0.5).to(torch.bfloat16).to(dev)
+    b1 = mk(C, sc=0.1).to(dev)
+    sets.append((c1, x, w2, w3, b2, b3, torch.empty_like(x), torch.empty_like(c1), torch.empty_like(x), w1, b1, torch.empty_like(x), torch.empty_like(c1)))
+c1, x, w2, w3, b2, b3, yf, c2u, yu, w1, b1, y3, c1u = sets[0]
+
+def unfused3(s):
+    c1, x, w2, w3, b2, b3, yf, c2u, yu, w1, b1, y3, c1u = s
+    enc.conv_bf16(x, w1, b1, None, ksize=1, pool=False, act=1, out=c1u)
+    enc.conv_bf16(c1u, w2, b2, None, ksize=3, pool=False, act=1, out=c2u)
+    enc.conv_bf16(c2u, w3, b3, x, ksize=1, pool=False, act=1, out=yu)
+
+def fused3(s):
+    c1, x, w2, w3, b2, b3, yf, c2u, yu, w1, b1, y3, c1u = s
+    enc.bneck_conv123_bf16(x, w1, b1, w2, b2, w3, b3, out=y3)
 
 def unfused(s):
-    c1, x, w2, w3, b2, b3, yf, c2u, yu = s
+    c1, x, w2, w3, b2, b3, yf, c2u, yu = s[:9]
     enc.conv_bf16(c1, w2, b2, None, ksize=3, pool=False, act=1, out=c2u)
     enc.conv_bf16(c2u, w3, b3, x, ksize=1, pool=False, act=1, out=yu)
 
 def fused(s):
-    c1, x, w2, w3, b2, b3, yf, c2u, yu = s
+    c1, x, w2, w3, b2, b3, yf, c2u, yu = s[:9]
     enc.bneck_conv23_bf16(c1, w2, b2, w3, b3, x, out=yf)
 
 unfused(sets[0]); fused(sets[0]); torch.cuda.synchronize()
 d = (yf.float() - yu.float())
 print(f"fused vs unfused: equal={torch.equal(yf, yu)} max|d|={d.abs().max().item():.4g} rel={d.norm().item() / yu.float().norm().item():.3g} "
       f"nonzero={(yf != 0).float().mean().item():.3f}")
+unfused3(sets[0]); fused3(sets[0]); torch.cuda.synchronize()
+d3 = (y3.float() - yu.float())
+print(f"whole block fused vs three conv launches: equal={torch.equal(y3, yu)} max|d|={d3.abs().max().item():.4g} rel={d3.norm().item() / yu.float().norm().item():.3g}")
 streams = [torch.cuda.Stream() for _ in range(a.streams)]
-for name, fn in (("unfused (3x3 + 1x1+res)", unfused), ("fused bneck23", fused)):
+for st in streams:            # (first use of a stream is slow: not inside a timed region)
+    with torch.cuda.stream(st):
+        fused(sets[0])
+torch.cuda.synchronize()
+for name, fn in (("unfused (3x3 + 1x1+res)", unfused), ("fused bneck23", fused), ("unfused (1x1, 3x3, 1x1+res)", unfused3), ("fused bneck123", fused3)):
     for _ in range(3):
         for s in sets: fn(s)
     torch.cuda.synchronize()
@@ -55,7 +74,7 @@ for name, fn in (("unfused (3x3 + 1x1+res)", unfused), ("fused bneck23", fused))
     for st in streams: torch.cuda.current_stream().wait_stream(st)
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / a.iters * 1e3
-    fl = 2.0 * a.B * a.streams * H * H * (C * 9 * C + 4 * C * C)
+    fl = 2.0 * a.B * a.streams * H * H * (C * 9 * C + 4 * C * C + (4 * C * C if '1x1, 3x3' in name or '123' in name else 0))
     print(f"{name:26s} B={a.B} x {a.streams} stream(s): {us:8.1f} us  {fl / us / 1e6:7.0f} TFLOP/s")
 
 if a.stamps:
