@@ -26,6 +26,9 @@ SIGNATURES = {
     "ec_bneck3_packed_elems": (c_size_t, [c_int]),
     "ec_bneck3_pack_weights": (c_int, [c_void_p] * 4 + [c_int, c_void_p]),
     "ec_bneck_conv123_bf16": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_void_p]),
+    "ec_bneck_band_packed_elems": (c_size_t, []),
+    "ec_bneck_band_pack_weights": (c_int, [c_void_p] * 5),
+    "ec_bneck_band_bf16": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_void_p]),
     "ec_bneck_set_debug": (None, [c_void_p]),
     "ec_bneck_packed_elems": (c_size_t, [c_int]),
     "ec_bneck_pack_weights": (c_int, [c_void_p] * 3 + [c_int, c_void_p]),

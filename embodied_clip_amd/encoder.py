@@ -472,6 +472,25 @@ def bneck_conv123_bf16(x, w1, b1, w2, b2, w3, b3, out=None):
     return out
 
 
+@_guard_first
+def bneck_band_bf16(x, w1, b1, w2, b2, w3, b3, out=None):
+    """The whole stride-1 Bottleneck of the 28 x 28 stage in one launch (``ec_bneck_band_bf16``): x bf16 [B,28,28,512], w1 bf16
+    [128,512], w2 bf16 [128,1152], w3 bf16 [512,128] -> bf16 [B,28,28,512]."""
+    lib = _lib.load()
+    B, H, W, C4 = x.shape
+    packed = _packed_lookup("band", (w1, w2, w3))
+    if packed is None:
+        packed = torch.empty(lib.ec_bneck_band_packed_elems(), dtype=torch.bfloat16, device=x.device)
+        _lib.check(lib.ec_bneck_band_pack_weights(w1.data_ptr(), w2.data_ptr(), w3.data_ptr(), packed.data_ptr(), _lib.stream_ptr()),
+                   "ec_bneck_band_pack_weights")
+        _packed_store("band", (w1, w2, w3), packed)
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.check(lib.ec_bneck_band_bf16(x.data_ptr(), packed.data_ptr(), b1.data_ptr(), b2.data_ptr(), b3.data_ptr(), out.data_ptr(),
+                                      B, H, W, C4 // 4, _lib.stream_ptr()), "ec_bneck_band_bf16")
+    return out
+
+
 _BNECK_PACKED = {}
 
 

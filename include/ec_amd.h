@@ -171,6 +171,16 @@ int ec_bneck3_pack_weights(const void* w1, const void* w2, const void* w3, void*
 int ec_bneck_conv123_bf16(const void* x, const void* packed, const float* b1, const float* b2, const float* b3,
                           void* y, int B, int H, int W, int C, ec_stream_t stream);
 
+/* The whole stride-1 Bottleneck of the 28 x 28 stage (planes C = 128, 512 channels in / out: CLIP-RN50 layer2.1 .. layer2.3) in
+ * one launch, one workgroup per band of 7 output rows; conv1's output for the band + a halo row on each side lives in LDS
+ * (the halo rows' conv1 is recomputed), c1 / c2 never exist in HBM.  packed = ec_bneck_band_pack_weights(w1 bf16 [128][512],
+ * w2 bf16 [128][3*3*128], w3 bf16 [512][128]) (ec_bneck_band_packed_elems() elements).  x / y bf16 [B,28,28,512].  Bit-identical
+ * to the three ec_conv_bf16 calls.  EC_ERR_SHAPE for any other geometry. */
+size_t ec_bneck_band_packed_elems(void);
+int ec_bneck_band_pack_weights(const void* w1, const void* w2, const void* w3, void* packed, ec_stream_t stream);
+int ec_bneck_band_bf16(const void* x, const void* packed, const float* b1, const float* b2, const float* b3,
+                       void* y, int B, int H, int W, int C, ec_stream_t stream);
+
 /* relu(bn2(conv2(x))) of a late Bottleneck for SMALL launches (<= 64 frames: the per-GPU batches of strong scaling,
  * readme_files/baselines_habitat.md:63-73): one workgroup per (image, 32/64-channel slice), the image's map resident in
  * LDS, the eight waves split K and their partial tiles are folded through LDS in a fixed order (deterministic; equal to

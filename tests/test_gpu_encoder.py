@@ -563,6 +563,36 @@ def test_whole_bottleneck_launch_is_bit_identical_to_the_three_conv_launches(dev
         assert _rel(got.cpu(), y) < 6e-3, (B, _rel(got.cpu(), y))
 
 
+def test_band_fused_layer2_bottleneck_is_bit_identical_to_the_three_conv_launches(dev):
+    """bneck_band_kernel (round 4, measured prototype -- not in the trunk's plan: DESIGN.md section 4.7): the whole stride-1
+    Bottleneck of the 28 x 28 stage ([U] clip/model.py Bottleneck.forward, layer2.1 .. layer2.3) in one launch, a workgroup per
+    band of 7 rows with conv1's output for the band + halo rows in LDS.  Bit-identical to the three conv launches (image borders,
+    band borders, odd frame counts), and against a torch fp32 reference with c1 / c2 rounded to bf16 where the kernels round."""
+    from embodied_clip_amd import encoder as enc
+    C, H = 128, 28
+    for B in (1, 3, 33):
+        g = torch.Generator().manual_seed(400 + B)
+        x = _bf(torch.randn(B, H, H, 4 * C, generator=g).relu())
+        w1 = _bf(torch.randn(C, 4 * C, generator=g) * (4 * C) ** -0.5)
+        w2 = _bf(torch.randn(C, 3, 3, C, generator=g) * (9 * C) ** -0.5)
+        w3 = _bf(torch.randn(4 * C, C, generator=g) * C ** -0.5)
+        b1, b2, b3 = (torch.randn(n, generator=g) * 0.1 for n in (C, C, 4 * C))
+        d = lambda t: t.to(dev)
+        got = enc.bneck_band_bf16(d(x), d(w1), d(b1), d(w2.reshape(C, -1)), d(b2), d(w3), d(b3))
+        c1u = enc.conv_bf16(d(x), d(w1), d(b1), None, ksize=1, act=1)
+        c2u = enc.conv_bf16(c1u, d(w2.reshape(C, -1)), d(b2), None, ksize=3, act=1)
+        yu = enc.conv_bf16(c2u, d(w3), d(b3), d(x), ksize=1, act=1)
+        torch.cuda.synchronize()
+        assert torch.equal(got, yu), B
+        xf = x.float().permute(0, 3, 1, 2)
+        c1 = F.relu(F.conv2d(xf, w1.float()[:, :, None, None], b1)).to(torch.bfloat16).float()
+        c2 = F.relu(F.conv2d(c1, w2.float().permute(0, 3, 1, 2), b2, padding=1)).to(torch.bfloat16).float()
+        y = F.relu(F.conv2d(c2, w3.float()[:, :, None, None], b3) + xf).permute(0, 2, 3, 1)
+        assert _rel(got.cpu(), y) < 6e-3, (B, _rel(got.cpu(), y))
+    with pytest.raises(Exception):      # any other geometry is refused (EC_ERR_SHAPE), never a silent fallback
+        enc.bneck_band_bf16(torch.zeros(1, 14, 14, 512, dtype=torch.bfloat16, device=dev), d(w1), d(b1), d(w2.reshape(C, -1)), d(b2), d(w3), d(b3))
+
+
 def test_fused_bottleneck_launch_matches_reference_and_the_two_conv_launches(dev):
     """conv_bneck.hip (round 4): conv2 (3x3) + bn2 + ReLU and conv3 (1x1) + bn3 + identity + ReLU of a stride-1
     Bottleneck ([U] clip/model.py Bottleneck.forward) in one launch, one workgroup per image, the 14 x 14 x 256 map

@@ -80,7 +80,7 @@ for name, fn in (("unfused (3x3 + 1x1+res)", unfused), ("fused bneck23", fused),
 if a.stamps:
     from embodied_clip_amd import _lib
     lib = _lib.load()
-    buf = torch.zeros(16, dtype=torch.int64, device=dev)
+    buf = torch.zeros(64, dtype=torch.int64, device=dev)
     lib.ec_bneck_set_debug(buf.data_ptr())
     for _ in range(3):
         for s in sets: fused(s)
@@ -92,3 +92,7 @@ if a.stamps:
         dc, dr = t[2 * i] - t[2 * i - 2], t[2 * i + 1] - t[2 * i - 1]
         print(f"  {names[i]:12s} +{dc:8d} clk  +{dr / 100.0:7.2f} us  ({dc / max(dr, 1) * 100:.0f} MHz)")
     print(f"  total {t[14] - t[0]} clk, {(t[15] - t[1]) / 100.0:.2f} us")
+    t0 = t[6]   # (c2 in T: the shader clock at conv3's start)
+    for w in (0, 1):
+        row = t[16 + 16 * w: 32 + 16 * w]
+        print(f"  wave {4 * w}: " + "  ".join(f"pass {q}: start {row[4 * q] - t0:6d} K-loop end {row[4 * q + 1] - t0:6d} end {row[4 * q + 2] - t0:6d}" for q in range(4)))
