@@ -61,6 +61,8 @@ EcConfig read_config() {
     c.rn50_img3 = env_int("EC_RN50_IMG3", 1);
     c.bneck_stagger = env_int("EC_BNECK_STAGGER", 0);
     c.rn50_bneck3 = env_int("EC_RN50_BNECK3", 1);
+    c.rn50_band = env_int("EC_RN50_BAND", 0);
+    c.rn50_band_max = env_int("EC_RN50_BAND_MAX", 1 << 30);
     c.conv_splitk = env_int("EC_CONV_SPLITK", 0);
     c.conv_splitk_tiles = env_int("EC_CONV_SPLITK_TILES", 200);
     c.conv_splitk_target = env_int("EC_CONV_SPLITK_TARGET", 400);
@@ -86,6 +88,6 @@ uint64_t ec_config_hash() {
     mix(c.conv_waves); mix(c.conv_big); mix(c.conv8_min_tiles); mix(c.conv8_bn128); mix(c.conv_t224); mix(c.conv_t64);
     mix(c.conv_ring); mix(c.conv_regw); mix(c.conv_regw_wide); mix(c.gemm_no_x3); mix(c.act_split); mix(c.tail_fused);
     mix(c.gru_fused); mix(c.c1_pingpong); mix(c.dw1_tr); mix(c.rn50_fuse); mix(c.wih_perm); mix(c.dw_transposed); mix(c.conv8_dirb); mix(c.conv8_longseg); mix(c.conv8_lowfill); mix(c.conv8_lowfill_k); mix(c.conv8_res128);
-    mix(c.conv_ring_ilv); mix(c.conv_ring_w8); mix(c.rn50_side); mix(c.rn50_bneck); mix(c.rn50_img3); mix(c.bneck_stagger); mix(c.rn50_bneck3); mix(c.conv_splitk); mix(c.conv_splitk_tiles); mix(c.conv_splitk_target); mix(c.conv_splitk_ns); mix(c.conv_splitk_tile);
+    mix(c.conv_ring_ilv); mix(c.conv_ring_w8); mix(c.rn50_side); mix(c.rn50_bneck); mix(c.rn50_img3); mix(c.bneck_stagger); mix(c.rn50_bneck3); mix(c.rn50_band); mix(c.rn50_band_max); mix(c.conv_splitk); mix(c.conv_splitk_tiles); mix(c.conv_splitk_target); mix(c.conv_splitk_ns); mix(c.conv_splitk_tile);
     return x;
 }

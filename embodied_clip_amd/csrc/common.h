@@ -165,6 +165,8 @@ struct EcConfig {
     int conv_ring_w8;     // EC_CONV_RING_W8  (0)   128x128 ring launches on 8 waves (2 x 4) instead of 4
     int rn50_side;        // EC_RN50_SIDE     (0)   launches of at most this many frames run the stride-2 blocks' downsample branch on a side stream (0: never; measured: slower)
     int rn50_bneck;       // EC_RN50_BNECK    (128) launches of at least this many frames run layer3.1-5's conv2 + conv3 as ONE fused launch (conv_bneck.hip); 0: never
+    int rn50_band;        // EC_RN50_BAND     (0)   fewest frames per launch for which layer2.1-3 run as band-fused launches (0: never)
+    int rn50_band_max;    // EC_RN50_BAND_MAX (1 << 30) ... and the most
     int rn50_bneck3;      // EC_RN50_BNECK3   (1)   the fused bottleneck launches include conv1 (the whole block in one launch)
     int bneck_stagger;    // EC_BNECK_STAGGER (0)   units of 512 clocks by which waves 4-7 of the fused bottleneck launch enter conv3 late
     int rn50_img3;        // EC_RN50_IMG3     (1)   small launches run the 14x14x256 (<= 32 frames) / 7x7x512 (<= 64 frames) 3x3 convs on the image-resident K-split kernel

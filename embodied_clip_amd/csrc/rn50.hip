@@ -39,6 +39,12 @@ struct Op {
     // branch's ops, `join` on the op that consumes its result (conv3)
     int fork = 0, side = 0, join = 0;
     long wc1_off = -1, bc1_off = -1;   // OP_BNECK with conv1 folded in (whole block in one launch): conv1's weight / bias offsets; its input is `res`
+    // EC_RN50_BAND: stride-1 blocks of the 28x28 stage (planes 128) as ONE band-fused launch (conv_bneck.hip bneck_band_kernel) for
+    // launches inside the configured frame window.  The plan itself is unchanged; rn50_run skips the ops marked band_skip (the
+    // block's conv1 / conv2), runs the op marked `band` (the block's closing conv3 / boundary launch) as the fused launch with
+    // x = res, y = dst, and runs a boundary launch marked band_half as its first half only (conv3 + identity + ReLU).
+    int band = 0, band_skip = 0, band_half = 0;
+    long band_w1 = -1, band_b1 = -1, band_w2 = -1, band_b2 = -1, wband_off = -1;
     long wimg_off = -1;      // offset (elements, into wbneck) of this 3x3 conv's streaming-order weights for the small-launch kernel
 };
 
@@ -123,6 +129,9 @@ extern "C" int ec_rn50_create(ec_rn50_t** out, int width, const int* layers4, in
             const int y = (x == 0) ? 4 : 0;
             const int Ro = R / stride;
             int c1 = 1;
+            const bool band_blk = ec_config().rn50_band > 0 && width == 64 && !ds && stride == 1 && planes == 128 && R == 28 && inplanes == 512;
+            const long band_w1 = (long)wo, band_b1 = (long)bo;   // this block's conv1 slot
+            int band_c1_op = -1;
             if (conv1_done) {   // weights are still laid out conv1, conv2, conv3, downsample: skip the slot
                 wo += (size_t)planes * inplanes;
                 bo += planes;
@@ -130,8 +139,18 @@ extern "C" int ec_rn50_create(ec_rn50_t** out, int width, const int* layers4, in
                 c1 = c1_buf;
             } else {
                 conv(x, 1, -1, R, R, inplanes, planes, 1, 0, EC_ACT_RELU);
+                band_c1_op = (int)h->ops.size() - 1;
             }
             conv(c1, 2, -1, R, R, planes, planes, 3, stride > 1 ? 1 : 0, EC_ACT_RELU);
+            const int band_c2_op = (int)h->ops.size() - 1;
+            const long band_w2 = (long)h->ops.back().w_off, band_b2 = (long)h->ops.back().b_off;
+            auto mark_band = [&](Op& closing) {   // (called on the block's closing op before it is pushed)
+                if (!band_blk) return;
+                closing.band = 1;
+                closing.band_w1 = band_w1; closing.band_b1 = band_b1; closing.band_w2 = band_w2; closing.band_b2 = band_b2;
+                h->ops[band_c2_op].band_skip = 1;
+                if (band_c1_op >= 0) h->ops[band_c1_op].band_skip = 1;
+            };
             int idt = x;
             // weights are laid out conv1, conv2, conv3, downsample; the downsample conv
             // has to run BEFORE conv3 (conv3 consumes its output as the residual), so
@@ -198,6 +217,9 @@ extern "C" int ec_rn50_create(ec_rn50_t** out, int width, const int* layers4, in
                 o.dst2 = (idt == 1) ? 3 : 1;      // block 0 with a pooled input keeps its identity in buffer 1
                 o.N2 = planes;
                 o.w2_off = wo; o.b2_off = bo;     // == the next block's conv1 slot
+                mark_band(o);
+                // the next block is band-fused too when the window applies: this launch's second half (its conv1) is then not needed
+                o.band_half = (ec_config().rn50_band > 0 && width == 64) ? 1 : 0;
                 h->ops.push_back(o);
                 track(Ro, Ro, planes * 4);
                 conv1_done = true;
@@ -225,6 +247,7 @@ extern "C" int ec_rn50_create(ec_rn50_t** out, int width, const int* layers4, in
             } else {
                 Op o{OP_CONV, 2, y, idt, Ro, Ro, planes, planes * 4, 1, 0, EC_ACT_RELU, w_c3, b_c3};
                 o.join = side_grp;
+                mark_band(o);
                 h->ops.push_back(o);
                 track(Ro, Ro, planes * 4);
             }
@@ -242,6 +265,7 @@ extern "C" int ec_rn50_create(ec_rn50_t** out, int width, const int* layers4, in
         size_t tot = 0;
         for (Op& o : h->ops) {
             if (o.kind == OP_BNECK) { o.w2_off = tot; o.wimg_off = (long)tot; tot += ec_bneck3_packed_elems(o.Cin); }   // (packed conv2 comes first; room for conv1 too)
+            if (o.band) { o.wband_off = (long)tot; tot += ec_bneck_band_packed_elems(); }
             // the un-pooled 3x3 convs of the 7x7 stage: streaming-order weights for the small-launch kernel (conv3x3_img_kernel)
             if (o.kind == OP_CONV && o.ks == 3 && o.Cin == 512 && o.Cout == 512 && ec_config().rn50_img3 &&
                 ((!o.pool && o.H == 7 && o.W == 7) || (o.pool && o.H == 14 && o.W == 14))) {   // (layer4.0's conv2 + AvgPool2d: the chunked variant)
@@ -257,6 +281,8 @@ extern "C" int ec_rn50_create(ec_rn50_t** out, int width, const int* layers4, in
                     rc = o.wc1_off >= 0 ? ec_bneck3_pack_weights(h->w + o.wc1_off, h->w + o.w_off, h->w + o.w1_off, h->wbneck + o.w2_off, o.Cin, nullptr)
                                         : ec_bneck_pack_weights(h->w + o.w_off, h->w + o.w1_off, h->wbneck + o.w2_off, o.Cin, nullptr);
                 else if (o.wimg_off >= 0) rc = ec_conv3x3_img_pack(h->w + o.w_off, h->wbneck + o.wimg_off, o.Cin, nullptr);
+                if (rc == EC_OK && o.band)
+                    rc = ec_bneck_band_pack_weights(h->w + o.band_w1, h->w + o.band_w2, h->w + o.w_off, h->wbneck + o.wband_off, nullptr);
                 if (rc != EC_OK) { delete h; return EC_ERR_LAUNCH; }
             }
             (void)hipStreamSynchronize(nullptr);
@@ -297,7 +323,7 @@ extern "C" uint64_t ec_rn50_plan_hash(const ec_rn50_t* h) {
     mix(h->width); mix(h->res); mix(h->conv8_min_tiles);
     for (const Op& o : h->ops) {
         mix(o.kind); mix(o.src); mix(o.dst); mix(o.res); mix(o.H); mix(o.W); mix(o.Cin); mix(o.Cout); mix(o.ks);
-        mix(o.pool); mix(o.act); mix(o.src1); mix(o.dst2); mix(o.N2); mix(o.dst3); mix(o.side); mix(o.wc1_off >= 0);
+        mix(o.pool); mix(o.act); mix(o.src1); mix(o.dst2); mix(o.N2); mix(o.dst3); mix(o.side); mix(o.wc1_off >= 0); mix(o.band + 2 * o.band_skip + 4 * o.band_half);
     }
     return x;
 }
@@ -373,9 +399,24 @@ int rn50_run(const ec_rn50_t* h, const void* rgb, bool u8, const float* mean3, c
         // 32 frames, neutral at 64, and 36.7 -> 26.4 k env-frames/s with two 32-frame slices in flight (four streams
         // contending: the event hand-offs serialise the slices) -- kept as an experiment switch only.
         const bool side_on = h->side_stream && nb <= ec_config().rn50_side;
+        // EC_RN50_BAND / EC_RN50_BAND_MAX: the frame window in which layer2.1-3 run as band-fused launches
+        const bool band_on = ec_config().rn50_band > 0 && nb >= ec_config().rn50_band && nb <= ec_config().rn50_band_max;
         for (const Op& o : h->ops) {
             int rc;
             hipStream_t stream = (hipStream_t)stream_main;
+            if (band_on && o.band_skip) continue;
+            if (band_on && o.band) {
+                rc = ec_bneck_band_bf16(buf(o.res), h->wbneck + o.wband_off, h->bias + o.band_b1, h->bias + o.band_b2, h->bias + o.b_off,
+                                        buf(o.dst), nb, o.H, o.W, o.Cin, stream);
+                if (rc != EC_OK) return rc;
+                continue;
+            }
+            if (band_on && o.band_half && o.kind == OP_PAIR) {   // the boundary launch in front of a band-fused block: conv3 + identity + ReLU only
+                rc = ec_conv_bf16(buf(o.src), h->w + o.w_off, h->bias + o.b_off, o.res >= 0 ? buf(o.res) : nullptr, buf(o.dst), nb, o.H,
+                                  o.W, o.Cin, o.Cout, 1, 0, EC_ACT_RELU, stream);
+                if (rc != EC_OK) return rc;
+                continue;
+            }
             if (side_on) {
                 if (o.fork) { if (hipEventRecord(h->ev_fork[o.fork - 1], (hipStream_t)stream_main) != hipSuccess) return EC_ERR_LAUNCH; }
                 if (o.join) { if (hipStreamWaitEvent((hipStream_t)stream_main, h->ev_join[o.join - 1], 0) != hipSuccess) return EC_ERR_LAUNCH; }

@@ -654,6 +654,36 @@ def test_trunk_with_fused_bottlenecks_is_bit_identical_to_the_unfused_plan(dev, 
     assert _rel(got["small"], small) <= 1e-2, _rel(got["small"], small)
 
 
+def test_trunk_with_band_fused_layer2_blocks_is_bit_identical(dev, tmp_path):
+    """EC_RN50_BAND (default 0: measured neutral-to-slower end to end): launches inside the frame window run
+    layer2.1 .. layer2.3 as band-fused launches (bneck_band_kernel) and the boundary launch in front as its conv3 half only.
+    Same features, bit for bit, as the default plan, for a launch inside the window (130 frames) and one below it (5)."""
+    import os
+    import subprocess
+    import sys
+    from embodied_clip_amd.encoder import RN50Trunk
+    x = syn.synthetic_rgb(22, 8).repeat(17, 1, 1, 1).roll(1, dims=2)[:130].contiguous().to(dev)
+    base = RN50Trunk(syn.rn50_visual_state_dict(0), device=dev)
+    ref = base.forward(x).float().cpu()
+    small = base.forward(x[:5].contiguous()).float().cpu()
+    out = str(tmp_path / "band.pt")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, torch; sys.path.insert(0, %r)\n"
+            "from embodied_clip_amd import synthetic as syn\n"
+            "from embodied_clip_amd.encoder import RN50Trunk\n"
+            "t = RN50Trunk(syn.rn50_visual_state_dict(0), device='cuda:0')\n"
+            "x = syn.synthetic_rgb(22, 8).repeat(17, 1, 1, 1).roll(1, dims=2)[:130].contiguous().to('cuda:0')\n"
+            "torch.save({'feat': t.forward(x).float().cpu(), 'small': t.forward(x[:5].contiguous()).float().cpu(),\n"
+            "            'hash': t.plan_hash(), 'ops': t.lib.ec_rn50_num_ops(t.h)}, %r)\n") % (root, out)
+    r = subprocess.run([sys.executable, "-c", code], env={**os.environ, "EC_RN50_BAND": "64"}, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = torch.load(out)
+    assert got["hash"] != base.plan_hash() and got["ops"] == base.lib.ec_rn50_num_ops(base.h)   # (same ops; the executor skips / fuses)
+    assert torch.equal(got["feat"], ref)
+    assert torch.equal(got["small"], small)
+
+
 @pytest.mark.parametrize("H,C", [(14, 256), (7, 512)])
 def test_small_launch_image_resident_3x3_kernel(dev, H, C):
     """conv3x3_img_kernel (round 4): the late 3x3 convs of SMALL launches (32-64 frames per GPU: strong scaling's operating

@@ -7,7 +7,7 @@ for f in ("bench_line.json", "bench_vit_line.json", "bench_zeroshot_line.json", 
           "bench_64actors_line.json", "bench_32actors_line.json", "bench_kernel_stats.csv", "fetch_calibration.json",
           "strong_scaling_projection.json", "trunk_b128_per_kernel.txt", "trunk_b256_per_kernel.txt",
           "update_kernel_stats.txt", "update_pmc_by_kernel.txt", "update_ms.txt", "vit_b128_per_kernel.txt",
-          "trunk_b32_per_kernel.txt", "bneck_stamps.txt", "img3x3_vs_conv_igemm.txt", "act_step_us.txt", "env_step_32actors.txt"):
+          "trunk_b32_per_kernel.txt", "bneck_stamps.txt", "img3x3_vs_conv_igemm.txt", "band_prototype.txt", "act_step_us.txt", "env_step_32actors.txt"):
     if os.path.exists(f"{O}/{f}"):
         shutil.copy(f"{O}/{f}", f"profiles/{R}_{f}")
     else:
