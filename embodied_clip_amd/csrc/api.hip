@@ -41,6 +41,7 @@ EcConfig read_config() {
     c.conv_regw = env_int("EC_CONV_REGW", 1);
     c.conv_regw_wide = env_int("EC_CONV_REGW_WIDE", 0);
     c.gemm_no_x3 = env_int("EC_GEMM_NO_X3", 0);
+    c.gemm_bwd3 = env_int("EC_GEMM_BWD3", 0);
     c.act_split = env_int("EC_ACT_SPLIT", 1);
     c.tail_fused = env_int("EC_TAIL_FUSED", 1);
     c.gru_fused = env_int("EC_GRU_FUSED", 2);
@@ -88,6 +89,6 @@ uint64_t ec_config_hash() {
     mix(c.conv_waves); mix(c.conv_big); mix(c.conv8_min_tiles); mix(c.conv8_bn128); mix(c.conv_t224); mix(c.conv_t64);
     mix(c.conv_ring); mix(c.conv_regw); mix(c.conv_regw_wide); mix(c.gemm_no_x3); mix(c.act_split); mix(c.tail_fused);
     mix(c.gru_fused); mix(c.c1_pingpong); mix(c.dw1_tr); mix(c.rn50_fuse); mix(c.wih_perm); mix(c.dw_transposed); mix(c.conv8_dirb); mix(c.conv8_longseg); mix(c.conv8_lowfill); mix(c.conv8_lowfill_k); mix(c.conv8_res128);
-    mix(c.conv_ring_ilv); mix(c.conv_ring_w8); mix(c.rn50_side); mix(c.rn50_bneck); mix(c.rn50_img3); mix(c.bneck_stagger); mix(c.rn50_bneck3); mix(c.rn50_band); mix(c.rn50_band_max); mix(c.conv_splitk); mix(c.conv_splitk_tiles); mix(c.conv_splitk_target); mix(c.conv_splitk_ns); mix(c.conv_splitk_tile);
+    mix(c.conv_ring_ilv); mix(c.conv_ring_w8); mix(c.rn50_side); mix(c.rn50_bneck); mix(c.rn50_img3); mix(c.bneck_stagger); if (c.gemm_bwd3) mix(1000 + c.gemm_bwd3); mix(c.rn50_bneck3); mix(c.rn50_band); mix(c.rn50_band_max); mix(c.conv_splitk); mix(c.conv_splitk_tiles); mix(c.conv_splitk_target); mix(c.conv_splitk_ns); mix(c.conv_splitk_tile);
     return x;
 }

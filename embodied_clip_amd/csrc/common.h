@@ -148,6 +148,7 @@ struct EcConfig {
     int conv_regw;        // EC_CONV_REGW     (1)   register-weight 1x1 kernel
     int conv_regw_wide;   // EC_CONV_REGW_WIDE(0)   ... also for the wide (channel-group) shapes
     int gemm_no_x3;       // EC_GEMM_NO_X3    (0)   policy GEMMs on the fp32 MFMA instead of bf16x3
+    int gemm_bwd3;        // EC_GEMM_BWD3     (0)   ec_policy_backward's large gradient GEMMs on three of the six bf16x3 products
     int act_split;        // EC_ACT_SPLIT     (1)   act step: fixed 4-way K split of the two long-K GEMMs
     int tail_fused;       // EC_TAIL_FUSED    (1)   compressor tail / combiner fused kernels
     int gru_fused;        // EC_GRU_FUSED     (2)   0 GEMM + gate kernels, 1 fused 32x32-tile step kernels, 2 + 16x16-tile kernels in the update

@@ -41,6 +41,7 @@ struct GemmArgs {
     int relu, accumulate, splitk;
     int ntn;
     long part_stride;           // > 0: split-K slice z writes its partial sums to C + z * part_stride (no atomics)
+    int maxsum;                 // bf16x3 path: plane pairs (pa, pb) with pa + pb <= maxsum are multiplied (2: all six; 1: EC_GEMM_3PRODUCTS)
 };
 
 // element (r, k) of an operand lives at src[r*sr + k*sk]; tile rows r0.., k0..
@@ -434,6 +435,7 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(GemmArgs p) {
                 for (int pa = 0; pa < PA; ++pa) {
                     const int pb = sum - pa;
                     if (pb < 0 || pb >= PB) continue;
+                    if (sum > p.maxsum) continue;                    // (wave-uniform)
 #pragma unroll
                     for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -558,6 +560,7 @@ extern "C" int ec_gemm_f32(const void* A, const void* B, float* Cp, int M, int N
     a.b_bf16 = (flags & EC_GEMM_B_BF16) ? 1 : 0;
     a.relu = (flags & EC_GEMM_RELU) ? 1 : 0;
     a.accumulate = (flags & EC_GEMM_ACCUMULATE) ? 1 : 0;
+    a.maxsum = (flags & EC_GEMM_3PRODUCTS) ? 1 : 2;
     const bool parts = (flags & EC_GEMM_SPLIT_PARTS) != 0;
     a.bias = bias; a.gbias = gbias; a.gidx = gidx; a.group = group;
     a.dmask = dmask; a.rowscale = rowscale;

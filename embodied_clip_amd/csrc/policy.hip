@@ -1852,12 +1852,16 @@ extern "C" int ec_policy_backward2(const ec_policy_t* h, const float* params, co
         RC(ec_gemm_f32(ws + w.dghb + o3, W(P_WHH), ws + w.dhc, N, H, 3 * H, 3 * H, 1, H, 1, H, EC_GEMM_ACCUMULATE, nullptr,
                        nullptr, nullptr, 0, nullptr, masks + (size_t)t * N, step_splitk(N, H, 3 * H), stream));
     }
+    // EC_GEMM_BWD3: the large gradient GEMMs (weight gradients over all T*N rows, dx = dgi @ W_ih) on the three leading bf16
+    // products of the bf16x3 split (relative product error 2^-16; the parameters' gradients then agree with the fp32 oracle to
+    // ~1e-5 instead of ~1e-6)
+    const int bwd3 = ec_config().gemm_bwd3 ? EC_GEMM_3PRODUCTS : 0;
     // weight grads of the recurrence / input projection (TN over all T*N rows)
     auto tn = [&](const float* dY, int ldy, const void* X, int ldx, int x_bf16, float* dW, int Mo, int No, long K,
                   int ldc) {
         const int sk = pick_splitk(Mo, No, K);   // grads += ... (atomics when split, += otherwise)
         return ec_gemm_f32(dY, X, dW, Mo, No, (int)K, 1, ldy, ldx, 1, ldc,
-                           EC_GEMM_ACCUMULATE | (x_bf16 ? EC_GEMM_B_BF16 : 0), nullptr, nullptr, nullptr, 0, nullptr,
+                           EC_GEMM_ACCUMULATE | (x_bf16 ? EC_GEMM_B_BF16 : 0) | bwd3, nullptr, nullptr, nullptr, 0, nullptr,
                            nullptr, sk, stream);
     };
     // EC_DW_TRANSPOSED (default 1): the GRU's two weight-gradient GEMMs contract over the T*N rows, i.e. BOTH operands are
@@ -1869,7 +1873,7 @@ extern "C" int ec_policy_backward2(const ec_policy_t* h, const float* params, co
                            ws + w.tA, (int)K, Mo);
         hipLaunchKernelGGL(transpose_f32_kernel, dim3((unsigned)((No + 31) / 32), (unsigned)((K + 31) / 32)), dim3(256), 0, s, X,
                            ws + w.tB, (int)K, No);
-        return ec_gemm_f32(ws + w.tA, ws + w.tB, dW, Mo, No, (int)K, K, 1, 1, K, ldc, EC_GEMM_ACCUMULATE, nullptr, nullptr, nullptr,
+        return ec_gemm_f32(ws + w.tA, ws + w.tB, dW, Mo, No, (int)K, K, 1, 1, K, ldc, EC_GEMM_ACCUMULATE | bwd3, nullptr, nullptr, nullptr,
                            0, nullptr, nullptr, pick_splitk(Mo, No, K), stream);
     };
     if (dw_t) RC(tn_t(ws + w.dghb, ws + w.hp, G(P_WHH), 3 * H, H, B, H));
@@ -1899,11 +1903,11 @@ extern "C" int ec_policy_backward2(const ec_policy_t* h, const float* params, co
                     // strided-B staging runs at half the rate (263 vs ~130 us at 32 actors, 770 vs ~540 at 128)
         hipLaunchKernelGGL(transpose_f32_kernel, dim3((unsigned)((flat + 31) / 32), (unsigned)(3 * H / 32)), dim3(256), 0, s,
                            ws + w.wihP, ws + w.gwihP, 3 * H, flat);
-        RC(ec_gemm_f32(ws + w.dgi, ws + w.gwihP, ws + w.dx4, B, flat, 3 * H, 3 * H, 1, 1, 3 * H, flat, 0, nullptr, nullptr,
+        RC(ec_gemm_f32(ws + w.dgi, ws + w.gwihP, ws + w.dx4, B, flat, 3 * H, 3 * H, 1, 1, 3 * H, flat, bwd3, nullptr, nullptr,
                        nullptr, 0, nullptr, nullptr, 1, stream));
     }
     else
-        RC(ec_gemm_f32(ws + w.dgi, W(P_WIH), ws + w.dx, B, flat, 3 * H, 3 * H, 1, flat, 1, flat, 0, nullptr, nullptr, nullptr,
+        RC(ec_gemm_f32(ws + w.dgi, W(P_WIH), ws + w.dx, B, flat, 3 * H, 3 * H, 1, flat, 1, flat, bwd3, nullptr, nullptr, nullptr,
                        0, nullptr, nullptr, 1, stream));
     for (int sidx = 0; sidx < nstream; ++sidx) {   // dual encoder: the depth stream re-uses the gradient temporaries (one HIP stream)
     const void* featS = sidx ? feat2 : feat;

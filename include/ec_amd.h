@@ -264,8 +264,11 @@ enum {
     EC_GEMM_B_BF16 = 2,
     EC_GEMM_RELU = 4,
     EC_GEMM_ACCUMULATE = 8,  /* C += ... */
-    EC_GEMM_SPLIT_PARTS = 16 /* splitk > 1: slice z writes its partial sums to C + z * M * ldc (no atomics; the caller folds
+    EC_GEMM_SPLIT_PARTS = 16,/* splitk > 1: slice z writes its partial sums to C + z * M * ldc (no atomics; the caller folds
                               * the parts in a fixed order); bias goes into part 0; no ReLU / mask / row scale */
+    EC_GEMM_3PRODUCTS = 32   /* bf16x3 path: only the three leading bf16 products a0 b0 + a0 b1 + a1 b0 of an fp32 x fp32 product
+                              * (relative error 2^-16 per product instead of 2^-24; half the MFMAs).  Meant for GRADIENT GEMMs
+                              * (ec_policy_backward with EC_GEMM_BWD3=1); ignored on the exact-fp32 MFMA path */
 };
 int ec_gemm_f32(const void* A, const void* B, float* C, int M, int N, int K, long sam, long sak, long sbk, long sbn,
                 int ldc, int flags, const float* bias, const float* gbias, const int* gidx, int group,

@@ -46,6 +46,26 @@ def test_gemm_f32_nt(dev, M, N, K):
     assert _rel(c, ref) < 2e-5, _rel(c, ref)
 
 
+def test_gemm_three_leading_products_option(dev):
+    """EC_GEMM_3PRODUCTS (what EC_GEMM_BWD3=1 passes for ec_policy_backward's large gradient GEMMs; default off): only
+    a0 b0 + a0 b1 + a1 b0 of the bf16x3 split.  Against an fp64 product: the six-product result is fp32-exact (~1e-7), the
+    three-product one carries the dropped 2^-16 terms (~1e-5 .. 1e-6 after a K = 1536 dot product) -- inside the 2e-4 the
+    gradient parity tests allow, and visibly different from the exact path (so the flag is really taken)."""
+    M, N, K = 512, 1568, 1536
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(M, K, generator=g); w = torch.randn(N, K, generator=g) * K ** -0.5
+    ref = a.double() @ w.double().t()
+    ad, wd = a.to(dev), w.to(dev)
+    c6, c3 = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev)
+    _gemm(dev, ad, wd, c6, M, N, K, K, 1, 1, K, N)
+    _gemm(dev, ad, wd, c3, M, N, K, K, 1, 1, K, N, flags=32)
+    e6 = ((c6.cpu().double() - ref).norm() / ref.norm()).item()
+    e3 = ((c3.cpu().double() - ref).norm() / ref.norm()).item()
+    assert e6 < 1e-6, e6
+    assert 1e-7 < e3 < 3e-5, e3
+    assert not torch.equal(c3, c6)
+
+
 @pytest.mark.parametrize("M,N,K,bf16a", [(6272, 128, 2048, True), (128, 1536, 1568, False), (70, 96, 160, False)])
 def test_gemm_split_parts_sum_to_the_full_product(dev, M, N, K, bf16a):
     """EC_GEMM_SPLIT_PARTS (flag 16): K slices write separate partial matrices (bias in part 0, no atomics); their sum in
