@@ -214,31 +214,41 @@ __global__ __launch_bounds__(512, 2) void bneck23_kernel(BneckArgs p) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w1, (lds_void_t*)(ring + stg * STAGE + j * 1024), 16, wo, 0, 0, 0);
             }
         };
+        // Schedule per K-tile kt (stage kt % 3): the fragments of its first k-step were read right after the barrier that published
+        // it; read the second k-step's, run the first k-step's MFMAs under those reads, wait for the own pieces of K-tile kt + 1,
+        // barrier (K-tile kt + 1 landed everywhere, nobody reads K-tile kt any more), issue K-tile kt + 3 into K-tile kt's stage,
+        // read the first k-step of K-tile kt + 1 and run the second k-step's MFMAs under those reads.  Every LDS read of the eight
+        // waves (128 KB per K-tile) runs under MFMAs; the barrier sits between the two halves instead of in front of both.
+        auto rd_x = [&]<int KS>(std::integral_constant<int, KS>, int stg) {
+            const unsigned xa = t_lds + stg * XSTAGE + boff[KS];                  // (row swizzle depends on frow only)
+            [&]<int... I>(std::integer_sequence<int, I...>) { (lds_read16<I * 2048>(fa[KS][I], xa), ...); }(std::make_integer_sequence<int, MB>{});
+            lds_read16<0>(fb[KS], ring_lds + stg * STAGE + boff[KS]);
+        };
         issue1(0, 0);
         issue1(1, 1);
+        issue1(2, 2);
         zero_acc();
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");         // this wave's four pieces of K-tile 0
+        __builtin_amdgcn_s_barrier();
+        rd_x(std::integral_constant<int, 0>{}, 0);
         int s1 = 0;
         for (int kt = 0; kt < NK1; ++kt) {
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // this wave's four pieces of K-tile kt (kt + 1's may be in flight)
-            __builtin_amdgcn_s_barrier();                        // everyone's landed; everyone is done reading K-tile kt - 1
-            int s2 = s1 + 2; s2 = s2 >= NS ? s2 - NS : s2;
-            issue1(kt + 2, s2);                                  // into the stages K-tile kt - 1 has left
-            const unsigned xa0 = t_lds + s1 * XSTAGE + boff[0], xa1 = t_lds + s1 * XSTAGE + boff[1];   // (row swizzle depends on frow only)
-            const unsigned wb = ring_lds + s1 * STAGE;
-            [&]<int... I>(std::integer_sequence<int, I...>) { (lds_read16<I * 2048>(fa[0][I], xa0), ...); }(std::make_integer_sequence<int, MB>{});
-            lds_read16<0>(fb[0], wb + boff[0]);
-            [&]<int... I>(std::integer_sequence<int, I...>) { (lds_read16<I * 2048>(fa[1][I], xa1), ...); }(std::make_integer_sequence<int, MB>{});
-            lds_read16<0>(fb[1], wb + boff[1]);
+            const int s1n = s1 + 1 == NS ? 0 : s1 + 1;
+            rd_x(std::integral_constant<int, 1>{}, s1);
             asm volatile("s_waitcnt lgkmcnt(%0)" : : "n"(MB + 1));
             [&]<int... I>(std::integer_sequence<int, I...>) { (tie(fa[0][I]), ...); }(std::make_integer_sequence<int, MB>{});
             tie(fb[0]);
             mma(0);
-            asm volatile("s_waitcnt lgkmcnt(0)");
+            asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");   // own pieces of K-tile kt + 1 (kt + 2's in flight); second k-step in registers
+            __builtin_amdgcn_s_barrier();                        // K-tile kt + 1 landed everywhere; everyone is done reading K-tile kt
+            issue1(kt + 3, s1);                                  // into the stage K-tile kt has left
+            rd_x(std::integral_constant<int, 0>{}, s1n);
             [&]<int... I>(std::integer_sequence<int, I...>) { (tie(fa[1][I]), ...); }(std::make_integer_sequence<int, MB>{});
             tie(fb[1]);
             mma(1);
-            s1 = s1 + 1 == NS ? 0 : s1 + 1;
+            s1 = s1n;
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (the reads of the zero-filled K-tile past the end)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // (the zero-filled tail tiles)
         issue_w2(0, 0);                                          // conv2's first K-tiles under the c1 write
         issue_w2(1, 1);
