@@ -50,6 +50,11 @@ SIGNATURES = {
     "ec_spatial_mean_bf16": (c_int, [c_void_p] * 2 + [c_int] * 3 + [c_void_p]),
     "ec_rn50_create": (c_int, [C.POINTER(c_void_p), c_int, C.POINTER(c_int), c_int, c_void_p, c_void_p, c_size_t,
                                c_void_p, c_size_t]),
+    "ec_rn50tv_create": (c_int, [C.POINTER(c_void_p), C.POINTER(c_int), c_int, c_void_p, c_void_p, c_size_t, c_void_p,
+                                 c_size_t]),
+    "ec_conv_bf16_s2": (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_void_p]),
+    "ec_stem7_pool": (c_int, [c_void_p, c_int, C.POINTER(c_float), C.POINTER(c_float), c_void_p, c_void_p, c_void_p,
+                              c_int, c_int, c_int, c_void_p]),
     "ec_rn50_destroy": (None, [c_void_p]),
     "ec_rn50_workspace_bytes": (c_size_t, [c_void_p, c_int]),
     "ec_rn50_out_channels": (c_int, [c_void_p]),

@@ -126,24 +126,26 @@ class ClipResNetPreprocessor(_PreprocessorBase):
         a frame's features do not depend on how the batch is sliced).
 
         ASYNCHRONOUS with respect to the caller's stream (round 4): nothing here depends on work the caller has in
-        flight (the input is host memory, the staging buffers are the preprocessor's own, the output is allocated on a
-        side stream), so the copies and the encoder launches start at once -- beside the policy's act step of the previous
+        flight (the input is host memory, the staging buffers, the two encoder handles and their workspaces are this
+        path's own -- never the primary handle the caller's stream uses -- and the output is allocated on a side stream), so the copies and the encoder launches start at once -- beside the policy's act step of the previous
         env step, which is still running on the caller's stream -- and the caller's stream merely WAITS (an event, no
         host sync) for the two halves before whatever consumes the returned tensor.  The host blocks only until the
         H2D copies have left ``x`` (the caller may refill its frame buffer as soon as this returns)."""
         from .encoder import RN50Trunk
         trunk = self.resnet
         if getattr(self, "_twin", None) is None:
-            self._twin = RN50Trunk(None, device=self.device, chunk=self._chunk, weights_from=trunk)
-            self._twin.set_conv8_min_tiles(50)    # (the twin only ever runs beside the primary trunk)
+            # TWO dedicated handles (borrowing the primary trunk's packed weights), one per side stream: a handle's cached
+            # workspace is then only ever touched by launches on its own stream, in that stream's order.  The primary handle
+            # (and its workspace) stays with the caller's stream -- process() for < 64 frames / device input / pool=True and
+            # process_bf16_nhwc() -- so a direct call followed by a pipelined one (or mixed use of one preprocessor) can never
+            # put two launches on one workspace (ADVICE r4).
+            self._twin = [RN50Trunk(None, device=self.device, chunk=self._chunk, weights_from=trunk) for _ in range(2)]
+            for t in self._twin:
+                t.set_conv8_min_tiles(50)         # two launches in flight: the lower 8-wave dispatch threshold (ec_rn50_set_conv8_min_tiles)
         if getattr(self, "_streams", None) is None:
             self._streams = [torch.cuda.Stream(device=self.device) for _ in range(2)]
             self._copy_stream = torch.cuda.Stream(device=self.device)
             self._stage, self._stage_free, self._calls = {}, {}, 0
-        # two launches in flight: the lower 8-wave dispatch threshold (see ec_rn50_set_conv8_min_tiles) -- on the PRIMARY
-        # trunk only while this call issues its launches (the handle's value is read at issue time); a later batch that runs
-        # alone takes the default again
-        trunk.set_conv8_min_tiles(50)
         N = x.shape[0]
         nck = max(2, int(os.environ.get("EC_PLUGIN_CHUNKS", "2")))   # pieces of the batch (alternating over the two streams)
         cuts = [round(i * N / nck) for i in range(nck + 1)]
@@ -179,7 +181,7 @@ class ClipResNetPreprocessor(_PreprocessorBase):
         out.record_stream(self._streams[1])
         out.record_stream(cur)
         for k, ((a, b), (key, xs), ev) in enumerate(zip(spans, halves, copied)):
-            tr, st = (trunk, self._twin)[k & 1], self._streams[k & 1]
+            tr, st = self._twin[k & 1], self._streams[k & 1]
             st.wait_event(ev)
             with torch.cuda.stream(st):
                 if xs.dtype == torch.uint8:
@@ -192,7 +194,6 @@ class ClipResNetPreprocessor(_PreprocessorBase):
             self._stage_free[key] = done
         for st in self._streams:
             cur.wait_stream(st)                                  # an event wait on the caller's stream; the host does not block
-        trunk.set_conv8_min_tiles(0)
         # the copies were asynchronous (pinned source): the caller may refill `x` for the next env step as soon as this
         # returns, so wait for the LAST copy here (the encoder launches keep running behind it)
         copied[-1].synchronize()

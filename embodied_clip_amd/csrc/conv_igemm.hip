@@ -240,7 +240,7 @@ __device__ __forceinline__ void fr_step(FragRing<R>& ring, AddrFn& addr, MmaFn& 
 // 32 KB of a 128 x 128 K-tile keep the issuing waves blocked for ~1,100 clk, and with ONE workgroup per CU (the ring
 // launches of small per-GPU batches) all four waves sit in that phase together, then in the MFMA phase together -- the two
 // add up (~2,000 clk per K-tile measured at 32 frames).  Issued between MFMAs, the pieces drain while the matrix pipe works.
-template <int BM, int BN, int WM, int WN, int KS, bool POOL, bool PF, int MV, int NS, bool SPLIT = false, bool ILV = false>
+template <int BM, int BN, int WM, int WN, int KS, bool POOL, bool PF, int MV, int NS, bool SPLIT = false, bool ILV = false, bool S2 = false>
 __global__ __launch_bounds__(WM * WN * 64, (BM > 192) ? 2 : ((WM * WN == 8) ? 4 : (NS >= 3 ? 2 : 3))) void conv_igemm_kernel(ConvArgs p) {
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int FM = TM / 32, FN = TN / 32;
@@ -294,6 +294,17 @@ __global__ __launch_bounds__(WM * WN * 64, (BM > 192) ? 2 : ((WM * WN == 8) ? 4 
                 const int yp = r2 / Wp;
                 y = 2 * yp + (s2 >> 1);
                 x = 2 * (r2 - yp * Wp) + (s2 & 1);
+                pix = (b * p.H + y) * p.W + x;
+            } else if (S2) {
+                // stride 2 (torchvision's Bottleneck conv2 / downsample conv): row m is an OUTPUT pixel of the H/2 x W/2 map,
+                // its centre tap is input pixel (2 yo, 2 xo); the tap-validity mask below is in input coordinates
+                static_assert(!S2 || !POOL, "stride-2 instances have no fused pool");
+                const int Ho = p.H >> 1, Wo = p.W >> 1;
+                const int b = m / (Ho * Wo);
+                const int r2 = m - b * (Ho * Wo);
+                const int yo = r2 / Wo;
+                y = 2 * yo;
+                x = 2 * (r2 - yo * Wo);
                 pix = (b * p.H + y) * p.W + x;
             } else if (KS == 1) {
                 pix = m;               // raster order: pixel index == m, no halo
@@ -600,7 +611,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM > 192) ? 2 : ((WM * WN == 8) ? 4 
     }
 }
 
-template <int BM, int BN, int WM, int WN, int KS, bool POOL, bool PF = false, int MV = BM, int NS = 0, bool ILV = false>
+template <int BM, int BN, int WM, int WN, int KS, bool POOL, bool PF = false, int MV = BM, int NS = 0, bool ILV = false, bool S2 = false>
 int launch(const ConvArgs& a, hipStream_t s) {
     ConvArgs p = a;
     p.ntn = a.Cout / BN;
@@ -614,7 +625,7 @@ int launch(const ConvArgs& a, hipStream_t s) {
     p.ablate = ablate;
     size_t lds = (size_t)(NS >= 3 ? NS : p.nbuf) * (BM + BN) * ROW_BYTES;
     if (lds < epi) lds = epi;
-    auto kern = conv_igemm_kernel<BM, BN, WM, WN, KS, POOL, PF, MV, NS, false, ILV>;
+    auto kern = conv_igemm_kernel<BM, BN, WM, WN, KS, POOL, PF, MV, NS, false, ILV, S2>;
     static std::atomic<uint64_t> attr_done{0};
     if (auto attr_g_ = ec_attr_needed(attr_done)) {
         const size_t want = NS >= 3 ? lds : (lds_max > epi ? lds_max : epi);
@@ -1510,6 +1521,50 @@ int ec_conv_bf16_wf(const void* in, const void* w, const void* wf, const float* 
         return EC_OK;
     if (ksize == 3) return pool ? dispatch_tile<3, true>(a, s) : dispatch_tile<3, false>(a, s);
     return pool ? dispatch_tile<1, true>(a, s) : dispatch_tile<1, false>(a, s);
+}
+
+// Stride-2 convolution (1x1, or 3x3 pad 1) + folded BatchNorm + residual + activation: torchvision's ResNet v1.5 strides inside
+// the Bottleneck's 3x3 conv and in the 1x1 downsample conv (the `resnet_model` of
+// primitive_probing/generate_data/thor_image_features.py:46-49), where CLIP's ModifiedResNet pools instead.  Same implicit
+// GEMM: only the row decode differs (row m = output pixel, centre tap at input pixel (2 yo, 2 xo)).
+extern "C" int ec_conv_bf16_s2(const void* in, const void* w, const float* bias, const void* res, void* out, int B, int H, int W,
+                               int Cin, int Cout, int ksize, int act, ec_stream_t stream) {
+    if (!in || !w || !out) return EC_ERR_ARG;
+    if (B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return EC_ERR_SHAPE;
+    if (ksize != 1 && ksize != 3) return EC_ERR_SHAPE;
+    if (Cin < 8 || Cin % 8 != 0 || Cout % 64 != 0) return EC_ERR_SHAPE;
+    if (act != EC_ACT_RELU && act != EC_ACT_NONE) return EC_ERR_UNSUPPORTED;
+    if (H >= 4096 || W >= 65536) return EC_ERR_SHAPE;
+    const int Ho = H / 2, Wo = W / 2;
+    ConvArgs a;
+    a.in = (const uint16_t*)in;
+    a.w = (const uint16_t*)w;
+    a.bias = bias;
+    a.res = (const uint16_t*)res;
+    a.out = (uint16_t*)out;
+    a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    a.K = ksize * ksize * Cin;
+    a.M = B * Ho * Wo;
+    a.cin_log2 = (Cin & (Cin - 1)) == 0 ? ec_ilog2(Cin) : -1;
+    a.act = act;
+    a.ntn = 0;
+    if ((long)B * H * W * Cin * 2 >= (1L << 31) || (long)Cout * a.K * 2 >= (1L << 31)) return EC_ERR_SHAPE;
+    a.in_bytes = (unsigned)((long)B * H * W * Cin * 2);
+    a.w_bytes = (unsigned)((long)Cout * a.K * 2);
+    if (res && (long)B * Ho * Wo * Cout * 2 >= (1L << 32) - 16) return EC_ERR_SHAPE;
+    a.res_bytes = res ? (unsigned)((long)B * Ho * Wo * Cout * 2) : 0u;
+    hipStream_t s = (hipStream_t)stream;
+    // 128 x 128 tiles (three workgroups per CU) where Cout allows, 64 x 64 ring tiles for launches that would leave CUs idle
+    if (Cout % 128 == 0) {
+        const long t128 = (long)((a.M + 127) / 128) * (Cout / 128);
+        if (t128 < 256 && a.K >= 512)
+            return ksize == 3 ? launch<64, 64, 2, 2, 3, false, false, 64, 4, false, true>(a, s)
+                              : launch<64, 64, 2, 2, 1, false, false, 64, 4, false, true>(a, s);
+        return ksize == 3 ? launch<128, 128, 2, 2, 3, false, false, 128, 0, false, true>(a, s)
+                          : launch<128, 128, 2, 2, 1, false, false, 128, 0, false, true>(a, s);
+    }
+    return ksize == 3 ? launch<256, 64, 4, 1, 3, false, false, 256, 0, false, true>(a, s)
+                      : launch<256, 64, 4, 1, 1, false, false, 256, 0, false, true>(a, s);
 }
 
 // out[M, N] (fp32) = act(A[M, K] (bf16) @ W^T + bias) with W given as three bf16 planes [N][3][K] (ec_split3_bf16):

@@ -22,7 +22,7 @@
 
 namespace {
 
-enum OpKind { OP_STEM1, OP_CONV, OP_POOL, OP_PAIR, OP_BNECK };
+enum OpKind { OP_STEM1, OP_CONV, OP_POOL, OP_PAIR, OP_BNECK, OP_STEM7 };
 
 struct Op {
     OpKind kind;
@@ -45,6 +45,7 @@ struct Op {
     // x = res, y = dst, and runs a boundary launch marked band_half as its first half only (conv3 + identity + ReLU).
     int band = 0, band_skip = 0, band_half = 0;
     long band_w1 = -1, band_b1 = -1, band_w2 = -1, band_b2 = -1, wband_off = -1;
+    int stride = 1;          // OP_CONV: 2 = torchvision's strided conv (ec_conv_bf16_s2); H, W are the INPUT dims
     long wimg_off = -1;      // offset (elements, into wbneck) of this 3x3 conv's streaming-order weights for the small-launch kernel
 };
 
@@ -52,6 +53,7 @@ struct Op {
 
 struct ec_rn50 {
     int width, res, out_c, out_sp;
+    int tv = 0;                   // 1: torchvision ResNet (7x7 stem + max-pool, stride inside conv2 / the downsample conv): ec_rn50tv_create
     std::vector<Op> ops;
     size_t max_elems_per_frame;   // largest activation (bf16 elements) per frame
     const float* stem_w;
@@ -81,9 +83,34 @@ constexpr int NBUF = 5;
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 }  // namespace
 
+extern "C" int ec_stem7_pool(const void* rgb, int u8, const float* h_mean3, const float* h_std3, const void* w,
+                             const float* bias, void* out, int B, int H, int W, ec_stream_t stream);
+extern "C" int ec_conv_bf16_s2(const void* in, const void* w, const float* bias, const void* res, void* out, int B, int H, int W,
+                               int Cin, int Cout, int ksize, int act, ec_stream_t stream);
+
+namespace {
+int rn50_build(ec_rn50_t** out, bool tv, int width, const int* layers4, int input_resolution, const void* stem_w,
+               const void* w_bf16, size_t n_w, const float* bias, size_t n_bias);
+}
+
 extern "C" int ec_rn50_create(ec_rn50_t** out, int width, const int* layers4, int input_resolution,
                               const float* stem_w_f32, const void* w_bf16, size_t n_w, const float* bias,
                               size_t n_bias) {
+    return rn50_build(out, false, width, layers4, input_resolution, stem_w_f32, w_bf16, n_w, bias, n_bias);
+}
+
+// torchvision ResNet (v1.5) trunk == Sequential(*list(resnet50.children())[:-2])
+// (primitive_probing/generate_data/thor_image_features.py:46-49): the same executor and, for every stride-1 conv, the same
+// launches as the CLIP trunk; the stem is ONE launch (7x7 s2 conv + bn + relu + 3x3 s2 max-pool, stem7.hip) and the first
+// block of layers 2-4 strides inside its 3x3 conv and its 1x1 downsample conv (ec_conv_bf16_s2) instead of pooling.
+extern "C" int ec_rn50tv_create(ec_rn50_t** out, const int* layers4, int input_resolution, const void* stem_w_bf16,
+                                const void* w_bf16, size_t n_w, const float* bias, size_t n_bias) {
+    return rn50_build(out, true, 64, layers4, input_resolution, stem_w_bf16, w_bf16, n_w, bias, n_bias);
+}
+
+namespace {
+int rn50_build(ec_rn50_t** out, bool tv, int width, const int* layers4, int input_resolution, const void* stem_w_f32,
+               const void* w_bf16, size_t n_w, const float* bias, size_t n_bias) {
     if (!out || !layers4 || !stem_w_f32 || !w_bf16 || !bias) return EC_ERR_ARG;
     if (width % 32 != 0 || width < 32 || input_resolution % 32 != 0) return EC_ERR_SHAPE;
     // stem channels: width/2, rounded up to the 32-channel granule of the conv kernels (RN50x16: 48 -> 64; the
@@ -91,20 +118,27 @@ extern "C" int ec_rn50_create(ec_rn50_t** out, int width, const int* layers4, in
     const int sc = (width / 2 + 31) / 32 * 32;
     ec_rn50* h = new (std::nothrow) ec_rn50();
     if (!h) return EC_ERR_ALLOC;
-    h->width = width; h->res = input_resolution;
-    h->stem_w = stem_w_f32; h->w = (const uint16_t*)w_bf16; h->bias = bias;
+    h->width = width; h->res = input_resolution; h->tv = tv ? 1 : 0;
+    h->stem_w = (const float*)stem_w_f32; h->w = (const uint16_t*)w_bf16; h->bias = bias;
     size_t wo = 0, bo = 0, mx = 0;
     auto track = [&](int H, int W, int C) { mx = std::max(mx, (size_t)H * W * C); };
-    auto conv = [&](int src, int dst, int res, int H, int W, int Cin, int Cout, int ks, int pool, int act) {
+    auto conv = [&](int src, int dst, int res, int H, int W, int Cin, int Cout, int ks, int pool, int act, int stride = 1) {
         Op o{OP_CONV, src, dst, res, H, W, Cin, Cout, ks, pool, act, wo, bo};
+        o.stride = stride;
         wo += (size_t)Cout * ks * ks * Cin;
         bo += Cout;
         h->ops.push_back(o);
-        track(pool ? H / 2 : H, pool ? W / 2 : W, Cout);
+        track((pool || stride == 2) ? H / 2 : H, (pool || stride == 2) ? W / 2 : W, Cout);
     };
     int R = input_resolution / 2;
     // buffers: 0 = X (block input / output), 1,2 = temporaries, 3 = identity path, 4 = Y
-    {   // stem
+    if (tv) {   // conv1 7x7 s2 + bn1 + relu + maxpool 3x3 s2 in one launch: frame -> buffer 0 at R/2 x R/2 x 64
+        Op o{OP_STEM7, -2, 0, -1, input_resolution, input_resolution, 3, width, 7, 0, EC_ACT_RELU, 0, bo};
+        bo += width;
+        h->ops.push_back(o);
+        R /= 2;
+        track(R, R, width);
+    } else {   // stem
         Op o{OP_STEM1, -2, 1, -1, input_resolution, input_resolution, 3, sc, 3, 0, EC_ACT_RELU, 0, bo};
         bo += sc;
         h->ops.push_back(o);
@@ -141,6 +175,9 @@ extern "C" int ec_rn50_create(ec_rn50_t** out, int width, const int* layers4, in
                 conv(x, 1, -1, R, R, inplanes, planes, 1, 0, EC_ACT_RELU);
                 band_c1_op = (int)h->ops.size() - 1;
             }
+            if (tv && stride > 1) {   // torchvision: the 3x3 conv itself strides (no pool)
+                conv(c1, 2, -1, R, R, planes, planes, 3, 0, EC_ACT_RELU, 2);
+            } else
             conv(c1, 2, -1, R, R, planes, planes, 3, stride > 1 ? 1 : 0, EC_ACT_RELU);
             const int band_c2_op = (int)h->ops.size() - 1;
             const long band_w2 = (long)h->ops.back().w_off, band_b2 = (long)h->ops.back().b_off;
@@ -169,7 +206,7 @@ extern "C" int ec_rn50_create(ec_rn50_t** out, int width, const int* layers4, in
                 }
                 o.dst2 = 1;
                 o.N2 = last_of_layer ? planes * 2 : planes;          // next conv1: 256 -> planes (same layer) | 2*planes
-                if (last_of_layer && !ds && (R % 8) == 0) {          // the next block pools its input: emit it here
+                if (!tv && last_of_layer && !ds && (R % 8) == 0) {   // the next block pools its input: emit it here
                     o.dst3 = 3;
                     pooled_in = 3;
                     track(R / 2, R / 2, planes * 4);
@@ -186,6 +223,9 @@ extern "C" int ec_rn50_create(ec_rn50_t** out, int width, const int* layers4, in
             int side_grp = 0;
             if (ds) {
                 int dsrc = x, ddst = 3;
+                if (tv) {
+                    // torchvision: downsample = Conv2d(1x1, stride) + BatchNorm2d straight on the block input
+                } else
                 if (stride > 1 && pooled_in >= 0) {   // pooled input came with the previous boundary launch (buffer 3);
                     dsrc = pooled_in;                 // buffer 1 (this block's conv1 output) is free after conv2
                     ddst = 1;
@@ -205,6 +245,9 @@ extern "C" int ec_rn50_create(ec_rn50_t** out, int width, const int* layers4, in
                     track(Ro, Ro, inplanes);
                     dsrc = y;
                 }
+                if (tv && stride > 1) {
+                    conv(dsrc, ddst, -1, R, R, inplanes, planes * 4, 1, 0, EC_ACT_NONE, 2);
+                } else
                 conv(dsrc, ddst, -1, Ro, Ro, inplanes, planes * 4, 1, 0, EC_ACT_NONE);
                 h->ops.back().side = side_grp;
                 idt = ddst;
@@ -305,6 +348,7 @@ extern "C" int ec_rn50_create(ec_rn50_t** out, int width, const int* layers4, in
     *out = h;
     return EC_OK;
 }
+}  // namespace
 
 extern "C" void ec_rn50_destroy(ec_rn50_t* h) { delete h; }
 extern "C" int ec_rn50_out_channels(const ec_rn50_t* h) { return h ? h->out_c : 0; }
@@ -320,10 +364,10 @@ extern "C" uint64_t ec_rn50_plan_hash(const ec_rn50_t* h) {
         for (int i = 0; i < 8; ++i) { x ^= (uint64_t)((v >> (8 * i)) & 0xff); x *= 1099511628211ull; }
     };
     mix(ec_version()); mix((long)ec_config_hash());
-    mix(h->width); mix(h->res); mix(h->conv8_min_tiles);
+    mix(h->width); mix(h->res); mix(h->conv8_min_tiles); mix(h->tv);
     for (const Op& o : h->ops) {
         mix(o.kind); mix(o.src); mix(o.dst); mix(o.res); mix(o.H); mix(o.W); mix(o.Cin); mix(o.Cout); mix(o.ks);
-        mix(o.pool); mix(o.act); mix(o.src1); mix(o.dst2); mix(o.N2); mix(o.dst3); mix(o.side); mix(o.wc1_off >= 0); mix(o.band + 2 * o.band_skip + 4 * o.band_half);
+        mix(o.pool); mix(o.act); mix(o.stride); mix(o.src1); mix(o.dst2); mix(o.N2); mix(o.dst3); mix(o.side); mix(o.wc1_off >= 0); mix(o.band + 2 * o.band_skip + 4 * o.band_half);
     }
     return x;
 }
@@ -436,6 +480,11 @@ int rn50_run(const ec_rn50_t* h, const void* rgb, bool u8, const float* mean3, c
                         rc = ec_stem_conv1((const float*)rgb + (size_t)b0 * rgb_stride, h->stem_w, h->bias + o.b_off,
                                            buf(o.dst), nb, o.H, o.W, o.Cout, stream);
                     break;
+                case OP_STEM7:
+                    rc = ec_stem7_pool(u8 ? (const void*)((const uint8_t*)rgb + (size_t)b0 * rgb_stride)
+                                          : (const void*)((const float*)rgb + (size_t)b0 * rgb_stride),
+                                       u8 ? 1 : 0, mean3, std3, h->stem_w, h->bias + o.b_off, buf(o.dst), nb, o.H, o.W, stream);
+                    break;
                 case OP_POOL:
                     rc = ec_avgpool2_bf16(buf(o.src), buf(o.dst), nb, o.H, o.W, o.Cin, stream);
                     break;
@@ -485,6 +534,11 @@ int rn50_run(const ec_rn50_t* h, const void* rgb, bool u8, const float* mean3, c
                     }
                     break;
                 default:
+                    if (o.stride == 2) {
+                        rc = ec_conv_bf16_s2(buf(o.src), h->w + o.w_off, h->bias + o.b_off, o.res >= 0 ? buf(o.res) : nullptr, buf(o.dst),
+                                             nb, o.H, o.W, o.Cin, o.Cout, o.ks, o.act, stream);
+                        break;
+                    }
                     if (o.wimg_off >= 0 && o.kind == OP_CONV && nb <= (o.pool ? 16 : 64)) {   // 7x7x512 3x3 convs of small launches (two rounds of
                         // workgroups at most); layer4.0's pooled 14x14x512 conv2 (two channel chunks, 16 slices per image: one round of workgroups) up to 16 frames -- at 32 it ties with conv_igemm (47.6 vs 46.6 us)
                         rc = ec_conv3x3_img_bf16(buf(o.src), h->wbneck + o.wimg_off, h->bias + o.b_off, buf(o.dst), nb, o.H, o.W, o.Cin, o.pool, stream);

@@ -1,0 +1,204 @@
+// Stem of torchvision's ResNet-50: conv1 (7x7, stride 2, pad 3, 3 -> 64) + bn1 (folded) + ReLU + MaxPool2d(3, 2, 1)
+// in ONE launch -- the first four children of `Sequential(*list(resnet50.children())[:-2])`
+// (primitive_probing/generate_data/thor_image_features.py:46-49, reachable_image_features.py:48-51), the network behind
+// the `imagenet_conv` / `imagenet_avgpool` features (:102-106, :130-131).
+//
+// The 112 x 112 x 64 conv output (1.6 MB per frame in bf16) never touches HBM: a workgroup owns an 8 x 14 tile of the
+// POOLED 56 x 56 map, computes the 17 x 29 conv pixels its 3 x 3 / stride-2 windows cover (1.14 x recompute at the tile
+// seams) on the bf16 MFMA, keeps them in LDS and pools from there.  Per frame: 602 KB of fp32 image in (150 KB as uint8),
+// 401 KB out.
+//
+//   * K = 7 x 7 x 3 = 147 is laid out as 7 rows of 24 (ky; kx * 3 + ci < 21 real, 3 zero weights) + 8 zeros = 176 =
+//     11 k-steps of v_mfma_f32_32x32x16_bf16: with the NHWC frame a window row (7 pixels x 3 channels) is 21 CONTIGUOUS
+//     elements of the staged patch row, so a lane's 8-element operand slice is 16 contiguous bytes of LDS (4-byte
+//     aligned: four ds_read_b32).  The slots past 21 read the neighbouring pixels' values against zero weights.
+//   * the patch (40 rows x 63 pixels, frame -> bf16 while staging, zero outside the frame = zero padding in the
+//     NORMALISED domain, as `Normalize` precedes the conv in the reference) is 15 KB, the conv tile 72 KB.
+//   * swapped MFMA operands (D[channel][pixel]) as in conv_igemm.hip: a lane owns one pixel and 4 consecutive channels
+//     per 4 accumulator registers -> bias + ReLU + one rounding to bf16 + 8-byte LDS stores.
+//   * the weights (64 x 176 bf16 = 22 KB) live in registers as ready-made MFMA fragments for the whole persistent launch.
+//   * max-pool on the bf16 bit patterns: every value is >= 0 after the ReLU, where bf16 order == unsigned 16-bit order
+//     (v_pk_max_u16); out-of-frame conv pixels are stored as 0, which never wins against the window's real values >= 0
+//     (PyTorch pads the pool with -inf: same result).
+#include "common.h"
+
+namespace {
+
+constexpr int TPH = 8, TPW = 14;                 // pooled tile
+constexpr int CTH = 2 * TPH + 1, CTW = 2 * TPW + 1;   // conv tile 17 x 29
+constexpr int NPX = CTH * CTW;                   // 493
+constexpr int NBLK = (NPX + 31) / 32;            // 16 MFMA pixel blocks
+constexpr int PROWS = 2 * CTH + 5 + 1;           // 39 patch rows + 1 (the zero-weight K row 7 reads it)
+constexpr int PPITCH = 192;                      // elements per patch row (63 pixels x 3 = 189)
+constexpr int KROW = 24, KP = 176, NKS = KP / 16;
+constexpr int CT_PITCH = 64 * 2 + 16;            // bytes per conv pixel in LDS (+16: staggers the banks)
+constexpr int PATCH_BYTES = PROWS * PPITCH * 2;  // 15,360
+constexpr int LDS_BYTES = PATCH_BYTES + NBLK * 32 * CT_PITCH;   // + 73,728
+
+typedef unsigned short u16x8_t __attribute__((ext_vector_type(8)));
+
+template <bool U8>
+__global__ __launch_bounds__(512, 2) void stem7_pool_kernel(const void* __restrict__ rgb_, const uint16_t* __restrict__ w,
+                                                            const float* __restrict__ bias, uint16_t* __restrict__ out,
+                                                            int B, int H, int W, int tiles_x, int tiles_y, float3 nscale,
+                                                            float3 nshift) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint16_t* patch = reinterpret_cast<uint16_t*>(smem);
+    unsigned char* ct = smem + PATCH_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int frow = lane & 31, fhalf = lane >> 5;
+    const int Hc = H >> 1, Wc = W >> 1, Hp = Hc >> 1, Wp = Wc >> 1;
+
+    // weight fragments, once per workgroup: row n = j * 32 + frow, k = ks * 16 + fhalf * 8 .. + 7
+    s16x8_t bfr[2][NKS];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+            bfr[j][ks] = *reinterpret_cast<const s16x8_t*>(w + (size_t)(j * 32 + frow) * KP + ks * 16 + fhalf * 8);
+    float4 bv[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bv[j][g] = *reinterpret_cast<const float4*>(bias + j * 32 + 8 * g + 4 * fhalf);
+
+    const int ntiles = B * tiles_x * tiles_y;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int t = tile;
+        const int tx = t % tiles_x; t /= tiles_x;
+        const int ty = t % tiles_y;
+        const int b = t / tiles_y;
+        const int py0 = ty * TPH, px0 = tx * TPW;
+        const int iy0 = 4 * py0 - 5, ie0 = (4 * px0 - 5) * 3;     // frame row / row element of patch (0, 0)
+        const long img = (long)b * H * W * 3;
+        // ---- stage the patch: frame -> bf16, two elements per thread and store ----
+        for (int e = tid; e < PROWS * (PPITCH / 2); e += 512) {
+            const int r = e / (PPITCH / 2), q = e - r * (PPITCH / 2);
+            const int iy = iy0 + r;
+            float v[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int ie = ie0 + 2 * q + u;
+                v[u] = 0.f;
+                if (iy >= 0 && iy < H && ie >= 0 && ie < W * 3) {
+                    const long idx = img + (long)iy * W * 3 + ie;
+                    if (U8) {
+                        const int ch = ie % 3;
+                        const float sc = ch == 0 ? nscale.x : (ch == 1 ? nscale.y : nscale.z);
+                        const float sh = ch == 0 ? nshift.x : (ch == 1 ? nshift.y : nshift.z);
+                        v[u] = (float)reinterpret_cast<const unsigned char*>(rgb_)[idx] * sc + sh;
+                    } else {
+                        v[u] = reinterpret_cast<const float*>(rgb_)[idx];
+                    }
+                }
+            }
+            *reinterpret_cast<uint32_t*>(patch + r * PPITCH + 2 * q) = ec_pack2(v[0], v[1]);
+        }
+        __syncthreads();
+        // ---- conv: wave w owns pixel blocks 2w, 2w + 1 of the 17 x 29 tile, all 64 channels ----
+        f32x16_t acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        int pbase[2], cyv[2], cxv[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int idx = (wave * 2 + i) * 32 + frow;
+            idx = idx < NPX ? idx : NPX - 1;                      // (padding rows of the last block: results discarded)
+            cyv[i] = idx / CTW; cxv[i] = idx - cyv[i] * CTW;
+            pbase[i] = (2 * cyv[i]) * PPITCH + 6 * cxv[i];       // element index of the window's (ky = 0, kx = 0, ci = 0)
+        }
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const int kk = ks * 16 + fhalf * 8;
+            const int ky = kk / KROW, off = kk - ky * KROW;
+            s16x8_t af[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const uint32_t* src = reinterpret_cast<const uint32_t*>(patch + pbase[i] + ky * PPITCH + off);
+                uint4 v4 = make_uint4(src[0], src[1], src[2], src[3]);
+                af[i] = __builtin_bit_cast(s16x8_t, v4);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, bfr[j][ks]),
+                                                                        __builtin_bit_cast(bf16x8_t, af[i]), acc[i][j], 0, 0, 0);
+        }
+        // ---- bias + ReLU + rounding -> conv tile in LDS (out-of-frame conv pixels = 0) ----
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = (wave * 2 + i) * 32 + frow;
+            const int gy = 2 * py0 - 1 + cyv[i], gx = 2 * px0 - 1 + cxv[i];
+            const bool ok = idx < NPX && gy >= 0 && gy < Hc && gx >= 0 && gx < Wc;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float v0 = fmaxf(acc[i][j][4 * g + 0] + bv[j][g].x, 0.f), v1 = fmaxf(acc[i][j][4 * g + 1] + bv[j][g].y, 0.f);
+                    float v2 = fmaxf(acc[i][j][4 * g + 2] + bv[j][g].z, 0.f), v3 = fmaxf(acc[i][j][4 * g + 3] + bv[j][g].w, 0.f);
+                    uint2 o;
+                    o.x = ok ? ec_pack2(v0, v1) : 0u;
+                    o.y = ok ? ec_pack2(v2, v3) : 0u;
+                    *reinterpret_cast<uint2*>(ct + idx * CT_PITCH + (j * 32 + 8 * g + 4 * fhalf) * 2) = o;
+                }
+        }
+        __syncthreads();
+        // ---- 3 x 3 / stride-2 max-pool out of LDS: one (pooled pixel, 8-channel chunk) per thread and pass ----
+        for (int e = tid; e < TPH * TPW * 8; e += 512) {
+            const int pp = e >> 3, c8 = e & 7;
+            const int ppy = pp / TPW, ppx = pp - ppy * TPW;
+            const int py = py0 + ppy, px = px0 + ppx;
+            if (py < Hp && px < Wp) {
+                u16x8_t m = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const u16x8_t v = *reinterpret_cast<const u16x8_t*>(ct + ((2 * ppy + dy) * CTW + 2 * ppx + dx) * CT_PITCH + c8 * 16);
+                        m = __builtin_elementwise_max(m, v);
+                    }
+                *reinterpret_cast<u16x8_t*>(out + (((long)b * Hp + py) * Wp + px) * 64 + c8 * 8) = m;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+// rgb: fp32 NHWC [B,H,W,3] ImageNet-normalised (u8 == 0) or raw uint8 NHWC with /255 + mean/std fused (u8 == 1; h_mean3 /
+// h_std3 host pointers); w bf16 [64][176] (K layout above; encoder.pack_tv_resnet), bias f32 [64]; out bf16 [B,H/4,W/4,64].
+extern "C" int ec_stem7_pool(const void* rgb, int u8, const float* h_mean3, const float* h_std3, const void* w,
+                             const float* bias, void* out, int B, int H, int W, ec_stream_t stream) {
+    if (!rgb || !w || !bias || !out) return EC_ERR_ARG;
+    if (B <= 0 || H < 8 || W < 8 || (H & 3) || (W & 3)) return EC_ERR_SHAPE;
+    if (u8 && (!h_mean3 || !h_std3)) return EC_ERR_ARG;
+    const int Hp = H / 4, Wp = W / 4;
+    const int tiles_y = (Hp + TPH - 1) / TPH, tiles_x = (Wp + TPW - 1) / TPW;
+    const long ntiles = (long)B * tiles_x * tiles_y;
+    if (ntiles >= (1L << 31)) return EC_ERR_SHAPE;
+    float3 sc = make_float3(1.f, 1.f, 1.f), sh = make_float3(0.f, 0.f, 0.f);
+    if (u8) {
+        sc = make_float3(1.f / (255.f * h_std3[0]), 1.f / (255.f * h_std3[1]), 1.f / (255.f * h_std3[2]));
+        sh = make_float3(-h_mean3[0] / h_std3[0], -h_mean3[1] / h_std3[1], -h_mean3[2] / h_std3[2]);
+    }
+    const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);
+    static std::atomic<uint64_t> attr_done{0};
+    if (auto g = ec_attr_needed(attr_done)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stem7_pool_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stem7_pool_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    }
+    if (u8)
+        hipLaunchKernelGGL(stem7_pool_kernel<true>, dim3(grid), dim3(512), LDS_BYTES, (hipStream_t)stream, rgb, (const uint16_t*)w,
+                           bias, (uint16_t*)out, B, H, W, tiles_x, tiles_y, sc, sh);
+    else
+        hipLaunchKernelGGL(stem7_pool_kernel<false>, dim3(grid), dim3(512), LDS_BYTES, (hipStream_t)stream, rgb, (const uint16_t*)w,
+                           bias, (uint16_t*)out, B, H, W, tiles_x, tiles_y, sc, sh);
+    EC_CHECK_LAUNCH();
+    return EC_OK;
+}

@@ -38,14 +38,21 @@ def allreduce_flat(flat_grads: torch.Tensor, group=None, force: bool = False) ->
     return flat_grads
 
 
-def check_job_seed(seed: int, world: int, group=None) -> None:
+def check_job_seed(seed: int, world: int, group=None, device=None) -> None:
     """The minibatch shuffle stream must be IDENTICAL on every rank (every rank visits the same sampler range at the same
     optimiser step; only then is the SUM all-reduce with the fixed 1/world scale the global minibatch mean when
     N % num_mini_batch != 0).  With a process group up, the ranks compare their seeds (MIN == MAX) and a launcher that
     passed per-rank seeds fails here instead of training on silently inconsistent gradients."""
     if world <= 1 or not (dist.is_available() and dist.is_initialized()):
         return
-    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    # ``device``: the calling worker's GPU (a launcher may pass device="cuda:k" without torch.cuda.set_device: the tensors of
+    # an RCCL collective must live on THIS rank's GPU, not on the process default)
+    if dist.get_backend(group) == "nccl":
+        dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+    else:
+        dev = torch.device("cpu")
     lo = torch.tensor([float(seed)], dtype=torch.float64, device=dev)
     hi = lo.clone()
     dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)

@@ -145,23 +145,28 @@ class RN50Trunk:
             width, layers = weights_from._arch
             self.stem_w, self.w, self.bias = weights_from.stem_w, weights_from.w, weights_from.bias
         else:
-            (width, layers), stem_w, w, bias = pack_rn50(state_dict)
+            (width, layers), stem_w, w, bias = self._pack(state_dict)
             self.stem_w = stem_w.to(self.device)
             self.w = w.to(self.device)
             self.bias = bias.to(self.device)
         self._arch = (width, layers)
         self.input_resolution = input_resolution
         self.chunk = chunk
+        self.h = self._create(width, layers, input_resolution)
+        self.out_channels = self.lib.ec_rn50_out_channels(self.h)
+        self.out_spatial = self.lib.ec_rn50_out_spatial(self.h)
+        self._ws: Optional[torch.Tensor] = None
+        self._resize: Optional[ClipResizeCrop] = None
+
+    _pack = staticmethod(pack_rn50)
+
+    def _create(self, width, layers, input_resolution):
         h = C.c_void_p()
         arr = (C.c_int * 4)(*layers)
         _lib.check(self.lib.ec_rn50_create(C.byref(h), width, arr, input_resolution, self.stem_w.data_ptr(),
                                            self.w.data_ptr(), self.w.numel(), self.bias.data_ptr(),
                                            self.bias.numel()), "ec_rn50_create")
-        self.h = h
-        self.out_channels = self.lib.ec_rn50_out_channels(h)
-        self.out_spatial = self.lib.ec_rn50_out_spatial(h)
-        self._ws: Optional[torch.Tensor] = None
-        self._resize: Optional[ClipResizeCrop] = None
+        return h
 
     def __del__(self):
         try:
@@ -245,6 +250,59 @@ class RN50Trunk:
         _lib.check(self.lib.ec_spatial_mean_bf16(feat.data_ptr(), o.data_ptr(), B, S * S, Cc, _lib.stream_ptr()),
                    "ec_spatial_mean_bf16")
         return o
+
+
+IMAGENET_RGB_MEANS = (0.485, 0.456, 0.406)      # thor_image_features.py:41
+IMAGENET_RGB_STDS = (0.229, 0.224, 0.225)       # thor_image_features.py:42
+TV_STEM_KROW, TV_STEM_K = 24, 176               # ec_stem7_pool's K layout
+
+
+def pack_tv_resnet(sd: Dict[str, torch.Tensor]):
+    """``torchvision.models.resnet50().state_dict()`` (``fc.*`` ignored: the reference drops avgpool and fc,
+    thor_image_features.py:47) -> (cfg, stem_w bf16 [64,176], w bf16 flat, bias f32 flat) as ``ec_rn50tv_create`` documents."""
+    sd = {k: v.detach().cpu() for k, v in sd.items()}
+    width = sd["conv1.weight"].shape[0]
+    assert tuple(sd["conv1.weight"].shape[1:]) == (3, 7, 7), "not a torchvision ResNet state dict"
+    layers = _layers(sd)
+    w1, b1 = _fold(sd["conv1.weight"], sd, "bn1")                       # [w, 3, 7, 7]
+    rows = w1.permute(0, 2, 3, 1).reshape(width, 7, 21)                 # [(ky), (kx, ci)]
+    stem = torch.zeros(width, TV_STEM_K)
+    stem[:, :7 * TV_STEM_KROW].view(width, 7, TV_STEM_KROW)[:, :, :21] = rows
+    ws: List[torch.Tensor] = []
+    bs: List[torch.Tensor] = [b1]
+    for li, n in enumerate(layers, start=1):
+        for b in range(n):
+            p = f"layer{li}.{b}"
+            for conv, bn in ((".conv1", ".bn1"), (".conv2", ".bn2"), (".conv3", ".bn3"), (".downsample.0", ".downsample.1")):
+                if (p + conv + ".weight") not in sd:
+                    continue
+                w, bb = _fold(sd[p + conv + ".weight"], sd, p + bn)
+                bs.append(bb)
+                ws.append(w.permute(0, 2, 3, 1).reshape(-1).to(torch.bfloat16))
+    return (width, layers), stem.to(torch.bfloat16).contiguous(), torch.cat(ws), torch.cat(bs)
+
+
+class ImageNetRN50Trunk(RN50Trunk):
+    """Frozen torchvision ResNet-50 without avgpool / fc: the ``resnet_model`` of the feature scripts
+    (primitive_probing/generate_data/thor_image_features.py:46-49, reachable_image_features.py:48-51).
+    ``forward(rgb_nhwc_f32 ImageNet-normalised) -> bf16 [B,7,7,2048]`` == ``imagenet_conv`` (NHWC, before ``.float()``);
+    ``spatial_mean`` of it == ``imagenet_avgpool`` (:51-54,105-106).  Same executor and handle type as the CLIP trunk."""
+
+    _pack = staticmethod(pack_tv_resnet)
+
+    def _create(self, width, layers, input_resolution):
+        if width != 64:
+            raise _lib.EcError("ec_rn50tv_create: the 7x7 stem kernel is built for 64 channels (torchvision resnet50/101/152)")
+        h = C.c_void_p()
+        arr = (C.c_int * 4)(*layers)
+        _lib.check(self.lib.ec_rn50tv_create(C.byref(h), arr, input_resolution, self.stem_w.data_ptr(), self.w.data_ptr(),
+                                             self.w.numel(), self.bias.data_ptr(), self.bias.numel()), "ec_rn50tv_create")
+        return h
+
+    def forward_u8(self, rgb_u8, out=None, mean=IMAGENET_RGB_MEANS, std=IMAGENET_RGB_STDS):
+        """raw uint8 frames: Resize(224, BICUBIC) + CenterCrop (``resnet_preprocess``, thor_image_features.py:36-39, the
+        same Pillow-exact kernel as the CLIP branch) when needed, ToTensor + Normalize(ImageNet) fused into the stem."""
+        return super().forward_u8(rgb_u8, out=out, mean=mean, std=std)
 
 
 class AttentionPool:
@@ -417,6 +475,35 @@ def conv_bf16(x, w, bias, res=None, ksize=1, pool=False, act=1, workspace=None, 
         return out
     _lib.check(lib.ec_conv_bf16(x.data_ptr(), w.data_ptr(), _lib.ptr(bias), _lib.ptr(res), out.data_ptr(), B, H, W,
                                 Cin, Cout, ksize, int(pool), act, _lib.stream_ptr()), "ec_conv_bf16")
+    return out
+
+
+@_guard_first
+def conv_bf16_s2(x, w, bias, res=None, ksize=1, act=1, out=None):
+    """Stride-2 conv (torchvision Bottleneck conv2 / downsample conv, ``ec_conv_bf16_s2``): x bf16 [B,H,W,Cin],
+    w bf16 [Cout, k*k*Cin], res bf16 [B,H/2,W/2,Cout] -> bf16 [B,H/2,W/2,Cout]."""
+    lib = _lib.load()
+    B, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    if out is None:
+        out = torch.empty((B, H // 2, W // 2, Cout), dtype=torch.bfloat16, device=x.device)
+    _lib.check(lib.ec_conv_bf16_s2(x.data_ptr(), w.data_ptr(), _lib.ptr(bias), _lib.ptr(res), out.data_ptr(), B, H, W, Cin, Cout,
+                                   ksize, act, _lib.stream_ptr()), "ec_conv_bf16_s2")
+    return out
+
+
+@_guard_first
+def stem7_pool(rgb, stem_w, bias, mean=None, std=None):
+    """torchvision stem in one launch (``ec_stem7_pool``): rgb fp32 NHWC (normalised) or uint8 NHWC (then ``mean`` / ``std``
+    are fused) -> bf16 [B,H/4,W/4,64]."""
+    lib = _lib.load()
+    B, H, W, _ = rgb.shape
+    u8 = rgb.dtype == torch.uint8
+    out = torch.empty((B, H // 4, W // 4, 64), dtype=torch.bfloat16, device=rgb.device)
+    m3 = (C.c_float * 3)(*(mean or (0.0, 0.0, 0.0)))
+    s3 = (C.c_float * 3)(*(std or (1.0, 1.0, 1.0)))
+    _lib.check(lib.ec_stem7_pool(rgb.data_ptr(), int(u8), m3, s3, stem_w.data_ptr(), bias.data_ptr(), out.data_ptr(), B, H, W,
+                                 _lib.stream_ptr()), "ec_stem7_pool")
     return out
 
 

@@ -114,10 +114,10 @@ class Worker:
         # SUM all-reduce with the fixed 1/world scale is the global minibatch mean also when N % num_mini_batch != 0
         # (ranges of different sizes) -- with per-rank streams it would be a mean of differently-sized means
         self._mb_rng = random.Random(seed)                  # (`seed` is the job's seed: identical on every rank)
-        check_job_seed(seed, world)                         # ... which is ENFORCED when a process group is up
         self.dev = self.device = torch.device(device)
         if self.dev.index is None:
             self.dev = self.device = torch.device("cuda", torch.cuda.current_device())
+        check_job_seed(seed, world, device=self.dev)        # ... which is ENFORCED when a process group is up (on THIS worker's GPU)
         self._init(n_actors, T, seed, rank, world, update_repeats, lr, max_grad_norm, gamma, tau, encoder_sd, policy_sd,
                    lr_total_steps, encoder_chunk, encoder, encoder_streams, frames_u8, frames_host)
 

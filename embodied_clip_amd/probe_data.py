@@ -1,20 +1,22 @@
-"""Feature cache between the frozen encoder and the probe: writer and reader.
+"""Feature cache between the frozen encoders and the probe: writer and reader.
 
-Writer == the CLIP half of ``primitive_probing/generate_data/thor_image_features.py:57-68,105-140`` and
-``reachable_image_features.py:60-100``: trunk -> {conv fp32, attnpool, avgpool} per frame, stored as
+Writer == ``primitive_probing/generate_data/thor_image_features.py:36-68,102-140`` and
+``reachable_image_features.py:39-100``: both frozen trunks -> their embeddings per frame, stored as
 
-    thor_{split}.pt                {scene: [ {clip_conv [2048,7,7], clip_attnpool [1024], clip_avgpool [2048],
+    thor_{split}.pt                {scene: [ {imagenet_conv [2048,7,7], imagenet_avgpool [2048],
+                                              clip_conv [2048,7,7], clip_attnpool [1024], clip_avgpool [2048],
                                               object_presence int[52], object_localization int[9,52],
                                               free_space int} , ...]}
-    reachable_image_features.pt    {image: {clip_avgpool, clip_attnpool}}
+    reachable_image_features.pt    {image: {imagenet_avgpool, clip_avgpool, clip_attnpool}}
     reachable_{split}.pkl          [(image, obj_id, bool), ...]
 
-The encoder runs on the MI355X (``RN50Trunk.forward_u8`` with the CLIP normalisation fused into the stem,
-``AttentionPool`` on the native bf16 features, avgpool on the fp32-cast features -- the dtype split of
-thor_image_features.py:111-113).  Out of scope here: rendering / semantic-mask labelling (thor_frames.py,
-thor_image_features.py:70-127 -- simulator + numpy data prep), the PIL bicubic 300->224 resize of
-``clip_preprocess`` (frames are expected at 224x224), and the torchvision-ImageNet ``imagenet_*`` keys (a different
-pretrained network; the reader accepts them when present).
+The encoders run on the MI355X: CLIP -- ``RN50Trunk.forward_u8`` with the CLIP normalisation fused into the stem,
+``AttentionPool`` on the native bf16 features, avgpool on the fp32-cast features (the dtype split of
+thor_image_features.py:111-113); ImageNet -- ``ImageNetRN50Trunk.forward_u8`` (torchvision ResNet-50 minus avgpool / fc,
+ImageNet mean / std fused into its 7x7 stem; the reference runs this tower in fp32, here bf16 storage with fp32
+accumulation like every other conv of the path).  Both share ONE Pillow-exact Resize(224, BICUBIC) + CenterCrop(224) pass
+over the raw frame (``resnet_preprocess`` and ``clip_preprocess`` apply the same geometry, :36-39,108).  Out of scope
+here: rendering / semantic-mask labelling (thor_frames.py, thor_image_features.py:70-127 -- simulator + numpy data prep).
 
 Reader == ``primitive_probing/data.py:9-47`` (``THOREmbeddingsDataset``) and the DataLoader collate of
 ``THOREmbeddingsDataModule`` (data.py:50-88) without pytorch-lightning.
@@ -38,49 +40,68 @@ PREDICTION_TYPES = ("object_presence", "object_localization", "reachability", "f
 # ------------------------------------------------------------------------------------------------
 # writer
 # ------------------------------------------------------------------------------------------------
-class ClipFeatureExtractor:
-    """frames uint8 [n,H,W,3] -> the three CLIP embeddings the cache stores (all fp32, on the host).  Frames that are
-    not 224x224 (the reference renders 300x300: thor_frames.py:33-34) go through CLIP's Resize(224, BICUBIC) +
-    CenterCrop(224) on the GPU, bit-exact with the Pillow path of ``clip_preprocess`` (thor_image_features.py:108)."""
+CLIP_KEYS = ("clip_conv", "clip_attnpool", "clip_avgpool")
+IMAGENET_KEYS = ("imagenet_conv", "imagenet_avgpool")
 
-    def __init__(self, visual_state_dict, device="cuda:0", batch: int = 64):
-        from .encoder import AttentionPool, RN50Trunk
+
+class ClipFeatureExtractor:
+    """frames uint8 [n,H,W,3] -> the embeddings the cache stores (all fp32, on the host): the three ``clip_*`` keys and,
+    when a torchvision ResNet-50 state dict is given (``imagenet_state_dict``), the two ``imagenet_*`` keys.  Frames that
+    are not 224x224 (the reference renders 300x300: thor_frames.py:33-34) go through Resize(224, BICUBIC) +
+    CenterCrop(224) on the GPU ONCE for both towers, bit-exact with the Pillow path of ``clip_preprocess`` /
+    ``resnet_preprocess`` (thor_image_features.py:36-39,108)."""
+
+    def __init__(self, visual_state_dict, device="cuda:0", batch: int = 64, imagenet_state_dict=None):
+        from .encoder import AttentionPool, ClipResizeCrop, ImageNetRN50Trunk, RN50Trunk
         self.device = torch.device(device)
         self.trunk = RN50Trunk(visual_state_dict, device=self.device)
         self.attnpool = AttentionPool(visual_state_dict, device=self.device)
+        self.imagenet = ImageNetRN50Trunk(imagenet_state_dict, device=self.device) if imagenet_state_dict is not None else None
+        self.resize = ClipResizeCrop(self.device, self.trunk.input_resolution)
         self.batch = batch
+
+    @property
+    def keys(self):
+        return (IMAGENET_KEYS if self.imagenet is not None else ()) + CLIP_KEYS
 
     @torch.no_grad()
     def __call__(self, frames_u8: torch.Tensor) -> Dict[str, torch.Tensor]:
         assert frames_u8.dtype == torch.uint8 and frames_u8.dim() == 4 and frames_u8.shape[3] == 3
-        conv, attn, avg = [], [], []
+        cols: Dict[str, list] = {k: [] for k in self.keys}
+        R = self.trunk.input_resolution
         for i in range(0, frames_u8.shape[0], self.batch):
             x = frames_u8[i:i + self.batch].to(self.device).contiguous()
-            feat = self.trunk.forward_u8(x)                       # bf16 NHWC [b,7,7,2048]
-            conv.append(self.trunk.to_nchw_f32(feat).cpu())       # clip_features.float()        (:111)
-            attn.append(self.attnpool.forward(feat).float().cpu())        # clip_pool(clip_features)     (:112)
-            avg.append(self.trunk.spatial_mean(feat).cpu())       # clip_avgpool(features.float()) (:113)
-        return {"clip_conv": torch.cat(conv), "clip_attnpool": torch.cat(attn), "clip_avgpool": torch.cat(avg)}
+            if x.shape[1] != R or x.shape[2] != R:
+                x = self.resize(x)
+            if self.imagenet is not None:
+                f = self.imagenet.forward_u8(x)                                   # resnet_model(resnet_input)      (:103)
+                cols["imagenet_conv"].append(self.imagenet.to_nchw_f32(f).cpu())  # resnet_features[0]              (:105)
+                cols["imagenet_avgpool"].append(self.imagenet.spatial_mean(f).cpu())   # resnet_pool(...)           (:106)
+            feat = self.trunk.forward_u8(x)                                       # bf16 NHWC [b,7,7,2048]
+            cols["clip_conv"].append(self.trunk.to_nchw_f32(feat).cpu())          # clip_features.float()           (:111)
+            cols["clip_attnpool"].append(self.attnpool.forward(feat).float().cpu())    # clip_pool(clip_features)   (:112)
+            cols["clip_avgpool"].append(self.trunk.spatial_mean(feat).cpu())      # clip_avgpool(features.float())  (:113)
+        return {k: torch.cat(v) for k, v in cols.items()}
 
 
 def build_thor_features(extractor, scenes: Dict[str, List[dict]]) -> Dict[str, List[dict]]:
-    """``scenes``: {scene_name: [point, ...]}, point = {'frame' uint8 [224,224,3], 'object_presence' int[52],
-    'object_localization' int[9,52], 'free_space' int}.  Returns the thor_{split}.pt dictionary."""
+    """``scenes``: {scene_name: [point, ...]}, point = {'frame' uint8 [H,W,3], 'object_presence' int[52],
+    'object_localization' int[9,52], 'free_space' int}.  Returns the thor_{split}.pt dictionary
+    (thor_image_features.py:129-138; the ``imagenet_*`` entries when the extractor holds the ImageNet tower)."""
     out: Dict[str, List[dict]] = {}
     for scene_name, points in scenes.items():
         if not points:
             out[scene_name] = []
             continue
-        frames = torch.stack([torch.as_tensor(p["frame"]) for p in points])
-        f = extractor(frames)
-        out[scene_name] = [{
-            "clip_conv": f["clip_conv"][i].clone(),
-            "clip_attnpool": f["clip_attnpool"][i].clone(),
-            "clip_avgpool": f["clip_avgpool"][i].clone(),
-            "object_presence": torch.as_tensor(p["object_presence"], dtype=torch.int64),
-            "object_localization": torch.as_tensor(p["object_localization"], dtype=torch.int64),
-            "free_space": int(p["free_space"]),
-        } for i, p in enumerate(points)]
+        f = extractor(torch.stack([torch.as_tensor(p["frame"]) for p in points]))
+        rows = []
+        for i, p in enumerate(points):
+            row = {k: v[i].clone() for k, v in f.items()}
+            row["object_presence"] = torch.as_tensor(p["object_presence"], dtype=torch.int64)
+            row["object_localization"] = torch.as_tensor(p["object_localization"], dtype=torch.int64)
+            row["free_space"] = int(p["free_space"])
+            rows.append(row)
+        out[scene_name] = rows
     return out
 
 
@@ -92,13 +113,14 @@ def write_thor_cache(output_dir: str, split: str, features: Dict[str, List[dict]
 
 
 def build_reachable_features(extractor, images: Dict[str, torch.Tensor]) -> Dict[str, Dict[str, torch.Tensor]]:
-    """{image_name: uint8 frame} -> {image_name: {clip_avgpool, clip_attnpool}} (reachable_image_features.py:94-98)."""
+    """{image_name: uint8 frame} -> {image_name: {imagenet_avgpool, clip_avgpool, clip_attnpool}}
+    (reachable_image_features.py:94-98; the pooled embeddings only)."""
     names = list(images)
     if not names:
         return {}
     f = extractor(torch.stack([torch.as_tensor(images[n]) for n in names]))
-    return {n: {"clip_avgpool": f["clip_avgpool"][i].clone(), "clip_attnpool": f["clip_attnpool"][i].clone()}
-            for i, n in enumerate(names)}
+    keep = [k for k in ("imagenet_avgpool", "clip_avgpool", "clip_attnpool") if k in f]
+    return {n: {k: f[k][i].clone() for k in keep} for i, n in enumerate(names)}
 
 
 def write_reachable_cache(output_dir: str, image_features, split_triples: Dict[str, Sequence[Tuple[str, int, bool]]]):
@@ -112,31 +134,36 @@ def write_reachable_cache(output_dir: str, image_features, split_triples: Dict[s
 # ------------------------------------------------------------------------------------------------
 # reader
 # ------------------------------------------------------------------------------------------------
+# which file holds a prediction type's rows, and which stored key feeds the probe (data.py:15-19: the localisation probe
+# reads the conv map of the tower whose pooled embedding was asked for)
+_FRAME_TASKS = ("object_presence", "object_localization", "free_space")
+_CONV_KEY = {"imagenet_avgpool": "imagenet_conv", "clip_avgpool": "clip_conv"}
+
+
 class THOREmbeddingsDataset:
-    """data.py:9-47, same constructor and item format."""
+    """Reader of the cache schema with the constructor and item format of data.py:9-47: item = (embedding, prediction);
+    prediction = the stored label tensor / int, or (obj_idx, reachable) for the reachability triples."""
 
     def __init__(self, data_dir: str, split: str, embedding_type: str, prediction_type: str):
-        assert embedding_type in EMBEDDING_TYPES
-        assert prediction_type in PREDICTION_TYPES
+        if embedding_type not in EMBEDDING_TYPES or prediction_type not in PREDICTION_TYPES:
+            raise AssertionError((embedding_type, prediction_type))
         self.prediction_type = prediction_type
-        self.embeddings: list = []
-        self.predictions: list = []
-        if prediction_type in ("object_presence", "object_localization", "free_space"):
+        if prediction_type in _FRAME_TASKS:
+            key = embedding_type
             if prediction_type == "object_localization":
-                assert embedding_type in ("imagenet_avgpool", "clip_avgpool")
-                embedding_type = {"imagenet_avgpool": "imagenet_conv", "clip_avgpool": "clip_conv"}[embedding_type]
-            data = torch.load(os.path.join(data_dir, f"thor_{split}.pt"))
-            for _scene, frames in data.items():
-                for frame_features in frames:
-                    self.embeddings.append(frame_features[embedding_type])
-                    self.predictions.append(frame_features[prediction_type])
+                if embedding_type not in _CONV_KEY:
+                    raise AssertionError("object_localization probes the conv map: imagenet_avgpool / clip_avgpool only")
+                key = _CONV_KEY[embedding_type]
+            scenes = torch.load(os.path.join(data_dir, f"thor_{split}.pt"))
+            rows = [row for frames in scenes.values() for row in frames]
+            self.embeddings = [row[key] for row in rows]
+            self.predictions = [row[prediction_type] for row in rows]
         else:
-            image_features = torch.load(os.path.join(data_dir, "reachable_image_features.pt"))
-            with open(os.path.join(data_dir, f"reachable_{split}.pkl"), "rb") as f:
-                data = pickle.load(f)
-            for image, obj, reachable in data:
-                self.embeddings.append(image_features[image][embedding_type])
-                self.predictions.append((obj, torch.tensor(reachable, dtype=torch.int64)))
+            table = torch.load(os.path.join(data_dir, "reachable_image_features.pt"))
+            with open(os.path.join(data_dir, f"reachable_{split}.pkl"), "rb") as fh:
+                triples = pickle.load(fh)
+            self.embeddings = [table[image][embedding_type] for image, _obj, _r in triples]
+            self.predictions = [(obj, torch.tensor(r, dtype=torch.int64)) for _image, obj, r in triples]
 
     def __getitem__(self, index):
         return self.embeddings[index], self.predictions[index]

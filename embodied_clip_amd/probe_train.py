@@ -4,7 +4,7 @@
         --embedding-type clip_avgpool --prediction-type object_presence --gpus 1
 
 Extra flags (not in the reference): ``--synthetic-frames N`` first writes a synthetic feature cache into
-``--data-dir`` by running N seeded frames through the HIP CLIP-RN50 encoder (there are no simulator frames or
+``--data-dir`` by running N seeded frames through the HIP CLIP-RN50 and ImageNet-ResNet-50 encoders (there are no simulator frames or
 pretrained weights in this environment); ``--epochs`` (default 250 == ``max_epochs=250``, train.py:158);
 ``--batch-size`` (reference hard-codes 128, train.py:136; BASELINE config 1 quotes 32).
 
@@ -33,7 +33,8 @@ from .probe_data import (EMBEDDING_TYPES, PREDICTION_TYPES, ClipFeatureExtractor
 
 def write_synthetic_cache(data_dir: str, n_frames: int, device="cuda:0", seed: int = 1) -> float:
     """80/10/10 split of n_frames synthetic points; returns encoder frames/s."""
-    ex = ClipFeatureExtractor(syn.rn50_visual_state_dict(0), device=device)
+    # both towers of the feature scripts (thor_image_features.py:46-67): CLIP-RN50 and torchvision ResNet-50
+    ex = ClipFeatureExtractor(syn.rn50_visual_state_dict(0), device=device, imagenet_state_dict=syn.tv_resnet_state_dict(0))
     n_val = max(1, n_frames // 10)
     sizes = {"train": n_frames - 2 * n_val, "val": n_val, "test": n_val}
     t0 = time.time()

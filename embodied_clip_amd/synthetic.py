@@ -145,6 +145,53 @@ def rn50_visual_state_dict(seed: int = 0, width: int = 64, layers: Sequence[int]
 
 
 # --------------------------------------------------------------------------
+# torchvision ResNet-50 (the ImageNet branch of the feature scripts)
+# --------------------------------------------------------------------------
+
+IMAGENET_RGB_MEANS = (0.485, 0.456, 0.406)
+IMAGENET_RGB_STDS = (0.229, 0.224, 0.225)
+
+
+def tv_resnet_state_dict(seed: int = 0, width: int = 64, layers: Sequence[int] = (3, 4, 6, 3),
+                         with_fc: bool = False) -> "OrderedDict[str, torch.Tensor]":
+    """Synthetic ``torchvision.models.resnet50().state_dict()`` (the network behind ``imagenet_conv`` /
+    ``imagenet_avgpool``: primitive_probing/generate_data/thor_image_features.py:46-49).  Key layout: ``conv1.weight``
+    [w,3,7,7], ``bn1.*``, ``layer{1..4}.{b}.conv{1,2,3}.weight`` / ``bn{1,2,3}.*`` / ``downsample.{0,1}.*`` (+ ``fc.*``
+    with ``with_fc``; the reference drops avgpool and fc).  ResNet-50: 23,508,032 parameters without fc."""
+    sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    _conv(sd, seed, "tv.conv1.weight", width, 3, 7)
+    sd["conv1.weight"] = sd.pop("tv.conv1.weight")
+    _bn(sd, seed, "bn1", width)
+    inplanes = width
+    for li, (nblocks, mult) in enumerate(zip(layers, (1, 2, 4, 8)), start=1):
+        planes = width * mult
+        for b in range(nblocks):
+            stride = 2 if (b == 0 and li > 1) else 1
+            p = f"layer{li}.{b}"
+            _conv(sd, seed, p + ".conv1.weight", planes, inplanes, 1)
+            _bn(sd, seed, p + ".bn1", planes)
+            _conv(sd, seed, p + ".conv2.weight", planes, planes, 3)
+            _bn(sd, seed, p + ".bn2", planes)
+            _conv(sd, seed, p + ".conv3.weight", planes * 4, planes, 1)
+            _bn(sd, seed, p + ".bn3", planes * 4, gamma_scale=0.3)      # damped residual branch, as in rn50_visual_state_dict
+            if stride > 1 or inplanes != planes * 4:
+                _conv(sd, seed, p + ".downsample.0.weight", planes * 4, inplanes, 1)
+                _bn(sd, seed, p + ".downsample.1", planes * 4, gamma_scale=0.7)
+            inplanes = planes * 4
+    if with_fc:
+        sd["fc.weight"] = _normal(seed, "fc.weight", (1000, inplanes), inplanes ** -0.5)
+        sd["fc.bias"] = _normal(seed, "fc.bias", (1000,), 0.01)
+    return sd
+
+
+def normalize_rgb_imagenet(u8: torch.Tensor) -> torch.Tensor:
+    """ToTensor + Normalize(ImageNet mean / std) of ``resnet_preprocess`` (thor_image_features.py:36-44), NHWC."""
+    mean = torch.tensor(IMAGENET_RGB_MEANS, dtype=torch.float32, device=u8.device)
+    std = torch.tensor(IMAGENET_RGB_STDS, dtype=torch.float32, device=u8.device)
+    return (u8.to(torch.float32) / 255.0 - mean) / std
+
+
+# --------------------------------------------------------------------------
 # CLIP VisionTransformer (ViT-B/32) visual tower
 # --------------------------------------------------------------------------
 

@@ -192,6 +192,24 @@ int ec_conv3x3_img_pack(const void* w, void* packed, int C, ec_stream_t stream);
 int ec_conv3x3_img_bf16(const void* in, const void* packed, const float* bias, void* out, int B, int H, int W, int C,
                         int pool, ec_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * torchvision ResNet-50 pieces: the ImageNet half of the feature scripts,
+ * `resnet_model = Sequential(*list(models.resnet50(pretrained=True).children())[:-2])`
+ * (primitive_probing/generate_data/thor_image_features.py:46-49,102-106; reachable_image_features.py:48-51,81-85).
+ * ---------------------------------------------------------------------- */
+/* Stride-2 convolution (1x1, or 3x3 with pad 1) + folded BatchNorm (+ residual) + activation: ResNet v1.5 strides
+ * inside Bottleneck.conv2 and in the downsample conv, where CLIP's ModifiedResNet pools.  in bf16 [B,H,W,Cin] (H, W
+ * even); w bf16 [Cout][k*k*Cin]; res / out bf16 [B,H/2,W/2,Cout].  Cin % 8 == 0, Cout % 64 == 0; act NONE or RELU. */
+int ec_conv_bf16_s2(const void* in, const void* w, const float* bias, const void* res, void* out, int B, int H, int W,
+                    int Cin, int Cout, int ksize, int act, ec_stream_t stream);
+/* conv1 (7x7, stride 2, pad 3, 3 -> 64) + bn1 (folded) + ReLU + MaxPool2d(3, 2, 1) in one launch (the conv output never
+ * touches HBM).  rgb: fp32 NHWC [B,H,W,3], ImageNet-normalised (u8 == 0), or raw uint8 NHWC with ToTensor +
+ * Normalize(mean, std) of `resnet_preprocess` (thor_image_features.py:36-44) fused (u8 == 1; h_mean3 / h_std3 HOST
+ * pointers to 3 floats).  w bf16 [64][176]: K = 7 rows (ky) of 24 slots, slot kx*3+ci < 21 real, the rest and the
+ * last 8 zero; bias f32 [64]; out bf16 [B,H/4,W/4,64].  H, W multiples of 4. */
+int ec_stem7_pool(const void* rgb, int u8, const float* h_mean3, const float* h_std3, const void* w, const float* bias,
+                  void* out, int B, int H, int W, ec_stream_t stream);
+
 /* AvgPool2d(2) on bf16 NHWC ([U] Bottleneck downsample "-1"). C multiple of 8. */
 int ec_avgpool2_bf16(const void* in, void* out, int B, int H, int W, int C, ec_stream_t stream);
 
@@ -224,6 +242,13 @@ typedef struct ec_rn50 ec_rn50_t;
  * The handle borrows the device pointers (caller keeps them alive). */
 int ec_rn50_create(ec_rn50_t** out, int width, const int* layers4, int input_resolution,
                    const float* stem_w_f32, const void* w_bf16, size_t n_w, const float* bias, size_t n_bias);
+/* The torchvision ResNet trunk (width 64) behind the same handle type: every ec_rn50_* function below applies.
+ * stem_w_bf16 = conv1 in ec_stem7_pool's layout; `w_bf16` / `bias` hold per block conv1, conv2, conv3, [downsample]
+ * (bias: stem first) exactly as for ec_rn50_create.  ec_rn50_forward takes the ImageNet-normalised fp32 frame,
+ * ec_rn50_forward_u8 the raw frame + IMAGENET mean / std.  Output bf16 NHWC [B,R/32,R/32,2048] == `imagenet_conv`
+ * (thor_image_features.py:105,130) before its `.float()` / NCHW view. */
+int ec_rn50tv_create(ec_rn50_t** out, const int* layers4, int input_resolution, const void* stem_w_bf16,
+                     const void* w_bf16, size_t n_w, const float* bias, size_t n_bias);
 void ec_rn50_destroy(ec_rn50_t* h);
 size_t ec_rn50_workspace_bytes(const ec_rn50_t* h, int batch);
 int ec_rn50_out_channels(const ec_rn50_t* h);

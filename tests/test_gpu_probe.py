@@ -124,3 +124,59 @@ def test_feature_cache_writer_roundtrip_and_cli(tmp_path):
         probe_train.main(["--data-dir", d, "--log-dir", str(tmp_path / "logs"), "--epochs", "1", "--batch-size", "16",
                           "--embedding-type", emb, "--prediction-type", task])
     assert os.path.exists(str(tmp_path / "logs" / "clip_avgpool_object_presence.pt"))
+
+
+def test_feature_cache_all_five_embedding_keys_and_imagenet_probe(tmp_path):
+    """thor_image_features.py:129-138 stores FIVE embeddings per frame: imagenet_conv / imagenet_avgpool (torchvision ResNet-50
+    minus avgpool + fc, :46-54,102-106) next to the three clip_* keys; reachable_image_features.py:94-98 the three pooled ones.
+    Raw 300x300 frames (thor_frames.py:33-34) take ONE Pillow-exact resize for both towers.  The ImageNet embeddings are
+    checked against oracle/tv_resnet.py (pinned vs HuggingFace ResNetModel); then the probe CLI runs on imagenet_avgpool."""
+    from embodied_clip_amd import probe_data as pd
+    from embodied_clip_amd import probe_train
+    from oracle import preprocess as opp
+    from oracle import tv_resnet as otv
+    sd_clip, sd_tv = syn.rn50_visual_state_dict(0), syn.tv_resnet_state_dict(0)
+    ex = pd.ClipFeatureExtractor(sd_clip, device="cuda:0", batch=4, imagenet_state_dict=sd_tv)
+    raw = syn.synthetic_rgb_u8(12, 3, 300)
+    pts = [{"frame": raw[i], "object_presence": torch.zeros(52, dtype=torch.int64),
+            "object_localization": torch.zeros(9, 52, dtype=torch.int64), "free_space": i} for i in range(3)]
+    feats = pd.build_thor_features(ex, {"FloorPlan1": pts})
+    f0 = feats["FloorPlan1"][0]
+    assert set(f0) == {"imagenet_conv", "imagenet_avgpool", "clip_conv", "clip_attnpool", "clip_avgpool", "object_presence",
+                       "object_localization", "free_space"}
+    assert f0["imagenet_conv"].shape == (2048, 7, 7) and f0["imagenet_conv"].dtype == torch.float32
+    assert f0["imagenet_avgpool"].shape == (2048,)
+    # oracle: Pillow-exact resize (oracle/preprocess.py, checked against PIL) -> ImageNet normalisation -> torchvision trunk
+    resized = torch.stack([torch.from_numpy(opp.clip_resize_crop_u8(raw[i].numpy(), 224)) for i in range(2)])
+    ref_conv, ref_avg = otv.imagenet_features(syn.normalize_rgb_imagenet(resized), sd_tv)
+    rel = lambda a, b: float((a - b).norm() / b.norm())  # noqa: E731
+    got_conv = torch.stack([feats["FloorPlan1"][i]["imagenet_conv"] for i in range(2)])
+    got_avg = torch.stack([feats["FloorPlan1"][i]["imagenet_avgpool"] for i in range(2)])
+    assert rel(got_conv, ref_conv) < 2e-2, rel(got_conv, ref_conv)
+    assert rel(got_avg, ref_avg) < 2e-2
+    # cache round trip through the reader, every embedding type
+    d = str(tmp_path / "data")
+    for split in ("train", "val", "test"):
+        pd.write_thor_cache(d, split, feats)
+    reach = pd.build_reachable_features(ex, {f"img{i}": raw[i] for i in range(3)})
+    assert set(reach["img0"]) == {"imagenet_avgpool", "clip_avgpool", "clip_attnpool"}
+    assert torch.equal(reach["img1"]["imagenet_avgpool"], feats["FloorPlan1"][1]["imagenet_avgpool"])
+    pd.write_reachable_cache(d, reach, {s: pd.synthetic_reachability(k, list(reach), 5) for k, s in enumerate(("train", "val", "test"))})
+    for emb in pd.EMBEDDING_TYPES:
+        for task in pd.PREDICTION_TYPES:
+            if task == "object_localization" and emb == "clip_attnpool":
+                continue
+            ds = pd.THOREmbeddingsDataset(d, "train", emb, task)
+            x, _y = ds[0]
+            want = {"imagenet_avgpool": "imagenet_", "clip_avgpool": "clip_", "clip_attnpool": "clip_"}[emb]
+            if task == "object_localization":
+                assert torch.equal(x, f0[want + "conv"])
+            elif task != "reachability":
+                assert torch.equal(x, f0[emb])
+    # probe CLI over the ImageNet embeddings, synthetic cache with both towers
+    d2 = str(tmp_path / "data2")
+    probe_train.main(["--data-dir", d2, "--log-dir", str(tmp_path / "logs"), "--synthetic-frames", "40", "--epochs", "2",
+                      "--batch-size", "16", "--embedding-type", "imagenet_avgpool", "--prediction-type", "object_presence"])
+    probe_train.main(["--data-dir", d2, "--log-dir", str(tmp_path / "logs"), "--epochs", "1", "--batch-size", "16",
+                      "--embedding-type", "imagenet_avgpool", "--prediction-type", "object_localization"])
+    assert os.path.exists(str(tmp_path / "logs" / "imagenet_avgpool_object_presence.pt"))
