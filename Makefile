@@ -18,7 +18,20 @@ $(OUT): $(OBJS)
 	@mkdir -p $(dir $(OUT))
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
 
-clean:
-	rm -rf build $(OUT)
+# Tools-only build: the same sources with -DEC_TOOLS -DEC_CONV8_PROFILE -- adds the profiling exports that are NOT part of
+# the product library or of include/ec_amd.h (ec_bneck_set_debug, ec_debug_stamps, the EC_CONV_ABLATE instances of the
+# 8-wave kernel).  Used by tools/bench_bneck.py --stamps and tools/stamps8.py through tools/_toolslib.py.
+TOOLS_OUT  := embodied_clip_amd/lib/libec_amd_tools.so
+TOOLS_OBJS := $(patsubst $(CSRC)/%.hip,build_tools/%.o,$(SRCS))
+build_tools/%.o: $(CSRC)/%.hip $(CSRC)/common.h include/ec_amd.h
+	@mkdir -p build_tools
+	$(HIPCC) $(FLAGS) -DEC_TOOLS -DEC_CONV8_PROFILE -c $< -o $@
+$(TOOLS_OUT): $(TOOLS_OBJS)
+	@mkdir -p $(dir $(TOOLS_OUT))
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(TOOLS_OBJS)
+tools: $(TOOLS_OUT)
 
-.PHONY: all clean
+clean:
+	rm -rf build build_tools $(OUT) $(TOOLS_OUT)
+
+.PHONY: all clean tools

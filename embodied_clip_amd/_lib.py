@@ -20,24 +20,17 @@ SIGNATURES = {
     "ec_version": (c_int, []),
     "ec_strerror": (C.c_char_p, [c_int]),
     "ec_conv_bf16": (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p]),
-    "ec_conv_splitk_workspace_bytes": (c_size_t, [c_int] * 6),
     "ec_conv3x3_img_pack": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "ec_conv3x3_img_bf16": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
     "ec_bneck3_packed_elems": (c_size_t, [c_int]),
     "ec_bneck3_pack_weights": (c_int, [c_void_p] * 4 + [c_int, c_void_p]),
     "ec_bneck_conv123_bf16": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_void_p]),
-    "ec_bneck_band_packed_elems": (c_size_t, []),
-    "ec_bneck_band_pack_weights": (c_int, [c_void_p] * 5),
-    "ec_bneck_band_bf16": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_void_p]),
-    "ec_bneck_set_debug": (None, [c_void_p]),
     "ec_bneck_packed_elems": (c_size_t, [c_int]),
     "ec_bneck_pack_weights": (c_int, [c_void_p] * 3 + [c_int, c_void_p]),
     "ec_bneck_conv23_bf16": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_void_p]),
-    "ec_conv_bf16_ws": (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p, c_size_t, c_void_p]),
     "ec_clip_resize_table_ints": (c_size_t, [c_int, c_int, c_int]),
     "ec_clip_resize_table": (c_int, [c_int, c_int, c_int, c_void_p, c_size_t]),
     "ec_clip_resize_crop_u8": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
-    "ec_debug_stamps": (c_int, [c_void_p, c_int]),
     "ec_gemm_bf16": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
     "ec_split3_bf16": (c_int, [c_void_p] * 2 + [C.c_long, c_int, c_void_p]),
     "ec_gemm_bf16a_x3": (c_int, [c_void_p] * 4 + [C.c_long, c_int, c_int, c_int, c_void_p]),

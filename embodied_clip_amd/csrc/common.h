@@ -91,19 +91,6 @@ struct ec_min_tiles_scope {
     ~ec_min_tiles_scope() { ec_tls_conv8_min_tiles = prev; }
 };
 
-// Partial-sum workspace of the K-sliced conv launches (conv_igemm.hip dispatch_split): borrowed from the caller's workspace
-// for the duration of one call (ec_rn50_forward, ec_conv_bf16_ws); without it no launch is K-sliced.
-extern thread_local float* ec_tls_splitk_ws;
-extern thread_local size_t ec_tls_splitk_bytes;
-struct ec_splitk_scope {
-    float* prev; size_t prev_bytes;
-    ec_splitk_scope(void* ws, size_t bytes) : prev(ec_tls_splitk_ws), prev_bytes(ec_tls_splitk_bytes) {
-        ec_tls_splitk_ws = (float*)ws; ec_tls_splitk_bytes = ws ? bytes : 0;
-    }
-    ec_splitk_scope(const ec_splitk_scope&) = delete;
-    ~ec_splitk_scope() { ec_tls_splitk_ws = prev; ec_tls_splitk_bytes = prev_bytes; }
-};
-
 // Once-per-workgroup staging loops (weights -> LDS).  Written as `for (idx = tid; ...) lds[f(idx)] = global[g(idx)]` hipcc
 // emits load -> s_waitcnt vmcnt(0) -> ds_write per iteration: TOTAL / NT serial L2 round trips at the head of EVERY
 // launch (18 of them, ~15 us, in the narrow 3x3 kernels -- round-3 EC_ROWS_DBG ablation).  Here all of a thread's loads
@@ -132,56 +119,37 @@ __device__ __forceinline__ void ec_stage_all(int tid, LoadFn load, StoreFn store
 // ec_config_hash() goes into ec_rn50_plan_hash / ec_vit_plan_hash, so a profile under profiles/ names the switch
 // settings it was measured with.  DESIGN.md section 5.1 documents each variable.
 struct EcConfig {
+    // --- encoder: selection between ADOPTED kernel paths (each one is exercised by a parity test) ---
     int conv_narrow;      // EC_CONV_NARROW   (3)   narrow 3x3 kernels: 0 off, 1 gather (32 ch), 2 gather (also 64 ch), 3 row tiles
-    int conv_rowsn;       // EC_CONV_ROWSN    (1)   multi-row tiles for the un-pooled narrow 3x3 layers (2, 3: A/B variants)
-    int rows_dbg;         // EC_ROWS_DBG      (0)   profiling only: 1 no fetch, 2 no stores, 4 no MFMA stream
-    int conv_nbuf;        // EC_CONV_NBUF     (0)   force the LDS stage count of conv_igemm_kernel (0 = by tile size)
-    int conv_ablate;      // EC_CONV_ABLATE   (0)   profiling only (bit mask, see conv_igemm.hip)
-    int conv_wgs;         // EC_CONV_WGS      (768) persistent workgroup cap of conv_igemm_kernel
-    int conv_waves;       // EC_CONV_WAVES    (0)   8: 8-wave workgroups in conv_igemm_kernel
-    int conv_big;         // EC_CONV_BIG      (1)   0 no conv_igemm8, 1 where measured faster, 4 wherever it applies
+    int conv_rowsn;       // EC_CONV_ROWSN    (1)   multi-row tiles for the un-pooled narrow 3x3 layers (0: single-row tiles)
+    int conv_big;         // EC_CONV_BIG      (1)   0 no conv_igemm8, 1 where measured faster, 4 wherever it applies (tests)
     long conv8_min_tiles; // EC_CONV8_MIN_TILES (0) overrides the handles' dispatch threshold when > 0
     int conv8_bn128;      // EC_CONV8_BN128   (0)   1 with EC_CONV_BIG=4: force 128-wide tiles; -1: layer-2 3x3 convs stay on the 4-wave kernel
+    int conv8_longseg;    // EC_CONV8_LONGSEG (1)   conv_igemm8, 128-wide tiles: two segments per K-tile, three LDS stages (0: four segments)
     int conv_t224;        // EC_CONV_T224     (2)   196-of-224-row tiles: 0 off, 1 everywhere, 2 rule, 3 also 256-tile launches
     int conv_t64;         // EC_CONV_T64      (150) launches with fewer 128x128 tiles use 64x64 tiles
-    int conv_ring;        // EC_CONV_RING     (1)   ring pipeline for launches with <= 1-2 workgroups per CU (2: all, A/B)
+    int conv_ring;        // EC_CONV_RING     (1)   ring pipeline for launches with <= 1-2 workgroups per CU (0: single-stage loop)
     int conv_regw;        // EC_CONV_REGW     (1)   register-weight 1x1 kernel
-    int conv_regw_wide;   // EC_CONV_REGW_WIDE(0)   ... also for the wide (channel-group) shapes
+    int rn50_fuse;        // EC_RN50_FUSE     (1)   fused layer-1 / layer-2 block boundaries in the trunk plan
+    int rn50_bneck;       // EC_RN50_BNECK    (128) launches of at least this many frames run layer3.1-5 as fused bottleneck launches (conv_bneck.hip); 0: never
+    int rn50_bneck3;      // EC_RN50_BNECK3   (1)   the fused bottleneck launches include conv1 (the whole block in one launch)
+    int rn50_img3;        // EC_RN50_IMG3     (1)   small launches run the 14x14x256 (<= 32 frames) / 7x7x512 (<= 64 frames) 3x3 convs on the image-resident K-split kernel
+    // --- policy / update ---
     int gemm_no_x3;       // EC_GEMM_NO_X3    (0)   policy GEMMs on the fp32 MFMA instead of bf16x3
     int gemm_bwd3;        // EC_GEMM_BWD3     (0)   ec_policy_backward's large gradient GEMMs on three of the six bf16x3 products
-    int act_split;        // EC_ACT_SPLIT     (1)   act step: fixed 4-way K split of the two long-K GEMMs
+    int act_split;        // EC_ACT_SPLIT     (1)   act step: K-split kernels for its two long-K GEMMs
     int tail_fused;       // EC_TAIL_FUSED    (1)   compressor tail / combiner fused kernels
     int gru_fused;        // EC_GRU_FUSED     (2)   0 GEMM + gate kernels, 1 fused 32x32-tile step kernels, 2 + 16x16-tile kernels in the update
     int c1_pingpong;      // EC_C1_PINGPONG   (1)   compressor conv 1 over stored features on the 8-wave kernel
     int dw1_tr;           // EC_DW1_TR        (1)   dW1 on the transpose-read kernel
-    int rn50_fuse;        // EC_RN50_FUSE     (1)   fused layer-1 / layer-2 block boundaries in the trunk plan
     int wih_perm;         // EC_WIH_PERM      (1)   learn pass: re-ordered weight_ih instead of activation transposes
     int dw_transposed;    // EC_DW_TRANSPOSED (1)   GRU weight-gradient GEMMs on transposed (K-contiguous) operands
-    int conv8_dirb;       // EC_CONV8_DIRB    (0)   conv_igemm8: weight fragments global -> VGPR (only the im2col operand through LDS)
-    int conv8_longseg;    // EC_CONV8_LONGSEG (1)   conv_igemm8, 128-wide tiles: two segments per K-tile, three LDS stages
-    int conv8_res128;     // EC_CONV8_RES128  (1)   residual 1x1 launches, K 512..2047, < 100 256-wide tiles: 128-wide 8-wave tiles
-    int conv8_lowfill_k;  // EC_CONV8_LOWFILL_K (1024) shortest K of a low-fill 1x1 launch that takes 128-wide 8-wave tiles
-    int conv8_lowfill;    // EC_CONV8_LOWFILL (100) 3x3 launches with fewer 256-wide tiles than this take 128-wide ones
-    int conv_ring_ilv;    // EC_CONV_RING_ILV (1)   ring-mode launches issue their LDS-DMA pieces between the MFMAs of the running K-tile
-    int conv_ring_w8;     // EC_CONV_RING_W8  (0)   128x128 ring launches on 8 waves (2 x 4) instead of 4
-    int rn50_side;        // EC_RN50_SIDE     (0)   launches of at most this many frames run the stride-2 blocks' downsample branch on a side stream (0: never; measured: slower)
-    int rn50_bneck;       // EC_RN50_BNECK    (128) launches of at least this many frames run layer3.1-5's conv2 + conv3 as ONE fused launch (conv_bneck.hip); 0: never
-    int rn50_band;        // EC_RN50_BAND     (0)   fewest frames per launch for which layer2.1-3 run as band-fused launches (0: never)
-    int rn50_band_max;    // EC_RN50_BAND_MAX (1 << 30) ... and the most
-    int rn50_bneck3;      // EC_RN50_BNECK3   (1)   the fused bottleneck launches include conv1 (the whole block in one launch)
-    int bneck_stagger;    // EC_BNECK_STAGGER (0)   units of 512 clocks by which waves 4-7 of the fused bottleneck launch enter conv3 late
-    int rn50_img3;        // EC_RN50_IMG3     (1)   small launches run the 14x14x256 (<= 32 frames) / 7x7x512 (<= 64 frames) 3x3 convs on the image-resident K-split kernel
-    int conv_splitk;      // EC_CONV_SPLITK   (1)   fixed K partition for low-tile-count launches: 0 off, 1 rule, 2..8 forced slice count
-    int conv_splitk_tiles;  // EC_CONV_SPLITK_TILES (200) the rule applies below this many 128x128 tiles
-    int conv_splitk_target; // EC_CONV_SPLITK_TARGET (400) slices = ceil(target / tiles): workgroups the K-sliced launch aims at
-    int conv_splitk_ns;   // EC_CONV_SPLITK_NS (2)  LDS stages of the K-sliced launches (2: double buffer, 2 workgroups per CU; 3: ring)
-    int conv_splitk_tile; // EC_CONV_SPLITK_TILE (128) output tile of the K-sliced launches (64: 64x64 tiles, 4-stage ring)
 };
+// Fixed since round 5 (measured winners; the A/B numbers live in docs/experiments.md): 768 persistent workgroups, residual 1x1
+// launches of K 512..2047 with < 100 256-wide tiles on 128-wide 8-wave tiles, low-fill limits 100 tiles / K >= 1024, ring-mode
+// LDS-DMA pieces interleaved with the MFMAs, 128 x 128 ring tiles on 8 waves.
+constexpr int EC_CONV8_LOWFILL = 100, EC_CONV8_LOWFILL_K = 1024;
 const EcConfig& ec_config();          // api.hip
-// conv_igemm.hip (internal): ec_conv_bf16 with an optional fragment-order copy of the weights (ec_pack_wfrag)
-int ec_conv_bf16_wf(const void* in, const void* w, const void* wf, const float* bias, const void* res, void* out, int B, int H,
-                    int W, int Cin, int Cout, int ksize, int pool, int act, ec_stream_t stream);
-int ec_pack_wfrag(const void* w, void* wf, int Cout, int K, hipStream_t s);
 uint64_t ec_config_hash();            // FNV-1a over the fields above
 
 #define EC_CHECK_LAUNCH()                                   \

@@ -589,7 +589,7 @@ int launch_rowsN(const N3Args& p, hipStream_t s) {
     static_assert(lds <= 160 * 1024, "LDS budget");
     static_assert(((RT + 2) * RPB + 4 * PITCH) % 16 == 0, "image alignment");
     auto kern = conv3x3_rowsN_kernel<CIN, COUT, RT, NW, LEADK>;
-    const int dbg = ec_config().rows_dbg;
+    const int dbg = 0;   // (profiling field of the kernel arguments: EC_ROWS_DBG existed in rounds 3-4)
     N3Args q = p;
     q.dbg = dbg;
     static std::atomic<uint64_t> attr_done{0};

@@ -54,7 +54,6 @@ struct BneckArgs {
     const float* b1;       // F1: [C]
     int B;
     unsigned w2_bytes, w3_bytes, w1_bytes;
-    int stagger;               // units of 512 clocks by which waves 4-7 enter conv3 late
     unsigned long long* dbg;   // profiling only (ec_bneck_set_debug): workgroup 0 stores {s_memtime, s_memrealtime} at entry / phase ends
 };
 
@@ -80,13 +79,20 @@ __device__ __forceinline__ void tie2(u32x2_t& d) { asm volatile("" : "+v"(d)); }
 // ring of 16-KB K-tiles (256 rows x 32 k, inside T's still unused area; every wave issues two of a K-tile's sixteen 1-KB pieces
 // next to its two private weight pieces: four per wave and K-tile, so the counted vmcnt stays uniform) with ONE raw barrier per
 // K-tile (ring mode of conv_igemm: own pieces landed -> barrier -> issue K-tile kt + 2 -> fragments + MFMAs).
-template <int C, int HW, bool F1 = false>
+// WEMU (tools build only, tools/bench_bneck.py --wino-emu): FEED EMULATION of a Winograd F(2x2, 3x3) conv2 -- NOT a conv (the
+// results are garbage): conv2's K loop is run with the operand traffic and the MFMA count the Winograd form would have in this
+// kernel's structure -- 16 positions x (C / 32) K-tiles of PRIVATE transformed weights per wave (16 C^2 instead of 9 C^2
+// elements: 2.1 MB per image through the L2 -> LDS path) against 2 pixel blocks (49 tiles of 2 x 2 outputs -> 64 rows) instead
+// of 7 -- i.e. an UPPER bound of what the transform could buy (input / output transforms, their barriers and the LDS for the
+// transformed map are not charged).  docs/experiments.md section C has the stamps.
+template <int C, int HW, bool F1 = false, bool WEMU = false>
 __global__ __launch_bounds__(512, 2) void bneck23_kernel(BneckArgs p) {
     constexpr int PIX = HW * HW, MB = (PIX + 31) / 32;          // 196 pixels, 7 blocks of 32
     constexpr int PITCH = C * 2 + 16;                            // T row pitch (bytes): +16 staggers the banks between rows
     constexpr int T_BYTES = (PIX + 1) * PITCH;                   // + the zero row (index PIX)
     constexpr int BK = 32, NS = 3, STAGE = 32 * BK * 2, RING = NS * STAGE;   // per-wave weight ring: 3 x 2 KB
-    constexpr int K2 = 9 * C, NK2 = K2 / BK, KT_PER_TAP = C / BK;
+    constexpr int NTAP = WEMU ? 16 : 9, MBC2 = WEMU ? 2 : (PIX + 31) / 32;   // (taps | Winograd positions; pixel blocks of conv2's K loop)
+    constexpr int K2 = NTAP * C, NK2 = K2 / BK, KT_PER_TAP = C / BK;
     constexpr int K3 = C, NK3 = K3 / BK, NPASS = 4 * C / 256;
     static_assert(C == 256, "8 waves x 32 channels");
     static_assert(T_BYTES + 8 * RING <= 160 * 1024, "LDS budget");
@@ -189,6 +195,12 @@ __global__ __launch_bounds__(512, 2) void bneck23_kernel(BneckArgs p) {
                                                              acc[i], 0, 0, 0);
     };
 
+    [[maybe_unused]] auto mma2 = [&](int par) {                 // (WEMU: two pixel blocks)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fb[par]), __builtin_bit_cast(bf16x8_t, fa[par][i]),
+                                                             acc[i], 0, 0, 0);
+    };
     if constexpr (F1) {
         // =================================================================================================================
         // conv1: c1 = relu(x W1^T + b1), K = 4C; x through the shared ring in T's area, W1 through the private rings
@@ -277,17 +289,17 @@ __global__ __launch_bounds__(512, 2) void bneck23_kernel(BneckArgs p) {
     // =====================================================================================================================
     zero_acc();
     int st = 0;                                                  // ring stage of the K-tile being computed
-    for (int tap = 0; tap < 9; ++tap) {
+    for (int tap = 0; tap < NTAP; ++tap) {
         const int ky = (tap * 11) >> 5, kx = tap - ky * 3;       // tap / 3, tap % 3
-        const int shift = ((ky - 1) * HW + (kx - 1)) * PITCH;
+        const int shift = WEMU ? 0 : ((ky - 1) * HW + (kx - 1)) * PITCH;
         unsigned aaddr[MB];
 #pragma unroll
-        for (int i = 0; i < MB; ++i) aaddr[i] = ((pmask[i] >> tap) & 1u) ? pbase[i] + (unsigned)shift : zbase;
+        for (int i = 0; i < MB; ++i) aaddr[i] = (WEMU || ((pmask[i] >> tap) & 1u)) ? pbase[i] + (unsigned)shift : zbase;
         // first k-step of the tap: its K-tile's pieces must have landed (the two newest pieces in flight belong to the next tile)
         asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         {
             const unsigned bb = ring_lds + st * STAGE + boff[0];
-            [&]<int... I>(std::integer_sequence<int, I...>) { (lds_read16<0>(fa[0][I], aaddr[I]), ...); }(std::make_integer_sequence<int, MB>{});
+            [&]<int... I>(std::integer_sequence<int, I...>) { (lds_read16<0>(fa[0][I], aaddr[I]), ...); }(std::make_integer_sequence<int, MBC2>{});
             lds_read16<0>(fb[0], bb);
         }
         [&]<int... S>(std::integer_sequence<int, S...>) {
@@ -308,15 +320,15 @@ __global__ __launch_bounds__(512, 2) void bneck23_kernel(BneckArgs p) {
                     const unsigned bb = ring_lds + stn * STAGE + boff[ks1];
                     [&]<int... I>(std::integer_sequence<int, I...>) {
                         (lds_read16<j1 * 64 + ks1 * 32>(fa[par ^ 1][I], aaddr[I]), ...);
-                    }(std::make_integer_sequence<int, MB>{});
+                    }(std::make_integer_sequence<int, MBC2>{});
                     lds_read16<0>(fb[par ^ 1], bb);
-                    asm volatile("s_waitcnt lgkmcnt(%0)" : : "n"(MB + 1));
+                    asm volatile("s_waitcnt lgkmcnt(%0)" : : "n"(MBC2 + 1));
                 } else {
                     asm volatile("s_waitcnt lgkmcnt(0)");
                 }
-                [&]<int... I>(std::integer_sequence<int, I...>) { (tie(fa[par][I]), ...); }(std::make_integer_sequence<int, MB>{});
+                [&]<int... I>(std::integer_sequence<int, I...>) { (tie(fa[par][I]), ...); }(std::make_integer_sequence<int, MBC2>{});
                 tie(fb[par]);
-                mma(par);
+                if constexpr (WEMU) mma2(par); else mma(par);
                 if constexpr (ks == 1) { st = st + 1; st = st >= NS ? st - NS : st; }
             }(), ...);
         }(std::make_integer_sequence<int, 2 * KT_PER_TAP>{});
@@ -353,13 +365,6 @@ __global__ __launch_bounds__(512, 2) void bneck23_kernel(BneckArgs p) {
     issue_w3(0, 1, 1);
     __syncthreads();                                             // T now holds c2
     stamp(3);
-    // Anti-phase the two waves of every SIMD (waves w and w + 4): a conv3 pass is a K loop (3.6 k clocks of MFMA issue per
-    // wave) followed by an epilogue of dependent LDS round trips (~6 k clocks, no MFMAs).  Started together, both waves of a
-    // SIMD share the matrix pipe in the K loop and then leave it idle together (13.3 k clocks per pass); with one of them
-    // started ~one K loop later, each wave's epilogue runs beside the other's K loop.  (EC_BNECK_STAGGER clocks / 64.)
-    if (wave >= 4)
-        for (int q = 0; q < p.stagger; ++q) __builtin_amdgcn_s_sleep(8);      // 8 x 64 clocks per iteration
-
     // =====================================================================================================================
     // conv3: four passes of 256 output channels (32 per wave), K = C; epilogue per 32-pixel block through the free ring stage
     // =====================================================================================================================
@@ -744,369 +749,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_img_kernel(ImgArgs p) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// bneck_band_kernel: the whole stride-1 Bottleneck of the 28 x 28 stage (CLIP-RN50 layer2.1 .. layer2.3: 512 -> 128 -> 128 -> 512)
-// in ONE launch.  A 28 x 28 x 128 map is 200 KB, so a workgroup owns a BAND of 7 output rows of one image (196 pixels: the
-// M of the 14 x 14 stage) and keeps conv1's output for the band plus one halo row above and below resident in LDS (T: 252 rows
-// x 256 B + pad + a zero row = 69 KB); the halo rows' conv1 is recomputed by the neighbouring bands (9 / 7 of conv1's flops,
-// 4 % of the block's).  Today the block is two bandwidth-bound launches (`conv1x1_pair512_kernel` + a 3 x 3 conv: 3 KB per
-// pixel through HBM at 4.3 TB/s); fused it reads x once (+ the halo rows) and writes y once: 2 KB per pixel, c1 / c2 never in HBM.
-//   * 8 waves = 2 (M halves: pixel blocks 0-3 / 4-7) x 4 (N blocks of 32 channels); wave tile 4 x 1 accumulator tiles.  The
-//     two waves of an N block each stream their own copy of the weight K-tiles through a private 3-stage ring (2 KB tiles,
-//     streaming-order packed weights, counted vmcnt): no barrier in the conv2 / conv3 K loops.
-//   * conv1: the band's 252 x-rows stream through a SHARED 3-stage ring of 16-KB K-tiles inside T's still unused area, one raw
-//     barrier per K-tile (as bneck23_kernel<.., F1>); rows outside the image produce zeros in T (they are conv2's padding).
-//   * conv2: taps are row shifts inside T (the halo rows are physically there: only the left / right image border masks a
-//     tap, onto the zero row); conv3: four passes of 128 channels, epilogue per 32-pixel block through the wave's free ring
-//     stage with the identity rows (bias + identity + ReLU + one rounding), 64 B contiguous per pixel in and out.
-// Same rounding points and per-element K order as the unfused launches: bit-identical results.
-struct BandArgs {
-    const uint16_t* x;     // [B][28*28][512] block input (conv1's input and the identity)
-    const uint16_t* w;     // packed: conv2 [128][1152], conv3 [512][128], conv1 [128][512] in streaming order
-    const float *b1, *b2, *b3;
-    uint16_t* y;           // [B][784][512]
-    int B;
-    unsigned long long* dbg;   // profiling only (ec_bneck_set_debug)
-};
-
-__global__ __launch_bounds__(512, 1) void bneck_band_kernel(BandArgs p) {
-    constexpr int C = 128, CX = 512, IW = 28, BH = 7, NBAND = IW / BH, PIXB = BH * IW;       // 196 output pixels per band
-    constexpr int TROWS = (BH + 2) * IW;                         // 252 rows of c1 (band + halo rows)
-    constexpr int PITCH = C * 2 + 16, T_BYTES = (TROWS + 1) * PITCH;   // + the zero row (index TROWS)
-    constexpr int BK = 32, NS = 3, STAGE = 32 * BK * 2, RING = 5 * STAGE;   // per wave: 4 weight stages (3 in conv2) + the epilogue tile
-    constexpr int NX = 4;                                        // stages of conv1's shared x ring
-    constexpr int K1 = CX, NK1 = K1 / BK, K2 = 9 * C, NK2 = K2 / BK, KT_PER_TAP = C / BK, K3 = C, NK3 = K3 / BK, NPASS = CX / C;
-    constexpr int FM = 4;                                        // pixel blocks per wave
-    constexpr int XSTAGE = 256 * BK * 2;
-    static_assert(NX * XSTAGE <= TROWS * PITCH && T_BYTES + 8 * RING <= 160 * 1024, "LDS budget");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* T = smem;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nb = wave & 3, mh = wave >> 2;                     // N block (32 channels) / M half
-    const int frow = lane & 31, hh = lane >> 5;
-    unsigned char* ring = smem + T_BYTES + wave * RING;
-    const unsigned ring_lds = (unsigned)(unsigned long)(lds_void_t*)ring;
-    const unsigned t_lds = (unsigned)(unsigned long)(lds_void_t*)T;
-    const int img = blockIdx.x / NBAND, band = blockIdx.x - img * NBAND;
-    const uint16_t* w2p = p.w;
-    const uint16_t* w3p = p.w + (size_t)C * K2;
-    const uint16_t* w1p = w3p + (size_t)CX * K3;
-    const __amdgpu_buffer_rsrc_t rs_w1 = __builtin_amdgcn_make_buffer_rsrc((void*)w1p, 0, (unsigned)(C * K1 * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_w2 = __builtin_amdgcn_make_buffer_rsrc((void*)w2p, 0, (unsigned)(C * K2 * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_w3 = __builtin_amdgcn_make_buffer_rsrc((void*)w3p, 0, (unsigned)(CX * K3 * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)img * IW * IW * CX), 0,
-                                                                          (unsigned)(IW * IW * CX * 2), 0x00020000);
-    unsigned boff[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) boff[ks] = (unsigned)(frow * 64 + (((2 * ks + hh) ^ ((frow >> 2) & 3)) << 4));
-    if (tid < PITCH / 16) *reinterpret_cast<uint4*>(T + TROWS * PITCH + tid * 16) = make_uint4(0, 0, 0, 0);   // T's zero row
-
-    auto stamp = [&](int slot) {   // profiling only (ec_bneck_set_debug)
-        if (p.dbg && blockIdx.x == 0 && tid == 0) {
-            p.dbg[2 * slot] = __builtin_amdgcn_s_memtime();
-            p.dbg[2 * slot + 1] = __builtin_amdgcn_s_memrealtime();
-        }
-    };
-    stamp(0);
-    f32x16_t acc[FM];
-    auto zero_acc = [&]() {
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    };
-    u32x4_t fa[2][FM], fb[2];
-    auto mma = [&](int par) {
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fb[par]), __builtin_bit_cast(bf16x8_t, fa[par][i]),
-                                                             acc[i], 0, 0, 0);
-    };
-    // weight K-tile kt of 32-row slice `slice` (of a matrix with nk K-tiles) -> ring stage stg
-    auto issue_w = [&](const __amdgpu_buffer_rsrc_t& rs, int slice, int nk, int kt, int stg) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const unsigned off = kt < nk ? (unsigned)((slice * nk + kt) * STAGE + j * 1024 + lane * 16) : 0xFFFFFFF0u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(ring + stg * STAGE + j * 1024), 16, off, 0, 0, 0);
-        }
-    };
-
-    // =====================================================================================================================
-    // conv1 over the band's 252 rows (256 with padding): c1 = relu(x W1^T + b1); rows outside the image -> 0
-    // =====================================================================================================================
-    {
-        unsigned xsrc[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {                            // ring piece (2 wave + j): T rows 16 (2 wave + j) + lane / 4
-            const int t = (2 * wave + j) * 16 + (lane >> 2), sc = (lane & 3) ^ ((t >> 2) & 3);
-            const int gy = band * BH - 1 + t / IW, gx = t - (t / IW) * IW;
-            xsrc[j] = (t < TROWS && gy >= 0 && gy < IW) ? (unsigned)(((gy * IW + gx) * CX + sc * 8) * 2) : 0xFFFFFFF0u;
-        }
-        auto issue1 = [&](int kt, int stg) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const unsigned xo = (kt < NK1 && xsrc[j] != 0xFFFFFFF0u) ? xsrc[j] + (unsigned)kt * (BK * 2) : 0xFFFFFFF0u;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_t*)(T + stg * XSTAGE + (2 * wave + j) * 1024), 16, xo, 0, 0, 0);
-            }
-            issue_w(rs_w1, nb, NK1, kt, stg);
-        };
-        // Fragments run one K-tile ahead of the MFMAs, across the K-tile's barrier: right after the barrier that publishes K-tile
-        // kt + 1 a wave issues its LDS reads, then the MFMAs of K-tile kt (whose fragments it read one iteration earlier), so the
-        // LDS reads of all eight waves (80 KB per K-tile) run under the MFMAs instead of in a phase of their own.
-        u32x4_t ga[2][2][FM], gb[2][2];
-        auto rd1 = [&]<int SET>(std::integral_constant<int, SET>, int stg) {
-            const unsigned xa0 = t_lds + stg * XSTAGE + mh * (FM * 2048) + boff[0], xa1 = t_lds + stg * XSTAGE + mh * (FM * 2048) + boff[1];
-            const unsigned wb = ring_lds + stg * STAGE;
-            [&]<int... I>(std::integer_sequence<int, I...>) { (lds_read16<I * 2048>(ga[SET][0][I], xa0), ...); }(std::make_integer_sequence<int, FM>{});
-            lds_read16<0>(gb[SET][0], wb + boff[0]);
-            [&]<int... I>(std::integer_sequence<int, I...>) { (lds_read16<I * 2048>(ga[SET][1][I], xa1), ...); }(std::make_integer_sequence<int, FM>{});
-            lds_read16<0>(gb[SET][1], wb + boff[1]);
-        };
-        auto mm1 = [&]<int SET>(std::integral_constant<int, SET>) {
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-                for (int i = 0; i < FM; ++i) tie(ga[SET][ks][i]);
-                tie(gb[SET][ks]);
-#pragma unroll
-                for (int i = 0; i < FM; ++i)
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, gb[SET][ks]),
-                                                                     __builtin_bit_cast(bf16x8_t, ga[SET][ks][i]), acc[i], 0, 0, 0);
-            }
-        };
-        issue1(0, 0);
-        issue1(1, 1);
-        issue1(2, 2);
-        issue1(3, 3);
-        zero_acc();
-        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");        // this wave's pieces of K-tile 0
-        __builtin_amdgcn_s_barrier();
-        rd1(std::integral_constant<int, 0>{}, 0);
-        for (int kt = 0; kt < NK1; kt += 2) {
-            asm volatile("s_waitcnt vmcnt(8)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");   // own pieces of K-tile kt + 1; K-tile kt in registers
-            __builtin_amdgcn_s_barrier();                        // K-tile kt + 1 landed everywhere; nobody reads stage kt & 3 any more
-            issue1(kt + 4, kt & (NX - 1));
-            rd1(std::integral_constant<int, 1>{}, (kt + 1) & (NX - 1));
-            mm1(std::integral_constant<int, 0>{});
-            asm volatile("s_waitcnt vmcnt(8)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            issue1(kt + 5, (kt + 1) & (NX - 1));
-            rd1(std::integral_constant<int, 0>{}, (kt + 2) & (NX - 1));
-            mm1(std::integral_constant<int, 1>{});
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (the reads of the zero-filled K-tile past the end)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        issue_w(rs_w2, nb, NK2, 0, 0);                           // conv2's first K-tiles under the c1 write
-        issue_w(rs_w2, nb, NK2, 1, 1);
-        __builtin_amdgcn_s_barrier();                            // the x ring is dead: T becomes c1 (raw barriers: weight tiles stay in flight)
-        const int n0 = nb * 32;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 bv = *reinterpret_cast<const float4*>(p.b1 + n0 + 8 * g + 4 * hh);
-#pragma unroll
-            for (int i = 0; i < FM; ++i) {
-                const int t = (mh * FM + i) * 32 + frow, gy = band * BH - 1 + t / IW;
-                const bool in = gy >= 0 && gy < IW;              // (rows outside the image are conv2's zero padding)
-                uint2 o;
-                o.x = in ? ec_pack2(bn_relu(acc[i][4 * g + 0] + bv.x), bn_relu(acc[i][4 * g + 1] + bv.y)) : 0u;
-                o.y = in ? ec_pack2(bn_relu(acc[i][4 * g + 2] + bv.z), bn_relu(acc[i][4 * g + 3] + bv.w)) : 0u;
-                if (t < TROWS) *reinterpret_cast<uint2*>(T + t * PITCH + (n0 + 8 * g + 4 * hh) * 2) = o;
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                            // T holds c1 (band + halo rows)
-        stamp(1);
-    }
-
-    // ---- geometry of the wave's four output pixel blocks: T row of the centre tap, left / right validity ----
-    unsigned pbase[FM], pmask[FM];
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-        const int px = (mh * FM + i) * 32 + frow;                // band-local output pixel
-        const int by = px / IW, bx = px - by * IW;
-        unsigned m = 0;
-        if (px < PIXB) {
-            const unsigned xm = (bx > 0 ? 1u : 0u) | 2u | (bx < IW - 1 ? 4u : 0u);
-            m = xm | (xm << 3) | (xm << 6);                      // (rows above / below exist in T: halo rows, zero outside the image)
-        }
-        pmask[i] = m;
-        pbase[i] = t_lds + (unsigned)(px < PIXB ? px + IW : TROWS) * PITCH + hh * 16;
-    }
-    const unsigned zbase = t_lds + TROWS * PITCH + hh * 16;
-    constexpr int G = FM + 1;
-    // generic barrier-free K loop over K-tiles [0, nk) of one weight slice: fragments one k-step ahead
-    auto k_loop = [&](const __amdgpu_buffer_rsrc_t& rs, int slice, int nk, auto&& addr_of) {
-        unsigned a_cur[FM], a_nxt[FM];
-        addr_of(0, a_cur);
-        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");         // K-tile 0 landed (K-tile 1's pieces may be in flight)
-        [&]<int... I>(std::integer_sequence<int, I...>) { (lds_read16<0>(fa[0][I], a_cur[I]), ...); }(std::make_integer_sequence<int, FM>{});
-        lds_read16<0>(fb[0], ring_lds + boff[0]);
-        int st = 0;
-        for (int kk = 0; kk < nk; ++kk) {
-            int st2 = st + 2; st2 = st2 >= NS ? st2 - NS : st2;
-            int st1 = st + 1; st1 = st1 >= NS ? st1 - NS : st1;
-            issue_w(rs, slice, nk, kk + 2, st2);
-            [&]<int... I>(std::integer_sequence<int, I...>) { (lds_read16<32>(fa[1][I], a_cur[I]), ...); }(std::make_integer_sequence<int, FM>{});
-            lds_read16<0>(fb[1], ring_lds + st * STAGE + boff[1]);
-            asm volatile("s_waitcnt lgkmcnt(%0)" : : "n"(G));
-            [&]<int... I>(std::integer_sequence<int, I...>) { (tie(fa[0][I]), ...); }(std::make_integer_sequence<int, FM>{});
-            tie(fb[0]);
-            mma(0);
-            if (kk + 1 < nk) {
-                addr_of(kk + 1, a_nxt);
-                asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                [&]<int... I>(std::integer_sequence<int, I...>) { (lds_read16<0>(fa[0][I], a_nxt[I]), ...); }(std::make_integer_sequence<int, FM>{});
-                lds_read16<0>(fb[0], ring_lds + st1 * STAGE + boff[0]);
-                asm volatile("s_waitcnt lgkmcnt(%0)" : : "n"(G));
-            } else {
-                asm volatile("s_waitcnt lgkmcnt(0)");
-            }
-            [&]<int... I>(std::integer_sequence<int, I...>) { (tie(fa[1][I]), ...); }(std::make_integer_sequence<int, FM>{});
-            tie(fb[1]);
-            mma(1);
-#pragma unroll
-            for (int i = 0; i < FM; ++i) a_cur[i] = a_nxt[i];
-            st = st1;
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // (the zero-filled tail tiles)
-    };
-
-    // =====================================================================================================================
-    // conv2: K = 9 taps x 128 channels out of T
-    // =====================================================================================================================
-    zero_acc();
-    k_loop(rs_w2, nb, NK2, [&](int q, unsigned (&a)[FM]) {
-        const int tap = q / KT_PER_TAP, j = q - tap * KT_PER_TAP;
-        const int ky = (tap * 11) >> 5, kx = tap - ky * 3;
-        const unsigned sh = (unsigned)(((ky - 1) * IW + (kx - 1)) * PITCH + j * (BK * 2));
-#pragma unroll
-        for (int i = 0; i < FM; ++i) a[i] = ((pmask[i] >> tap) & 1u) ? pbase[i] + sh : zbase;
-    });
-    stamp(2);
-    __builtin_amdgcn_s_barrier();                                // every wave is done reading T as c1
-    {
-        const int n0 = nb * 32;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 bv = *reinterpret_cast<const float4*>(p.b2 + n0 + 8 * g + 4 * hh);
-#pragma unroll
-            for (int i = 0; i < FM; ++i) {
-                const int px = (mh * FM + i) * 32 + frow;
-                uint2 o;
-                o.x = ec_pack2(bn_relu(acc[i][4 * g + 0] + bv.x), bn_relu(acc[i][4 * g + 1] + bv.y));
-                o.y = ec_pack2(bn_relu(acc[i][4 * g + 2] + bv.z), bn_relu(acc[i][4 * g + 3] + bv.w));
-                if (px < PIXB) *reinterpret_cast<uint2*>(T + px * PITCH + (n0 + 8 * g + 4 * hh) * 2) = o;
-            }
-        }
-    }
-    // conv3 pass 0's whole weight slice (4 K-tiles -> ring stages 0 .. 3) and identity rows stream in under the c2 barrier
-    const size_t pix0 = (size_t)img * IW * IW + (size_t)band * PIXB;     // the band's first pixel (raster order: 7 full rows)
-    const int ec = lane & 3, er0 = lane >> 2, er1 = (lane >> 2) + 16;
-    u32x4_t res[FM][2];
-    auto load_res = [&](int pass, int i) {                       // identity rows of pixel block i, channels [pass*128 + nb*32, +32)
-        const uint16_t* xr = p.x + pix0 * CX + pass * C + nb * 32 + ec * 8;
-        int px0 = (mh * FM + i) * 32 + er0, px1 = (mh * FM + i) * 32 + er1;
-        px0 = px0 < PIXB ? px0 : PIXB - 1; px1 = px1 < PIXB ? px1 : PIXB - 1;
-        res[i][0] = *reinterpret_cast<const u32x4_t*>(xr + (size_t)px0 * CX);
-        res[i][1] = *reinterpret_cast<const u32x4_t*>(xr + (size_t)px1 * CX);
-    };
-    auto issue_w3 = [&](int pass) {
-#pragma unroll
-        for (int q = 0; q < NK3; ++q) issue_w(rs_w3, pass * 4 + nb, NK3, q, q);
-    };
-    issue_w3(0);
-#pragma unroll
-    for (int i = 0; i < FM; ++i) load_res(0, i);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                                // T rows [0, 196) hold c2 (weights + identity rows stay in flight)
-    stamp(3);
-
-    // =====================================================================================================================
-    // conv3: four passes of 128 output channels (32 per N block), K = 128: the pass's four weight K-tiles are resident in the
-    // wave's ring (streamed in under the previous epilogue), its identity rows are loaded into registers one pass ahead
-    // (block i's as soon as the previous pass's epilogue has consumed block i's): no memory latency on the pass's chain.
-    // =====================================================================================================================
-    unsigned p3[FM];
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-        const int px = (mh * FM + i) * 32 + frow;
-        p3[i] = t_lds + (unsigned)(px < PIXB ? px : TROWS) * PITCH + hh * 16;
-    }
-    // E = the wave's fifth 2-KB tile: [32 px][64 B], chunk c of pixel r at c ^ ((r >> 2) & 3); the epilogue's LDS traffic is inline asm
-    // (see lds_read8m): two dependent round trips per block, block i + 1's first one issued behind block i's second one
-    const unsigned e_lds = ring_lds + 4 * STAGE;
-    const unsigned e0a = e_lds + er0 * 64 + ((ec ^ ((er0 >> 2) & 3)) << 4), e1a = e_lds + er1 * 64 + ((ec ^ ((er1 >> 2) & 3)) << 4);
-    unsigned sa[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) sa[g] = e_lds + frow * 64 + ((g ^ ((frow >> 2) & 3)) << 4) + hh * 8;
-    for (int pass = 0; pass < NPASS; ++pass) {
-        zero_acc();
-        // loads are returned in order: <= 8 outstanding means the 8 weight pieces (older than the 8 identity loads) have landed
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        auto rd = [&]<int S>(std::integral_constant<int, S>) {
-            constexpr int q = S >> 1, ks = S & 1;
-            [&]<int... I>(std::integer_sequence<int, I...>) { (lds_read16<q * 64 + ks * 32>(fa[ks][I], p3[I]), ...); }(std::make_integer_sequence<int, FM>{});
-            lds_read16<q * STAGE>(fb[ks], ring_lds + boff[ks]);
-        };
-        auto tie0 = [&]() { [&]<int... I>(std::integer_sequence<int, I...>) { (tie(fa[0][I]), ...); }(std::make_integer_sequence<int, FM>{}); tie(fb[0]); };
-        auto tie1 = [&]() { [&]<int... I>(std::integer_sequence<int, I...>) { (tie(fa[1][I]), ...); }(std::make_integer_sequence<int, FM>{}); tie(fb[1]); };
-        rd(std::integral_constant<int, 0>{});
-        [&]<int... S>(std::integer_sequence<int, S...>) {
-            ([&] {
-                if constexpr (S + 1 < 2 * NK3) {
-                    rd(std::integral_constant<int, S + 1>{});
-                    asm volatile("s_waitcnt lgkmcnt(%0)" : : "n"(G));
-                } else {
-                    asm volatile("s_waitcnt lgkmcnt(0)");
-                }
-                if constexpr (S & 1) tie1(); else tie0();
-                mma(S & 1);
-            }(), ...);
-        }(std::make_integer_sequence<int, 2 * NK3>{});
-        if (pass + 1 < NPASS) issue_w3(pass + 1);                // (every ring read of this pass has completed)
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");         // this pass's identity rows (older than the pieces just issued)
-        const int n0 = pass * C + nb * 32;
-        float4 bv[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) bv[g] = *reinterpret_cast<const float4*>(p.b3 + n0 + 8 * g + 4 * hh);
-        uint16_t* yo = p.y + pix0 * CX + n0 + ec * 8;
-        u32x2_t rr[4];
-        auto stage_a = [&](int i) {
-            lds_write16m(e0a, res[i][0]);
-            lds_write16m(e1a, res[i][1]);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) lds_read8m(rr[g], sa[g]);
-        };
-        stage_a(0);
-#pragma unroll
-        for (int i = 0; i < FM; ++i) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int g = 0; g < 4; ++g) tie2(rr[g]);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                u32x2_t o;
-                o.x = ec_pack2(bn_relu(acc[i][4 * g + 0] + bv[g].x + ec_lo(rr[g].x)), bn_relu(acc[i][4 * g + 1] + bv[g].y + ec_hi(rr[g].x)));
-                o.y = ec_pack2(bn_relu(acc[i][4 * g + 2] + bv[g].z + ec_lo(rr[g].y)), bn_relu(acc[i][4 * g + 3] + bv[g].w + ec_hi(rr[g].y)));
-                lds_write8m(sa[g], o);
-            }
-            u32x4_t v0, v1;
-            lds_read16m(v0, e0a);
-            lds_read16m(v1, e1a);
-            if (i + 1 < FM) stage_a(i + 1);
-            if (pass + 1 < NPASS) load_res(pass + 1, i);         // (block i's registers were consumed by stage_a(i))
-            if (i + 1 < FM) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
-            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            tie(v0); tie(v1);
-            const int px0 = (mh * FM + i) * 32 + er0, px1 = (mh * FM + i) * 32 + er1;
-            if (px0 < PIXB) *reinterpret_cast<u32x4_t*>(yo + (size_t)px0 * CX) = v0;
-            if (px1 < PIXB) *reinterpret_cast<u32x4_t*>(yo + (size_t)px1 * CX) = v1;
-        }
-        stamp(4 + pass);
-    }
-}
-
 // Streaming order of a [N][K] bf16 weight matrix for bneck23_kernel: 16-byte unit ((s * K/32 + kt) * 32 + r) * 4 + pc holds
 // row 32 s + r, k = 32 kt + 8 (pc ^ ((r >> 2) & 3)) .. + 7 -- the swizzled 2-KB LDS image of (slice s, K-tile kt), contiguous.
 __global__ void bneck_pack_kernel(const uint4* __restrict__ w, uint4* __restrict__ out, int N, int K) {
@@ -1165,7 +807,9 @@ extern "C" int ec_conv3x3_img_bf16(const void* in, const void* packed, const flo
 // profiling only: device buffer of 16 x u64 that workgroup 0 of every following fused launch fills with {shader clock,
 // 100-MHz real time} stamps (entry, T loaded, conv2 done, c2 written, after each conv3 pass); nullptr switches it off
 namespace { unsigned long long* g_bneck_dbg = nullptr; }
+#ifdef EC_TOOLS   // tools-only build (`make tools`): not part of the product library or of include/ec_amd.h
 extern "C" void ec_bneck_set_debug(void* dev_u64x16) { g_bneck_dbg = (unsigned long long*)dev_u64x16; }
+#endif
 
 // Packs conv2's [C][9C] and conv3's [4C][C] bf16 weights into the fused kernel's streaming order: packed holds C * 9C
 // elements of conv2 followed by 4C * C of conv3 (ec_bneck_packed_elems).  Once per set of weights.
@@ -1187,7 +831,7 @@ extern "C" int ec_bneck_pack_weights(const void* w2, const void* w3, void* packe
 // packed = ec_bneck_pack_weights(w2 [C][3*3*C], w3 [4C][C]), x / y bf16 [B,14,14,4C].  EC_ERR_SHAPE for any other geometry (the
 // caller then runs the two convs separately).
 namespace {
-template <bool F1>
+template <bool F1, bool WEMU = false>
 int launch_bneck(const void* c1, const void* packed, const float* b1, const float* b2, const float* b3, const void* x, void* y,
                  int B, int H, int W, int C, ec_stream_t stream) {
     if (!packed || !b2 || !b3 || !x || !y || (F1 ? !b1 : !c1)) return EC_ERR_ARG;
@@ -1198,14 +842,13 @@ int launch_bneck(const void* c1, const void* packed, const float* b1, const floa
     a.w3 = (const uint16_t*)packed + (size_t)C * 9 * C; a.b3 = b3;
     a.w1 = (const uint16_t*)packed + (size_t)C * 9 * C + (size_t)4 * C * C; a.b1 = b1;
     a.xres = (const uint16_t*)x; a.y = (uint16_t*)y; a.B = B;
-    a.w2_bytes = (unsigned)((size_t)C * 9 * C * 2);
+    a.w2_bytes = WEMU ? (unsigned)(ec_bneck3_packed_elems(C) * 2) : (unsigned)((size_t)C * 9 * C * 2);   // (WEMU reads 2 MB of whatever follows conv2's weights)
     a.w3_bytes = (unsigned)((size_t)4 * C * C * 2);
     a.w1_bytes = (unsigned)((size_t)C * 4 * C * 2);
     a.dbg = g_bneck_dbg;
-    a.stagger = ec_config().bneck_stagger;
     constexpr int PITCH = 256 * 2 + 16;
     const size_t lds = (size_t)(196 + 1) * PITCH + 8 * 3 * 2048;
-    auto kern = bneck23_kernel<256, 14, F1>;
+    auto kern = bneck23_kernel<256, 14, F1, WEMU>;
     static std::atomic<uint64_t> attr_done{0};
     if (auto attr_g_ = ec_attr_needed(attr_done))
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1218,41 +861,6 @@ int launch_bneck(const void* c1, const void* packed, const float* b1, const floa
 extern "C" int ec_bneck_conv23_bf16(const void* c1, const void* packed, const float* b2, const float* b3,
                                     const void* x, void* y, int B, int H, int W, int C, ec_stream_t stream) {
     return launch_bneck<false>(c1, packed, nullptr, b2, b3, x, y, B, H, W, C, stream);
-}
-
-// The whole stride-1 Bottleneck of the 28 x 28 stage (planes 128, 512 in / out channels) in one launch, one workgroup per band
-// of 7 rows (bneck_band_kernel).  packed = ec_bneck_band_pack_weights(w1 [128][512], w2 [128][1152], w3 [512][128])
-// (ec_bneck_band_packed_elems() elements: conv2, conv3, conv1).  x / y bf16 [B,28,28,512].  Bit-identical to the three
-// ec_conv_bf16 calls.
-extern "C" size_t ec_bneck_band_packed_elems(void) { return (size_t)128 * 1152 + (size_t)512 * 128 + (size_t)128 * 512; }
-extern "C" int ec_bneck_band_pack_weights(const void* w1, const void* w2, const void* w3, void* packed, ec_stream_t stream) {
-    if (!w1 || !w2 || !w3 || !packed) return EC_ERR_ARG;
-    uint16_t* d = (uint16_t*)packed;
-    auto pack = [&](const void* w, uint16_t* dst, int N, int K) {
-        const long n = (long)N * K / 8;
-        hipLaunchKernelGGL(bneck_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint4*)w,
-                           (uint4*)dst, N, K);
-    };
-    pack(w2, d, 128, 1152);
-    pack(w3, d + 128 * 1152, 512, 128);
-    pack(w1, d + 128 * 1152 + 512 * 128, 128, 512);
-    EC_CHECK_LAUNCH();
-    return EC_OK;
-}
-extern "C" int ec_bneck_band_bf16(const void* x, const void* packed, const float* b1, const float* b2, const float* b3, void* y,
-                                  int B, int H, int W, int C, ec_stream_t stream) {
-    if (!x || !packed || !b1 || !b2 || !b3 || !y) return EC_ERR_ARG;
-    if (B <= 0 || H != 28 || W != 28 || C != 128) return EC_ERR_SHAPE;
-    BandArgs a;
-    a.x = (const uint16_t*)x; a.w = (const uint16_t*)packed; a.b1 = b1; a.b2 = b2; a.b3 = b3; a.y = (uint16_t*)y; a.B = B;
-    a.dbg = g_bneck_dbg;
-    const size_t lds = (size_t)(252 + 1) * (128 * 2 + 16) + 8 * 5 * 2048;
-    static std::atomic<uint64_t> attr_done{0};
-    if (auto attr_g_ = ec_attr_needed(attr_done))
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bneck_band_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(bneck_band_kernel, dim3((unsigned)(B * 4)), dim3(512), lds, (hipStream_t)stream, a);
-    EC_CHECK_LAUNCH();
-    return EC_OK;
 }
 
 // The WHOLE Bottleneck in one launch: y = relu(conv3(relu(conv2(relu(conv1(x) + b1)) + b2)) + b3 + x).  packed =
@@ -1272,3 +880,9 @@ extern "C" int ec_bneck_conv123_bf16(const void* x, const void* packed, const fl
                                      void* y, int B, int H, int W, int C, ec_stream_t stream) {
     return launch_bneck<true>(nullptr, packed, b1, b2, b3, x, y, B, H, W, C, stream);
 }
+#ifdef EC_TOOLS   // tools-only build: the Winograd feed emulation of bneck23_kernel (timing only, garbage results)
+extern "C" int ec_bneck_wino_emu(const void* x, const void* packed, const float* b1, const float* b2, const float* b3,
+                                 void* y, int B, int H, int W, int C, ec_stream_t stream) {
+    return launch_bneck<true, true>(nullptr, packed, b1, b2, b3, x, y, B, H, W, C, stream);
+}
+#endif

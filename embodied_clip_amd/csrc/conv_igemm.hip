@@ -51,10 +51,18 @@
 #include "common.h"
 
 thread_local int ec_tls_conv8_min_tiles = EC_CONV8_MIN_TILES_DEFAULT;   // common.h: set per call from the encoder handle
-thread_local float* ec_tls_splitk_ws = nullptr;                         // common.h (ec_splitk_scope): partial-sum workspace
-thread_local size_t ec_tls_splitk_bytes = 0;
 
 namespace {
+
+// profiling switch of the tools-only build (`make tools`, -DEC_TOOLS); the product library never ablates
+inline int ec_tools_ablate() {
+#ifdef EC_TOOLS
+    static const int v = [] { const char* e = getenv("EC_CONV_ABLATE"); return e ? atoi(e) : 0; }();
+    return v;
+#else
+    return 0;
+#endif
+}
 
 constexpr int BK = 64;              // K-tile (bf16 elements) = 128 B rows in LDS
 constexpr int ROW_BYTES = BK * 2;   // 128
@@ -73,13 +81,7 @@ struct ConvArgs {
     int nbuf;  // LDS stages: 2 (double buffer) or 1
     unsigned in_bytes, w_bytes;   // buffer-descriptor extents (out-of-range loads return 0)
     unsigned res_bytes;           // ... of the residual tensor (= output extent)
-    int ablate;                   // profiling only (EC_CONV_ABLATE): 1 no global loads, 2 no MFMA, 4 no LDS stores, 8 no epilogue
-    const uint16_t* wf = nullptr; // the weights in MFMA-fragment order (ec_pack_wfrag), or null: conv_igemm8's DIRECT-B variant
-    // fixed K partition (SPLIT instances of conv_igemm_kernel): ksplit slices of the K-tile range, slice z writes its raw fp32
-    // accumulators to part + z * part_stride ([M][Cout] each); splitk_reduce_kernel folds them in slice order
-    int ksplit = 1;
-    float* part = nullptr;
-    long part_stride = 0;
+    int ablate;                   // profiling only (tools build, EC_CONV_ABLATE): 1 no global loads, 2 no MFMA, 8 no epilogue; 0 in the product library
 };
 
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
@@ -230,17 +232,12 @@ __device__ __forceinline__ void fr_step(FragRing<R>& ring, AddrFn& addr, MmaFn& 
 // waves.  The K walk and the per-element summation order are those of the other modes (bit-identical results); what changes
 // is that a K-tile no longer costs a full L2 round trip: measured (round 3, rocprofv3) a 64x64 tile of the single-stage mode
 // takes ~750 ns per K-tile with one workgroup per CU -- 128 clk of MFMA issue per wave.
-// SPLIT: the launch covers ntiles x ksplit VIRTUAL tiles; virtual tile vt = (K slice z = vt / ntiles, output tile vt % ntiles)
-// walks K-tiles [z nk / S, (z + 1) nk / S) only and leaves its accumulators as raw fp32 in the slice's partial matrix --
-// a FIXED partition of the K walk (decided by the dispatch from the layer's shape and the launch's tile count), folded in
-// slice order by splitk_reduce_kernel: deterministic, no atomics.  For launches with fewer output tiles than CUs (small
-// per-GPU batches: the 14x14 / 7x7 maps at 32-64 frames) every workgroup is otherwise one serial chain of 16-72 K-tiles.
 // ILV (ring mode only): the LDS-DMA pieces of K-tile kt + NS - 1 are issued INSIDE the MFMA stream of K-tile kt (a share of
 // them after every k-step) instead of in front of it.  A CU's L2 -> LDS path moves ~30 B/clk (round 2/3 measurements): the
 // 32 KB of a 128 x 128 K-tile keep the issuing waves blocked for ~1,100 clk, and with ONE workgroup per CU (the ring
 // launches of small per-GPU batches) all four waves sit in that phase together, then in the MFMA phase together -- the two
 // add up (~2,000 clk per K-tile measured at 32 frames).  Issued between MFMAs, the pieces drain while the matrix pipe works.
-template <int BM, int BN, int WM, int WN, int KS, bool POOL, bool PF, int MV, int NS, bool SPLIT = false, bool ILV = false, bool S2 = false>
+template <int BM, int BN, int WM, int WN, int KS, bool POOL, bool PF, int MV, int NS, bool ILV = false, bool S2 = false>
 __global__ __launch_bounds__(WM * WN * 64, (BM > 192) ? 2 : ((WM * WN == 8) ? 4 : (NS >= 3 ? 2 : 3))) void conv_igemm_kernel(ConvArgs p) {
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int FM = TM / 32, FN = TN / 32;
@@ -261,13 +258,11 @@ __global__ __launch_bounds__(WM * WN * 64, (BM > 192) ? 2 : ((WM * WN == 8) ? 4 
     // tiles in flight at any moment are neighbours and each XCD owns a contiguous run of them).
     const unsigned grid = gridDim.x;
     const unsigned lb = ec_xcd_remap(blockIdx.x, grid);
-    static_assert(!SPLIT || (!PF && MV == BM), "K-sliced instances: no residual prefetch, no padded tiles");
     static_assert(!ILV || (NS >= 3 && !PF && FM + FN <= 4), "interleaved pieces: ring mode with the inline-asm fragment stream");
-    const int nvt = SPLIT ? p.ntiles * p.ksplit : p.ntiles;     // virtual tiles of the launch
+    const int nvt = p.ntiles;
     int vt = (int)lb;
     if (vt >= nvt) return;
-    int kz = SPLIT ? vt / p.ntiles : 0;                         // K slice of this virtual tile
-    int tile = SPLIT ? vt - kz * p.ntiles : vt;
+    int tile = vt;
     static_assert(MV <= BM && (MV == BM || !POOL), "padded tiles: non-pooled only");
     int m0 = (tile / p.ntn) * MV;
     int n0 = (tile % p.ntn) * BN;
@@ -340,15 +335,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM > 192) ? 2 : ((WM * WN == 8) ? 4 
     const int wave_lds = wave * 1024;                       // 64 lanes x 16 B
     // per-K-tile addressing state shared by the pieces of one tile
     const int nk = (p.K + BK - 1) / BK;
-    int kt0 = 0, kt1 = nk, k_lim = p.K;         // this virtual tile's K-tile range; k >= k_lim reads as zeros
-    auto krange = [&]() {
-        if constexpr (SPLIT) {
-            kt0 = (int)((long)kz * nk / p.ksplit);
-            kt1 = (int)((long)(kz + 1) * nk / p.ksplit);
-            k_lim = kt1 * BK < p.K ? kt1 * BK : p.K;
-        }
-    };
-    krange();
+    const int kt0 = 0, kt1 = nk, k_lim = p.K;   // the K-tile range; k >= k_lim reads as zeros
     int g_toff = 0; unsigned g_tapbit = 0; bool g_kin = false; int g_kt = 0;
     unsigned char* g_sa = smem; unsigned char* g_sb = smem;
     auto glds_begin = [&](int kt, int buf) {
@@ -535,42 +522,14 @@ __global__ __launch_bounds__(WM * WN * 64, (BM > 192) ? 2 : ((WM * WN == 8) ? 4 
             }
         }
         }   // NS < 3
-        const int e_kz = kz;
         vt += (int)grid;
         const bool has_next = vt < nvt;
         if (has_next) {
-            kz = SPLIT ? vt / p.ntiles : 0;
-            tile = SPLIT ? vt - kz * p.ntiles : vt;
+            tile = vt;
             m0 = (tile / p.ntn) * MV;
             n0 = (tile % p.ntn) * BN;
             decode();
-            krange();
         }
-        if constexpr (SPLIT) {
-            // raw fp32 accumulators -> LDS image (swapped operands: a lane owns one pixel and, per 4 registers, 4 consecutive
-            // channels = one 16-byte slot) -> the slice's partial matrix as coalesced 16-byte row chunks
-            constexpr int PITCH4 = BN * 4 + 16, CH4 = BN / 4, RPP4 = NT / CH4;
-#pragma unroll
-            for (int j = 0; j < FN; ++j)
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-#pragma unroll
-                    for (int i = 0; i < FM; ++i) {
-                        const int lrow_px = wm * TM + i * 32 + frow, lcol = wn * TN + j * 32 + 8 * g + 4 * fhalf;
-                        *reinterpret_cast<float4*>(smem + lrow_px * PITCH4 + lcol * 4) =
-                            make_float4(acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-                    }
-            __syncthreads();
-            float* dst = p.part + (long)e_kz * p.part_stride;
-            const int srow4 = tid / CH4, sch4 = tid % CH4;
-#pragma unroll
-            for (int r0 = 0; r0 < BM; r0 += RPP4) {
-                const int row = r0 + srow4;
-                if (e_m0 + row < p.M)
-                    *reinterpret_cast<float4*>(dst + (long)(e_m0 + row) * p.Cout + e_n0 + sch4 * 4) =
-                        *reinterpret_cast<const float4*>(smem + row * PITCH4 + sch4 * 16);
-            }
-        } else
         if (!(p.ablate & 8)) {
     // ---- epilogue: staged through LDS so every global access is a coalesced 16-B chunk ----
     //   1. prefetched residual tile -> LDS                [only with a residual]
@@ -619,108 +578,23 @@ int launch(const ConvArgs& a, hipStream_t s) {
     p.ntiles = ntm * p.ntn;
     const size_t lds_max = 2 * (size_t)(BM + BN) * ROW_BYTES;
     const size_t epi = (size_t)(POOL ? BM / 4 : BM) * (BN * 2 + 16);
-    const int nbuf_force = ec_config().conv_nbuf;
-    p.nbuf = nbuf_force ? nbuf_force : ((BM * BN >= 256 * 256) ? 2 : 1);
-    const int ablate = ec_config().conv_ablate;
-    p.ablate = ablate;
+    p.nbuf = (BM * BN >= 256 * 256) ? 2 : 1;
+    p.ablate = ec_tools_ablate();
     size_t lds = (size_t)(NS >= 3 ? NS : p.nbuf) * (BM + BN) * ROW_BYTES;
     if (lds < epi) lds = epi;
-    auto kern = conv_igemm_kernel<BM, BN, WM, WN, KS, POOL, PF, MV, NS, false, ILV, S2>;
+    auto kern = conv_igemm_kernel<BM, BN, WM, WN, KS, POOL, PF, MV, NS, ILV, S2>;
     static std::atomic<uint64_t> attr_done{0};
     if (auto attr_g_ = ec_attr_needed(attr_done)) {
         const size_t want = NS >= 3 ? lds : (lds_max > epi ? lds_max : epi);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
     }
     // persistent: 3 workgroups per CU (<= 168 VGPRs, single 35-KB LDS stage), each walking several tiles
-    const int wg_cap = ec_config().conv_wgs;
+    const int wg_cap = 768;
     // ring mode: as many workgroups per CU as its NS stages fit (160 KiB of LDS, 2 waves per SIMD by registers)
     const int ring_per_cu = NS >= 3 ? (int)std::min<size_t>(2, (160 * 1024) / lds) : 0;
     const int cap = NS >= 3 ? 256 * ring_per_cu : ((BM * BN >= 256 * 256) ? 256 : wg_cap);      // 8-wave 256x256 tiles: one workgroup per CU
     const int nwg = p.ntiles < cap ? p.ntiles : cap;
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(WM * WN * 64), lds, s, p);
-    EC_CHECK_LAUNCH();
-    return EC_OK;
-}
-
-
-// ---- fixed K partition for launches with fewer output tiles than CUs (round 4) --------------------------------------
-// out[m][n] = act(sum_z part[z][m][n] + bias[n] (+ res[m][n])) -> bf16, slices folded in index order (deterministic).
-// POOL: rows are ordered m = 4 q + (dy 2 + dx) (conv_igemm_kernel's POOL decode): out[q] = mean_s relu(...), summed as
-// (s0 + s1) + (s2 + s3) like the fused epilogue's two DPP adds.  One thread = 8 consecutive channels of one output row.
-template <bool POOL>
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, long stride, int S,
-                                                            const float* __restrict__ bias, const uint16_t* __restrict__ res,
-                                                            uint16_t* __restrict__ out, int Mout, int Cout, int relu) {
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    const int c8 = Cout >> 3;
-    const long row = idx / c8;
-    if (row >= Mout) return;
-    const int col = (int)(idx - row * c8) * 8;
-    float b[8];
-    {
-        const float4 b0 = bias ? *reinterpret_cast<const float4*>(bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 b1 = bias ? *reinterpret_cast<const float4*>(bias + col + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        b[0] = b0.x; b[1] = b0.y; b[2] = b0.z; b[3] = b0.w; b[4] = b1.x; b[5] = b1.y; b[6] = b1.z; b[7] = b1.w;
-    }
-    constexpr int R = POOL ? 4 : 1;
-    float v[R][8];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const float* src = part + ((long)row * R + r) * Cout + col;
-        float4 a0 = *reinterpret_cast<const float4*>(src), a1 = *reinterpret_cast<const float4*>(src + 4);
-        for (int z = 1; z < S; ++z) {
-            const float4 c0 = *reinterpret_cast<const float4*>(src + z * stride), c1 = *reinterpret_cast<const float4*>(src + z * stride + 4);
-            a0.x += c0.x; a0.y += c0.y; a0.z += c0.z; a0.w += c0.w;
-            a1.x += c1.x; a1.y += c1.y; a1.z += c1.z; a1.w += c1.w;
-        }
-        v[r][0] = a0.x + b[0]; v[r][1] = a0.y + b[1]; v[r][2] = a0.z + b[2]; v[r][3] = a0.w + b[3];
-        v[r][4] = a1.x + b[4]; v[r][5] = a1.y + b[5]; v[r][6] = a1.z + b[6]; v[r][7] = a1.w + b[7];
-    }
-    float o[8];
-    if constexpr (POOL) {
-#pragma unroll
-        for (int c = 0; c < 8; ++c)
-            o[c] = 0.25f * ((ec_relu(v[0][c]) + ec_relu(v[1][c])) + (ec_relu(v[2][c]) + ec_relu(v[3][c])));
-    } else {
-        if (res) {
-            const uint4 rr = *reinterpret_cast<const uint4*>(res + row * Cout + col);
-            v[0][0] += ec_lo(rr.x); v[0][1] += ec_hi(rr.x); v[0][2] += ec_lo(rr.y); v[0][3] += ec_hi(rr.y);
-            v[0][4] += ec_lo(rr.z); v[0][5] += ec_hi(rr.z); v[0][6] += ec_lo(rr.w); v[0][7] += ec_hi(rr.w);
-        }
-#pragma unroll
-        for (int c = 0; c < 8; ++c) o[c] = relu ? ec_relu(v[0][c]) : v[0][c];
-    }
-    uint4 w;
-    w.x = ec_pack2(o[0], o[1]); w.y = ec_pack2(o[2], o[3]); w.z = ec_pack2(o[4], o[5]); w.w = ec_pack2(o[6], o[7]);
-    *reinterpret_cast<uint4*>(out + row * Cout + col) = w;
-}
-
-// NS: LDS stages of the K-sliced launch (>= 3: ring mode; 2: plain double buffer, 64 KB for 128x128 tiles = 2 workgroups per CU)
-template <int BM, int BN, int WM, int WN, int KS, bool POOL, int NS>
-int launch_split(const ConvArgs& a, int S, float* part, hipStream_t s) {
-    ConvArgs p = a;
-    p.ntn = a.Cout / BN;
-    p.ntiles = ((a.M + BM - 1) / BM) * p.ntn;
-    p.ksplit = S;
-    p.part = part;
-    p.part_stride = (long)a.M * a.Cout;
-    p.nbuf = 2;
-    p.ablate = 0;
-    size_t lds = (size_t)(NS >= 3 ? NS : 2) * (BM + BN) * ROW_BYTES;
-    const size_t raw = (size_t)BM * (BN * 4 + 16);
-    if (lds < raw) lds = raw;
-    auto kern = conv_igemm_kernel<BM, BN, WM, WN, KS, POOL, false, BM, (NS >= 3 ? NS : 0), true>;
-    static std::atomic<uint64_t> attr_done{0};
-    if (auto attr_g_ = ec_attr_needed(attr_done))
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const int per_cu = (int)std::min<size_t>(NS >= 3 ? 2 : 3, (160 * 1024) / lds);
-    const int nvt = p.ntiles * S, cap = 256 * per_cu;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(nvt < cap ? nvt : cap)), dim3(WM * WN * 64), lds, s, p);
-    EC_CHECK_LAUNCH();
-    const int Mout = POOL ? a.M / 4 : a.M;
-    const long threads = (long)Mout * (a.Cout / 8);
-    hipLaunchKernelGGL(splitk_reduce_kernel<POOL>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, part, p.part_stride, S,
-                       a.bias, POOL ? nullptr : a.res, a.out, Mout, a.Cout, a.act == EC_ACT_RELU ? 1 : 0);
     EC_CHECK_LAUNCH();
     return EC_OK;
 }
@@ -751,7 +625,7 @@ int launch_split(const ConvArgs& a, int S, float* part, hipStream_t s) {
 // Operand fetch (implicit im2col, out-of-range buffer offsets for padding), LDS swizzle, swapped MFMA operands and the epilogue
 // (bias / residual / ReLU / fused 2x2 average pool through LDS, 16-byte coalesced stores) are those of conv_igemm_kernel.
 // Requires Cin % 64 == 0 (a K-tile never straddles a 3x3 tap) and Cout % BN == 0.
-__device__ unsigned long long ec_dbg_stamps[2 * 1024];   // profiling only (EC_CONV_ABLATE & 32): s_memtime stamps of block 0
+__device__ unsigned long long ec_dbg_stamps[2 * 1024];   // profiling only (tools build, EC_CONV_ABLATE & 32): s_memtime stamps of block 0
 
 // X3 (policy compressor, ec_gemm_bf16a_x3): the weight operand is an fp32 matrix split into three bf16 planes
 // ([Cout][3][K], lowest plane first in the K walk); a K-tile of A is walked three times, once against each plane, into
@@ -902,7 +776,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
     for (int j = 0; j < FN; ++j)
         bfo[j] = (unsigned)((n0 >> 5) + wn * (TN / 32) + j) * (unsigned)(p.K >> 4) * 1024u + (unsigned)lane * 16u;
 #if defined(__HIP_DEVICE_COMPILE__)
-    const __amdgpu_buffer_rsrc_t rs_wf = __builtin_amdgcn_make_buffer_rsrc((void*)(DB ? p.wf : p.w), 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_wf = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
 #endif
     s16x8_t fbd[2][2][FN];                              // [half][k-step][fragment]
     auto bload = [&](int kt, int h, int u) {            // fragments (kt, k-step 2h + u) of this wave's FN column blocks
@@ -1214,7 +1088,7 @@ int launch8(const ConvArgs& a, hipStream_t s) {
     ConvArgs p = a;
     p.ntn = a.Cout / BN;
     p.ntiles = ((a.M + 255) / 256) * p.ntn;
-    const int ablate = ec_config().conv_ablate;
+    const int ablate = ec_tools_ablate();
     p.ablate = ablate;
     const bool ls = BN == 128 && ec_config().conv8_longseg;
     // (long segments: three stages; X3: two A chunks + three plane tiles)
@@ -1253,13 +1127,6 @@ int launch8(const ConvArgs& a, hipStream_t s) {
         return EC_OK;
     }
 #endif
-    if constexpr (!X3 && BN == 256) {
-        if (ec_config().conv8_dirb && a.wf) {
-            go(conv_igemm8_kernel<BN, KS, POOL, 256, X3>);
-            EC_CHECK_LAUNCH();
-            return EC_OK;
-        }
-    }
     if constexpr (BN == 128) {
         if (ls) {
             go(conv_igemm8_kernel<BN, KS, POOL, 512, X3>);
@@ -1273,42 +1140,8 @@ int launch8(const ConvArgs& a, hipStream_t s) {
 }
 
 
-// Fixed K partition (round 4): launches with too few output tiles to fill the chip -- the 14x14 / 7x7 maps of layers 3-4 at
-// 32-64 frames per launch.  The slice count is a function of the layer's shape and the launch's tile count only, so a
-// given launch shape always sums in the same order (run-to-run determinism, bit-identity for a fixed launch shape);
-// ACROSS launch shapes results agree to fp32-accumulation rounding (tests: rel-L2 <= 1e-3 on the bf16 features).
-// EC_CONV_SPLITK: 0 off; 1 (default) the rule below; 2..8: force that many slices wherever the preconditions hold (tests).
-// Needs the caller's partial-sum workspace (ec_splitk_scope: set by ec_rn50_forward / ec_conv_bf16_ws).
-template <int KS, bool POOL>
-int dispatch_split(const ConvArgs& a, hipStream_t s) {
-    const int mode = ec_config().conv_splitk;
-    if (mode == 0 || !ec_tls_splitk_ws || a.Cout % 128 != 0 || a.Cin % 8 != 0 || a.act == EC_ACT_QUICKGELU) return EC_ERR_SHAPE;
-    if (POOL && (a.M % 4) != 0) return EC_ERR_SHAPE;
-    const int nk = (a.K + BK - 1) / BK;
-    const long t128 = (long)((a.M + 127) / 128) * (a.Cout / 128);
-    int S;
-    if (mode >= 2) S = mode;
-    else {
-        // the rule: fewer 128x128 tiles than ~3/4 of the CUs and a K walk of >= 16 tiles: as many slices as bring the
-        // launch to ~1.5-2 workgroups per CU, each slice keeping >= 4 K-tiles
-        if (t128 >= ec_config().conv_splitk_tiles || nk < 16) return EC_ERR_SHAPE;
-        S = (int)((ec_config().conv_splitk_target + t128 - 1) / t128);
-        if (S > 8) S = 8;
-    }
-    while (S > 1 && nk / S < 4) --S;
-    if (S < 2) return EC_ERR_SHAPE;
-    if ((size_t)S * (size_t)a.M * (size_t)a.Cout * 4 > ec_tls_splitk_bytes) return EC_ERR_SHAPE;
-    if constexpr (!POOL) {
-        if (ec_config().conv_splitk_tile == 64) return launch_split<64, 64, 2, 2, KS, POOL, 4>(a, S, ec_tls_splitk_ws, s);
-    }
-    if (ec_config().conv_splitk_ns >= 3) return launch_split<128, 128, 2, 2, KS, POOL, 3>(a, S, ec_tls_splitk_ws, s);
-    return launch_split<128, 128, 2, 2, KS, POOL, 2>(a, S, ec_tls_splitk_ws, s);
-}
-
 template <int KS, bool POOL>
 int dispatch_tile(const ConvArgs& a, hipStream_t s) {
-    if (dispatch_split<KS, POOL>(a, s) == EC_OK) return EC_OK;
-    const int force = ec_config().conv_waves;
     // Tile choice: 128x128 wherever Cout allows; 256-row tiles for the narrow early layers.
     // (Fatter 128x256 / 256x128 tiles were measured: no gain, and they spill once loads run two tiles ahead.)
     // EC_CONV_BIG: 0 off; 1 (default) the 8-wave ping-pong kernel (conv_igemm8) where it was measured to win; 4 conv_igemm8
@@ -1329,7 +1162,7 @@ int dispatch_tile(const ConvArgs& a, hipStream_t s) {
         const long mint = mint_env > 0 ? mint_env : (long)ec_tls_conv8_min_tiles;
         // 3x3 launches whose 256-wide tiles would fill only a fraction of the chip take 128-wide ones (twice the tiles; with
         // long segments, EC_CONV8_LONGSEG, a 128-wide K-tile costs half a 256-wide one): EC_CONV8_LOWFILL = tile-count limit
-        if (KS == 3 && !POOL && a.Cout % 256 == 0 && a.K >= 2304 && nt256 >= mint && nt256 < ec_config().conv8_lowfill && nt128 >= mint)
+        if (KS == 3 && !POOL && a.Cout % 256 == 0 && a.K >= 2304 && nt256 >= mint && nt256 < EC_CONV8_LOWFILL && nt128 >= mint)
             return launch8<128, KS, POOL>(a, s);
         if (KS == 3 && a.Cout % 256 == 0 && nt256 >= mint) return launch8<256, KS, POOL>(a, s);
         // 3x3 convs with too few 256-wide tiles (layer 4 @7x7 in a single 256-frame launch: 98) but enough 128-wide ones:
@@ -1346,14 +1179,14 @@ int dispatch_tile(const ConvArgs& a, hipStream_t s) {
         // out_proj 768->768 + residual is slower (31 -> 35) and keeps the 4-wave kernel
         // long-K 1x1 launches that would fill less than ~40 % of the chip with 256-wide tiles take 128-wide ones (twice the
         // tiles, same per-tile efficiency): ViT-B/32 c_proj at 6,400 tokens is 75 tiles x 48 K-tiles (same-box A/B: +2.4 % on the ViT config, +0.4 % RN50)
-        if (KS == 1 && !POOL && ec_config().conv8_bn128 >= 0 && a.K >= ec_config().conv8_lowfill_k && a.Cout % 256 == 0 && nt256 >= mint && nt256 < 100 &&
+        if (KS == 1 && !POOL && ec_config().conv8_bn128 >= 0 && a.K >= EC_CONV8_LOWFILL_K && a.Cout % 256 == 0 && nt256 >= mint && nt256 < 100 &&
             nt128 >= mint)
             return launch8<128, KS, POOL>(a, s);
         // residual 1x1 launches with K = 512 .. 2047 that would fill less than ~40 % of the chip with 256-wide tiles (ViT-B/32
         // out_proj at 6,400 tokens: 75 tiles x 12 K-tiles) on the long-segment 128-wide tiles: same-box A/B 74.9 -> 76.3 k
         // env-frames/s on the ViT config, forward 2.10 -> 2.05 ms; with the limit at 150 tiles the rule also caught layer 4's
         // conv3 at 2 x 64 frames (104 tiles) and cost the RN50 config 0.4-1.3 % there.  EC_CONV8_RES128 = 0: off
-        if (KS == 1 && !POOL && a.res && ec_config().conv8_res128 && a.K >= 512 && a.K < 2048 && a.Cout % 128 == 0 && nt256 < 100 && nt128 >= mint)
+        if (KS == 1 && !POOL && a.res && a.K >= 512 && a.K < 2048 && a.Cout % 128 == 0 && nt256 < 100 && nt128 >= mint)
             return launch8<128, KS, POOL>(a, s);
         if (KS == 1 && !POOL && ((!a.res && a.K >= 768) || (a.res && (a.K >= 2048 || (a.K >= 512 && nt256 >= 150))))) {   // (residual, K = 512: 49.5 -> 45.7 us on 512 -> 2048 @7x7; ViT out_proj, 75 tiles x 12 K-tiles, stays on the 4-wave kernel: 19.8 vs 23.3 us)
             if (a.Cout % 256 == 0 && nt256 >= mint) return launch8<256, KS, POOL>(a, s);
@@ -1397,33 +1230,22 @@ int dispatch_tile(const ConvArgs& a, hipStream_t s) {
                 // (deeper rings -- 6 / 8 stages for launches with at most one workgroup per CU, 4 stages for the 128x128 ring --
                 //  measured round 3: 0.944 -> 0.95-0.96 ms at 32 frames, 1.50 -> 1.50-1.51 at 64: stages in flight are not
                 //  what bounds these launches any more; what is left per K-tile is barrier + piece issue)
-                return ring ? (ec_config().conv_ring_ilv ? launch<64, 64, 2, 2, KS, POOL, false, 64, 4, true>(a, s)
-                                                          : launch<64, 64, 2, 2, KS, POOL, false, 64, 4>(a, s))
-                            : launch<64, 64, 2, 2, KS, POOL>(a, s);
+                return ring ? launch<64, 64, 2, 2, KS, POOL, false, 64, 4, true>(a, s) : launch<64, 64, 2, 2, KS, POOL>(a, s);
         }
         {
             const long t128 = (long)((a.M + 127) / 128) * (a.Cout / 128);
             const bool pf = (KS == 1 && !POOL && a.res && a.K <= 256);
-            if (force != 8 && !pf && a.K >= 512 && ((ring == 1 && t128 <= 256) || ring == 2)) {
-                // EC_CONV_RING_W8: the one-workgroup-per-CU ring launches on 8 waves (2 x 4, wave tile 64 x 32): two waves
-                // per SIMD, so one wave's fragment reads / piece issue run beside the other's MFMAs
-                if (ec_config().conv_ring_w8)
-                    return ec_config().conv_ring_ilv ? launch<128, 128, 2, 4, KS, POOL, false, 128, 3, true>(a, s)
-                                                     : launch<128, 128, 2, 4, KS, POOL, false, 128, 3>(a, s);
-                return ec_config().conv_ring_ilv ? launch<128, 128, 2, 2, KS, POOL, false, 128, 3, true>(a, s)
-                                                 : launch<128, 128, 2, 2, KS, POOL, false, 128, 3>(a, s);
+            if (!pf && a.K >= 512 && ((ring == 1 && t128 <= 256) || ring == 2)) {
+                // the one-workgroup-per-CU ring launches run on 8 waves (2 x 4, wave tile 64 x 32): two waves per SIMD, so one
+                // wave's fragment reads / piece issue run beside the other's MFMAs; pieces interleaved with the MFMAs (ILV)
+                return launch<128, 128, 2, 4, KS, POOL, false, 128, 3, true>(a, s);
             }
         }
         // residual register prefetch only for the short-K, bandwidth-bound expanding 1x1 convs
-        if (force != 8) {
-            if (KS == 1 && !POOL && a.res && a.K <= 256) return launch<128, 128, 2, 2, KS, POOL, (KS == 1 && !POOL)>(a, s);
-            return launch<128, 128, 2, 2, KS, POOL>(a, s);
-        }
-        // 8 waves x (64x32): 32 accumulator registers per lane -> 4 waves/SIMD resident (2 workgroups per CU)
-        if (KS == 1 && !POOL && a.res && a.K <= 256) return launch<128, 128, 2, 4, KS, POOL, (KS == 1 && !POOL)>(a, s);
-        return launch<128, 128, 2, 4, KS, POOL>(a, s);
+        if (KS == 1 && !POOL && a.res && a.K <= 256) return launch<128, 128, 2, 2, KS, POOL, (KS == 1 && !POOL)>(a, s);
+        return launch<128, 128, 2, 2, KS, POOL>(a, s);
     }
-    if (a.Cout % 64 == 0) return force != 8 ? launch<256, 64, 4, 1, KS, POOL>(a, s) : launch<256, 64, 8, 1, KS, POOL>(a, s);
+    if (a.Cout % 64 == 0) return launch<256, 64, 4, 1, KS, POOL>(a, s);
     if (a.Cout % 32 == 0) return launch<256, 32, 4, 1, KS, POOL>(a, s);   // (one stem layer; 32 B rows < 8-wave loader pass)
     return EC_ERR_SHAPE;
 }
@@ -1438,56 +1260,15 @@ int ec_conv3x3_narrow(const void* in, const void* w, const float* bias, void* ou
 int ec_conv1x1_regw(const void* a, const void* w, const float* bias, const void* res, void* y, long M, int K, int N, int act,
                     hipStream_t s);
 
-extern "C" int ec_debug_stamps(unsigned long long* host_dst, int n) {   // profiling only
+#ifdef EC_TOOLS   // tools-only build (`make tools`): the stamp read-back of the 8-wave kernel's profiling instances
+extern "C" int ec_debug_stamps(unsigned long long* host_dst, int n) {
     if (!host_dst || n <= 0 || n > 2048) return EC_ERR_ARG;
     return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(ec_dbg_stamps), (size_t)n * 8) == hipSuccess ? EC_OK : EC_ERR_LAUNCH;
 }
-
-// Fragment-order copy of a [Cout][K] bf16 weight matrix for conv_igemm8's DIRECT-B variant (Cout % 32 == 0, K % 16 == 0):
-// 16-byte unit ((nb * K/16 + ks) * 64 + l) = row nb * 32 + (l & 31), k = ks * 16 + (l >> 5) * 8 .. + 7.
-__global__ void pack_wfrag_kernel(const uint4* __restrict__ w, uint4* __restrict__ wf, int Cout, int K) {
-    const long t = (long)blockIdx.x * 256 + threadIdx.x;
-    const long total = (long)Cout * K / 8;
-    if (t >= total) return;
-    const int l = (int)(t & 63);
-    const long f = t >> 6;
-    const int kf = K >> 4;
-    const int nb = (int)(f / kf), ks = (int)(f - (long)nb * kf);
-    const long row = (long)nb * 32 + (l & 31);
-    wf[t] = w[(row * K + ks * 16 + (l >> 5) * 8) >> 3];
-}
-int ec_pack_wfrag(const void* w, void* wf, int Cout, int K, hipStream_t s) {
-    if (!w || !wf || Cout % 32 != 0 || K % 16 != 0) return EC_ERR_SHAPE;
-    const long total = (long)Cout * K / 8;
-    hipLaunchKernelGGL(pack_wfrag_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const uint4*)w, (uint4*)wf, Cout, K);
-    EC_CHECK_LAUNCH();
-    return EC_OK;
-}
+#endif
 
 extern "C" int ec_conv_bf16(const void* in, const void* w, const float* bias, const void* res, void* out, int B,
                             int H, int W, int Cin, int Cout, int ksize, int pool, int act, ec_stream_t stream) {
-    return ec_conv_bf16_wf(in, w, nullptr, bias, res, out, B, H, W, Cin, Cout, ksize, pool, act, stream);
-}
-
-// ... with a caller-owned fp32 workspace for the K-sliced launches (dispatch_split); without one (ec_conv_bf16) no launch
-// is K-sliced.  ec_conv_splitk_workspace_bytes: the most such a launch of this shape can use (0: never K-sliced).
-extern "C" size_t ec_conv_splitk_workspace_bytes(int B, int H, int W, int Cin, int Cout, int ksize) {
-    const long M = (long)B * H * W, K = (long)ksize * ksize * Cin;
-    if (B <= 0 || Cout % 128 != 0 || K < 16 * BK) return 0;
-    const long t128 = ((M + 127) / 128) * (Cout / 128);
-    const int mode = ec_config().conv_splitk;
-    if (mode == 0 || (mode == 1 && t128 >= ec_config().conv_splitk_tiles)) return 0;
-    return (size_t)8 * (size_t)M * (size_t)Cout * 4;
-}
-extern "C" int ec_conv_bf16_ws(const void* in, const void* w, const float* bias, const void* res, void* out, int B,
-                               int H, int W, int Cin, int Cout, int ksize, int pool, int act, void* workspace,
-                               size_t ws_bytes, ec_stream_t stream) {
-    const ec_splitk_scope scope(workspace, ws_bytes);
-    return ec_conv_bf16_wf(in, w, nullptr, bias, res, out, B, H, W, Cin, Cout, ksize, pool, act, stream);
-}
-
-int ec_conv_bf16_wf(const void* in, const void* w, const void* wf, const float* bias, const void* res, void* out, int B,
-                    int H, int W, int Cin, int Cout, int ksize, int pool, int act, ec_stream_t stream) {
     if (!in || !w || !out) return EC_ERR_ARG;
     if (B <= 0 || H <= 0 || W <= 0) return EC_ERR_SHAPE;
     if (ksize != 1 && ksize != 3) return EC_ERR_SHAPE;
@@ -1499,7 +1280,6 @@ int ec_conv_bf16_wf(const void* in, const void* w, const void* wf, const float* 
     ConvArgs a;
     a.in = (const uint16_t*)in;
     a.w = (const uint16_t*)w;
-    a.wf = (const uint16_t*)wf;
     a.bias = bias;
     a.res = (const uint16_t*)res;
     a.out = (uint16_t*)out;

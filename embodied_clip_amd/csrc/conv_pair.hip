@@ -729,9 +729,6 @@ extern "C" int ec_conv1x1_pair_pool_bf16(const void* a0, const void* w0, const f
 int ec_conv1x1_regw(const void* a, const void* w, const float* bias, const void* res, void* y, long M, int K, int N, int act,
                     hipStream_t s) {
     const bool on = ec_config().conv_regw != 0;
-    // Channel groups (grid y) extend the scheme to wider layers; measured for layer-3 conv3 (256 -> 1024 + residual,
-    // two groups of 512): 66 us vs 64.5 us on conv_igemm at 256 frames, 42 vs 36 us at 128 -- not used by default.
-    const int wide = ec_config().conv_regw_wide;
     if (!on || (M % PX) != 0 || M / PX > 0x7fffffffL) return EC_ERR_SHAPE;
     const long tiles = M / PX;
     RegwArgs p{(const uint16_t*)a, (const uint16_t*)w, (const uint16_t*)res, bias, (uint16_t*)y, (int)tiles, N};
@@ -740,8 +737,5 @@ int ec_conv1x1_regw(const void* a, const void* w, const float* bias, const void*
         if (K == 512 && N == 256 && !res && act == EC_ACT_RELU) return launch_regw<512, 256, false, true>(p, s);
         if (K == 128 && N == 512 && res && act == EC_ACT_RELU) return launch_regw<128, 512, true, true>(p, s);
     }
-    // layer-3 conv3 (256 -> 1024 + residual @14x14): two channel groups of 512
-    if (wide && tiles * 2 >= 1024 && K == 256 && N == 1024 && res && act == EC_ACT_RELU)
-        return launch_regw<256, 512, true, true>(p, s, 2);
     return EC_ERR_SHAPE;
 }

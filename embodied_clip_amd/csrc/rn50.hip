@@ -34,17 +34,7 @@ struct Op {
     int src1 = -1, dst2 = -1, N2 = 0;
     int dst3 = -1;           // OP_PAIR at the layer-1 -> layer-2 boundary: AvgPool2d(2)(y) for the downsample path
     size_t w1_off = 0, b1_off = 0, w2_off = 0, b2_off = 0;
-    // side branch (small batches): the downsample path of a stride-2 block (AvgPool2d + 1x1 conv) is independent of the
-    // block's conv1 -> conv2 chain; group g > 0: `fork` on the op before which the branch may start (conv1), `side` on the
-    // branch's ops, `join` on the op that consumes its result (conv3)
-    int fork = 0, side = 0, join = 0;
     long wc1_off = -1, bc1_off = -1;   // OP_BNECK with conv1 folded in (whole block in one launch): conv1's weight / bias offsets; its input is `res`
-    // EC_RN50_BAND: stride-1 blocks of the 28x28 stage (planes 128) as ONE band-fused launch (conv_bneck.hip bneck_band_kernel) for
-    // launches inside the configured frame window.  The plan itself is unchanged; rn50_run skips the ops marked band_skip (the
-    // block's conv1 / conv2), runs the op marked `band` (the block's closing conv3 / boundary launch) as the fused launch with
-    // x = res, y = dst, and runs a boundary launch marked band_half as its first half only (conv3 + identity + ReLU).
-    int band = 0, band_skip = 0, band_half = 0;
-    long band_w1 = -1, band_b1 = -1, band_w2 = -1, band_b2 = -1, wband_off = -1;
     int stride = 1;          // OP_CONV: 2 = torchvision's strided conv (ec_conv_bf16_s2); H, W are the INPUT dims
     long wimg_off = -1;      // offset (elements, into wbneck) of this 3x3 conv's streaming-order weights for the small-launch kernel
 };
@@ -61,20 +51,9 @@ struct ec_rn50 {
     const float* bias;
     size_t n_w, n_b;
     int conv8_min_tiles = 0;      // 0 = library default (ec_rn50_set_conv8_min_tiles)
-    uint16_t* wfrag = nullptr;    // EC_CONV8_DIRB: fragment-order copies of the 256-multiple-Cout convs' weights (same offsets as w)
     uint16_t* wbneck = nullptr;   // streaming-order weights of the fused bottleneck launches (ec_bneck_pack_weights), one block per OP_BNECK
-    // side branch of the stride-2 blocks (EC_RN50_SIDE): the handle's own non-blocking stream + fork / join events per group
-    hipStream_t side_stream = nullptr;
-    hipEvent_t ev_fork[4] = {nullptr, nullptr, nullptr, nullptr}, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
-    int n_side = 0;
     ~ec_rn50() {
-        if (wfrag) (void)hipFree(wfrag);
         if (wbneck) (void)hipFree(wbneck);
-        for (int i = 0; i < 4; ++i) {
-            if (ev_fork[i]) (void)hipEventDestroy(ev_fork[i]);
-            if (ev_join[i]) (void)hipEventDestroy(ev_join[i]);
-        }
-        if (side_stream) (void)hipStreamDestroy(side_stream);
     }
 };
 
@@ -163,9 +142,6 @@ int rn50_build(ec_rn50_t** out, bool tv, int width, const int* layers4, int inpu
             const int y = (x == 0) ? 4 : 0;
             const int Ro = R / stride;
             int c1 = 1;
-            const bool band_blk = ec_config().rn50_band > 0 && width == 64 && !ds && stride == 1 && planes == 128 && R == 28 && inplanes == 512;
-            const long band_w1 = (long)wo, band_b1 = (long)bo;   // this block's conv1 slot
-            int band_c1_op = -1;
             if (conv1_done) {   // weights are still laid out conv1, conv2, conv3, downsample: skip the slot
                 wo += (size_t)planes * inplanes;
                 bo += planes;
@@ -173,21 +149,11 @@ int rn50_build(ec_rn50_t** out, bool tv, int width, const int* layers4, int inpu
                 c1 = c1_buf;
             } else {
                 conv(x, 1, -1, R, R, inplanes, planes, 1, 0, EC_ACT_RELU);
-                band_c1_op = (int)h->ops.size() - 1;
             }
             if (tv && stride > 1) {   // torchvision: the 3x3 conv itself strides (no pool)
                 conv(c1, 2, -1, R, R, planes, planes, 3, 0, EC_ACT_RELU, 2);
             } else
             conv(c1, 2, -1, R, R, planes, planes, 3, stride > 1 ? 1 : 0, EC_ACT_RELU);
-            const int band_c2_op = (int)h->ops.size() - 1;
-            const long band_w2 = (long)h->ops.back().w_off, band_b2 = (long)h->ops.back().b_off;
-            auto mark_band = [&](Op& closing) {   // (called on the block's closing op before it is pushed)
-                if (!band_blk) return;
-                closing.band = 1;
-                closing.band_w1 = band_w1; closing.band_b1 = band_b1; closing.band_w2 = band_w2; closing.band_b2 = band_b2;
-                h->ops[band_c2_op].band_skip = 1;
-                if (band_c1_op >= 0) h->ops[band_c1_op].band_skip = 1;
-            };
             int idt = x;
             // weights are laid out conv1, conv2, conv3, downsample; the downsample conv
             // has to run BEFORE conv3 (conv3 consumes its output as the residual), so
@@ -220,7 +186,6 @@ int rn50_build(ec_rn50_t** out, bool tv, int width, const int* layers4, int inpu
                 inplanes = planes * 4;
                 continue;
             }
-            int side_grp = 0;
             if (ds) {
                 int dsrc = x, ddst = 3;
                 if (tv) {
@@ -232,15 +197,8 @@ int rn50_build(ec_rn50_t** out, bool tv, int width, const int* layers4, int inpu
                     pooled_in = -1;
                 } else if (stride > 1) {
                     // the pooled block input goes to the block's OUTPUT buffer y (free until conv3 writes it), not to the
-                    // conv1 / conv2 temporaries: the downsample branch then shares no buffer with the conv1 -> conv2 chain
-                    // and can run beside it (rn50_run, EC_RN50_SIDE)
+                    // conv1 / conv2 temporaries
                     Op o{OP_POOL, x, y, -1, R, R, inplanes, inplanes, 0, 0, 0, 0, 0};
-                    if (h->n_side < 4 && h->ops.size() >= 2 && h->ops[h->ops.size() - 2].kind == OP_CONV &&
-                        h->ops[h->ops.size() - 2].src == x) {
-                        side_grp = ++h->n_side;
-                        h->ops[h->ops.size() - 2].fork = side_grp;      // this block's conv1
-                        o.side = side_grp;
-                    }
                     h->ops.push_back(o);
                     track(Ro, Ro, inplanes);
                     dsrc = y;
@@ -249,7 +207,6 @@ int rn50_build(ec_rn50_t** out, bool tv, int width, const int* layers4, int inpu
                     conv(dsrc, ddst, -1, R, R, inplanes, planes * 4, 1, 0, EC_ACT_NONE, 2);
                 } else
                 conv(dsrc, ddst, -1, Ro, Ro, inplanes, planes * 4, 1, 0, EC_ACT_NONE);
-                h->ops.back().side = side_grp;
                 idt = ddst;
             }
             // Layer-2 block boundaries (28x28, 128 -> 512 -> 128): conv3 + identity + ReLU and the next block's conv1 in
@@ -260,9 +217,6 @@ int rn50_build(ec_rn50_t** out, bool tv, int width, const int* layers4, int inpu
                 o.dst2 = (idt == 1) ? 3 : 1;      // block 0 with a pooled input keeps its identity in buffer 1
                 o.N2 = planes;
                 o.w2_off = wo; o.b2_off = bo;     // == the next block's conv1 slot
-                mark_band(o);
-                // the next block is band-fused too when the window applies: this launch's second half (its conv1) is then not needed
-                o.band_half = (ec_config().rn50_band > 0 && width == 64) ? 1 : 0;
                 h->ops.push_back(o);
                 track(Ro, Ro, planes * 4);
                 conv1_done = true;
@@ -289,8 +243,6 @@ int rn50_build(ec_rn50_t** out, bool tv, int width, const int* layers4, int inpu
                 track(Ro, Ro, planes * 4);
             } else {
                 Op o{OP_CONV, 2, y, idt, Ro, Ro, planes, planes * 4, 1, 0, EC_ACT_RELU, w_c3, b_c3};
-                o.join = side_grp;
-                mark_band(o);
                 h->ops.push_back(o);
                 track(Ro, Ro, planes * 4);
             }
@@ -308,7 +260,6 @@ int rn50_build(ec_rn50_t** out, bool tv, int width, const int* layers4, int inpu
         size_t tot = 0;
         for (Op& o : h->ops) {
             if (o.kind == OP_BNECK) { o.w2_off = tot; o.wimg_off = (long)tot; tot += ec_bneck3_packed_elems(o.Cin); }   // (packed conv2 comes first; room for conv1 too)
-            if (o.band) { o.wband_off = (long)tot; tot += ec_bneck_band_packed_elems(); }
             // the un-pooled 3x3 convs of the 7x7 stage: streaming-order weights for the small-launch kernel (conv3x3_img_kernel)
             if (o.kind == OP_CONV && o.ks == 3 && o.Cin == 512 && o.Cout == 512 && ec_config().rn50_img3 &&
                 ((!o.pool && o.H == 7 && o.W == 7) || (o.pool && o.H == 14 && o.W == 14))) {   // (layer4.0's conv2 + AvgPool2d: the chunked variant)
@@ -324,26 +275,10 @@ int rn50_build(ec_rn50_t** out, bool tv, int width, const int* layers4, int inpu
                     rc = o.wc1_off >= 0 ? ec_bneck3_pack_weights(h->w + o.wc1_off, h->w + o.w_off, h->w + o.w1_off, h->wbneck + o.w2_off, o.Cin, nullptr)
                                         : ec_bneck_pack_weights(h->w + o.w_off, h->w + o.w1_off, h->wbneck + o.w2_off, o.Cin, nullptr);
                 else if (o.wimg_off >= 0) rc = ec_conv3x3_img_pack(h->w + o.w_off, h->wbneck + o.wimg_off, o.Cin, nullptr);
-                if (rc == EC_OK && o.band)
-                    rc = ec_bneck_band_pack_weights(h->w + o.band_w1, h->w + o.band_w2, h->w + o.w_off, h->wbneck + o.wband_off, nullptr);
                 if (rc != EC_OK) { delete h; return EC_ERR_LAUNCH; }
             }
             (void)hipStreamSynchronize(nullptr);
         }
-    }
-    if (h->n_side > 0 && ec_config().rn50_side > 0) {
-        bool ok = hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking) == hipSuccess;
-        for (int i = 0; i < h->n_side && ok; ++i)
-            ok = hipEventCreateWithFlags(&h->ev_fork[i], hipEventDisableTiming) == hipSuccess &&
-                 hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming) == hipSuccess;
-        if (!ok) { delete h; return EC_ERR_LAUNCH; }
-    }
-    if (ec_config().conv8_dirb) {   // fragment-order weights of every conv the 8-wave kernel's direct-B variant can take
-        if (hipMalloc(&h->wfrag, wo * sizeof(uint16_t)) != hipSuccess) { h->wfrag = nullptr; delete h; return EC_ERR_LAUNCH; }
-        for (const Op& o : h->ops)
-            if (o.kind == OP_CONV && o.Cin % 64 == 0 && o.Cout % 256 == 0)
-                if (ec_pack_wfrag(h->w + o.w_off, h->wfrag + o.w_off, o.Cout, o.ks * o.ks * o.Cin, nullptr) != EC_OK) { delete h; return EC_ERR_LAUNCH; }
-        (void)hipStreamSynchronize(nullptr);
     }
     *out = h;
     return EC_OK;
@@ -367,7 +302,7 @@ extern "C" uint64_t ec_rn50_plan_hash(const ec_rn50_t* h) {
     mix(h->width); mix(h->res); mix(h->conv8_min_tiles); mix(h->tv);
     for (const Op& o : h->ops) {
         mix(o.kind); mix(o.src); mix(o.dst); mix(o.res); mix(o.H); mix(o.W); mix(o.Cin); mix(o.Cout); mix(o.ks);
-        mix(o.pool); mix(o.act); mix(o.stride); mix(o.src1); mix(o.dst2); mix(o.N2); mix(o.dst3); mix(o.side); mix(o.wc1_off >= 0); mix(o.band + 2 * o.band_skip + 4 * o.band_half);
+        mix(o.pool); mix(o.act); mix(o.stride); mix(o.src1); mix(o.dst2); mix(o.N2); mix(o.dst3); mix(o.wc1_off >= 0);
     }
     return x;
 }
@@ -378,20 +313,9 @@ extern "C" int ec_rn50_set_conv8_min_tiles(ec_rn50_t* h, int n) {
     return EC_OK;
 }
 
-extern "C" size_t ec_conv_splitk_workspace_bytes(int B, int H, int W, int Cin, int Cout, int ksize);
-namespace {
-// fp32 partial-sum region for the K-sliced launches of small batches (conv_igemm.hip dispatch_split), behind the five
-// activation buffers: the largest any conv of the plan can use at this batch (0 at large batches: nothing is K-sliced)
-size_t rn50_splitk_bytes(const ec_rn50_t* h, int batch) {
-    size_t mx = 0;
-    for (const Op& o : h->ops)
-        if (o.kind == OP_CONV) mx = std::max(mx, ec_conv_splitk_workspace_bytes(batch, o.H, o.W, o.Cin, o.Cout, o.ks));
-    return align_up(mx, 256);
-}
-}  // namespace
 extern "C" size_t ec_rn50_workspace_bytes(const ec_rn50_t* h, int batch) {
     if (!h || batch <= 0) return 0;
-    return NBUF * align_up(h->max_elems_per_frame * 2 * (size_t)batch, 256) + rn50_splitk_bytes(h, batch);
+    return NBUF * align_up(h->max_elems_per_frame * 2 * (size_t)batch, 256);
 }
 
 extern "C" int ec_stem_conv1_u8(const uint8_t* rgb_u8, const float* mean3, const float* std3, const float* w,
@@ -428,7 +352,6 @@ int rn50_run(const ec_rn50_t* h, const void* rgb, bool u8, const float* mean3, c
     const ec_min_tiles_scope mint_scope(h->conv8_min_tiles);   // this handle's dispatch threshold, for this call only
     const size_t bufsz = align_up(h->max_elems_per_frame * 2 * (size_t)chunk, 256);
     unsigned char* base = (unsigned char*)workspace;
-    const ec_splitk_scope splitk_scope(base + NBUF * bufsz, rn50_splitk_bytes(h, chunk));   // (the region behind the buffers)
     const size_t rgb_stride = (size_t)h->res * h->res * 3;
     const size_t out_stride = (size_t)h->out_sp * h->out_sp * h->out_c;
     for (int b0 = 0; b0 < batch; b0 += chunk) {
@@ -437,40 +360,9 @@ int rn50_run(const ec_rn50_t* h, const void* rgb, bool u8, const float* mean3, c
             if (id == -3) return (uint16_t*)feat + (size_t)b0 * out_stride;
             return base + (size_t)id * bufsz;
         };
-        // EC_RN50_SIDE = n (default 0 = off): in launches of at most n frames -- where no single conv fills the chip -- the
-        // downsample branch of the stride-2 blocks (AvgPool2d + 1x1 conv) runs on the handle's side stream beside the
-        // block's conv1 -> conv2 chain: forked before conv1, joined before conv3.  MEASURED (round 4): 0.929 -> 0.963 ms at
-        // 32 frames, neutral at 64, and 36.7 -> 26.4 k env-frames/s with two 32-frame slices in flight (four streams
-        // contending: the event hand-offs serialise the slices) -- kept as an experiment switch only.
-        const bool side_on = h->side_stream && nb <= ec_config().rn50_side;
-        // EC_RN50_BAND / EC_RN50_BAND_MAX: the frame window in which layer2.1-3 run as band-fused launches
-        const bool band_on = ec_config().rn50_band > 0 && nb >= ec_config().rn50_band && nb <= ec_config().rn50_band_max;
         for (const Op& o : h->ops) {
             int rc;
-            hipStream_t stream = (hipStream_t)stream_main;
-            if (band_on && o.band_skip) continue;
-            if (band_on && o.band) {
-                rc = ec_bneck_band_bf16(buf(o.res), h->wbneck + o.wband_off, h->bias + o.band_b1, h->bias + o.band_b2, h->bias + o.b_off,
-                                        buf(o.dst), nb, o.H, o.W, o.Cin, stream);
-                if (rc != EC_OK) return rc;
-                continue;
-            }
-            if (band_on && o.band_half && o.kind == OP_PAIR) {   // the boundary launch in front of a band-fused block: conv3 + identity + ReLU only
-                rc = ec_conv_bf16(buf(o.src), h->w + o.w_off, h->bias + o.b_off, o.res >= 0 ? buf(o.res) : nullptr, buf(o.dst), nb, o.H,
-                                  o.W, o.Cin, o.Cout, 1, 0, EC_ACT_RELU, stream);
-                if (rc != EC_OK) return rc;
-                continue;
-            }
-            if (side_on) {
-                if (o.fork) { if (hipEventRecord(h->ev_fork[o.fork - 1], (hipStream_t)stream_main) != hipSuccess) return EC_ERR_LAUNCH; }
-                if (o.join) { if (hipStreamWaitEvent((hipStream_t)stream_main, h->ev_join[o.join - 1], 0) != hipSuccess) return EC_ERR_LAUNCH; }
-                if (o.side) {
-                    stream = h->side_stream;
-                    if (o.kind == OP_POOL && hipStreamWaitEvent(h->side_stream, h->ev_fork[o.side - 1], 0) != hipSuccess) return EC_ERR_LAUNCH;
-                }
-            }
-            const ec_splitk_scope side_nosplit(o.side && side_on ? nullptr : (void*)ec_tls_splitk_ws,
-                                               o.side && side_on ? 0 : ec_tls_splitk_bytes);   // (one partial-sum region: main stream only)
+            const hipStream_t stream = (hipStream_t)stream_main;
             switch (o.kind) {
                 case OP_STEM1:
                     if (u8)
@@ -518,7 +410,7 @@ int rn50_run(const ec_rn50_t* h, const void* rgb, bool u8, const float* mean3, c
                                                   buf(o.res), buf(o.dst), nb, o.H, o.W, o.Cin, stream);
                     else {   // small launches: the convs separately (buffer 1 = conv1's, buffer 2 = conv2's output, as in the unfused plan)
                         if (o.wc1_off >= 0) {
-                            rc = ec_conv_bf16_wf(buf(o.res), h->w + o.wc1_off, nullptr, h->bias + o.bc1_off, nullptr, buf(o.src), nb, o.H, o.W,
+                            rc = ec_conv_bf16(buf(o.res), h->w + o.wc1_off, h->bias + o.bc1_off, nullptr, buf(o.src), nb, o.H, o.W,
                                                  o.Cout, o.Cin, 1, 0, EC_ACT_RELU, stream);
                             if (rc != EC_OK) return rc;
                         }
@@ -526,10 +418,10 @@ int rn50_run(const ec_rn50_t* h, const void* rgb, bool u8, const float* mean3, c
                         if (ec_config().rn50_img3 && nb * 8 <= 256)
                             rc = ec_conv3x3_img_bf16(buf(o.src), h->wbneck + o.wimg_off, h->bias + o.b_off, buf(2), nb, o.H, o.W, o.Cin, 0, stream);
                         else
-                        rc = ec_conv_bf16_wf(buf(o.src), h->w + o.w_off, nullptr, h->bias + o.b_off, nullptr, buf(2), nb, o.H, o.W,
+                        rc = ec_conv_bf16(buf(o.src), h->w + o.w_off, h->bias + o.b_off, nullptr, buf(2), nb, o.H, o.W,
                                              o.Cin, o.Cin, 3, 0, EC_ACT_RELU, stream);
                         if (rc == EC_OK)
-                            rc = ec_conv_bf16_wf(buf(2), h->w + o.w1_off, nullptr, h->bias + o.b1_off, buf(o.res), buf(o.dst), nb, o.H,
+                            rc = ec_conv_bf16(buf(2), h->w + o.w1_off, h->bias + o.b1_off, buf(o.res), buf(o.dst), nb, o.H,
                                                  o.W, o.Cin, o.Cout, 1, 0, EC_ACT_RELU, stream);
                     }
                     break;
@@ -544,14 +436,10 @@ int rn50_run(const ec_rn50_t* h, const void* rgb, bool u8, const float* mean3, c
                         rc = ec_conv3x3_img_bf16(buf(o.src), h->wbneck + o.wimg_off, h->bias + o.b_off, buf(o.dst), nb, o.H, o.W, o.Cin, o.pool, stream);
                         break;
                     }
-                    rc = ec_conv_bf16_wf(buf(o.src), h->w + o.w_off,
-                                         (h->wfrag && o.Cin % 64 == 0 && o.Cout % 256 == 0) ? h->wfrag + o.w_off : nullptr,
-                                         h->bias + o.b_off, o.res >= 0 ? buf(o.res) : nullptr,
-                                         buf(o.dst), nb, o.H, o.W, o.Cin, o.Cout, o.ks, o.pool, o.act, stream);
+                    rc = ec_conv_bf16(buf(o.src), h->w + o.w_off, h->bias + o.b_off, o.res >= 0 ? buf(o.res) : nullptr,
+                                      buf(o.dst), nb, o.H, o.W, o.Cin, o.Cout, o.ks, o.pool, o.act, stream);
             }
             if (rc != EC_OK) return rc;
-            if (side_on && o.side && o.kind == OP_CONV &&
-                hipEventRecord(h->ev_join[o.side - 1], h->side_stream) != hipSuccess) return EC_ERR_LAUNCH;
         }
     }
     return EC_OK;

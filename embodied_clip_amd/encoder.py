@@ -458,21 +458,14 @@ def _guard_first(fn):
 
 
 @_guard_first
-def conv_bf16(x, w, bias, res=None, ksize=1, pool=False, act=1, workspace=None, out=None):
-    """x bf16 [B,H,W,Cin]; w bf16 [Cout, k*k*Cin]; bias f32 [Cout] -> bf16 [B,H',W',Cout].
-    ``workspace`` (a uint8 device tensor, e.g. ``conv_splitk_workspace(...)``): lets low-tile-count launches run as a fixed
-    K partition (``ec_conv_bf16_ws``)."""
+def conv_bf16(x, w, bias, res=None, ksize=1, pool=False, act=1, out=None):
+    """x bf16 [B,H,W,Cin]; w bf16 [Cout, k*k*Cin]; bias f32 [Cout] -> bf16 [B,H',W',Cout]."""
     lib = _lib.load()
     B, H, W, Cin = x.shape
     Cout = w.shape[0]
     Ho, Wo = (H // 2, W // 2) if pool else (H, W)
     if out is None:
         out = torch.empty((B, Ho, Wo, Cout), dtype=torch.bfloat16, device=x.device)
-    if workspace is not None:
-        _lib.check(lib.ec_conv_bf16_ws(x.data_ptr(), w.data_ptr(), _lib.ptr(bias), _lib.ptr(res), out.data_ptr(), B, H, W,
-                                       Cin, Cout, ksize, int(pool), act, workspace.data_ptr(), workspace.numel(),
-                                       _lib.stream_ptr()), "ec_conv_bf16_ws")
-        return out
     _lib.check(lib.ec_conv_bf16(x.data_ptr(), w.data_ptr(), _lib.ptr(bias), _lib.ptr(res), out.data_ptr(), B, H, W,
                                 Cin, Cout, ksize, int(pool), act, _lib.stream_ptr()), "ec_conv_bf16")
     return out
@@ -559,25 +552,6 @@ def bneck_conv123_bf16(x, w1, b1, w2, b2, w3, b3, out=None):
     return out
 
 
-@_guard_first
-def bneck_band_bf16(x, w1, b1, w2, b2, w3, b3, out=None):
-    """The whole stride-1 Bottleneck of the 28 x 28 stage in one launch (``ec_bneck_band_bf16``): x bf16 [B,28,28,512], w1 bf16
-    [128,512], w2 bf16 [128,1152], w3 bf16 [512,128] -> bf16 [B,28,28,512]."""
-    lib = _lib.load()
-    B, H, W, C4 = x.shape
-    packed = _packed_lookup("band", (w1, w2, w3))
-    if packed is None:
-        packed = torch.empty(lib.ec_bneck_band_packed_elems(), dtype=torch.bfloat16, device=x.device)
-        _lib.check(lib.ec_bneck_band_pack_weights(w1.data_ptr(), w2.data_ptr(), w3.data_ptr(), packed.data_ptr(), _lib.stream_ptr()),
-                   "ec_bneck_band_pack_weights")
-        _packed_store("band", (w1, w2, w3), packed)
-    if out is None:
-        out = torch.empty_like(x)
-    _lib.check(lib.ec_bneck_band_bf16(x.data_ptr(), packed.data_ptr(), b1.data_ptr(), b2.data_ptr(), b3.data_ptr(), out.data_ptr(),
-                                      B, H, W, C4 // 4, _lib.stream_ptr()), "ec_bneck_band_bf16")
-    return out
-
-
 _BNECK_PACKED = {}
 
 
@@ -613,13 +587,6 @@ def bneck_pack_weights(w2, w3):
     _lib.check(lib.ec_bneck_pack_weights(w2.data_ptr(), w3.data_ptr(), packed.data_ptr(), C, _lib.stream_ptr()), "ec_bneck_pack_weights")
     _packed_store("bneck", (w2, w3), packed)
     return packed
-
-
-def conv_splitk_workspace(x, w, ksize=1):
-    """The fp32 partial-sum workspace ``conv_bf16(..., workspace=)`` can use for this shape (None: never K-sliced)."""
-    B, H, W, Cin = x.shape
-    n = _lib.load().ec_conv_splitk_workspace_bytes(B, H, W, Cin, w.shape[0], ksize)
-    return torch.empty(n, dtype=torch.uint8, device=x.device) if n else None
 
 
 @_guard_first

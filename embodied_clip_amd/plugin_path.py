@@ -6,7 +6,9 @@ only, with the reference's tensor contracts at every hand-over:
       -> rollout storage (fp32 NCHW, [T+1,N,2048,7,7])   [U] ``RolloutStorage.insert``
       -> ``ResnetTensorObjectNavActorCritic.forward``    T=1 act steps (no_grad), ``Memory`` round trip, ``sample()``
     -> ``compute_returns`` (GAE) -> ``update_repeats`` x { forward over [T,N] -> ``PPO.loss`` -> ``backward()`` ->
-       per-parameter ``.grad`` -> ``clip_grad_norm_`` -> ``torch.optim.Adam.step()`` }
+       per-parameter ``.grad`` -> ``optimizer.step()`` }, the optimiser being what the config's ``optimizer_builder`` names:
+       ``FusedClipAdam`` (clip + Adam in one launch over the policy's flat bucket: INTEGRATION.md shows the one-line swap) or,
+       with ``optimizer="torch"``, the reference's ``clip_grad_norm_`` + ``torch.optim.Adam``
 
 (readme_files/baselines_robothor_objectnav.md:25,48-51: this is what ``allenact_main`` runs when the experiment configs
 are used unchanged.)  ``engine.Worker`` is the same arithmetic with the MI355X-native data flow (bf16 NHWC features
@@ -24,7 +26,7 @@ from . import spaces
 from . import synthetic as syn
 from .clip_preprocessors import ClipResNetPreprocessor
 from .policy import Memory, ResnetTensorObjectNavActorCritic
-from .ppo import PPO, compute_returns, linear_decay_lr
+from .ppo import PPO, FusedClipAdam, compute_returns, linear_decay_lr
 
 
 class PluginPathRunner:
@@ -33,7 +35,7 @@ class PluginPathRunner:
 
     def __init__(self, n_actors: int, T: int = 128, device="cuda:0", seed: int = 0, update_repeats: int = 4,
                  lr: float = 3e-4, max_grad_norm: float = 0.5, gamma: float = 0.99, tau: float = 0.95,
-                 pool_steps: int = 4, frames_u8: bool = False):
+                 pool_steps: int = 4, frames_u8: bool = False, optimizer: str = "fused"):
         """``frames_u8``: the RGB sensor hands over raw uint8 HWC frames (``ClipResNetPreprocessor.process`` then fuses /255
         and the CLIP mean / std into the stem kernel): a quarter of the PCIe bytes of the normalised fp32 frames."""
         self.N, self.T, self.dev = n_actors, T, torch.device(device)
@@ -45,7 +47,11 @@ class PluginPathRunner:
                                                       rgb_resnet_preprocessor_uuid="rgb_clip_resnet",
                                                       state_dict=syn.policy_state_dict(0), device=dev)
         self.loss = PPO()
-        self.opt = torch.optim.Adam(self.model.parameters(), lr=lr)
+        self.optimizer_kind = optimizer
+        if optimizer == "fused":     # Builder(FusedClipAdam, dict(lr=lr, max_grad_norm=0.5)) in the experiment config
+            self.opt = FusedClipAdam(self.model.parameters(), lr=lr, max_grad_norm=max_grad_norm)
+        else:                        # the reference's Builder(optim.Adam, dict(lr=lr)) + the engine's clip_grad_norm_
+            self.opt = torch.optim.Adam(self.model.parameters(), lr=lr)
         (dims, _), = self.model.recurrent_memory_specification.values()
         self.sampler_dim = [d[0] for d in dims].index("sampler")
         H = self.model.recurrent_hidden_state_size
@@ -66,6 +72,13 @@ class PluginPathRunner:
         self.total_steps, self._k = 0, 0
         self.feat[0] = self.pre.process({"rgb": self._observe()})
         self.info: Dict[str, float] = {}
+
+    def step_optimizer(self):
+        if self.optimizer_kind != "fused":
+            torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.max_grad_norm)
+        for g in self.opt.param_groups:
+            g["lr"] = linear_decay_lr(self.lr, self.total_steps, 300_000_000)
+        self.opt.step()
 
     def _observe(self) -> torch.Tensor:
         f = self.host_frames[self._k % len(self.host_frames)]
@@ -100,10 +113,7 @@ class PluginPathRunner:
             total, self.info = self.loss.loss(self.total_steps, batch, out)
             self.opt.zero_grad()
             total.backward()
-            torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.max_grad_norm)
-            for g in self.opt.param_groups:
-                g["lr"] = linear_decay_lr(self.lr, self.total_steps, 300_000_000)
-            self.opt.step()
+            self.step_optimizer()
         with torch.no_grad():
             self.feat[0].copy_(self.feat[T])
             self.memory[0].copy_(self.memory[T])
@@ -111,8 +121,8 @@ class PluginPathRunner:
 
 
 def time_plugin_path(n_actors: int, T: int, device, steps: int = 1, warmup: int = 1, update_repeats: int = 4,
-                     frames_u8: bool = False) -> Dict:
-    r = PluginPathRunner(n_actors, T, device, update_repeats=update_repeats, frames_u8=frames_u8)
+                     frames_u8: bool = False, optimizer: str = "fused") -> Dict:
+    r = PluginPathRunner(n_actors, T, device, update_repeats=update_repeats, frames_u8=frames_u8, optimizer=optimizer)
     for _ in range(warmup):
         r.iteration()
     torch.cuda.synchronize()
@@ -126,4 +136,5 @@ def time_plugin_path(n_actors: int, T: int, device, steps: int = 1, warmup: int 
             "route": ("HOST uint8 HWC frames (raw sensor output; /255 + CLIP mean/std fused into the stem)" if frames_u8 else
                       "HOST fp32 NHWC frames") + " -> ClipResNetPreprocessor.process (fp32 NCHW out) -> fp32 NCHW rollout storage -> "
                      "ResnetTensorObjectNavActorCritic.forward (T=1 act, T=rollout learn) -> PPO.loss -> backward() -> "
-                     "per-parameter grads -> clip_grad_norm_ -> torch.optim.Adam"}
+                     "per-parameter grads -> " + ("FusedClipAdam.step (clip + Adam, one launch on the flat bucket)" if optimizer == "fused"
+                                                  else "clip_grad_norm_ -> torch.optim.Adam")}

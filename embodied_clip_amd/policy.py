@@ -246,8 +246,23 @@ class ResnetTensorObjectNavActorCritic(ActorCriticModel):
 
     # -- flat bucket maintenance -----------------------------------------------------------------
     def _named(self):
-        d = dict(self.named_parameters())
-        return [(n, d[n]) for n in self.handle.param_order]
+        """[(name, Parameter)] in the handle's order.  Cached: ``named_parameters()`` walks the module tree (~0.2 ms of host
+        time per call, three calls per forward -- it showed in the act step of the plugin route); the Parameter OBJECTS are
+        stable (``.to()`` / ``load_state_dict`` change ``.data`` in place), and ``_apply`` / ``register_parameter`` drop the
+        cache in case a caller replaces them."""
+        c = self.__dict__.get("_named_cache")
+        if c is None:
+            d = dict(self.named_parameters())
+            c = self.__dict__["_named_cache"] = [(n, d[n]) for n in self.handle.param_order]
+        return c
+
+    def _apply(self, fn, *args, **kwargs):
+        self.__dict__["_named_cache"] = None
+        return super()._apply(fn, *args, **kwargs)
+
+    def register_parameter(self, name, param):
+        self.__dict__["_named_cache"] = None
+        return super().register_parameter(name, param)
 
     def _bind_grads(self):
         """(Re)bind every ``p.grad`` to its view of the flat gradient bucket.  ``optimizer.zero_grad()`` of recent
@@ -374,8 +389,12 @@ class ResnetTensorObjectNavActorCritic(ActorCriticModel):
         goal = goal.reshape(T * N).to(torch.int64).contiguous()
         h0 = memory.tensor("rnn").reshape(N, self._hidden_size).to(torch.float32).contiguous()
         m = masks.reshape(T * N).to(torch.float32).contiguous()
-        params = [p for _, p in self._named()]
-        hv, h_final = _PolicyFn.apply(self.handle, self, self._flat, rows, rows2, goal, h0, m, T, N, *params)
+        if torch.is_grad_enabled():
+            params = [p for _, p in self._named()]
+            hv, h_final = _PolicyFn.apply(self.handle, self, self._flat, rows, rows2, goal, h0, m, T, N, *params)
+        else:   # act steps (the engine's no_grad rollout): straight to the inference plan, no autograd node, no 17-tensor argument list
+            ws = torch.empty(self.handle.workspace_bytes(T, N, False), dtype=torch.uint8, device=self._flat.device)
+            hv, h_final = self.handle.forward(self._flat, rows, goal, h0, m, T, N, ws, for_backward=False, feat2=rows2)
         A = self.handle.A
         hv = hv.view(T, N, A + 1)
         out = ActorCriticOutput(distributions=CategoricalDistr(logits=hv[..., :A]), values=hv[..., A:], extras={})

@@ -9,7 +9,8 @@ readme_files/baselines_robothor_objectnav.md:48-51; SURVEY.md §8a a15-a17, §8b
     use_clipped_value_loss True, normalize_advantage True;
   * ``compute_returns`` == ``RolloutStorage.compute_returns(next_value, use_gae=True, gamma, tau)``;
   * ``FlatAdam`` == ``clip_grad_norm_(max_grad_norm)`` + ``torch.optim.Adam.step()`` as ONE launch
-    over the policy's flat parameter bucket.
+    over the policy's flat parameter bucket; ``FusedClipAdam`` is the same launch behind the
+    ``torch.optim.Optimizer`` interface (what an AllenAct ``optimizer_builder`` instantiates).
 """
 from __future__ import annotations
 
@@ -132,6 +133,118 @@ class FlatAdam:
 
     def grad_norm(self) -> float:
         return float(self.sumsq.sqrt().item())
+
+
+class FusedClipAdam(torch.optim.Optimizer):
+    """``torch.optim.Adam`` drop-in (same ``param_groups`` / ``lr`` / ``betas`` / ``eps`` keys, per-parameter ``state`` with
+    ``step`` / ``exp_avg`` / ``exp_avg_sq`` so that ``state_dict()`` checkpoints keep torch's layout) whose ``step()`` is ONE
+    ``ec_clip_adam_step`` launch per parameter group -- global-norm gradient clipping (``max_grad_norm``; ``None`` = off, e.g.
+    when the engine has already called ``clip_grad_norm_``) + Adam over a flat fp32 bucket, no host synchronisation.
+
+    [U] AllenAct builds its optimiser from the experiment config (``optimizer_builder=Builder(optim.Adam, dict(lr=lr))``,
+    the RoboTHOR ObjectNav mixin behind readme_files/baselines_robothor_objectnav.md:51) and steps it in
+    ``OnPolicyTrainer.backprop_step`` after ``nn.utils.clip_grad_norm_``; the swap is that one ``Builder`` line
+    (INTEGRATION.md).  Parameters that already are views of one flat buffer -- ``ResnetTensorObjectNavActorCritic`` keeps
+    its 17 tensors and their ``.grad`` s that way -- are used IN PLACE (zero copies); any other parameter set is flattened
+    once (``p.data`` re-pointed into a new flat buffer) and its gradients are gathered into a flat scratch per step.
+    Not implemented (raises): ``weight_decay != 0``, ``amsgrad``, sparse or non-fp32 parameters, a group in which only some
+    parameters have a gradient."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False, max_grad_norm=None):
+        if weight_decay != 0.0 or amsgrad:
+            raise NotImplementedError("FusedClipAdam: weight_decay / amsgrad are not implemented (AllenAct's PPO configs use neither)")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=0.0, amsgrad=False, max_grad_norm=max_grad_norm))
+        self.lib = _lib.load()
+        self._buckets: Dict[int, dict] = {}
+
+    @staticmethod
+    def _span(tensors):
+        """(storage offset of the first element, numel of the covering span) when ``tensors`` are non-overlapping contiguous
+        fp32 views of ONE storage in increasing order; else None."""
+        st = tensors[0].untyped_storage().data_ptr()
+        lo, end = None, None
+        for t in tensors:
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.untyped_storage().data_ptr() != st:
+                return None
+            o = t.storage_offset()
+            if end is not None and o < end:
+                return None
+            lo = o if lo is None else lo
+            end = o + t.numel()
+        return lo, end - lo
+
+    @staticmethod
+    def _flat_view(t: torch.Tensor, off: int, n: int) -> torch.Tensor:
+        return torch.empty(0, dtype=torch.float32, device=t.device).set_(t.untyped_storage(), off, (n,), (1,))
+
+    def _bucket(self, gi: int, ps):
+        b = self._buckets.get(gi)
+        if b is not None and b["ptrs"] == tuple(p.data_ptr() for p in ps):
+            return b
+        span = self._span([p.data for p in ps])
+        if span is None:        # flatten once: the parameters become views of one new buffer (values preserved)
+            flat = torch.cat([p.data.reshape(-1).float() for p in ps])
+            o = 0
+            for p in ps:
+                p.data = flat[o:o + p.numel()].view(p.shape)
+                o += p.numel()
+            span = (0, flat.numel())
+        off, n = span
+        flat = self._flat_view(ps[0].data, off, n)
+        m, v = torch.zeros_like(flat), torch.zeros_like(flat)
+        rel = [p.data.storage_offset() - off for p in ps]
+        for p, r in zip(ps, rel):
+            stt = self.state[p]
+            if "exp_avg" in stt and stt["exp_avg"].numel() == p.numel():      # resumed from a torch-format checkpoint
+                m[r:r + p.numel()].copy_(stt["exp_avg"].reshape(-1))
+                v[r:r + p.numel()].copy_(stt["exp_avg_sq"].reshape(-1))
+            stt["exp_avg"], stt["exp_avg_sq"] = m[r:r + p.numel()].view(p.shape), v[r:r + p.numel()].view(p.shape)
+            stt.setdefault("step", torch.tensor(0.0))
+        b = self._buckets[gi] = dict(ptrs=tuple(p.data_ptr() for p in ps), off=off, n=n, flat=flat, m=m, v=v, rel=rel,
+                                     sumsq=torch.zeros(1, dtype=torch.float64, device=flat.device), gscratch=None)
+        return b
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for gi, group in enumerate(self.param_groups):
+            ps = [p for p in group["params"] if p.numel() > 0]
+            if not ps:
+                continue
+            if any(p.grad is None for p in ps):
+                if all(p.grad is None for p in ps):
+                    continue
+                raise NotImplementedError("FusedClipAdam: a parameter group with gradients on only some of its parameters")
+            if any(p.grad.is_sparse for p in ps):
+                raise NotImplementedError("FusedClipAdam: sparse gradients")
+            b = self._bucket(gi, ps)
+            gs = [p.grad for p in ps]
+            gspan = self._span(gs)
+            if gspan is not None and gspan[1] == b["n"] and all(g.storage_offset() - gspan[0] == r for g, r in zip(gs, b["rel"])):
+                gflat = self._flat_view(gs[0], gspan[0], gspan[1])          # the module's flat gradient bucket, in place
+            else:                                                           # gather (plumbing copies; the arithmetic stays in the kernel)
+                if b["gscratch"] is None:
+                    b["gscratch"] = torch.zeros_like(b["flat"])
+                gflat = b["gscratch"]
+                for g, r in zip(gs, b["rel"]):
+                    gflat[r:r + g.numel()].copy_(g.reshape(-1))
+            step = int(self.state[ps[0]]["step"]) + 1
+            mg = group.get("max_grad_norm")
+            with _lib.tensor_guard(b["flat"]):
+                _lib.check(self.lib.ec_clip_adam_step(b["flat"].data_ptr(), gflat.data_ptr(), b["m"].data_ptr(), b["v"].data_ptr(),
+                                                      b["sumsq"].data_ptr(), b["n"], float(mg) if mg else 0.0, float(group["lr"]),
+                                                      group["betas"][0], group["betas"][1], group["eps"], step, _lib.stream_ptr()),
+                           "ec_clip_adam_step")
+            for p in ps:
+                self.state[p]["step"] = torch.tensor(float(step))
+        return loss
+
+    def grad_norm(self, group: int = 0) -> float:
+        """Global gradient norm the last ``step()`` of ``group`` saw (one host sync; for logging)."""
+        return float(self._buckets[group]["sumsq"].sqrt().item())
 
 
 def linear_decay_lr(base_lr: float, step: int, total_steps: int) -> float:

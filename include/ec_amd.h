@@ -64,21 +64,12 @@ const char* ec_strerror(int code);
 int ec_conv_bf16(const void* in, const void* w, const float* bias, const void* res, void* out,
                  int B, int H, int W, int Cin, int Cout, int ksize, int pool, int act,
                  ec_stream_t stream);
-/* The same conv with a caller-owned fp32 workspace: launches with fewer 128x128 output tiles than CUs and a K walk of
- * >= 16 tiles (the 14x14 / 7x7 maps of layers 3-4 at 32-64 frames per launch: the strong-scaling operating points of
- * readme_files/baselines_habitat.md:63-73, NUM_GPUS=8) run as a FIXED K partition -- 2..8 slices of the K-tile range,
- * each slice's fp32 partial sums in the workspace, folded in slice order (+ bias / residual / ReLU / AvgPool2d, one
- * rounding to bf16) by a second small launch: deterministic, no atomics; the slice count depends on the layer's shape
- * and the launch's tile count only.  Without a workspace (ec_conv_bf16) no launch is K-sliced.
- * ec_conv_splitk_workspace_bytes: the most a launch of this shape can use (0 = never K-sliced). */
-size_t ec_conv_splitk_workspace_bytes(int B, int H, int W, int Cin, int Cout, int ksize);
-int ec_conv_bf16_ws(const void* in, const void* w, const float* bias, const void* res, void* out,
-                    int B, int H, int W, int Cin, int Cout, int ksize, int pool, int act,
-                    void* workspace, size_t ws_bytes, ec_stream_t stream);
-
 /* Plain GEMM view of the same kernel: out[M,N] = act(A[M,K] W[N,K]^T + bias (+res)).
  * Replaces nn.Linear / nn.MultiheadAttention projections of [U] clip/model.py
  * ResidualAttentionBlock and AttentionPool2d.  K multiple of 8, N multiple of 32. */
+int ec_gemm_bf16(const void* A, const void* W, const float* bias, const void* res, void* out,
+                 int M, int N, int K, int act, ec_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * CLIP image preprocessing on raw uint8 frames: Resize(n_px, BICUBIC) + CenterCrop(n_px), bit-exact with Pillow.
  * Replaces the PIL/torchvision half of `clip_preprocess(frame)` (primitive_probing/generate_data/
@@ -95,10 +86,6 @@ int ec_clip_resize_table(int H, int W, int n_px, int* host_table, size_t n_ints)
 int ec_clip_resize_crop_u8(const uint8_t* frames_u8, const int* table_dev, int table_max_rows, uint8_t* out_u8, int B,
                            int H, int W, int n_px, ec_stream_t stream);
 
-/* profiling only: copies the s_memtime stamps the 8-wave conv kernel records under EC_CONV_ABLATE & 32 */
-int ec_debug_stamps(unsigned long long* host_dst, int n);
-int ec_gemm_bf16(const void* A, const void* W, const float* bias, const void* res, void* out,
-                 int M, int N, int K, int act, ec_stream_t stream);
 
 /* out[M, N] (fp32) = act(A[M, K] (bf16) @ W^T + bias), W an fp32 [N, K] matrix handed over as the three bf16 planes
  * ec_split3_bf16 writes ([N][3][K]): the exact-fp32 product of stored bf16 features with fp32 weights -- the first
@@ -156,9 +143,6 @@ int ec_stem_conv1_u8(const uint8_t* rgb_u8_nhwc, const float* h_mean3, const flo
  * Bit-identical to ec_conv_bf16(3x3) followed by ec_conv_bf16(1x1, res = x).  EC_ERR_SHAPE unless H = W = 14, C = 256. */
 size_t ec_bneck_packed_elems(int C);
 int ec_bneck_pack_weights(const void* w2, const void* w3, void* packed, int C, ec_stream_t stream);
-/* profiling only: a device buffer of 16 uint64 that workgroup 0 of every following fused launch fills with {shader clock,
- * 100-MHz real time} stamps at its phase boundaries (tools/bench_bneck.py --stamps); NULL switches it off */
-void ec_bneck_set_debug(void* dev_u64x16);
 int ec_bneck_conv23_bf16(const void* c1, const void* packed, const float* b2, const float* b3,
                          const void* x, void* y, int B, int H, int W, int C, ec_stream_t stream);
 
@@ -170,16 +154,6 @@ size_t ec_bneck3_packed_elems(int C);
 int ec_bneck3_pack_weights(const void* w1, const void* w2, const void* w3, void* packed, int C, ec_stream_t stream);
 int ec_bneck_conv123_bf16(const void* x, const void* packed, const float* b1, const float* b2, const float* b3,
                           void* y, int B, int H, int W, int C, ec_stream_t stream);
-
-/* The whole stride-1 Bottleneck of the 28 x 28 stage (planes C = 128, 512 channels in / out: CLIP-RN50 layer2.1 .. layer2.3) in
- * one launch, one workgroup per band of 7 output rows; conv1's output for the band + a halo row on each side lives in LDS
- * (the halo rows' conv1 is recomputed), c1 / c2 never exist in HBM.  packed = ec_bneck_band_pack_weights(w1 bf16 [128][512],
- * w2 bf16 [128][3*3*128], w3 bf16 [512][128]) (ec_bneck_band_packed_elems() elements).  x / y bf16 [B,28,28,512].  Bit-identical
- * to the three ec_conv_bf16 calls.  EC_ERR_SHAPE for any other geometry. */
-size_t ec_bneck_band_packed_elems(void);
-int ec_bneck_band_pack_weights(const void* w1, const void* w2, const void* w3, void* packed, ec_stream_t stream);
-int ec_bneck_band_bf16(const void* x, const void* packed, const float* b1, const float* b2, const float* b3,
-                       void* y, int B, int H, int W, int C, ec_stream_t stream);
 
 /* relu(bn2(conv2(x))) of a late Bottleneck for SMALL launches (<= 64 frames: the per-GPU batches of strong scaling,
  * readme_files/baselines_habitat.md:63-73): one workgroup per (image, 32/64-channel slice), the image's map resident in

@@ -138,7 +138,7 @@ def test_trunk_odd_batches_match_oracle(B):
     # a frame's features do not depend on what else is in the batch (up to fp32-accumulation rounding amplified through the
     # trunk: the launch shape decides which kernel -- and so which fixed summation order -- the late 3x3 convs take)
     one = trunk.to_nchw_f32(trunk.forward(x[:1].to(DEV))).cpu()
-    assert _rel(one[0], got[0]) <= 1e-2
+    assert _rel(one[0], got[0]) <= 7e-3
 
 
 def test_cabi_error_codes_not_exceptions():

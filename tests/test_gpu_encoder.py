@@ -203,7 +203,7 @@ def test_rn50_trunk_matches_oracle(dev, width, layers, res):
     # rounding (the K partition of the small layer-3/4 launches depends on the launch's tile count: tests/test_gpu_splitk.py)
     trunk.chunk = 2
     feat2 = trunk.forward(rgb.to(dev))
-    assert _rel(feat2.cpu(), feat.cpu()) <= 1e-2
+    assert _rel(feat2.cpu(), feat.cpu()) <= 7e-3       # across launch shapes: measured 4-5e-3
     # pool=True head
     pooled = trunk.spatial_mean(feat).cpu()
     assert torch.allclose(pooled, got.mean((2, 3)), atol=1e-3 * got.abs().max().item())
@@ -491,38 +491,6 @@ def test_real_clip_rn50_checkpoint_if_present(dev):
     assert cos.min() > 0.999 and _rel(out, ref) < 2e-2
 
 
-def test_direct_b_variant_of_the_8wave_kernel_is_bit_identical(dev, tmp_path):
-    """EC_CONV8_DIRB=1 (round-3 experiment, off by default: DESIGN 4.6): conv_igemm8 fetches its weight fragments
-    global -> VGPR out of a fragment-order copy of the weights (ec_pack_wfrag) and stages only the im2col operand through
-    LDS.  Same K walk, same products, same accumulation order: the trunk's features must be bit-identical to the default
-    kernel's.  The switch is read once per process, so the variant runs in a child; both sides set the 8-wave dispatch
-    threshold to 1 tile so that 8 frames already take the 8-wave kernel in layers 3-4."""
-    import os
-    import subprocess
-    import sys
-    from embodied_clip_amd.encoder import RN50Trunk
-    sd = syn.rn50_visual_state_dict(0)
-    x = syn.synthetic_rgb(11, 8).to(dev)
-    base = RN50Trunk(sd, device=dev)
-    base.set_conv8_min_tiles(1)
-    ref = base.forward(x).float().cpu()
-    out = str(tmp_path / "dirb.pt")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = ("import sys, torch; sys.path.insert(0, %r)\n"
-            "from embodied_clip_amd import synthetic as syn\n"
-            "from embodied_clip_amd.encoder import RN50Trunk\n"
-            "t = RN50Trunk(syn.rn50_visual_state_dict(0), device='cuda:0')\n"
-            "t.set_conv8_min_tiles(1)\n"
-            "f = t.forward(syn.synthetic_rgb(11, 8).to('cuda:0'))\n"
-            "torch.save({'feat': f.float().cpu(), 'hash': t.plan_hash()}, %r)\n") % (root, out)
-    r = subprocess.run([sys.executable, "-c", code], env={**os.environ, "EC_CONV8_DIRB": "1"}, capture_output=True, text=True,
-                       timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
-    got = torch.load(out)
-    assert got["hash"] != base.plan_hash()              # the switch is part of the plan hash
-    assert torch.equal(got["feat"], ref)
-
-
 def test_long_segment_variant_of_the_128_wide_8wave_tiles_is_bit_identical(dev, tmp_path):
     """EC_CONV8_LONGSEG (default 1, round 3): the 128-wide tiles of conv_igemm8 run two barrier-separated segments per
     K-tile (all fragments of a K-tile read at once, 16 MFMAs in one segment) out of three LDS stages instead of four
@@ -561,36 +529,6 @@ def test_whole_bottleneck_launch_is_bit_identical_to_the_three_conv_launches(dev
         c2 = F.relu(F.conv2d(c1, w2.float().permute(0, 3, 1, 2), b2, padding=1)).to(torch.bfloat16).float()
         y = F.relu(F.conv2d(c2, w3.float()[:, :, None, None], b3) + xf).permute(0, 2, 3, 1)
         assert _rel(got.cpu(), y) < 6e-3, (B, _rel(got.cpu(), y))
-
-
-def test_band_fused_layer2_bottleneck_is_bit_identical_to_the_three_conv_launches(dev):
-    """bneck_band_kernel (round 4, measured prototype -- not in the trunk's plan: DESIGN.md section 4.7): the whole stride-1
-    Bottleneck of the 28 x 28 stage ([U] clip/model.py Bottleneck.forward, layer2.1 .. layer2.3) in one launch, a workgroup per
-    band of 7 rows with conv1's output for the band + halo rows in LDS.  Bit-identical to the three conv launches (image borders,
-    band borders, odd frame counts), and against a torch fp32 reference with c1 / c2 rounded to bf16 where the kernels round."""
-    from embodied_clip_amd import encoder as enc
-    C, H = 128, 28
-    for B in (1, 3, 33):
-        g = torch.Generator().manual_seed(400 + B)
-        x = _bf(torch.randn(B, H, H, 4 * C, generator=g).relu())
-        w1 = _bf(torch.randn(C, 4 * C, generator=g) * (4 * C) ** -0.5)
-        w2 = _bf(torch.randn(C, 3, 3, C, generator=g) * (9 * C) ** -0.5)
-        w3 = _bf(torch.randn(4 * C, C, generator=g) * C ** -0.5)
-        b1, b2, b3 = (torch.randn(n, generator=g) * 0.1 for n in (C, C, 4 * C))
-        d = lambda t: t.to(dev)
-        got = enc.bneck_band_bf16(d(x), d(w1), d(b1), d(w2.reshape(C, -1)), d(b2), d(w3), d(b3))
-        c1u = enc.conv_bf16(d(x), d(w1), d(b1), None, ksize=1, act=1)
-        c2u = enc.conv_bf16(c1u, d(w2.reshape(C, -1)), d(b2), None, ksize=3, act=1)
-        yu = enc.conv_bf16(c2u, d(w3), d(b3), d(x), ksize=1, act=1)
-        torch.cuda.synchronize()
-        assert torch.equal(got, yu), B
-        xf = x.float().permute(0, 3, 1, 2)
-        c1 = F.relu(F.conv2d(xf, w1.float()[:, :, None, None], b1)).to(torch.bfloat16).float()
-        c2 = F.relu(F.conv2d(c1, w2.float().permute(0, 3, 1, 2), b2, padding=1)).to(torch.bfloat16).float()
-        y = F.relu(F.conv2d(c2, w3.float()[:, :, None, None], b3) + xf).permute(0, 2, 3, 1)
-        assert _rel(got.cpu(), y) < 6e-3, (B, _rel(got.cpu(), y))
-    with pytest.raises(Exception):      # any other geometry is refused (EC_ERR_SHAPE), never a silent fallback
-        enc.bneck_band_bf16(torch.zeros(1, 14, 14, 512, dtype=torch.bfloat16, device=dev), d(w1), d(b1), d(w2.reshape(C, -1)), d(b2), d(w3), d(b3))
 
 
 def test_fused_bottleneck_launch_matches_reference_and_the_two_conv_launches(dev):
@@ -651,37 +589,7 @@ def test_trunk_with_fused_bottlenecks_is_bit_identical_to_the_unfused_plan(dev, 
     assert torch.equal(got["feat"], ref)
     # 5 frames: the default plan runs layer 3's conv2 on the image-resident K-split kernel (fixed fold order), the child's
     # unfused plan on conv_igemm: equal up to fp32-accumulation rounding amplified through the rest of the trunk
-    assert _rel(got["small"], small) <= 1e-2, _rel(got["small"], small)
-
-
-def test_trunk_with_band_fused_layer2_blocks_is_bit_identical(dev, tmp_path):
-    """EC_RN50_BAND (default 0: measured neutral-to-slower end to end): launches inside the frame window run
-    layer2.1 .. layer2.3 as band-fused launches (bneck_band_kernel) and the boundary launch in front as its conv3 half only.
-    Same features, bit for bit, as the default plan, for a launch inside the window (130 frames) and one below it (5)."""
-    import os
-    import subprocess
-    import sys
-    from embodied_clip_amd.encoder import RN50Trunk
-    x = syn.synthetic_rgb(22, 8).repeat(17, 1, 1, 1).roll(1, dims=2)[:130].contiguous().to(dev)
-    base = RN50Trunk(syn.rn50_visual_state_dict(0), device=dev)
-    ref = base.forward(x).float().cpu()
-    small = base.forward(x[:5].contiguous()).float().cpu()
-    out = str(tmp_path / "band.pt")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = ("import sys, torch; sys.path.insert(0, %r)\n"
-            "from embodied_clip_amd import synthetic as syn\n"
-            "from embodied_clip_amd.encoder import RN50Trunk\n"
-            "t = RN50Trunk(syn.rn50_visual_state_dict(0), device='cuda:0')\n"
-            "x = syn.synthetic_rgb(22, 8).repeat(17, 1, 1, 1).roll(1, dims=2)[:130].contiguous().to('cuda:0')\n"
-            "torch.save({'feat': t.forward(x).float().cpu(), 'small': t.forward(x[:5].contiguous()).float().cpu(),\n"
-            "            'hash': t.plan_hash(), 'ops': t.lib.ec_rn50_num_ops(t.h)}, %r)\n") % (root, out)
-    r = subprocess.run([sys.executable, "-c", code], env={**os.environ, "EC_RN50_BAND": "64"}, capture_output=True, text=True,
-                       timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
-    got = torch.load(out)
-    assert got["hash"] != base.plan_hash() and got["ops"] == base.lib.ec_rn50_num_ops(base.h)   # (same ops; the executor skips / fuses)
-    assert torch.equal(got["feat"], ref)
-    assert torch.equal(got["small"], small)
+    assert _rel(got["small"], small) <= 7e-3, _rel(got["small"], small)
 
 
 @pytest.mark.parametrize("H,C", [(14, 256), (7, 512)])

@@ -137,7 +137,7 @@ def test_two_stream_encode_matches_one_stream():
     assert not w1.enc_streams and len(w2.enc_streams) == 2
     w1.iteration(); w2.iteration()
     torch.cuda.synchronize()
-    assert _rel(w1.feat, w2.feat) <= 1e-2
+    assert _rel(w1.feat, w2.feat) <= 7e-3
     assert (w1.actions == w2.actions).float().mean().item() >= 0.9
     # the policy update is run-to-run non-deterministic at rounding level (split-K fp32 atomics) and Adam's first
     # step maps a near-zero gradient to +-lr, so parameters can only be compared to within two steps of lr = 3e-4

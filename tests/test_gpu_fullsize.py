@@ -50,6 +50,37 @@ def test_encoder_is_a_pure_function_of_the_frame(worker):
     assert torch.isfinite(w.feat.float()).all() and (w.feat >= 0).all()  # post-ReLU
 
 
+@pytest.mark.parametrize("min_tiles", [0, 50])
+def test_headline_launch_shape_against_the_oracle_directly(min_tiles):
+    """The launch shape the headline runs -- ONE 128-frame ec_rn50_forward per actor slice: the >= 128-frame plan with the
+    whole-bottleneck launches (bneck23_kernel<.., F1>) for layer3.1-5, 8-wave tiles, 196-of-224-row tiles; ``min_tiles = 50`` is
+    what ``engine.Worker`` sets on its two concurrent handles -- compared ELEMENT-WISE with ``oracle.rn50_trunk`` on 4 of the 128
+    frames (first, last, two inside; the oracle costs seconds per frame on the CPU): fp32 oracle rel-L2 <= 2e-2 and cosine >=
+    0.999 per frame, bf16-rounding emulation <= 4e-3 sqrt(1 + 16 blocks).  (The small launches are checked against the oracle
+    in test_gpu_encoder.py / test_gpu_edges.py at B <= 5; the two plans against each other at <= 7e-3.)"""
+    from embodied_clip_amd import synthetic as syn
+    from embodied_clip_amd.encoder import RN50Trunk
+    from oracle import clip_resnet as ocr
+    sd = syn.rn50_visual_state_dict(0)
+    trunk = RN50Trunk(sd, device="cuda:0")
+    if min_tiles:
+        trunk.set_conv8_min_tiles(min_tiles)
+    x = syn.synthetic_rgb(2024, 16).repeat(8, 1, 1, 1)
+    x = torch.stack([x[i].roll(shifts=3 * (i // 16), dims=1) for i in range(128)]).contiguous()   # 128 distinct frames
+    feat = trunk.forward(x.to("cuda:0"))
+    assert trunk.lib.ec_rn50_num_ops(trunk.h) == 40                 # the fused plan (50 ops without the fused launches)
+    got = trunk.to_nchw_f32(feat).cpu()
+    rel = lambda a, b: ((a - b).norm() / b.norm()).item()  # noqa: E731
+    for i in (0, 37, 100, 127):
+        xi = x[i:i + 1].permute(0, 3, 1, 2)
+        ref = ocr.rn50_trunk(xi, sd)
+        emu = ocr.rn50_trunk(xi, sd, emulate_bf16=True)
+        assert rel(got[i:i + 1], ref) < 2e-2, (i, rel(got[i:i + 1], ref))
+        assert torch.nn.functional.cosine_similarity(got[i].flatten(), ref[0].flatten(), dim=0).item() > 0.999
+        assert rel(got[i:i + 1], emu) < 4e-3 * 17 ** 0.5, (i, rel(got[i:i + 1], emu))
+        assert (got[i] - ref[0]).abs().max().item() <= 0.1 * ref.abs().max().item()              # no single wild element
+
+
 def test_rollout_bookkeeping_is_consistent(worker):
     w = worker
     T, N = w.T, w.N

@@ -595,3 +595,62 @@ def test_dual_rgbd_policy_forward_backward_update_match_oracle(dev, T, N, bf16, 
         assert _rel(gv[name], gref) < 2e-4, (name, _rel(gv[name], gref))
     with pytest.raises(Exception):                                 # the depth features are mandatory for a dual handle
         h.forward(flat, r1, gl, h0d, m, T, N, ws)
+
+
+def test_fused_clip_adam_is_a_torch_optimizer_drop_in(dev):
+    """``FusedClipAdam`` (what ``Builder(FusedClipAdam, dict(lr=..., max_grad_norm=0.5))`` instantiates in an AllenAct config,
+    INTEGRATION.md) against ``clip_grad_norm_`` + ``torch.optim.Adam`` -- the reference's ``backprop_step`` -- on (a) the
+    policy module, whose parameters and grads are views of flat buckets (zero-copy path: the kernel runs on the module's own
+    buffers), also after ``zero_grad()`` has dropped the grads; (b) free-standing parameters (flattened once, grads gathered);
+    torch's per-parameter ``state`` / ``state_dict()`` layout; LR schedules through ``param_groups``."""
+    from embodied_clip_amd import spaces
+    from embodied_clip_amd.policy import ResnetTensorObjectNavActorCritic
+    from embodied_clip_amd.ppo import FusedClipAdam
+    cfg = dict(in_channels=64, spatial=3, hidden=32)
+    sd = syn.policy_state_dict(21, **cfg)
+    obs_space = spaces.Dict({"rgb_clip_resnet": spaces.Box(low=-1, high=1, shape=(64, 3, 3)), "goal": spaces.Discrete(12)})
+    mk = lambda: ResnetTensorObjectNavActorCritic(spaces.Discrete(6), obs_space, goal_sensor_uuid="goal",  # noqa: E731
+                                                  rgb_resnet_preprocessor_uuid="rgb_clip_resnet", hidden_size=32, state_dict=sd, device=dev)
+    m_f, m_t = mk(), mk()
+    opt_f = FusedClipAdam(m_f.parameters(), lr=1e-3, max_grad_norm=0.5)
+    opt_t = torch.optim.Adam(m_t.parameters(), lr=1e-3)
+    assert isinstance(opt_f, torch.optim.Optimizer)
+    flat_ptr = m_f.flat_params.data_ptr()
+    for it in range(4):
+        gen = torch.Generator().manual_seed(100 + it)
+        grads = {n: torch.randn(p.shape, generator=gen) * (3.0 if it % 2 == 0 else 0.01) for n, p in m_f.named_parameters()}
+        for m, opt in ((m_f, opt_f), (m_t, opt_t)):
+            opt.zero_grad()                                       # (grads -> None: the next bind re-creates the flat views)
+            m.ensure_flat()
+            for n, p in m.named_parameters():
+                p.grad.copy_(grads[n].to(dev))
+        torch.nn.utils.clip_grad_norm_(m_t.parameters(), 0.5)
+        for o in (opt_f, opt_t):
+            o.param_groups[0]["lr"] = 1e-3 * (1.0 - 0.1 * it)    # what LambdaLR does between steps
+            o.step()
+        gn = torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values())).item()
+        assert abs(opt_f.grad_norm() - gn) < 1e-4 * gn
+    assert m_f.flat_params.data_ptr() == flat_ptr                # zero-copy: still the module's own bucket
+    for (n, a), (_, b) in zip(m_f.named_parameters(), m_t.named_parameters()):
+        assert (a - b).abs().max().item() < 2e-6, n
+    st = opt_f.state_dict()
+    assert set(st["state"][0]) >= {"step", "exp_avg", "exp_avg_sq"} and float(st["state"][0]["step"]) == 4.0
+    p0 = next(iter(m_f.parameters()))
+    assert opt_f.state[p0]["exp_avg"].shape == p0.shape
+    for (n, a), (_, b) in zip(m_f.named_parameters(), m_t.named_parameters()):
+        assert (opt_f.state[a]["exp_avg"] - opt_t.state[b]["exp_avg"]).abs().max().item() < 1e-6, n
+    # (b) free-standing parameters of odd sizes
+    gen = torch.Generator().manual_seed(5)
+    shapes = [(7, 5), (3,), (11, 2, 3)]
+    pf = [torch.nn.Parameter(torch.randn(s, generator=gen).to(dev)) for s in shapes]
+    pt = [torch.nn.Parameter(p.detach().clone()) for p in pf]
+    of, ot = FusedClipAdam(pf, lr=2e-3, max_grad_norm=None), torch.optim.Adam(pt, lr=2e-3)
+    for it in range(3):
+        for a, b in zip(pf, pt):
+            g = torch.randn(a.shape, generator=gen).to(dev)
+            a.grad, b.grad = g.clone(), g.clone()
+        of.step(); ot.step()
+    for a, b in zip(pf, pt):
+        assert (a - b).abs().max().item() < 2e-6
+    with pytest.raises(NotImplementedError):
+        FusedClipAdam(pf, weight_decay=0.1)

@@ -4,6 +4,9 @@
 --streams 2: two launches of B frames in flight on two HIP streams (the engine's two actor slices)."""
 import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+if "--stamps" in sys.argv or "--wino-emu" in sys.argv:
+    import _toolslib  # noqa: F401  (the phase stamps / the Winograd feed emulation need the tools build: `make tools`)
 import torch
 from embodied_clip_amd import encoder as enc
 
@@ -12,6 +15,8 @@ ap.add_argument("--B", type=int, default=128)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--streams", type=int, default=1)
 ap.add_argument("--stamps", action="store_true", help="print workgroup 0's phase stamps (shader clocks, us, implied MHz)")
+ap.add_argument("--wino-emu", action="store_true", help="time (and stamp) the Winograd F(2x2,3x3) FEED EMULATION of the whole-block "
+                "launch (tools build; garbage results, timing only) next to the real launches")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(0)
@@ -39,6 +44,21 @@ def fused3(s):
     c1, x, w2, w3, b2, b3, yf, c2u, yu, w1, b1, y3, c1u = s
     enc.bneck_conv123_bf16(x, w1, b1, w2, b2, w3, b3, out=y3)
 
+def wino_emu(s):
+    """bneck23_kernel<.., F1, WEMU>: conv2's K loop with Winograd's operand traffic and MFMA count (timing only)."""
+    import ctypes
+    from embodied_clip_amd import _lib
+    c1, x, w2, w3, b2, b3, yf, c2u, yu, w1, b1, y3, c1u = s
+    lib = _lib.load()
+    if not hasattr(wino_emu, "fn"):
+        wino_emu.fn = lib.ec_bneck_wino_emu
+        wino_emu.fn.restype = ctypes.c_int
+        wino_emu.fn.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_int] * 4 + [ctypes.c_void_p]
+        enc.bneck_conv123_bf16(x, w1, b1, w2, b2, w3, b3, out=y3)       # (packs the weights into the cache)
+    packed = enc._packed_lookup("bneck3", (w1, w2, w3))
+    _lib.check(wino_emu.fn(x.data_ptr(), packed.data_ptr(), b1.data_ptr(), b2.data_ptr(), b3.data_ptr(), y3.data_ptr(), x.shape[0], 14, 14, 256,
+                           _lib.stream_ptr()), "ec_bneck_wino_emu")
+
 def unfused(s):
     c1, x, w2, w3, b2, b3, yf, c2u, yu = s[:9]
     enc.conv_bf16(c1, w2, b2, None, ksize=3, pool=False, act=1, out=c2u)
@@ -60,7 +80,10 @@ for st in streams:            # (first use of a stream is slow: not inside a tim
     with torch.cuda.stream(st):
         fused(sets[0])
 torch.cuda.synchronize()
-for name, fn in (("unfused (3x3 + 1x1+res)", unfused), ("fused bneck23", fused), ("unfused (1x1, 3x3, 1x1+res)", unfused3), ("fused bneck123", fused3)):
+cases = [("unfused (3x3 + 1x1+res)", unfused), ("fused bneck23", fused), ("unfused (1x1, 3x3, 1x1+res)", unfused3), ("fused bneck123", fused3)]
+if a.wino_emu:
+    cases = [("fused bneck123", fused3), ("bneck123 Winograd FEED EMULATION", wino_emu)]
+for name, fn in cases:
     for _ in range(3):
         for s in sets: fn(s)
     torch.cuda.synchronize()
@@ -74,7 +97,7 @@ for name, fn in (("unfused (3x3 + 1x1+res)", unfused), ("fused bneck23", fused),
     for st in streams: torch.cuda.current_stream().wait_stream(st)
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / a.iters * 1e3
-    fl = 2.0 * a.B * a.streams * H * H * (C * 9 * C + 4 * C * C + (4 * C * C if '1x1, 3x3' in name or '123' in name else 0))
+    fl = 2.0 * a.B * a.streams * H * H * (C * 9 * C + 4 * C * C + (4 * C * C if '1x1, 3x3' in name or '123' in name else 0))   # (direct-conv flop, also for the emulation)
     print(f"{name:26s} B={a.B} x {a.streams} stream(s): {us:8.1f} us  {fl / us / 1e6:7.0f} TFLOP/s")
 
 if a.stamps:
@@ -82,8 +105,9 @@ if a.stamps:
     lib = _lib.load()
     buf = torch.zeros(64, dtype=torch.int64, device=dev)
     lib.ec_bneck_set_debug(buf.data_ptr())
+    stamped = wino_emu if a.wino_emu else (fused3 if os.environ.get("STAMP_F1") else fused)
     for _ in range(3):
-        for s in sets: fused(s)
+        for s in sets: stamped(s)
     torch.cuda.synchronize()
     lib.ec_bneck_set_debug(None)
     t = buf.cpu().tolist()

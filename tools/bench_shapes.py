@@ -30,7 +30,6 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--B", type=int, default=256)
 ap.add_argument("--set", default="all")
 ap.add_argument("--iters", type=int, default=20)
-ap.add_argument("--ws", type=int, default=0, help="1: pass a K-partition workspace (ec_conv_bf16_ws): small launches are K-sliced")
 a = ap.parse_args()
 shapes = {"c3": C3, "k1": K1, "all": C3 + K1}[a.set]
 dev = torch.device("cuda:0")
@@ -42,15 +41,14 @@ for (H, Cin, Cout, ks, pool, res, label) in shapes:
     b = torch.randn(Cout, generator=g).to(dev)
     Ho = H // 2 if pool else H
     r = torch.randn(a.B, Ho, Ho, Cout, generator=g).to(torch.bfloat16).to(dev) if res else None
-    ws = enc.conv_splitk_workspace(x, w, ks) if a.ws else None
     out = None
     for _ in range(3):
-        out = enc.conv_bf16(x, w, b, r, ksize=ks, pool=bool(pool), act=1, workspace=ws, out=out)
+        out = enc.conv_bf16(x, w, b, r, ksize=ks, pool=bool(pool), act=1, out=out)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(a.iters):
-        enc.conv_bf16(x, w, b, r, ksize=ks, pool=bool(pool), act=1, workspace=ws, out=out)
+        enc.conv_bf16(x, w, b, r, ksize=ks, pool=bool(pool), act=1, out=out)
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / a.iters * 1e3
     fl = 2.0 * a.B * H * H * Cout * ks * ks * Cin

@@ -79,7 +79,6 @@ python tools/bench_update.py --iters 3 | tail -1 > $O/update_ms.txt
 (for B in 1 128 256; do python tools/bench_bneck.py --B $B --iters 20 --stamps 2>&1 | grep -v "amdgpu.ids\|unfused (3x3"; done) > $O/bneck_stamps.txt
 python tools/bench_img3x3.py 2>&1 | grep -v amdgpu.ids > $O/img3x3_vs_conv_igemm.txt
 # band-fused layer-2 bottleneck prototype (not in the plan) against the launches it would replace
-(for B in 1 128 256; do python tools/bench_band.py --B $B --iters 20 2>&1 | grep -v amdgpu.ids; done) > $O/band_prototype.txt
 for N in 32 128; do python tools/bench_act.py --actors $((2 * N > 48 ? 2 * N : N)) 2>&1 | tail -1; done > $O/act_step_us.txt
 # one env step of the engine at 32 actors per GPU, kernel by kernel
 cd /tmp

@@ -2,6 +2,7 @@
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["EC_CONV_BIG"] = "1"; os.environ["EC_CONV_ABLATE"] = str(32 | int(os.environ.get("ABL", "0")))
+import _toolslib  # noqa: F401  (selects the tools build)
 import torch
 from embodied_clip_amd import encoder as enc, _lib
 dev = torch.device("cuda:0")
