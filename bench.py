@@ -336,7 +336,10 @@ def run_rank(a, rank: int, local_rank: int, world: int, init_method=None):
                                      "next observation is served" if a.sync_actions else
                                      "free-running: the synthetic env does not read the actions (SURVEY.md 8d); see `sync_actions`"),
                        "parallelism": f"dp{world} (actors sharded; one flat 13.9 MB grad all-reduce per optimiser step)",
-                       "flop_per_frame": flop_per_frame},
+                       "flop_per_frame": flop_per_frame,
+                       "policy_gemm_mode": ("fp32 x fp32 as bf16x3: six exact products forward, THREE leading products in the backward's "
+                                            "large gradient GEMMs (EC_GEMM_BWD3=1)" if os.environ.get("EC_GEMM_BWD3", "0") not in ("", "0")
+                                            else "fp32 x fp32 as bf16x3, six exact products forward and backward (fp32-exact; EC_GEMM_BWD3=0)")},
             "rccl_ranks": rccl_ranks, "allreduce_ms_per_rank": None,
             "roofline": {"bound": "mfma",
                          "kernel": ("ec_rn50_forward (conv_igemm / conv_pair / conv3x3_narrow MFMA kernels)"

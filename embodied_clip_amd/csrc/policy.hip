@@ -16,7 +16,9 @@
 // E1 = embed_class @ W3[:, 32:]^T + b3, so the 64-channel concat is never built.
 #include <stdlib.h>
 
+#include <mutex>
 #include <new>
+#include <unordered_map>
 
 #include "common.h"
 
@@ -1317,6 +1319,13 @@ struct ec_policy {
     ec_policy_cfg c;
     size_t off[P_COUNT], num[P_COUNT], total;
     const float* goal_table = nullptr;   // fusion == 1: borrowed f32 [num_goals, in_channels]
+    // EC_POLICY_INFER_REUSE bookkeeping: which (T, N, feature dtype) the weight-derived tables in a given act workspace were
+    // built for.  The tables' offsets and WHICH of them exist (E1, W1's planes in fragment order, the re-ordered weight_ih and
+    // its fragment-order copy) follow from exactly these three values, so a REUSE call with another geometry or dtype than the
+    // call that built them (fp32 features first, bf16 next) rebuilds instead of reading uninitialised tables.
+    struct Built { int T, N, bf16; };
+    mutable std::mutex tables_mu;
+    mutable std::unordered_map<const void*, Built> tables;
 };
 
 namespace {
@@ -1552,7 +1561,18 @@ extern "C" int ec_policy_forward2(const ec_policy_t* h, const float* params, con
     const bool infer_only = for_backward == 0 || for_backward == EC_POLICY_INFER_REUSE;
     // EC_POLICY_INFER_REUSE: the weight-derived table E1 that an EC_POLICY_INFER call left in THIS workspace is still valid
     // (same parameters: every act step of a rollout after the first) -- one GEMM launch less on the act step's chain
-    const bool reuse_tables = for_backward == EC_POLICY_INFER_REUSE;
+    bool reuse_tables = for_backward == EC_POLICY_INFER_REUSE;
+    {
+        std::lock_guard<std::mutex> lk(h->tables_mu);
+        if (!infer_only) {
+            h->tables.erase(workspace);                          // a learn pass overwrites the workspace
+        } else {
+            auto it = h->tables.find(workspace);
+            if (reuse_tables && (it == h->tables.end() || it->second.T != T || it->second.N != N || it->second.bf16 != (feat_bf16 ? 1 : 0)))
+                reuse_tables = false;                            // nothing valid for THIS geometry / dtype in this workspace: build
+            if (!reuse_tables) h->tables[workspace] = ec_policy::Built{T, N, feat_bf16 ? 1 : 0};
+        }
+    }
     // learn pass: the GRU's input projection reads the combiner output where it lies (pixel-major rows) against a re-ordered
     // weight_ih (permute_row_kernel) -- no activation transposes in either direction
     const bool wih_perm = ec_config().wih_perm && !infer_only && !c.fusion && !c.dual && (size_t)c.comb_out * S * 4 <= 64 * 1024;

@@ -76,3 +76,18 @@ def test_text_tower_against_golden():
     rel = float((got - gold).norm() / gold.norm())
     assert rel < 2e-2, rel
     assert torch.nn.functional.cosine_similarity(got, gold).min().item() > 0.999
+
+
+def test_imagenet_resnet50_against_golden():
+    """The ImageNet tower (torchvision ResNet-50 minus avgpool / fc, thor_image_features.py:46-54,102-106) on HIP vs the committed
+    vectors of the HuggingFace-pinned oracle (tests/golden/tvresnet_golden.pt): imagenet_conv slice, imagenet_avgpool, norms."""
+    from embodied_clip_amd.encoder import ImageNetRN50Trunk
+    gold = torch.load(os.path.join(os.path.dirname(__file__), "golden", "tvresnet_golden.pt"))
+    dev = torch.device("cuda:0")
+    trunk = ImageNetRN50Trunk(syn.tv_resnet_state_dict(gold["seed_weights"]), device=dev)
+    raw = syn.synthetic_rgb_u8(gold["seed_rgb"], gold["n"])
+    for feat in (trunk.forward(syn.normalize_rgb_imagenet(raw).contiguous().to(dev)), trunk.forward_u8(raw.to(dev))):
+        f = trunk.to_nchw_f32(feat).cpu()
+        assert _rel(f[:, ::32], gold["conv_slice"]) < 2e-2
+        assert _rel(trunk.spatial_mean(feat), gold["avgpool"]) < 1e-2
+        assert _rel(f.flatten(1).norm(dim=1), gold["norm"]) < 5e-3

@@ -654,3 +654,32 @@ def test_fused_clip_adam_is_a_torch_optimizer_drop_in(dev):
         assert (a - b).abs().max().item() < 2e-6
     with pytest.raises(NotImplementedError):
         FusedClipAdam(pf, weight_decay=0.1)
+
+
+def test_infer_reuse_rebuilds_tables_when_geometry_or_dtype_changed(dev):
+    """EC_POLICY_INFER_REUSE promises 'the tables an EC_POLICY_INFER call left in THIS workspace are valid'.  Which tables exist
+    (and where) depends on (T, N, feature dtype): a REUSE call that does not match the call that built them (fp32 features first,
+    bf16 next; another N) must rebuild rather than read uninitialised tables -- and a matching one must still reuse."""
+    from embodied_clip_amd.policy import PolicyHandle
+    h = PolicyHandle()
+    sd = syn.policy_state_dict(31)
+    flat = h.flatten(sd, dev)
+    N = 8
+    g = torch.Generator().manual_seed(3)
+    f32 = torch.randn(N, 49, 2048, generator=g).abs().to(torch.bfloat16).float().to(dev)
+    b16 = f32.to(torch.bfloat16)
+    goal = syn.synthetic_goals(5, (N,)).to(dev)
+    h0 = (torch.randn(N, 512, generator=g) * 0.3).to(dev)
+    m = torch.ones(N, device=dev)
+    ws = torch.empty(h.workspace_bytes(1, 16, False), dtype=torch.uint8, device=dev)
+    ref_b, _ = h.forward(flat, b16, goal, h0, m, 1, N, torch.empty_like(ws), for_backward=False)
+    ref_f, _ = h.forward(flat, f32, goal, h0, m, 1, N, torch.empty_like(ws), for_backward=False)
+    ws.fill_(0xFF)                                                      # NaN patterns wherever a table is not (re)built
+    a, _ = h.forward(flat, f32, goal, h0, m, 1, N, ws, for_backward=False)
+    b, _ = h.forward(flat, b16, goal, h0, m, 1, N, ws, for_backward=False, reuse_tables=True)      # dtype flipped: rebuild
+    c, _ = h.forward(flat, b16, goal, h0, m, 1, N, ws, for_backward=False, reuse_tables=True)      # matching: reuse
+    d, _ = h.forward(flat, b16[:4].contiguous(), goal[:4].contiguous(), h0[:4].contiguous(), m[:4].contiguous(), 1, 4, ws,
+                     for_backward=False, reuse_tables=True)                                          # N changed: rebuild
+    torch.cuda.synchronize()
+    assert torch.equal(a, ref_f) and torch.equal(b, ref_b) and torch.equal(c, ref_b)
+    assert torch.isfinite(d).all() and _rel(d, ref_b[:4]) < 1e-5

@@ -1,13 +1,14 @@
 """Copies the evidence of `tools/profile_round.sh <round>` from gpurun_out/<round>/ (merged back by gpurun) into profiles/ and
 assembles profiles/{trunk,vit}_hbm_traffic.json (the files bench.py reads):  python tools/collect_profiles.py r03"""
 import json, os, shutil, sys
-R = sys.argv[1] if len(sys.argv) > 1 else "r04"
+R = sys.argv[1] if len(sys.argv) > 1 else "r05"
 O = f"gpurun_out/{R}"
 for f in ("bench_line.json", "bench_vit_line.json", "bench_zeroshot_line.json", "bench_rn50x16_line.json", "bench_128actors_line.json",
           "bench_64actors_line.json", "bench_32actors_line.json", "bench_kernel_stats.csv", "fetch_calibration.json",
           "strong_scaling_projection.json", "trunk_b128_per_kernel.txt", "trunk_b256_per_kernel.txt",
           "update_kernel_stats.txt", "update_pmc_by_kernel.txt", "update_ms.txt", "vit_b128_per_kernel.txt",
-          "trunk_b32_per_kernel.txt", "bneck_stamps.txt", "img3x3_vs_conv_igemm.txt", "band_prototype.txt", "act_step_us.txt", "env_step_32actors.txt"):
+          "trunk_b32_per_kernel.txt", "bneck_stamps.txt", "img3x3_vs_conv_igemm.txt", "act_step_us.txt", "env_step_32actors.txt",
+          "winograd_feed_emulation.txt", "bench_32actors_forcedist_line.json", "plugin_iteration_phases.txt", "tvresnet_b128.txt"):
     if os.path.exists(f"{O}/{f}"):
         shutil.copy(f"{O}/{f}", f"profiles/{R}_{f}")
     else:

@@ -78,6 +78,15 @@ python tools/bench_update.py --iters 3 | tail -1 > $O/update_ms.txt
 # fused bottleneck launch: phase stamps of workgroup 0 (shader clocks, wall time, implied clock) alone / 128 / 256 workgroups
 (for B in 1 128 256; do python tools/bench_bneck.py --B $B --iters 20 --stamps 2>&1 | grep -v "amdgpu.ids\|unfused (3x3"; done) > $O/bneck_stamps.txt
 python tools/bench_img3x3.py 2>&1 | grep -v amdgpu.ids > $O/img3x3_vs_conv_igemm.txt
+# Winograd feed emulation of the whole-block launch (tools build) next to the real launch
+(for B in 128 256; do python tools/bench_bneck.py --B $B --iters 20 --wino-emu --stamps 2>&1 | grep -v "amdgpu.ids"; done) > $O/winograd_feed_emulation.txt
+# the exchange step at world size 1 through RCCL (communicator + kernel really run): per-call time of the 13.9 MB bucket all-reduce
+python bench.py --gpus 1 --force-dist --actors 32 --steps 2 --warmup 1 --no-cpu-baseline --no-h2d --no-plugin --no-sync-actions --no-traffic > $O/bench_32actors_forcedist_line.json 2> $O/bench32fd.err
+# the plugin route's phases (one full iteration, fp32 and uint8 sensor frames)
+python tools/plugin_iter_phases.py 2>&1 | grep -v amdgpu.ids > $O/plugin_iteration_phases.txt
+U8=1 python tools/plugin_iter_phases.py 2>&1 | grep -v amdgpu.ids >> $O/plugin_iteration_phases.txt
+# the ImageNet (torchvision ResNet-50) tower: frames per second of one 128-frame launch, per-kernel time
+python tools/bench_tvresnet.py 2>&1 | grep -v amdgpu.ids > $O/tvresnet_b128.txt
 # band-fused layer-2 bottleneck prototype (not in the plan) against the launches it would replace
 for N in 32 128; do python tools/bench_act.py --actors $((2 * N > 48 ? 2 * N : N)) 2>&1 | tail -1; done > $O/act_step_us.txt
 # one env step of the engine at 32 actors per GPU, kernel by kernel
