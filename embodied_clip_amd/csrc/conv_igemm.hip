@@ -631,7 +631,7 @@ __device__ unsigned long long ec_dbg_stamps[2 * 1024];   // profiling only (tool
 // ([Cout][3][K], lowest plane first in the K walk); a K-tile of A is walked three times, once against each plane, into
 // the same accumulators, and the epilogue writes fp32 (bias / ReLU) -- the bf16x3 "exact fp32" product of gemm_f32.hip on
 // this kernel's schedule.
-template <int BN, int KS, bool POOL, int ABL, bool X3 = false>
+template <int BN, int KS, bool POOL, int ABL, bool X3 = false, bool S2 = false>
 __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
     // wave grid: 2 (M) x 4 (N) for 256-wide tiles (wave tile 128 x 64); 4 x 2 for 128-wide tiles (wave tile 64 x 64:
     // 4 fragment reads per 4 MFMAs instead of the 5 a 128 x 32 wave tile needs)
@@ -680,6 +680,15 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
             const int yp = r2 / Wp;
             y = 2 * yp + (s2 >> 1);
             x = 2 * (r2 - yp * Wp) + (s2 & 1);
+            pix = (b * p.H + y) * p.W + x;
+        } else if (S2) {      // stride 2 (torchvision's strided convs, ec_conv_bf16_s2): row m = output pixel, centre tap at (2 yo, 2 xo)
+            static_assert(!S2 || !POOL, "stride-2 instances have no fused pool");
+            const int Ho = p.H >> 1, Wo = p.W >> 1;
+            const int b = m / (Ho * Wo);
+            const int r2 = m - b * (Ho * Wo);
+            const int yo = r2 / Wo;
+            y = 2 * yo;
+            x = 2 * (r2 - yo * Wo);
             pix = (b * p.H + y) * p.W + x;
         } else if (KS == 1) {
             pix = m;
@@ -1083,7 +1092,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
     if constexpr ((ABL & 32) != 0) if (blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0) ec_dbg_stamps[grp * 1024 + 302] = __builtin_amdgcn_s_memtime();
 }
 
-template <int BN, int KS, bool POOL, bool X3 = false>
+template <int BN, int KS, bool POOL, bool X3 = false, bool S2 = false>
 int launch8(const ConvArgs& a, hipStream_t s) {
     ConvArgs p = a;
     p.ntn = a.Cout / BN;
@@ -1103,7 +1112,7 @@ int launch8(const ConvArgs& a, hipStream_t s) {
         hipLaunchKernelGGL(kern, dim3((unsigned)p.ntiles), dim3(512), lds, s, p);
     };
 #ifdef EC_CONV8_PROFILE   // ablation / stamp instances (tools/ablate8.sh, tools/stamps8.py): build with -DEC_CONV8_PROFILE
-    if constexpr (BN == 256 && KS == 3 && !POOL && !X3) {
+    if constexpr (BN == 256 && KS == 3 && !POOL && !X3 && !S2) {
         switch (ablate) {
             case 1: go(conv_igemm8_kernel<BN, KS, POOL, 1>); break;
             case 2: go(conv_igemm8_kernel<BN, KS, POOL, 2>); break;
@@ -1129,12 +1138,12 @@ int launch8(const ConvArgs& a, hipStream_t s) {
 #endif
     if constexpr (BN == 128) {
         if (ls) {
-            go(conv_igemm8_kernel<BN, KS, POOL, 512, X3>);
+            go(conv_igemm8_kernel<BN, KS, POOL, 512, X3, S2>);
             EC_CHECK_LAUNCH();
             return EC_OK;
         }
     }
-    go(conv_igemm8_kernel<BN, KS, POOL, 0, X3>);
+    go(conv_igemm8_kernel<BN, KS, POOL, 0, X3, S2>);
     EC_CHECK_LAUNCH();
     return EC_OK;
 }
@@ -1334,6 +1343,15 @@ extern "C" int ec_conv_bf16_s2(const void* in, const void* w, const float* bias,
     if (res && (long)B * Ho * Wo * Cout * 2 >= (1L << 32) - 16) return EC_ERR_SHAPE;
     a.res_bytes = res ? (unsigned)((long)B * Ho * Wo * Cout * 2) : 0u;
     hipStream_t s = (hipStream_t)stream;
+    // the 8-wave ping-pong kernel where the CLIP trunk's rule would take it (Cin % 64 == 0, K >= 512, enough tiles to fill the chip):
+    // 256-wide tiles from 150 tiles on, 128-wide ones when only those reach 150
+    if (Cin % 64 == 0 && a.K >= 512 && (ksize == 1 || a.cin_log2 >= 0) && ec_config().conv_big != 0) {
+        const long rt = (a.M + 255) / 256, nt256 = rt * (Cout / 256), nt128 = rt * (Cout / 128);
+        if (Cout % 256 == 0 && nt256 >= EC_CONV8_MIN_TILES_DEFAULT)
+            return ksize == 3 ? launch8<256, 3, false, false, true>(a, s) : launch8<256, 1, false, false, true>(a, s);
+        if (Cout % 128 == 0 && nt128 >= EC_CONV8_MIN_TILES_DEFAULT && (ksize == 3 || !res))
+            return ksize == 3 ? launch8<128, 3, false, false, true>(a, s) : launch8<128, 1, false, false, true>(a, s);
+    }
     // 128 x 128 tiles (three workgroups per CU) where Cout allows, 64 x 64 ring tiles for launches that would leave CUs idle
     if (Cout % 128 == 0) {
         const long t128 = (long)((a.M + 127) / 128) * (Cout / 128);

@@ -39,6 +39,11 @@ def dev():
     (40, 28, 28, 64, 128, 3, False, 1),     # many tiles (persistent workgroups walk several), K = 576
     (3, 12, 20, 32, 64, 3, True, 1),        # Cout = 64 (256x64 tiles), residual, non-square, ragged last tile
     (2, 6, 10, 64, 192, 1, True, 0),        # Cout = 192 -> 64-wide tiles
+    # the 8-wave ping-pong kernel's stride-2 instances (>= 150 tiles: what a >= 128-frame launch of the tower takes)
+    (200, 28, 28, 128, 128, 3, False, 1),   # 128-wide tiles, 3x3 (layer2.0 conv2 geometry at 28x28: 154 tiles, ragged last tile)
+    (200, 28, 28, 256, 256, 3, False, 1),   # 256-wide tiles, 3x3
+    (200, 14, 14, 512, 1024, 1, False, 0),  # 256-wide tiles, 1x1 downsample conv, no activation
+    (160, 14, 14, 1024, 2048, 1, True, 1),  # 256-wide tiles, 1x1 with a residual
 ])
 def test_stride2_conv_matches_torch(dev, B, H, W, Cin, Cout, ks, res, act):
     from embodied_clip_amd import encoder as enc

@@ -3,6 +3,9 @@ stem kernel alone.  torchvision resnet50 trunk = 4,087 MMAC per 224 x 224 frame 
 import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from embodied_clip_amd import _lib
+if os.environ.get("EC_AMD_LIB"):      # same-box A/B of two builds
+    _lib.LIB_PATH = os.environ["EC_AMD_LIB"]
 from embodied_clip_amd import encoder as enc, synthetic as syn
 
 ap = argparse.ArgumentParser()
