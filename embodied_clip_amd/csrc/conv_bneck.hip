@@ -55,6 +55,7 @@ struct BneckArgs {
     int B;
     unsigned w2_bytes, w3_bytes, w1_bytes;
     unsigned long long* dbg;   // profiling only (ec_bneck_set_debug): workgroup 0 stores {s_memtime, s_memrealtime} at entry / phase ends
+    int dbg_mode = 0;          // tools build only: 1 = return at entry (the launch's fixed cost), 2 = return after conv1
 };
 
 __device__ __forceinline__ float bn_relu(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, __builtin_inff()); }
@@ -111,7 +112,16 @@ __global__ __launch_bounds__(512, 2) void bneck23_kernel(BneckArgs p) {
             p.dbg[2 * slot + 1] = __builtin_amdgcn_s_memrealtime();
         }
     };
+#ifdef EC_TOOLS
+    if (p.dbg_mode == 1) return;
+#endif
     stamp(0);
+#ifdef EC_TOOLS   // tools build: EVERY workgroup's start / end on the 100-MHz real-time counter + its XCC id (slots 64 + 4 img ..)
+    if (p.dbg && tid == 0) {
+        p.dbg[64 + 4 * img] = __builtin_amdgcn_s_memrealtime();
+        p.dbg[64 + 4 * img + 2] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));   // HW_REG_XCC_ID[3:0]
+    }
+#endif
 
     const __amdgpu_buffer_rsrc_t rs_w2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w2, 0, p.w2_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w3 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w3, 0, p.w3_bytes, 0x00020000);
@@ -479,12 +489,20 @@ __global__ __launch_bounds__(512, 2) void bneck23_kernel(BneckArgs p) {
             }
             tie(v0); tie(v1);
             const int px0 = i * 32 + er0, px1 = i * 32 + er1;
+            // (write-through `sc1` and non-temporal stores here were A/B-ed in round 5: 113.1 / 115.2 against 113.8 us per 256 frames --
+            //  the 6-9 us between two launches are not the end-of-kernel write-back of dirty lines; docs/experiments.md section E)
             if (px0 < PIX) *reinterpret_cast<u32x4_t*>(yo + (size_t)px0 * (4 * C) + ec * 8) = v0;
             if (px1 < PIX) *reinterpret_cast<u32x4_t*>(yo + (size_t)px1 * (4 * C) + ec * 8) = v1;
         }
         wstamp(4 * pass + 2);
         stamp(4 + pass);
     }
+#ifdef EC_TOOLS
+    if (p.dbg && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        p.dbg[64 + 4 * img + 1] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -806,8 +824,9 @@ extern "C" int ec_conv3x3_img_bf16(const void* in, const void* packed, const flo
 
 // profiling only: device buffer of 16 x u64 that workgroup 0 of every following fused launch fills with {shader clock,
 // 100-MHz real time} stamps (entry, T loaded, conv2 done, c2 written, after each conv3 pass); nullptr switches it off
-namespace { unsigned long long* g_bneck_dbg = nullptr; }
-#ifdef EC_TOOLS   // tools-only build (`make tools`): not part of the product library or of include/ec_amd.h
+namespace { unsigned long long* g_bneck_dbg = nullptr; int g_bneck_mode = 0; }
+#ifdef EC_TOOLS
+extern "C" void ec_bneck_set_mode(int m) { g_bneck_mode = m; }   // tools-only build (`make tools`): not part of the product library or of include/ec_amd.h
 extern "C" void ec_bneck_set_debug(void* dev_u64x16) { g_bneck_dbg = (unsigned long long*)dev_u64x16; }
 #endif
 
@@ -846,6 +865,7 @@ int launch_bneck(const void* c1, const void* packed, const float* b1, const floa
     a.w3_bytes = (unsigned)((size_t)4 * C * C * 2);
     a.w1_bytes = (unsigned)((size_t)C * 4 * C * 2);
     a.dbg = g_bneck_dbg;
+    a.dbg_mode = g_bneck_mode;
     constexpr int PITCH = 256 * 2 + 16;
     const size_t lds = (size_t)(196 + 1) * PITCH + 8 * 3 * 2048;
     auto kern = bneck23_kernel<256, 14, F1, WEMU>;
@@ -880,6 +900,19 @@ extern "C" int ec_bneck_conv123_bf16(const void* x, const void* packed, const fl
                                      void* y, int B, int H, int W, int C, ec_stream_t stream) {
     return launch_bneck<true>(nullptr, packed, b1, b2, b3, x, y, B, H, W, C, stream);
 }
+#ifdef EC_TOOLS   // tools-only build: n back-to-back launches from C (no Python between them: the GPU-side launch period)
+extern "C" int ec_bneck_conv123_repeat(const void* x, const void* packed, const float* b1, const float* b2, const float* b3,
+                                       void* y, int B, int H, int W, int C, int n, ec_stream_t stream) {
+    unsigned long long* const base = g_bneck_dbg;       // (when set: launch i stamps into its own block of 64 + 4 B slots)
+    for (int i = 0; i < n; ++i) {
+        if (base) g_bneck_dbg = base + (size_t)i * (64 + 4 * (size_t)B);
+        const int rc = launch_bneck<true>(nullptr, packed, b1, b2, b3, x, y, B, H, W, C, stream);
+        if (rc != EC_OK) { g_bneck_dbg = base; return rc; }
+    }
+    g_bneck_dbg = base;
+    return EC_OK;
+}
+#endif
 #ifdef EC_TOOLS   // tools-only build: the Winograd feed emulation of bneck23_kernel (timing only, garbage results)
 extern "C" int ec_bneck_wino_emu(const void* x, const void* packed, const float* b1, const float* b2, const float* b3,
                                  void* y, int B, int H, int W, int C, ec_stream_t stream) {
