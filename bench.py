@@ -270,13 +270,23 @@ def run_rank(a, rank: int, local_rank: int, world: int, init_method=None):
     # alone is therefore taken over the UNION of their [start, end] intervals (first start -> last end of the step's
     # launches): the line's `frac`.  `frac_iteration` is the whole iteration's algorithmic flop over the timed wall clock.
     n_conc = max(1, per_gpu // max(1, w.encode_frames))
-    union_ms = []
+    # UNION of ALL encoder launch intervals of the timed region (sweep over the HIP-event [start, end] pairs of every launch on
+    # every slice stream): the time during which at least one encoder launch runs.  (Until round 4 the union was taken per env
+    # step over that step's launches only; the slices' streams drift against each other, so that per-step figure moved by
+    # +-10 % between runs at equal throughput and counted the overlap with the neighbouring steps' launches twice.)
+    avg_union_ms = avg_trunk_ms
     if w.trunk_events:
         ref = w.trunk_events[0][0]
-        for i in range(0, len(w.trunk_events) - n_conc + 1, n_conc):
-            grp = w.trunk_events[i:i + n_conc]
-            union_ms.append(max(ref.elapsed_time(e1) for _, e1 in grp) - min(ref.elapsed_time(e0) for e0, _ in grp))
-    avg_union_ms = sum(union_ms) / max(1, len(union_ms)) if union_ms else avg_trunk_ms
+        iv = sorted((ref.elapsed_time(e0), ref.elapsed_time(e1)) for e0, e1 in w.trunk_events)
+        busy, cur_s, cur_e = 0.0, iv[0][0], iv[0][1]
+        for s_, e_ in iv[1:]:
+            if s_ > cur_e:
+                busy += cur_e - cur_s
+                cur_s, cur_e = s_, e_
+            else:
+                cur_e = max(cur_e, e_)
+        busy += cur_e - cur_s
+        avg_union_ms = busy / max(1, len(w.trunk_events) // n_conc)        # per env step (n_conc launches each)
     info = w.loss_info()
     plan_hash = w.slices[0].enc.plan_hash() if hasattr(w.slices[0].enc, "plan_hash") else None
     enc_frames = w.encode_frames
@@ -352,8 +362,9 @@ def run_rank(a, rank: int, local_rank: int, world: int, init_method=None):
                          "hbm_achieved_tbs": round(hbm_tbs, 3) if hbm_tbs else None, "hbm_peak_tbs": HBM_ACHIEVABLE_TBS,
                          "frac_note": "frac = achieved / peak for the dominant kernel family, ec_rn50_forward: algorithmic_flop_per_launch x "
                                       "concurrent_launches / avg_step_union_ms, the launches' durations measured LIVE with HIP events on the "
-                                      "streams they run on (the engine keeps concurrent_launches encoder launches in flight, so the UNION of "
-                                      "their event intervals is the time the chip spends on them); frac_iteration = value x "
+                                      "streams they run on: avg_step_union_ms = (UNION of ALL encoder launch intervals of the timed region, "
+                                      "i.e. the time during which at least one encoder launch runs) / env steps -- the engine keeps "
+                                      "concurrent_launches launches in flight on as many streams; frac_iteration = value x "
                                       "config.flop_per_frame / n_gpus / peak: the WHOLE iteration's algorithmic flop (encoder + act step + "
                                       "4 update epochs, the fp32 policy included) over the timed wall clock, recomputable from value alone; "
                                       "frac_profiles = the committed rocprofv3 kernel trace of ONE engine launch (the plan with "

@@ -13,9 +13,9 @@ def test_partial_lgkmcnt_waits_never_overlap_scalar_loads():
     """The software-pipelined LDS streams wait with `s_waitcnt lgkmcnt(n)`, n > 0; scalar loads share that counter and
     return out of order, so none may be in flight at such a wait (tools/check_lgkmcnt.py scans the disassembly)."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_lgkmcnt.py")], capture_output=True, text=True,
-                       timeout=600)
+                       timeout=1200)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count(": ok") == 3, r.stdout
+    assert r.stdout.count(": ok") == 5, r.stdout      # conv_pair, conv_igemm, dw_tn, conv_bneck, policy
 
 
 def test_checker_flags_a_scalar_load_before_a_partial_wait():

@@ -1,11 +1,12 @@
-"""Static check for the hand-pipelined LDS streams (conv_pair.hip lds_stream_mfma, conv_igemm.hip fr_step, dw_tn.hip).
+"""Static check for the hand-pipelined LDS streams (conv_pair.hip lds_stream_mfma, conv_igemm.hip fr_step, dw_tn.hip, conv_bneck.hip's K loops
+and epilogues, policy.hip gru_lread).
 
 Those use PARTIAL waits (`s_waitcnt lgkmcnt(n)`, n > 0) on inline-asm LDS reads.  lgkmcnt also counts scalar memory
 loads, which return OUT OF ORDER: a partial wait is only meaningful while no `s_load` / `s_buffer_load` is in flight.  The
 compiler places scalar loads itself (kernel arguments, possibly re-loaded under SGPR pressure), so this script
 disassembles the device code and fails if any scalar load sits between the last full drain (`s_waitcnt lgkmcnt(0)`, a
 label or the function entry) and a partial wait.
-usage: python tools/check_lgkmcnt.py [file.hip ...]   (default: the three files above); exit code 1 on a violation."""
+usage: python tools/check_lgkmcnt.py [file.hip ...]   (default: the five files above); exit code 1 on a violation."""
 import os
 import re
 import subprocess
@@ -13,7 +14,7 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FILES = ["conv_pair.hip", "conv_igemm.hip", "dw_tn.hip"]
+FILES = ["conv_pair.hip", "conv_igemm.hip", "dw_tn.hip", "conv_bneck.hip", "policy.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
