@@ -185,6 +185,21 @@ class _Watchdog:
         self._t.cancel()
 
 
+def busy_union_ms(intervals):
+    """Total length of the union of [start, end] intervals (ms): the time during which at least one of them is open."""
+    iv = sorted(intervals)
+    if not iv:
+        return 0.0
+    busy, cur_s, cur_e = 0.0, iv[0][0], iv[0][1]
+    for s_, e_ in iv[1:]:
+        if s_ > cur_e:
+            busy += cur_e - cur_s
+            cur_s, cur_e = s_, e_
+        else:
+            cur_e = max(cur_e, e_)
+    return busy + (cur_e - cur_s)
+
+
 def _time_iterations(w, steps, warmup, barrier):
     for _ in range(warmup):
         w.iteration()
@@ -277,15 +292,7 @@ def run_rank(a, rank: int, local_rank: int, world: int, init_method=None):
     avg_union_ms = avg_trunk_ms
     if w.trunk_events:
         ref = w.trunk_events[0][0]
-        iv = sorted((ref.elapsed_time(e0), ref.elapsed_time(e1)) for e0, e1 in w.trunk_events)
-        busy, cur_s, cur_e = 0.0, iv[0][0], iv[0][1]
-        for s_, e_ in iv[1:]:
-            if s_ > cur_e:
-                busy += cur_e - cur_s
-                cur_s, cur_e = s_, e_
-            else:
-                cur_e = max(cur_e, e_)
-        busy += cur_e - cur_s
+        busy = busy_union_ms([(ref.elapsed_time(e0), ref.elapsed_time(e1)) for e0, e1 in w.trunk_events])
         avg_union_ms = busy / max(1, len(w.trunk_events) // n_conc)        # per env step (n_conc launches each)
     info = w.loss_info()
     plan_hash = w.slices[0].enc.plan_hash() if hasattr(w.slices[0].enc, "plan_hash") else None

@@ -65,3 +65,15 @@ def test_secondary_legs_fail_soft_and_under_a_watchdog():
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "not reached" not in r.stdout
     assert _last_json(r.stdout) == {"value": 1.0, "weak": {"error": "timeout"}}
+
+
+def test_busy_union_of_launch_intervals():
+    """roofline.frac is quoted over the UNION of all encoder launch intervals (bench.busy_union_ms): overlapping launches of two
+    streams count once, idle gaps (the update phase) not at all."""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.busy_union_ms([]) == 0.0
+    assert bench.busy_union_ms([(0.0, 2.0)]) == 2.0
+    assert bench.busy_union_ms([(0.0, 2.0), (1.0, 3.0), (2.5, 2.75)]) == 3.0            # two streams overlapping + one nested
+    assert bench.busy_union_ms([(5.0, 6.0), (0.0, 1.0), (1.0, 2.0)]) == 3.0             # unsorted, touching, a gap of 3
+    assert abs(bench.busy_union_ms([(i * 1.0, i * 1.0 + 0.75) for i in range(8)]) - 6.0) < 1e-12
