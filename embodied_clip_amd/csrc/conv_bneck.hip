@@ -6,7 +6,8 @@
 // out += identity; out = relu3(out)`), the two launches conv_igemm runs for layer3.1 .. layer3.5.
 //
 // Why (VERDICT r3 item 2 / SURVEY.md section 7 "hard parts"): tiled over output pixels, every 128..256-pixel tile of conv2
-// streams its im2col operand AND the weights through the CU's L2 -> LDS path (~30 B/clk/CU under load), and conv3 re-reads
+// streams its im2col operand AND the weights through the CU's L2 -> LDS path (~30 B/clk/CU as those kernels issue them; a pure L2-resident stream reaches 64-74 B/clk/CU,
+// tools/ubench/l2_feed.hip, round 5), and conv3 re-reads
 // conv2's output from HBM/L2 once per N tile; both launches sit at the sum of their MFMA and operand-feed times.  A 14x14x256
 // map is 98 KB: it FITS the LDS.  So a workgroup keeps one image's conv1 output resident (T, 196 rows x 512 B + a zero
 // row), reads the nine taps of the im2col operand straight out of it (a tap is a row shift; out-of-frame taps read the

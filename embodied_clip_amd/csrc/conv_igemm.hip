@@ -233,7 +233,8 @@ __device__ __forceinline__ void fr_step(FragRing<R>& ring, AddrFn& addr, MmaFn& 
 // is that a K-tile no longer costs a full L2 round trip: measured (round 3, rocprofv3) a 64x64 tile of the single-stage mode
 // takes ~750 ns per K-tile with one workgroup per CU -- 128 clk of MFMA issue per wave.
 // ILV (ring mode only): the LDS-DMA pieces of K-tile kt + NS - 1 are issued INSIDE the MFMA stream of K-tile kt (a share of
-// them after every k-step) instead of in front of it.  A CU's L2 -> LDS path moves ~30 B/clk (round 2/3 measurements): the
+// them after every k-step) instead of in front of it.  A CU's L2 -> LDS path moved ~30 B/clk in these kernels (round 2/3 measurements; not a hardware ceiling:
+// tools/ubench/l2_feed.hip streams 64-74 B/clk/CU): the
 // 32 KB of a 128 x 128 K-tile keep the issuing waves blocked for ~1,100 clk, and with ONE workgroup per CU (the ring
 // launches of small per-GPU batches) all four waves sit in that phase together, then in the MFMA phase together -- the two
 // add up (~2,000 clk per K-tile measured at 32 frames).  Issued between MFMAs, the pieces drain while the matrix pipe works.
