@@ -36,6 +36,18 @@ def test_error_strings_and_version(repo_root):
     # argument validation happens before any HIP call, so it is safe without a GPU
     assert lib.ec_conv_bf16(None, None, None, None, None, 1, 1, 1, 8, 32, 1, 0, 0, None) == -1
     assert lib.ec_gemm_bf16(None, None, None, None, None, 1, 32, 8, 0, None) == -1
+    # round-5 entry points (the ImageNet tower): null pointers -> EC_ERR_ARG, bad geometry -> EC_ERR_SHAPE, before any HIP call
+    assert lib.ec_conv_bf16_s2(None, None, None, None, None, 1, 8, 8, 64, 64, 3, 1, None) == -1
+    assert lib.ec_conv_bf16_s2(1, 1, None, None, 1, 1, 7, 8, 64, 64, 3, 1, None) == -2        # odd height
+    assert lib.ec_conv_bf16_s2(1, 1, None, None, 1, 1, 8, 8, 64, 48, 3, 1, None) == -2        # Cout % 64
+    assert lib.ec_conv_bf16_s2(1, 1, None, None, 1, 1, 8, 8, 64, 64, 5, 1, None) == -2        # 5x5
+    assert lib.ec_conv_bf16_s2(1, 1, None, None, 1, 1, 8, 8, 64, 64, 3, 2, None) == -6        # QuickGELU: unsupported
+    assert lib.ec_stem7_pool(None, 0, None, None, None, None, None, 1, 224, 224, None) == -1
+    assert lib.ec_stem7_pool(1, 0, None, None, 1, 1, 1, 1, 222, 224, None) == -2             # H % 4
+    assert lib.ec_stem7_pool(1, 1, None, None, 1, 1, 1, 1, 224, 224, None) == -1             # uint8 frames need mean / std
+    import ctypes as C
+    h = C.c_void_p()
+    assert lib.ec_rn50tv_create(C.byref(h), None, 224, None, None, 0, None, 0) == -1
 
 
 def test_missing_library_fails_loudly(monkeypatch, repo_root):
