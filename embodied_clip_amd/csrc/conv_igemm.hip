@@ -1356,9 +1356,12 @@ extern "C" int ec_conv_bf16_s2(const void* in, const void* w, const float* bias,
     // 128 x 128 tiles (three workgroups per CU) where Cout allows, 64 x 64 ring tiles for launches that would leave CUs idle
     if (Cout % 128 == 0) {
         const long t128 = (long)((a.M + 127) / 128) * (Cout / 128);
-        if (t128 < 256 && a.K >= 512)
+        if (t128 < ec_config().conv_t64 && a.K >= 512)       // (the CLIP trunk's rule: dispatch_tile)
             return ksize == 3 ? launch<64, 64, 2, 2, 3, false, false, 64, 4, false, true>(a, s)
                               : launch<64, 64, 2, 2, 1, false, false, 64, 4, false, true>(a, s);
+        if (t128 <= 256 && a.K >= 512 && !(ksize == 1 && res && a.K <= 256))   // one workgroup per CU: 8-wave ring tiles, pieces between the MFMAs
+            return ksize == 3 ? launch<128, 128, 2, 4, 3, false, false, 128, 3, true, true>(a, s)
+                              : launch<128, 128, 2, 4, 1, false, false, 128, 3, true, true>(a, s);
         return ksize == 3 ? launch<128, 128, 2, 2, 3, false, false, 128, 0, false, true>(a, s)
                           : launch<128, 128, 2, 2, 1, false, false, 128, 0, false, true>(a, s);
     }

@@ -44,6 +44,8 @@ def dev():
     (200, 28, 28, 256, 256, 3, False, 1),   # 256-wide tiles, 3x3
     (200, 14, 14, 512, 1024, 1, False, 0),  # 256-wide tiles, 1x1 downsample conv, no activation
     (160, 14, 14, 1024, 2048, 1, True, 1),  # 256-wide tiles, 1x1 with a residual
+    (128, 14, 14, 512, 512, 3, False, 1),   # layer4.0 conv2 at 128 frames: 196 tiles -> 128 x 128 ring tiles on 8 waves (3 stages)
+    (40, 14, 14, 1024, 512, 1, False, 0),   # 1x1, 64 tiles < 150 -> 64 x 64 ring tiles
 ])
 def test_stride2_conv_matches_torch(dev, B, H, W, Cin, Cout, ks, res, act):
     from embodied_clip_amd import encoder as enc

@@ -11,6 +11,7 @@ from embodied_clip_amd import encoder as enc, synthetic as syn
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=128)
 ap.add_argument("--iters", type=int, default=10)
+ap.add_argument("--trunk-only", action="store_true", help="only the fp32-frame trunk timing (the LAST launches of the process are one forward: what tools/pmc_summary.py joins)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 sd = syn.tv_resnet_state_dict(0)
@@ -32,6 +33,12 @@ def tm(fn):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / a.iters
 out = trunk.forward(x)
+if a.trunk_only:
+    ms = tm(lambda: trunk.forward(x, out))
+    print(f"batch={a.batch} {ms:.3f} ms/forward")
+    print('plan_hash', trunk.plan_hash())
+    print('num_ops', trunk.lib.ec_rn50_num_ops(trunk.h))
+    sys.exit(0)
 ms = tm(lambda: trunk.forward(x, out)); ms8 = tm(lambda: trunk.forward_u8(u8, out))
 (_w, _l), stem_w, _wf, bias = enc.pack_tv_resnet(sd)
 sw, sb = stem_w.to(dev), bias[:64].contiguous().to(dev)
