@@ -157,6 +157,12 @@ class FusedClipAdam(torch.optim.Optimizer):
         self.lib = _lib.load()
         self._buckets: Dict[int, dict] = {}
 
+    def load_state_dict(self, state_dict):
+        """torch's loader replaces the per-parameter state tensors: drop the flat buckets, the next ``step()`` rebuilds them
+        from the restored ``exp_avg`` / ``exp_avg_sq`` (and re-binds the state entries as views of the new flat moments)."""
+        super().load_state_dict(state_dict)
+        self._buckets = {}
+
     @staticmethod
     def _span(tensors):
         """(storage offset of the first element, numel of the covering span) when ``tensors`` are non-overlapping contiguous

@@ -654,6 +654,16 @@ def test_fused_clip_adam_is_a_torch_optimizer_drop_in(dev):
         assert (a - b).abs().max().item() < 2e-6
     with pytest.raises(NotImplementedError):
         FusedClipAdam(pf, weight_decay=0.1)
+    # checkpoint round trip (AllenAct saves optimizer.state_dict()): a fresh optimiser that loads it continues identically
+    of2 = FusedClipAdam(pf, lr=2e-3, max_grad_norm=None)
+    of2.load_state_dict(of.state_dict())
+    for a, b in zip(pf, pt):
+        g = torch.randn(a.shape, generator=gen).to(dev)
+        a.grad, b.grad = g.clone(), g.clone()
+    of2.step(); ot.step()
+    for a, b in zip(pf, pt):
+        assert (a - b).abs().max().item() < 2e-6
+    assert float(of2.state[pf[0]]["step"]) == 4.0
 
 
 def test_infer_reuse_rebuilds_tables_when_geometry_or_dtype_changed(dev):
