@@ -252,7 +252,8 @@ def run_rank(a, rank: int, local_rank: int, world: int, init_method=None):
         per_gpu = total
     wkw = dict(T=a.rollout, device=dev, seed=0, rank=rank, world=world, update_repeats=a.update_repeats,
                encoder_chunk=a.encoder_chunk, encoder=a.encoder, encoder_streams=a.encoder_streams,
-               frames_u8=a.frames_u8, num_mini_batch=a.num_mini_batch, force_allreduce=a.force_dist)
+               frames_u8=a.frames_u8, num_mini_batch=a.num_mini_batch, force_allreduce=a.force_dist,
+               overlap_allreduce=not a.no_overlap_allreduce)
     if a.encoder == "zeroshot":
         wkw.update(encoder="rn50", zeroshot=True)
     w = Worker(per_gpu, frames_host=a.frames_host, sync_actions=a.sync_actions, **wkw)
@@ -352,7 +353,9 @@ def run_rank(a, rank: int, local_rank: int, world: int, init_method=None):
                        "env_order": ("action-synchronous: the sampled actions are copied to the host every env step before the "
                                      "next observation is served" if a.sync_actions else
                                      "free-running: the synthetic env does not read the actions (SURVEY.md 8d); see `sync_actions`"),
-                       "parallelism": f"dp{world} (actors sharded; one flat 13.9 MB grad all-reduce per optimiser step)",
+                       "parallelism": f"dp{world} (actors sharded; the flat 13.9 MB gradient bucket SUM-all-reduced per optimiser step" +
+                                      (": one call after the backward)" if a.no_overlap_allreduce else
+                                       ": GRU + heads section (12.8 MB) under the goal encoder's backward, the remaining 1.1 MB after it)"),
                        "flop_per_frame": flop_per_frame,
                        "policy_gemm_mode": ("fp32 x fp32 as bf16x3: six exact products forward, THREE leading products in the backward's "
                                             "large gradient GEMMs (EC_GEMM_BWD3=1)" if os.environ.get("EC_GEMM_BWD3", "0") not in ("", "0")
@@ -573,6 +576,9 @@ def parse_args(argv=None):
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL (backend nccl) and run the flat-bucket all-reduce also at world size 1 -- the "
                          "first-contact check of the N > 1 path on a 1-GPU box (tests/test_gpu_multi.py)")
+    ap.add_argument("--no-overlap-allreduce", action="store_true",
+                    help="one 13.9-MB all-reduce AFTER the backward instead of the GRU + heads section reduced under the goal "
+                         "encoder's backward (engine.Worker(overlap_allreduce=False)); only matters with a collective")
     ap.add_argument("--secondary-budget-s", type=float, default=420.0,
                     help="wall-clock budget of ALL secondary legs together; on expiry the line is printed with what is there")
     ap.add_argument("--no-traffic", action="store_true", help="do not read profiles/*_hbm_traffic.json")

@@ -84,6 +84,8 @@ SIGNATURES = {
                                    c_void_p, c_size_t, c_int, c_void_p, c_void_p, c_void_p]),
     "ec_policy_backward2": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_size_t,
                                     c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ec_policy_backward3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_size_t,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ec_policy_set_goal_table": (c_int, [c_void_p, c_void_p]),
     "ec_policy_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_size_t,
                                    c_void_p, c_void_p, c_void_p, c_void_p]),

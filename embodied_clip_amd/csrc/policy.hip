@@ -1788,6 +1788,13 @@ extern "C" int ec_policy_backward(const ec_policy_t* h, const float* params, con
 extern "C" int ec_policy_backward2(const ec_policy_t* h, const float* params, const void* feat, const void* feat2, int feat_bf16,
                                    const float* masks, int T, int N, void* workspace, size_t ws_bytes, const float* dhv,
                                    const float* dh_final, float* grads, ec_stream_t stream) {
+    return ec_policy_backward3(h, params, feat, feat2, feat_bf16, masks, T, N, workspace, ws_bytes, dhv, dh_final, grads, nullptr,
+                               stream);
+}
+
+extern "C" int ec_policy_backward3(const ec_policy_t* h, const float* params, const void* feat, const void* feat2, int feat_bf16,
+                                   const float* masks, int T, int N, void* workspace, size_t ws_bytes, const float* dhv,
+                                   const float* dh_final, float* grads, ec_event_t recurrent_grads_ready, ec_stream_t stream) {
     if (!h || !params || !feat || !masks || !workspace || !dhv || !grads) return EC_ERR_ARG;
     if (h->c.dual && !feat2) return EC_ERR_ARG;
     if (T <= 0 || N <= 0) return EC_ERR_SHAPE;
@@ -1913,6 +1920,10 @@ extern "C" int ec_policy_backward2(const ec_policy_t* h, const float* params, co
     else
     RC(tn(ws + w.dgi, 3 * H, ws + w.x, flat, 0, G(P_WIH), 3 * H, flat, B, flat));
     colsum(ws + w.dgi, G(P_BIH), B, 3 * H, 3 * H);
+    // the gradients of the GRU and of both heads (tensors rnn.weight_ih_l0 .. critic.fc.bias: 92 % of the bucket) are final
+    // here; what follows only writes the goal encoder's.  A caller that sums the bucket over ranks starts that section's
+    // all-reduce behind this event, under the rest of this backward
+    if (recurrent_grads_ready && hipEventRecord((hipEvent_t)recurrent_grads_ready, s) != hipSuccess) return EC_ERR_LAUNCH;
     if (c.fusion) {   // the image embedding and the goal table are frozen: nothing trainable upstream of the GRU
         EC_CHECK_LAUNCH();
         return EC_OK;

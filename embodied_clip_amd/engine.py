@@ -95,7 +95,8 @@ class Worker:
                  tau: float = 0.95, encoder_sd=None, policy_sd=None, lr_total_steps: int = 300_000_000,
                  encoder_chunk: int = 0, encoder: str = "rn50", encoder_streams: int = 2, frames_u8: bool = False,
                  frames_host: bool = False, zeroshot: bool = False, text_sd=None, goal_tokens=None,
-                 num_mini_batch: int = 1, sync_actions: bool = False, force_allreduce: bool = False):
+                 num_mini_batch: int = 1, sync_actions: bool = False, force_allreduce: bool = False,
+                 overlap_allreduce: bool = True):
         """``zeroshot=True`` (BASELINE config 5, readme_files/zeroshot_objectnav.md): the observation is the CLIP image
         EMBEDDING (RN50 trunk + AttentionPool2d, 1024-d), the goal is the frozen CLIP text embedding of its prompt
         (text tower run once -> [12, 1024] table) and the policy is the fusion=1 variant (GRU + heads trainable)."""
@@ -107,6 +108,10 @@ class Worker:
         self.sync_actions = sync_actions
         # force_allreduce: run the flat-bucket collective also at world size 1 (RCCL first-contact check on a 1-GPU box)
         self.force_allreduce = force_allreduce
+        # overlap_allreduce (when there is a collective at all): the GRU + heads section of the flat bucket (92 % of its bytes,
+        # final first: ec_policy_backward3) is summed over ranks on a communication stream UNDER the rest of the backward;
+        # only the goal encoder's 1.1 MB is reduced after it.  False: one 13.9-MB all-reduce after the backward
+        self.overlap_allreduce = overlap_allreduce
         # [U] allenact RolloutStorage.recurrent_generator(num_mini_batch): contiguous sampler ranges, shuffled order
         assert 1 <= num_mini_batch <= n_actors, "num_mini_batch must not exceed the number of samplers"
         self.num_mini_batch = num_mini_batch
@@ -176,6 +181,8 @@ class Worker:
         self.H, self.A = self.policy.H, self.policy.A
         self.params = self.policy.flatten(policy_sd if policy_sd is not None else syn.policy_state_dict(0, **pkw), d)
         self.grads = torch.zeros_like(self.params)
+        self.rec = self.policy.recurrent_section()          # GRU + heads: the part of the bucket whose gradients are final first
+        self.comm_stream = torch.cuda.Stream(device=d)
         self.opt = FlatAdam(self.params, lr=lr, max_grad_norm=max_grad_norm)
         N, S2 = n_actors, self.S * self.S
         # [T, N] rollout scalars (global; tiny)
@@ -208,6 +215,8 @@ class Worker:
             sl.hv = torch.empty((T * n, self.A + 1), dtype=torch.float32, device=d)
             sl.dhv = torch.empty_like(sl.hv)
             sl.grads = self.grads if ns == 1 else torch.zeros_like(self.params)
+            sl.rec_ready = torch.cuda.Event()
+            sl.rec_ready.record()          # (torch creates the hipEvent_t at the first record: the library needs the handle)
             sl.sums = torch.zeros(4, dtype=torch.float64, device=d)
             sl.goal = sl.masks = sl.actions = sl.logp = sl.old_v = sl.ret = sl.nadv = None
             if frames_host:   # double-buffered device staging of the slice's frames + its own copy stream (SDMA)
@@ -462,9 +471,29 @@ class Worker:
         return (fm.view(T * m, self.S * self.S, self.C), c(sl.goal), c(sl.masks), c(sl.actions), c(sl.logp), c(sl.old_v),
                 c(sl.ret), c(sl.nadv))
 
+    def _sum_parts(self, parts, sec: slice):
+        """self.grads[sec] = sum of the slices' gradient buckets over ``sec`` (one slice: its bucket IS self.grads)."""
+        if self.ns == 1:
+            return
+        if len(parts) == 1:
+            self.grads[sec].copy_(parts[0][0].grads[sec])
+            return
+        torch.add(parts[0][0].grads[sec], parts[1][0].grads[sec], out=self.grads[sec])
+        for (sl, _, _) in parts[2:]:
+            self.grads[sec].add_(sl.grads[sec])
+
+    def _other_sections(self):
+        """What ``self.rec`` leaves of the flat bucket (the goal encoder's tensors; two pieces with the dual encoder)."""
+        n = self.grads.numel()
+        return [sec for sec in (slice(0, self.rec.start), slice(self.rec.stop, n)) if sec.stop > sec.start]
+
     @_lib.on_device
     def update(self):
         T = self.T
+        collective = self.world > 1 or self.force_allreduce
+        if collective:
+            import torch.distributed as tdist
+            collective = tdist.is_available() and tdist.is_initialized()
         self._gather_slice_batches()
         for _ in range(self.update_repeats):
             for (s0, s1) in self.minibatch_ranges():
@@ -475,6 +504,9 @@ class Worker:
                     if b > a:
                         parts.append((sl, a, b))
                 nmb = s1 - s0
+                early = collective and self.overlap_allreduce
+                if early:                      # (the previous optimiser step read self.grads on the main stream)
+                    self.comm_stream.wait_stream(torch.cuda.current_stream())
                 self._fork()
                 for (sl, a, b) in parts:
                     with self._on(sl):
@@ -492,18 +524,28 @@ class Worker:
                         ppo_loss_raw(hv, actions, logp, old_v, ret, nadv, self.A, grad_scale=grad_scale, dhv=dhv,
                                      sums=sl.sums)
                         sl.grads.zero_()
-                        self.policy.backward(self.params, feat, masks, T, m, sl.ws_learn, dhv, None, sl.grads)
+                        self.policy.backward(self.params, feat, masks, T, m, sl.ws_learn, dhv, None, sl.grads,
+                                             recurrent_ready=sl.rec_ready if early else None)
+                if early:
+                    # GRU + heads section: summed over the slices and over the ranks on the communication stream, behind the
+                    # events the backwards record -- i.e. under the goal encoder's backward (dx GEMM, tail, dW1) of every slice
+                    with torch.cuda.stream(self.comm_stream):
+                        for (sl, _, _) in parts:
+                            self.comm_stream.wait_event(sl.rec_ready)
+                        self._sum_parts(parts, self.rec)
+                        allreduce_flat(self.grads[self.rec], force=self.force_allreduce)
                 self._join()
                 self._loss_parts = [(sl, b - a) for (sl, a, b) in parts]
-                if self.ns > 1:
-                    if len(parts) == 1:
-                        self.grads.copy_(parts[0][0].grads)
-                    else:
-                        torch.add(parts[0][0].grads, parts[1][0].grads, out=self.grads)
-                        for (sl, _, _) in parts[2:]:
-                            self.grads.add_(sl.grads)
-                if self.world > 1 or self.force_allreduce:
-                    allreduce_flat(self.grads, force=self.force_allreduce)   # one flat 13.9 MB bucket over RCCL/xGMI
+                if early:
+                    # the goal encoder's section(s): after the backwards, on the main stream (1.1 MB)
+                    for sec in self._other_sections():
+                        self._sum_parts(parts, sec)
+                        allreduce_flat(self.grads[sec], force=self.force_allreduce)
+                    torch.cuda.current_stream().wait_stream(self.comm_stream)
+                else:
+                    self._sum_parts(parts, slice(0, self.grads.numel()))
+                    if collective:
+                        allreduce_flat(self.grads, force=self.force_allreduce)   # one flat 13.9 MB bucket over RCCL/xGMI
                 self.opt.step(self.grads, lr=linear_decay_lr(self.base_lr, self.total_steps, self.lr_total_steps))
                 self.invalidate_act_tables()
 

@@ -124,18 +124,33 @@ class PolicyHandle:
             hv.data_ptr(), h_final.data_ptr(), _lib.stream_ptr()), "ec_policy_forward2")
         return hv, h_final
 
-    def backward(self, flat_params, feat, masks, T, N, ws, dhv, dh_final, flat_grads, feat2=None):
+    def backward(self, flat_params, feat, masks, T, N, ws, dhv, dh_final, flat_grads, feat2=None, recurrent_ready=None):
+        """``recurrent_ready``: a ``torch.cuda.Event`` (already recorded once, so that its handle exists) the library records
+        on the current stream when ``flat_grads[self.recurrent_section()]`` is final (``ec_policy_backward3``)."""
         with _lib.tensor_guard(flat_params):
-            return self._backward(flat_params, feat, masks, T, N, ws, dhv, dh_final, flat_grads, feat2)
+            return self._backward(flat_params, feat, masks, T, N, ws, dhv, dh_final, flat_grads, feat2, recurrent_ready)
 
-    def _backward(self, flat_params, feat, masks, T, N, ws, dhv, dh_final, flat_grads, feat2=None):
+    def _backward(self, flat_params, feat, masks, T, N, ws, dhv, dh_final, flat_grads, feat2=None, recurrent_ready=None):
         if self.cfg["dual"]:
             assert feat2 is not None and feat2.is_contiguous() and feat2.dtype == feat.dtype and feat2.shape == feat.shape
-        _lib.check(self.lib.ec_policy_backward2(
+        ev = None
+        if recurrent_ready is not None:
+            ev = int(recurrent_ready.cuda_event)
+            assert ev, "record the event once before handing it over (torch creates the hipEvent_t lazily)"
+        _lib.check(self.lib.ec_policy_backward3(
             self.h, flat_params.data_ptr(), feat.data_ptr(), _lib.ptr(feat2), int(feat.dtype == torch.bfloat16), masks.data_ptr(),
             T, N, ws.data_ptr(), ws.numel() * ws.element_size(), dhv.data_ptr(), _lib.ptr(dh_final), flat_grads.data_ptr(),
-            _lib.stream_ptr()), "ec_policy_backward2")
+            ev, _lib.stream_ptr()), "ec_policy_backward3")
         return flat_grads
+
+    def recurrent_section(self) -> slice:
+        """The contiguous part of the flat bucket whose gradients ``ec_policy_backward3`` finishes first (GRU + both heads:
+        ``state_encoder.rnn.weight_ih_l0`` ... ``critic.fc.bias``); the rest is the goal encoder's."""
+        o0 = self.offsets["state_encoder.rnn.weight_ih_l0"][0]
+        o1, k1 = self.offsets["critic.fc.bias"]
+        end = o1 + k1
+        later = [o for (o, _) in self.offsets.values() if o >= end]      # (the depth stream's tensors of the dual encoder)
+        return slice(o0, min(later) if later else self.flat_size)
 
 
 class _PolicyFn(torch.autograd.Function):

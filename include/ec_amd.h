@@ -32,6 +32,7 @@ extern "C" {
 #endif
 
 typedef void* ec_stream_t;
+typedef void* ec_event_t;    /* hipEvent_t */
 
 enum {
     EC_OK = 0,
@@ -341,6 +342,14 @@ int ec_policy_backward(const ec_policy_t* h, const float* params, const void* fe
 int ec_policy_backward2(const ec_policy_t* h, const float* params, const void* feat, const void* feat2, int feat_bf16,
                         const float* masks, int T, int N, void* workspace, size_t ws_bytes, const float* dhv,
                         const float* dh_final, float* grads, ec_stream_t stream);
+/* ec_policy_backward2 that also records `recurrent_grads_ready` (a hipEvent_t, or NULL) on `stream` at the point where the
+ * gradients of rnn.weight_ih_l0 ... critic.fc.bias (one contiguous section of the flat bucket, 92 % of its bytes) are final
+ * and only the goal encoder's remain to be written: the data-parallel caller starts that section's SUM all-reduce behind the
+ * event, under the rest of the backward.  Replaces the `async_op=True` per-parameter all-reduces of [U] allenact
+ * OnPolicyTrainer.backprop_step (§8e "can be fully overlapped with the GRU-backward tail"). */
+int ec_policy_backward3(const ec_policy_t* h, const float* params, const void* feat, const void* feat2, int feat_bf16,
+                        const float* masks, int T, int N, void* workspace, size_t ws_bytes, const float* dhv,
+                        const float* dh_final, float* grads, ec_event_t recurrent_grads_ready, ec_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Rollout post-processing and the PPO update ([U] allenact onpolicy_sync:

