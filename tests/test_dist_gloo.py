@@ -44,7 +44,7 @@ def _grads(sd, feat, goal, h0, masks, actions, old_lp, old_v, ret, nadv, sl):
     return dict(zip(leaves.keys(), gs))
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, sectioned=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["GLOO_SOCKET_IFNAME"] = "lo"
     dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)
     try:
@@ -55,7 +55,13 @@ def _worker(rank, world, port, q):
         g = _grads(*case, slice(start, start + cnt))
         h = PolicyHandle(**CFG)
         flat = h.flatten(g, "cpu") * grad_scale(T * cnt, T * N)
-        allreduce_flat(flat)
+        if sectioned:    # engine.Worker(overlap_allreduce=True): GRU + heads section first, then what is left of the bucket
+            rec = h.recurrent_section()
+            assert 0 < rec.start < rec.stop == h.flat_size
+            allreduce_flat(flat[rec])
+            allreduce_flat(flat[:rec.start])
+        else:
+            allreduce_flat(flat)
         if rank == 0:
             q.put(flat)
     finally:
@@ -70,11 +76,14 @@ def test_shard_actors_partition():
 
 
 @pytest.mark.timeout(180)
-def test_two_rank_flat_allreduce_equals_unsharded():
+@pytest.mark.parametrize("sectioned", [False, True])
+def test_two_rank_flat_allreduce_equals_unsharded(sectioned):
+    """``sectioned``: the bucket reduced as the overlapped worker does it -- the contiguous GRU + heads section
+    (``PolicyHandle.recurrent_section()``) in one call, the goal encoder's section in another (in-place on views of the bucket)."""
     world, port = 2, _rendezvous()
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, sectioned)) for r in range(world)]
     for p in procs:
         p.start()
     flat = q.get()
