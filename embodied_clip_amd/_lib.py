@@ -20,8 +20,10 @@ SIGNATURES = {
     "ec_version": (c_int, []),
     "ec_strerror": (C.c_char_p, [c_int]),
     "ec_conv_bf16": (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p]),
+    "ec_conv_bf16_ld": (c_int, [c_void_p] * 5 + [c_int] * 9 + [c_void_p]),
     "ec_conv3x3_img_pack": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "ec_conv3x3_img_bf16": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
+    "ec_conv3x3_img_bf16_ld": (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_void_p]),
     "ec_bneck3_packed_elems": (c_size_t, [c_int]),
     "ec_bneck3_pack_weights": (c_int, [c_void_p] * 4 + [c_int, c_void_p]),
     "ec_bneck_conv123_bf16": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_void_p]),
@@ -38,6 +40,7 @@ SIGNATURES = {
     "ec_dw_tn_x3": (c_int, [c_void_p] * 4 + [C.c_long, c_int, c_void_p]),
     "ec_stem_conv1": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
     "ec_avgpool2_bf16": (c_int, [c_void_p] * 2 + [c_int] * 4 + [c_void_p]),
+    "ec_avgpool2_bf16_ld": (c_int, [c_void_p] * 2 + [c_int] * 5 + [c_void_p]),
     "ec_nhwc_bf16_to_nchw_f32": (c_int, [c_void_p] * 2 + [c_int] * 3 + [c_void_p]),
     "ec_nchw_f32_to_nhwc_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ec_spatial_mean_bf16": (c_int, [c_void_p] * 2 + [c_int] * 3 + [c_void_p]),

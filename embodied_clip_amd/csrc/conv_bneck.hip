@@ -523,6 +523,7 @@ struct ImgArgs {
     uint16_t* out;         // [B][PIX][C]
     int B;
     unsigned w_bytes;
+    int ldo;               // POOL variant: row stride of `out` in elements (C = dense)
 };
 
 // NCH > 1: the input map does not fit the LDS (14 x 14 x 512 = 200 KB): it is made resident in NCH channel chunks, one after
@@ -738,7 +739,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_img_kernel(ImgArgs p) {
             const f32x4_t o = ((a + b) + (c + d)) * 0.25f;       // (the fused epilogue's order: (s0 + s1) + (s2 + s3))
             uint2 w;
             w.x = ec_pack2(o[0], o[1]); w.y = ec_pack2(o[2], o[3]);
-            *reinterpret_cast<uint2*>(p.out + ((size_t)img * PP + q) * C + n0 + c4 * 4) = w;
+            *reinterpret_cast<uint2*>(p.out + ((size_t)img * PP + q) * p.ldo + n0 + c4 * 4) = w;
         }
         return;
     }
@@ -797,10 +798,18 @@ extern "C" int ec_conv3x3_img_pack(const void* w, void* packed, int C, ec_stream
 }
 extern "C" int ec_conv3x3_img_bf16(const void* in, const void* packed, const float* bias, void* out, int B, int H, int W, int C,
                                    int pool, ec_stream_t stream) {
+    return ec_conv3x3_img_bf16_ld(in, packed, bias, out, B, H, W, C, pool, C, stream);
+}
+
+// ... the pooled geometry writing a column block of a wider tensor (out_row_stride elements per pooled pixel; see ec_conv_bf16_ld)
+extern "C" int ec_conv3x3_img_bf16_ld(const void* in, const void* packed, const float* bias, void* out, int B, int H, int W, int C,
+                                      int pool, int out_row_stride, ec_stream_t stream) {
     if (!in || !packed || !bias || !out) return EC_ERR_ARG;
     if (B <= 0 || H != W) return EC_ERR_SHAPE;
+    if (out_row_stride != C && (!pool || out_row_stride < C || (out_row_stride & 7))) return EC_ERR_SHAPE;
     ImgArgs a;
     a.in = (const uint16_t*)in; a.w = (const uint16_t*)packed; a.bias = bias; a.out = (uint16_t*)out; a.B = B;
+    a.ldo = out_row_stride;
     a.w_bytes = (unsigned)((size_t)C * 9 * C * 2);
     auto go = [&](auto kern, int nslice, size_t lds, std::atomic<uint64_t>& done) {
         if (auto attr_g_ = ec_attr_needed(done))

@@ -74,6 +74,7 @@ struct ConvArgs {
     const uint16_t* res;
     uint16_t* out;
     int H, W, Cin, Cout, K, M;
+    int ldo;   // row stride of `out` in elements (== Cout for a dense tensor; > Cout writes a column block of a wider one)
     int cin_log2;
     int act;
     int ntn;   // number of N tiles
@@ -562,7 +563,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM > 192) ? 2 : ((WM * WN == 8) ? 4 
     for (int r0 = 0; r0 < OUT_ROWS; r0 += RPP) {
         const int row = r0 + srow;
         if (orow0 + row < Mout && (MV == BM || row < MV))
-            *reinterpret_cast<uint4*>(p.out + (long)(orow0 + row) * p.Cout + e_n0 + schunk * 8) =
+            *reinterpret_cast<uint4*>(p.out + (long)(orow0 + row) * p.ldo + e_n0 + schunk * 8) =
                 *reinterpret_cast<const uint4*>(smem + row * PITCH + schunk * 16);
     }
         }   // !(ablate & 8)
@@ -1087,7 +1088,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
     for (int r0 = 0; r0 < OUT_ROWS; r0 += RPP) {
         const int row = r0 + srow;
         if (orow0 + row < Mout && !(ABL & 128))         // (ABL & 128, profiling only: LDS staging without the global stores)
-            *reinterpret_cast<uint4*>(p.out + (long)(orow0 + row) * p.Cout + n0 + schunk * 8) =
+            *reinterpret_cast<uint4*>(p.out + (long)(orow0 + row) * p.ldo + n0 + schunk * 8) =
                 *reinterpret_cast<const uint4*>(smem + row * PITCH + schunk * 16);
     }
     if constexpr ((ABL & 32) != 0) if (blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0) ec_dbg_stamps[grp * 1024 + 302] = __builtin_amdgcn_s_memtime();
@@ -1279,8 +1280,19 @@ extern "C" int ec_debug_stamps(unsigned long long* host_dst, int n) {
 
 extern "C" int ec_conv_bf16(const void* in, const void* w, const float* bias, const void* res, void* out, int B,
                             int H, int W, int Cin, int Cout, int ksize, int pool, int act, ec_stream_t stream) {
+    return ec_conv_bf16_ld(in, w, bias, res, out, B, H, W, Cin, Cout, ksize, pool, act, Cout, stream);
+}
+
+// ec_conv_bf16 writing a COLUMN BLOCK of a wider tensor: output row m starts at out + m * out_row_stride (elements).  What the
+// trunk uses to lay a Bottleneck's pooled conv2 output and its pooled block input side by side, so that conv3 and the
+// downsample conv become ONE GEMM over the concatenated K axis (rn50.hip).
+extern "C" int ec_conv_bf16_ld(const void* in, const void* w, const float* bias, const void* res, void* out, int B,
+                               int H, int W, int Cin, int Cout, int ksize, int pool, int act, int out_row_stride,
+                               ec_stream_t stream) {
     if (!in || !w || !out) return EC_ERR_ARG;
     if (B <= 0 || H <= 0 || W <= 0) return EC_ERR_SHAPE;
+    if (out_row_stride < Cout || (out_row_stride & 7)) return EC_ERR_SHAPE;
+    const bool dense = out_row_stride == Cout;
     if (ksize != 1 && ksize != 3) return EC_ERR_SHAPE;
     if (Cin < 8 || Cin % 8 != 0 || Cout % 32 != 0) return EC_ERR_SHAPE;
     if (pool && ((H & 1) || (W & 1) || res != nullptr || act != EC_ACT_RELU)) return EC_ERR_SHAPE;
@@ -1293,7 +1305,7 @@ extern "C" int ec_conv_bf16(const void* in, const void* w, const float* bias, co
     a.bias = bias;
     a.res = (const uint16_t*)res;
     a.out = (uint16_t*)out;
-    a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.ldo = Cout;
     a.K = ksize * ksize * Cin;
     a.M = B * H * W;
     a.cin_log2 = (Cin & (Cin - 1)) == 0 ? ec_ilog2(Cin) : -1;
@@ -1304,9 +1316,11 @@ extern "C" int ec_conv_bf16(const void* in, const void* w, const float* bias, co
     a.w_bytes = (unsigned)((long)Cout * a.K * 2);
     if (res && (long)B * H * W * Cout * 2 >= (1L << 32) - 16) return EC_ERR_SHAPE;
     a.res_bytes = res ? (unsigned)((long)B * H * W * Cout * 2) : 0u;
+    a.ldo = out_row_stride;
     hipStream_t s = (hipStream_t)stream;
-    if (ksize == 1 && !pool && ec_conv1x1_regw(in, w, bias, res, out, (long)B * H * W, Cin, Cout, act, s) == EC_OK) return EC_OK;
-    if (ksize == 3 && !res && act == EC_ACT_RELU && Cin <= 64 && Cout <= 64 &&
+    // (the register-weight and resident-weight kernels write dense tensors only)
+    if (dense && ksize == 1 && !pool && ec_conv1x1_regw(in, w, bias, res, out, (long)B * H * W, Cin, Cout, act, s) == EC_OK) return EC_OK;
+    if (dense && ksize == 3 && !res && act == EC_ACT_RELU && Cin <= 64 && Cout <= 64 &&
         ec_conv3x3_narrow(in, w, bias, out, B, H, W, Cin, Cout, pool, s) == EC_OK)
         return EC_OK;
     if (ksize == 3) return pool ? dispatch_tile<3, true>(a, s) : dispatch_tile<3, false>(a, s);
@@ -1332,7 +1346,7 @@ extern "C" int ec_conv_bf16_s2(const void* in, const void* w, const float* bias,
     a.bias = bias;
     a.res = (const uint16_t*)res;
     a.out = (uint16_t*)out;
-    a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.ldo = Cout;
     a.K = ksize * ksize * Cin;
     a.M = B * Ho * Wo;
     a.cin_log2 = (Cin & (Cin - 1)) == 0 ? ec_ilog2(Cin) : -1;
@@ -1388,7 +1402,7 @@ extern "C" int ec_gemm_bf16a_x3(const void* A, const void* Wplanes, const float*
         a.bias = bias;
         a.res = nullptr;
         a.out = reinterpret_cast<uint16_t*>(out + r0 * N);
-        a.H = 1; a.W = (int)rows; a.Cin = K; a.Cout = N;
+        a.H = 1; a.W = (int)rows; a.Cin = K; a.Cout = N; a.ldo = N;
         a.K = K; a.M = (int)rows;
         a.cin_log2 = 0;
         a.act = act;
@@ -1414,7 +1428,7 @@ extern "C" int ec_gemm_bf16(const void* A, const void* Wt, const float* bias, co
     a.bias = bias;
     a.res = (const uint16_t*)res;
     a.out = (uint16_t*)out;
-    a.H = 1; a.W = M; a.Cin = K; a.Cout = N;
+    a.H = 1; a.W = M; a.Cin = K; a.Cout = N; a.ldo = N;
     a.K = K; a.M = M;
     a.cin_log2 = 0;
     a.act = act;

@@ -37,6 +37,9 @@ struct Op {
     long wc1_off = -1, bc1_off = -1;   // OP_BNECK with conv1 folded in (whole block in one launch): conv1's weight / bias offsets; its input is `res`
     int stride = 1;          // OP_CONV: 2 = torchvision's strided conv (ec_conv_bf16_s2); H, W are the INPUT dims
     long wimg_off = -1;      // offset (elements, into wbneck) of this 3x3 conv's streaming-order weights for the small-launch kernel
+    int ldo = 0, ocol = 0;   // OP_CONV / OP_POOL writing a column block of a wider tensor: row stride (0 = dense) and first column (elements)
+    long wcat_off = -1;      // OP_CONV over a concatenated K axis (conv3 | downsample conv of a stride-2 block): its [Cout][K1 + K2] weights in wbneck,
+    long bcat_off = -1;      // ... its summed bias in bias_cat; w_off / b_off = conv3's, w1_off / b1_off = the downsample conv's, Cin = K1 + K2, N2 = K1
 };
 
 }  // namespace
@@ -52,8 +55,10 @@ struct ec_rn50 {
     size_t n_w, n_b;
     int conv8_min_tiles = 0;      // 0 = library default (ec_rn50_set_conv8_min_tiles)
     uint16_t* wbneck = nullptr;   // streaming-order weights of the fused bottleneck launches (ec_bneck_pack_weights), one block per OP_BNECK
+    float* bias_cat = nullptr;    // summed biases of the K-concatenated convs (Op::bcat_off)
     ~ec_rn50() {
         if (wbneck) (void)hipFree(wbneck);
+        if (bias_cat) (void)hipFree(bias_cat);
     }
 };
 
@@ -186,6 +191,32 @@ int rn50_build(ec_rn50_t** out, bool tv, int width, const int* layers4, int inpu
                 inplanes = planes * 4;
                 continue;
             }
+            // Stride-2 blocks of layers 3-4 (CLIP: AvgPool2d(2) after conv2 and in front of the downsample conv): the pooled conv2
+            // output [M, planes] and the pooled block input [M, inplanes] are laid side by side in buffer 2, and
+            //   relu(conv3(c2) + b3 + downsample(xp) + bd) == relu([c2 | xp] . [W3 | Wd]^T + (b3 + bd))
+            // is ONE GEMM with K = planes + inplanes: the downsample output (M x 4 planes) is never written or re-read, one
+            // launch less, and the sum is rounded to bf16 once instead of twice.  (layer 2's first block gets its pooled
+            // input from the layer-1 boundary launch and chains conv3 into the next conv1: left as is.)
+            if (ds && !tv && stride > 1 && li >= 2 && pooled_in < 0 && ec_config().rn50_dscat && (planes % 8) == 0) {
+                const int Kc = planes + inplanes;
+                Op& c2op = h->ops.back();                       // conv2 (+ pool) -> buffer 2, columns [0, planes)
+                c2op.ldo = Kc;
+                Op pl{OP_POOL, x, 2, -1, R, R, inplanes, inplanes, 0, 0, 0, 0, 0};
+                pl.ldo = Kc; pl.ocol = planes;                 // pooled block input -> buffer 2, columns [planes, Kc)
+                h->ops.push_back(pl);
+                track(Ro, Ro, Kc);
+                Op o{OP_CONV, 2, y, -1, Ro, Ro, Kc, planes * 4, 1, 0, EC_ACT_RELU, w_c3, b_c3};
+                o.w1_off = wo; o.b1_off = bo;                   // the downsample conv's slot
+                o.N2 = planes;
+                o.wcat_off = 0;                                 // (assigned below, with the other packed weights)
+                wo += (size_t)planes * 4 * inplanes; bo += planes * 4;
+                h->ops.push_back(o);
+                track(Ro, Ro, planes * 4);
+                x = y;
+                inplanes = planes * 4;
+                R = Ro;
+                continue;
+            }
             if (ds) {
                 int dsrc = x, ddst = 3;
                 if (tv) {
@@ -257,7 +288,13 @@ int rn50_build(ec_rn50_t** out, bool tv, int width, const int* layers4, int inpu
     h->n_w = wo; h->n_b = bo;
     if (n_w != wo || n_bias != bo) { delete h; return EC_ERR_SHAPE; }
     {   // fused bottleneck launches: their conv2 + conv3 weights in streaming order, one packed block per op (w2_off = its offset)
-        size_t tot = 0;
+        size_t tot = 0, btot = 0;
+        for (Op& o : h->ops)
+            if (o.wcat_off >= 0) {   // K-concatenated conv3 | downsample conv: [Cout][K1 + K2] weights, summed bias
+                o.wcat_off = (long)tot; tot += (size_t)o.Cout * o.Cin;
+                o.bcat_off = (long)btot; btot += (size_t)o.Cout;
+            }
+        if (btot && hipMalloc(&h->bias_cat, btot * sizeof(float)) != hipSuccess) { h->bias_cat = nullptr; delete h; return EC_ERR_LAUNCH; }
         for (Op& o : h->ops) {
             if (o.kind == OP_BNECK) { o.w2_off = tot; o.wimg_off = (long)tot; tot += ec_bneck3_packed_elems(o.Cin); }   // (packed conv2 comes first; room for conv1 too)
             // the un-pooled 3x3 convs of the 7x7 stage: streaming-order weights for the small-launch kernel (conv3x3_img_kernel)
@@ -271,6 +308,20 @@ int rn50_build(ec_rn50_t** out, bool tv, int width, const int* layers4, int inpu
             if (hipMalloc(&h->wbneck, tot * sizeof(uint16_t)) != hipSuccess) { h->wbneck = nullptr; delete h; return EC_ERR_LAUNCH; }
             for (const Op& o : h->ops) {
                 int rc = EC_OK;
+                if (o.wcat_off >= 0) {
+                    const int K1 = o.N2, K2 = o.Cin - o.N2;
+                    uint16_t* wc = h->wbneck + o.wcat_off;
+                    if (hipMemcpy2D(wc, (size_t)o.Cin * 2, h->w + o.w_off, (size_t)K1 * 2, (size_t)K1 * 2, (size_t)o.Cout,
+                                    hipMemcpyDeviceToDevice) != hipSuccess ||
+                        hipMemcpy2D(wc + K1, (size_t)o.Cin * 2, h->w + o.w1_off, (size_t)K2 * 2, (size_t)K2 * 2, (size_t)o.Cout,
+                                    hipMemcpyDeviceToDevice) != hipSuccess) { delete h; return EC_ERR_LAUNCH; }
+                    std::vector<float> b3((size_t)o.Cout), bd((size_t)o.Cout);
+                    if (hipMemcpy(b3.data(), h->bias + o.b_off, (size_t)o.Cout * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+                        hipMemcpy(bd.data(), h->bias + o.b1_off, (size_t)o.Cout * 4, hipMemcpyDeviceToHost) != hipSuccess) { delete h; return EC_ERR_LAUNCH; }
+                    for (int i = 0; i < o.Cout; ++i) b3[(size_t)i] += bd[(size_t)i];
+                    if (hipMemcpy(h->bias_cat + o.bcat_off, b3.data(), (size_t)o.Cout * 4, hipMemcpyHostToDevice) != hipSuccess) { delete h; return EC_ERR_LAUNCH; }
+                    continue;
+                }
                 if (o.kind == OP_BNECK)
                     rc = o.wc1_off >= 0 ? ec_bneck3_pack_weights(h->w + o.wc1_off, h->w + o.w_off, h->w + o.w1_off, h->wbneck + o.w2_off, o.Cin, nullptr)
                                         : ec_bneck_pack_weights(h->w + o.w_off, h->w + o.w1_off, h->wbneck + o.w2_off, o.Cin, nullptr);
@@ -302,7 +353,7 @@ extern "C" uint64_t ec_rn50_plan_hash(const ec_rn50_t* h) {
     mix(h->width); mix(h->res); mix(h->conv8_min_tiles); mix(h->tv);
     for (const Op& o : h->ops) {
         mix(o.kind); mix(o.src); mix(o.dst); mix(o.res); mix(o.H); mix(o.W); mix(o.Cin); mix(o.Cout); mix(o.ks);
-        mix(o.pool); mix(o.act); mix(o.stride); mix(o.src1); mix(o.dst2); mix(o.N2); mix(o.dst3); mix(o.wc1_off >= 0);
+        mix(o.pool); mix(o.act); mix(o.stride); mix(o.src1); mix(o.dst2); mix(o.N2); mix(o.dst3); mix(o.wc1_off >= 0); mix(o.ldo); mix(o.ocol); mix(o.wcat_off >= 0);
     }
     return x;
 }
@@ -378,6 +429,8 @@ int rn50_run(const ec_rn50_t* h, const void* rgb, bool u8, const float* mean3, c
                                        u8 ? 1 : 0, mean3, std3, h->stem_w, h->bias + o.b_off, buf(o.dst), nb, o.H, o.W, stream);
                     break;
                 case OP_POOL:
+                    if (o.ldo) rc = ec_avgpool2_bf16_ld(buf(o.src), (uint16_t*)buf(o.dst) + o.ocol, nb, o.H, o.W, o.Cin, o.ldo, stream);
+                    else
                     rc = ec_avgpool2_bf16(buf(o.src), buf(o.dst), nb, o.H, o.W, o.Cin, stream);
                     break;
                 case OP_PAIR:
@@ -433,11 +486,18 @@ int rn50_run(const ec_rn50_t* h, const void* rgb, bool u8, const float* mean3, c
                     }
                     if (o.wimg_off >= 0 && o.kind == OP_CONV && nb <= (o.pool ? 16 : 64)) {   // 7x7x512 3x3 convs of small launches (two rounds of
                         // workgroups at most); layer4.0's pooled 14x14x512 conv2 (two channel chunks, 16 slices per image: one round of workgroups) up to 16 frames -- at 32 it ties with conv_igemm (47.6 vs 46.6 us)
-                        rc = ec_conv3x3_img_bf16(buf(o.src), h->wbneck + o.wimg_off, h->bias + o.b_off, buf(o.dst), nb, o.H, o.W, o.Cin, o.pool, stream);
+                        rc = ec_conv3x3_img_bf16_ld(buf(o.src), h->wbneck + o.wimg_off, h->bias + o.b_off, (uint16_t*)buf(o.dst) + o.ocol, nb, o.H, o.W,
+                                                    o.Cin, o.pool, o.ldo ? o.ldo : o.Cin, stream);
                         break;
                     }
-                    rc = ec_conv_bf16(buf(o.src), h->w + o.w_off, h->bias + o.b_off, o.res >= 0 ? buf(o.res) : nullptr,
-                                      buf(o.dst), nb, o.H, o.W, o.Cin, o.Cout, o.ks, o.pool, o.act, stream);
+                    if (o.wcat_off >= 0) {   // conv3 | downsample conv over the concatenated K axis
+                        rc = ec_conv_bf16(buf(o.src), h->wbneck + o.wcat_off, h->bias_cat + o.bcat_off, nullptr, buf(o.dst), nb, o.H, o.W,
+                                          o.Cin, o.Cout, 1, 0, o.act, stream);
+                        break;
+                    }
+                    rc = ec_conv_bf16_ld(buf(o.src), h->w + o.w_off, h->bias + o.b_off, o.res >= 0 ? buf(o.res) : nullptr,
+                                         (uint16_t*)buf(o.dst) + o.ocol, nb, o.H, o.W, o.Cin, o.Cout, o.ks, o.pool, o.act,
+                                         o.ldo ? o.ldo : o.Cout, stream);
             }
             if (rc != EC_OK) return rc;
         }

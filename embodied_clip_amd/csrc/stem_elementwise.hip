@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void stem_conv1_kernel(const void* __restrict_
 
 // AvgPool2d(2) on bf16 NHWC, 8 channels (16 B) per lane.
 __global__ __launch_bounds__(256) void avgpool2_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out,
-                                                      int H, int W, int C8, long total) {
+                                                      int H, int W, int C8, long total, int ld8) {
     const int Ho = H >> 1, Wo = W >> 1;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         long t = i;
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void avgpool2_kernel(const uint16_t* __restric
                        0.25f * (ec_hi(a.z) + ec_hi(bq.z) + ec_hi(cq.z) + ec_hi(d.z)));
         o.w = ec_pack2(0.25f * (ec_lo(a.w) + ec_lo(bq.w) + ec_lo(cq.w) + ec_lo(d.w)),
                        0.25f * (ec_hi(a.w) + ec_hi(bq.w) + ec_hi(cq.w) + ec_hi(d.w)));
-        reinterpret_cast<uint4*>(out)[i] = o;
+        reinterpret_cast<uint4*>(out)[(i / C8) * ld8 + c] = o;      // (ld8 == C8: the dense tensor, index i)
     }
 }
 
@@ -405,13 +405,19 @@ extern "C" int ec_stem_conv1_u8(const uint8_t* rgb_u8, const float* mean3, const
 }
 
 extern "C" int ec_avgpool2_bf16(const void* in, void* out, int B, int H, int W, int C, ec_stream_t stream) {
+    return ec_avgpool2_bf16_ld(in, out, B, H, W, C, C, stream);
+}
+
+// ... writing a column block of a wider tensor: pooled pixel q goes to out + q * out_row_stride (elements); see ec_conv_bf16_ld
+extern "C" int ec_avgpool2_bf16_ld(const void* in, void* out, int B, int H, int W, int C, int out_row_stride, ec_stream_t stream) {
     if (!in || !out) return EC_ERR_ARG;
     if (B <= 0 || (H & 1) || (W & 1) || C % 8 != 0) return EC_ERR_SHAPE;
+    if (out_row_stride < C || (out_row_stride & 7) || ((size_t)out & 15)) return EC_ERR_SHAPE;
     const long total = (long)B * (H / 2) * (W / 2) * (C / 8);
     long blocks = (total + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(avgpool2_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                       (const uint16_t*)in, (uint16_t*)out, H, W, C / 8, total);
+                       (const uint16_t*)in, (uint16_t*)out, H, W, C / 8, total, out_row_stride / 8);
     EC_CHECK_LAUNCH();
     return EC_OK;
 }

@@ -459,15 +459,38 @@ def _guard_first(fn):
 
 @_guard_first
 def conv_bf16(x, w, bias, res=None, ksize=1, pool=False, act=1, out=None):
-    """x bf16 [B,H,W,Cin]; w bf16 [Cout, k*k*Cin]; bias f32 [Cout] -> bf16 [B,H',W',Cout]."""
+    """x bf16 [B,H,W,Cin]; w bf16 [Cout, k*k*Cin]; bias f32 [Cout] -> bf16 [B,H',W',Cout].
+    ``out`` may be a COLUMN BLOCK ``wide[..., c0:c0 + Cout]`` of a wider contiguous NHWC tensor (``ec_conv_bf16_ld``)."""
     lib = _lib.load()
     B, H, W, Cin = x.shape
     Cout = w.shape[0]
     Ho, Wo = (H // 2, W // 2) if pool else (H, W)
     if out is None:
         out = torch.empty((B, Ho, Wo, Cout), dtype=torch.bfloat16, device=x.device)
-    _lib.check(lib.ec_conv_bf16(x.data_ptr(), w.data_ptr(), _lib.ptr(bias), _lib.ptr(res), out.data_ptr(), B, H, W,
-                                Cin, Cout, ksize, int(pool), act, _lib.stream_ptr()), "ec_conv_bf16")
+    ld = _row_stride(out, (B, Ho, Wo, Cout))
+    _lib.check(lib.ec_conv_bf16_ld(x.data_ptr(), w.data_ptr(), _lib.ptr(bias), _lib.ptr(res), out.data_ptr(), B, H, W,
+                                   Cin, Cout, ksize, int(pool), act, ld, _lib.stream_ptr()), "ec_conv_bf16_ld")
+    return out
+
+
+def _row_stride(out, shape) -> int:
+    """Row stride (elements) of ``out`` [B,H,W,C]: C for a contiguous tensor, the parent's channel count for a column block."""
+    assert tuple(out.shape) == tuple(shape) and out.dtype == torch.bfloat16, (out.shape, shape, out.dtype)
+    B, H, W, C = shape
+    ld = out.stride(2)
+    assert out.stride(3) == 1 and ld >= C and out.stride(1) == W * ld and (B == 1 or out.stride(0) == H * W * ld), out.stride()
+    return ld
+
+
+@_guard_first
+def avgpool2_bf16(x, out=None):
+    """AvgPool2d(2) on bf16 NHWC (``ec_avgpool2_bf16_ld``); ``out`` may be a column block of a wider NHWC tensor."""
+    lib = _lib.load()
+    B, H, W, C = x.shape
+    if out is None:
+        out = torch.empty((B, H // 2, W // 2, C), dtype=torch.bfloat16, device=x.device)
+    ld = _row_stride(out, (B, H // 2, W // 2, C))
+    _lib.check(lib.ec_avgpool2_bf16_ld(x.data_ptr(), out.data_ptr(), B, H, W, C, ld, _lib.stream_ptr()), "ec_avgpool2_bf16_ld")
     return out
 
 
@@ -527,8 +550,9 @@ def conv3x3_img_bf16(x, w, bias, out=None, pool=False):
         _packed_store("img", (w,), packed)
     if out is None:
         out = torch.empty((B, H // 2, W // 2, C), dtype=x.dtype, device=x.device) if pool else torch.empty_like(x)
-    _lib.check(lib.ec_conv3x3_img_bf16(x.data_ptr(), packed.data_ptr(), bias.data_ptr(), out.data_ptr(), B, H, W, C, int(pool),
-                                       _lib.stream_ptr()), "ec_conv3x3_img_bf16")
+    ld = _row_stride(out, (B, H // 2, W // 2, C) if pool else (B, H, W, C))      # (a column block only with pool=True)
+    _lib.check(lib.ec_conv3x3_img_bf16_ld(x.data_ptr(), packed.data_ptr(), bias.data_ptr(), out.data_ptr(), B, H, W, C, int(pool),
+                                          ld, _lib.stream_ptr()), "ec_conv3x3_img_bf16_ld")
     return out
 
 

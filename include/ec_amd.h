@@ -65,6 +65,14 @@ const char* ec_strerror(int code);
 int ec_conv_bf16(const void* in, const void* w, const float* bias, const void* res, void* out,
                  int B, int H, int W, int Cin, int Cout, int ksize, int pool, int act,
                  ec_stream_t stream);
+/* ec_conv_bf16 writing a COLUMN BLOCK of a wider tensor: output row m starts at out + m * out_row_stride (elements;
+ * >= Cout, multiple of 8; == Cout is ec_conv_bf16).  The trunk lays a stride-2 Bottleneck's pooled conv2 output
+ * [M, planes] and its pooled block input [M, inplanes] (ec_avgpool2_bf16_ld) side by side, so that conv3 and the
+ * downsample conv of [U] clip/model.py Bottleneck.forward (`out = relu(bn3(conv3(out)) + downsample(x))`) are ONE GEMM
+ * over the concatenated K axis: the downsample output is never written or re-read. */
+int ec_conv_bf16_ld(const void* in, const void* w, const float* bias, const void* res, void* out,
+                    int B, int H, int W, int Cin, int Cout, int ksize, int pool, int act, int out_row_stride,
+                    ec_stream_t stream);
 /* Plain GEMM view of the same kernel: out[M,N] = act(A[M,K] W[N,K]^T + bias (+res)).
  * Replaces nn.Linear / nn.MultiheadAttention projections of [U] clip/model.py
  * ResidualAttentionBlock and AttentionPool2d.  K multiple of 8, N multiple of 32. */
@@ -166,6 +174,9 @@ int ec_bneck_conv123_bf16(const void* x, const void* packed, const float* b1, co
 int ec_conv3x3_img_pack(const void* w, void* packed, int C, ec_stream_t stream);
 int ec_conv3x3_img_bf16(const void* in, const void* packed, const float* bias, void* out, int B, int H, int W, int C,
                         int pool, ec_stream_t stream);
+/* ... its pooled geometry with an output row stride (see ec_conv_bf16_ld); out_row_stride != C needs pool = 1. */
+int ec_conv3x3_img_bf16_ld(const void* in, const void* packed, const float* bias, void* out, int B, int H, int W, int C,
+                           int pool, int out_row_stride, ec_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * torchvision ResNet-50 pieces: the ImageNet half of the feature scripts,
@@ -187,6 +198,9 @@ int ec_stem7_pool(const void* rgb, int u8, const float* h_mean3, const float* h_
 
 /* AvgPool2d(2) on bf16 NHWC ([U] Bottleneck downsample "-1"). C multiple of 8. */
 int ec_avgpool2_bf16(const void* in, void* out, int B, int H, int W, int C, ec_stream_t stream);
+/* ... writing a column block of a wider tensor: pooled pixel q goes to out + q * out_row_stride (elements; see
+ * ec_conv_bf16_ld).  `out` 16-B aligned. */
+int ec_avgpool2_bf16_ld(const void* in, void* out, int B, int H, int W, int C, int out_row_stride, ec_stream_t stream);
 
 /* bf16 NHWC [B,HW,C] -> fp32 NCHW [B,C,HW]: the `.float()` + layout the
  * reference exposes (thor_image_features.py:111; observation_space (2048,7,7)). */

@@ -635,3 +635,110 @@ def test_small_launch_image_resident_pooled_3x3_kernel(dev):
         assert a1.shape == (B, 7, 7, C) and torch.equal(a1, a2), B
         assert _rel(a1, ref) < 4e-3, (B, _rel(a1, ref))
         assert _rel(a1, plain) <= 1e-3, (B, _rel(a1, plain))
+
+
+@pytest.mark.parametrize("B,H,C,ks,pool,kernel", [
+    (64, 28, 256, 3, True, "8-wave"),        # layer3.0 conv2 + pool at a large launch (conv_igemm8 POOL epilogue)
+    (3, 28, 256, 3, True, "4-wave"),         # ... at a small one (conv_igemm POOL epilogue)
+    (40, 14, 512, 3, True, "4-wave ring"),   # layer4.0 conv2 + pool
+    (5, 14, 256, 1, False, "1x1"),           # a plain 1x1 launch
+])
+def test_conv_writes_a_column_block_of_a_wider_tensor(dev, B, H, C, ks, pool, kernel):
+    """``ec_conv_bf16_ld``: the same launch with an output row stride -- the block must equal the dense result bit for bit and
+    the neighbouring columns must stay untouched (what the trunk relies on when it lays conv2's pooled output and the pooled
+    block input side by side for the K-concatenated conv3 | downsample GEMM)."""
+    from embodied_clip_amd import encoder as enc
+    g = torch.Generator().manual_seed(77 + B)
+    x = _bf(torch.randn(B, H, H, C, generator=g).relu()).to(dev)
+    w = _bf(torch.randn(C, ks * ks * C, generator=g) * (ks * ks * C) ** -0.5).to(dev)
+    b = (torch.randn(C, generator=g) * 0.1).to(dev)
+    dense = enc.conv_bf16(x, w, b, None, ksize=ks, pool=pool, act=1)
+    Ho = H // 2 if pool else H
+    for c0, wide_c in ((0, 3 * C), (C, 3 * C), (2 * C, 3 * C + 64)):
+        wide = torch.full((B, Ho, Ho, wide_c), 7.0, dtype=torch.bfloat16, device=dev)
+        enc.conv_bf16(x, w, b, None, ksize=ks, pool=pool, act=1, out=wide[..., c0:c0 + C])
+        torch.cuda.synchronize()
+        assert torch.equal(wide[..., c0:c0 + C], dense), (kernel, c0)
+        rest = torch.cat([wide[..., :c0], wide[..., c0 + C:]], -1)
+        assert bool((rest == 7.0).all()), (kernel, c0)
+
+
+def test_img_kernel_and_avgpool_write_column_blocks(dev):
+    from embodied_clip_amd import encoder as enc
+    g = torch.Generator().manual_seed(5)
+    C = 512
+    x = _bf(torch.randn(3, 14, 14, C, generator=g).relu()).to(dev)
+    w = _bf(torch.randn(C, 9 * C, generator=g) * (9 * C) ** -0.5).to(dev)
+    b = (torch.randn(C, generator=g) * 0.1).to(dev)
+    dense = enc.conv3x3_img_bf16(x, w, b, pool=True)
+    wide = torch.full((3, 7, 7, C + 1024), -3.0, dtype=torch.bfloat16, device=dev)
+    enc.conv3x3_img_bf16(x, w, b, pool=True, out=wide[..., :C])
+    xin = _bf(torch.randn(3, 14, 14, 1024, generator=g)).to(dev)
+    pooled = enc.avgpool2_bf16(xin)
+    enc.avgpool2_bf16(xin, out=wide[..., C:])
+    torch.cuda.synchronize()
+    assert torch.equal(wide[..., :C], dense) and torch.equal(wide[..., C:], pooled)
+    ref = F.avg_pool2d(xin.float().cpu().permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+    assert _rel(pooled.cpu(), ref) < 4e-3
+    lib = enc._lib.load()
+    assert lib.ec_conv3x3_img_bf16_ld(x.data_ptr(), w.data_ptr(), b.data_ptr(), wide.data_ptr(), 3, 14, 14, C, 0, C + 1024, 0) == -2   # EC_ERR_SHAPE: stride needs pool
+    assert lib.ec_avgpool2_bf16_ld(xin.data_ptr(), wide.data_ptr(), 3, 14, 14, 1024, 1000, 0) == -2
+    assert lib.ec_conv_bf16_ld(x.data_ptr(), w.data_ptr(), b.data_ptr(), None, wide.data_ptr(), 3, 14, 14, C, C, 3, 1, 1, C - 8, 0) == -2
+
+
+@pytest.mark.parametrize("B,R,K1", [(2, 14, 256), (33, 7, 512)])
+def test_downsample_conv_folded_into_conv3_over_the_concatenated_k_axis(dev, B, R, K1):
+    """The identity behind EC_RN50_DSCAT: relu(conv3(c2) + b3 + downsample(xp) + bd) == relu([c2 | xp] . [W3 | Wd]^T + (b3 + bd)),
+    against the fp32 reference of [U] clip/model.py Bottleneck.forward's last line and against the two chained launches (which
+    round the downsample output to bf16 first: the folded form is the closer one)."""
+    from embodied_clip_amd import encoder as enc
+    g = torch.Generator().manual_seed(31 + B)
+    K2, Co = 2 * K1, 4 * K1
+    c2 = _bf(torch.randn(B, R, R, K1, generator=g).relu())
+    xp = _bf(torch.randn(B, R, R, K2, generator=g).relu())
+    w3 = _bf(torch.randn(Co, K1, generator=g) * K1 ** -0.5)
+    wd = _bf(torch.randn(Co, K2, generator=g) * K2 ** -0.5)
+    b3, bd = torch.randn(Co, generator=g) * 0.1, torch.randn(Co, generator=g) * 0.1
+    ref = F.relu(c2.float() @ w3.float().t() + b3 + xp.float() @ wd.float().t() + bd)
+    dv = lambda t: t.to(dev)
+    cat = torch.empty(B, R, R, K1 + K2, dtype=torch.bfloat16, device=dev)
+    cat[..., :K1] = dv(c2); cat[..., K1:] = dv(xp)
+    folded = enc.conv_bf16(cat, dv(torch.cat([w3, wd], 1).contiguous()), dv(b3 + bd), None, ksize=1, act=1)
+    ds = enc.conv_bf16(dv(xp), dv(wd), dv(bd), None, ksize=1, act=0)
+    chained = enc.conv_bf16(dv(c2), dv(w3), dv(b3), ds, ksize=1, act=1)
+    torch.cuda.synchronize()
+    rf, rc = _rel(folded.cpu(), ref), _rel(chained.cpu(), ref)
+    assert rf < 3e-3 and rf <= rc + 1e-4, (rf, rc)
+    assert _rel(folded.cpu(), chained.cpu()) < 7e-3
+
+
+def test_trunk_with_folded_downsample_convs_matches_the_chained_plan(dev, tmp_path):
+    """EC_RN50_DSCAT=0 (child process: the library reads its switches once) builds the round-4 plan -- AvgPool2d, downsample conv,
+    conv3 + residual -- for layer3.0 / layer4.0; the default plan has one launch less per block and never writes the downsample
+    output.  Both against the fp32 oracle; the folded plan rounds once where the chained one rounds twice."""
+    import os
+    import subprocess
+    import sys
+    from embodied_clip_amd.encoder import RN50Trunk
+    sd = syn.rn50_visual_state_dict(0)
+    x = syn.synthetic_rgb(5, 3).to(dev)
+    folded = RN50Trunk(sd, device=dev)
+    out = str(tmp_path / "chained.pt")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, torch; sys.path.insert(0, %r)\n"
+            "from embodied_clip_amd import synthetic as syn\n"
+            "from embodied_clip_amd.encoder import RN50Trunk\n"
+            "t = RN50Trunk(syn.rn50_visual_state_dict(0), device='cuda:0')\n"
+            "x = syn.synthetic_rgb(5, 3).to('cuda:0')\n"
+            "f = t.forward(x)\n"
+            "torch.save({'nchw': t.to_nchw_f32(f).cpu(), 'ops': t.lib.ec_rn50_num_ops(t.h), 'hash': t.plan_hash()}, %r)\n") % (root, out)
+    r = subprocess.run([sys.executable, "-c", code], env={**os.environ, "EC_RN50_DSCAT": "0"}, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    chained = torch.load(out)
+    assert folded.lib.ec_rn50_num_ops(folded.h) == chained["ops"] - 2 and folded.plan_hash() != chained["hash"]
+    a = folded.to_nchw_f32(folded.forward(x)).cpu()
+    ref = ocr.clip_resnet_preprocessor(x.cpu(), sd)
+    ra, rb = _rel(a, ref), _rel(chained["nchw"], ref)
+    assert ra < 2e-2 and rb < 2e-2 and ra <= rb + 5e-4, (ra, rb)
+    assert _rel(a, chained["nchw"]) < 7e-3
