@@ -214,8 +214,30 @@ def _time_iterations(w, steps, warmup, barrier):
     return time.perf_counter() - t0
 
 
+_LINE_OUT = None     # the process's REAL stdout, kept aside by _claim_stdout(): only the JSON line is written to it
+
+
+def _claim_stdout():
+    """The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints a version banner through C
+    stdio, which is flushed at exit, i.e. AFTER the line): from here on file descriptor 1 is stderr for everybody, and the
+    line goes out through a private handle on the original stdout."""
+    global _LINE_OUT
+    if _LINE_OUT is None:
+        sys.stdout.flush()
+        _LINE_OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+    return _LINE_OUT
+
+
+def _print_line(obj):
+    out = _claim_stdout()
+    out.write(json.dumps(obj) + "\n")
+    out.flush()
+
+
 def run_rank(a, rank: int, local_rank: int, world: int, init_method=None):
     dist = torch.distributed
+    _claim_stdout()
     if a.dry_run:   # launcher / rendezvous / bucket all-reduce only (CPU, gloo): what tests/test_bench_launch.py runs
         if world > 1:
             dist.init_process_group("gloo", init_method=init_method, rank=rank, world_size=world)
@@ -225,8 +247,8 @@ def run_rank(a, rank: int, local_rank: int, world: int, init_method=None):
             allreduce_flat(bucket)
         ok = bool((bucket == world * (world + 1) / 2).all())
         if rank == 0:
-            print(json.dumps({"dry_run": True, "n_gpus": world, "rccl_ranks": dist.get_world_size() if world > 1 else 1,
-                              "bucket_elems": POLICY_FLAT_PARAMS, "allreduce_ok": ok}), flush=True)
+            _print_line({"dry_run": True, "n_gpus": world, "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+                         "bucket_elems": POLICY_FLAT_PARAMS, "allreduce_ok": ok})
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -406,7 +428,7 @@ def run_rank(a, rank: int, local_rank: int, world: int, init_method=None):
                 line = dict(out)
                 if timeout_leg is not None:
                     line.setdefault(timeout_leg, {"error": f"timeout: secondary legs exceeded {a.secondary_budget_s} s"})
-                print(json.dumps(line), flush=True)
+                _print_line(line)
 
     dog = _Watchdog(a.secondary_budget_s, emit)
 

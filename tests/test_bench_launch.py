@@ -77,3 +77,17 @@ def test_busy_union_of_launch_intervals():
     assert bench.busy_union_ms([(0.0, 2.0), (1.0, 3.0), (2.5, 2.75)]) == 3.0            # two streams overlapping + one nested
     assert bench.busy_union_ms([(5.0, 6.0), (0.0, 1.0), (1.0, 2.0)]) == 3.0             # unsorted, touching, a gap of 3
     assert abs(bench.busy_union_ms([(i * 1.0, i * 1.0 + 0.75) for i in range(8)]) - 6.0) < 1e-12
+
+
+def test_only_the_json_line_reaches_stdout():
+    """Native libraries print to file descriptor 1 behind Python's back (RCCL's version banner goes through C stdio and is
+    flushed at exit, i.e. after the line).  bench.py claims the real stdout for the line alone: whatever else writes to fd 1
+    afterwards lands on stderr."""
+    code = ("import os, sys, json; sys.path.insert(0, %r); import bench\n"
+            "bench._print_line({'a': 1})\n"
+            "os.write(1, b'banner through fd 1\\n')\n"          # a C library's write(1, ...)
+            "print('python print after the claim')\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout == '{"a": 1}\n', r.stdout
+    assert "banner through fd 1" in r.stderr and "python print after the claim" in r.stderr
