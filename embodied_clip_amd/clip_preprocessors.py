@@ -21,7 +21,7 @@ from typing import Any, Dict, List, Optional
 import numpy as np
 import torch
 
-from . import spaces
+from . import _lib, spaces
 from .allenact_compat import Preprocessor
 
 
@@ -143,8 +143,10 @@ class ClipResNetPreprocessor(_PreprocessorBase):
             for t in self._twin:
                 t.set_conv8_min_tiles(50)         # two launches in flight: the lower 8-wave dispatch threshold (ec_rn50_set_conv8_min_tiles)
         if getattr(self, "_streams", None) is None:
-            self._streams = [torch.cuda.Stream(device=self.device) for _ in range(2)]
-            self._copy_stream = torch.cuda.Stream(device=self.device)
+            # two compute streams + the copy stream, verified to run concurrently (streams that land on one hardware queue
+            # would serialise the two halves and their copies: _lib.concurrent_streams)
+            st = _lib.concurrent_streams(3, self.device)
+            self._streams, self._copy_stream = st[:2], st[2]
             self._stage, self._stage_free, self._calls = {}, {}, 0
         N = x.shape[0]
         nck = max(2, int(os.environ.get("EC_PLUGIN_CHUNKS", "2")))   # pieces of the batch (alternating over the two streams)

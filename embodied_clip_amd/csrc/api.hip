@@ -72,3 +72,68 @@ uint64_t ec_config_hash() {
     mix(c.dw1_tr); mix(c.wih_perm); mix(c.dw_transposed);
     return x;
 }
+
+// ---- stream plumbing ------------------------------------------------------------------------------------------------
+// The HIP runtime binds a stream to one of its few hardware queues lazily, at the stream's first submission, and two
+// streams that land on the SAME hardware queue run their launches one after the other.  Measured (tools/sync_probe.py): a
+// worker whose two actor-slice streams saw their first work back to back on an idle device shared a queue in every second
+// worker of a process -- 48.4 k instead of 63.1 k env-frames/s, the two encoder launches serialised -- while streams whose
+// first submissions found the other streams BUSY got queues of their own.  ec_bind_streams gives every stream its first
+// work while the others are busy; ec_stream_pair_overlap measures whether a pair really runs concurrently.
+namespace {
+__global__ void spin_kernel(unsigned long long ticks) {      // 100-MHz constant clock
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+}  // namespace
+
+extern "C" int ec_bind_streams(ec_stream_t* streams, int n, int spin_us) {
+    if (!streams || n <= 0 || spin_us <= 0 || spin_us > 100000) return EC_ERR_ARG;
+    if (hipDeviceSynchronize() != hipSuccess) return EC_ERR_LAUNCH;
+    for (int round = 0; round < 2; ++round)                    // (second round: every stream busy while every other one submits)
+        for (int i = 0; i < n; ++i)
+            hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)streams[i], (unsigned long long)spin_us * 100ull);
+    EC_CHECK_LAUNCH();
+    return hipDeviceSynchronize() == hipSuccess ? EC_OK : EC_ERR_LAUNCH;
+}
+
+// *ratio = wall time of one spin kernel on each of the two streams, submitted together, over the time of one alone:
+// ~1 = the streams run concurrently, ~2 = they are serialised (same hardware queue).  Blocking; set-up time only.
+extern "C" int ec_stream_pair_overlap(ec_stream_t a, ec_stream_t b, int spin_us, float* ratio) {
+    if (!ratio || spin_us <= 0 || spin_us > 100000 || a == b) return EC_ERR_ARG;
+    hipStream_t sa = (hipStream_t)a, sb = (hipStream_t)b;
+    hipEvent_t e[4];
+    for (auto& ev : e)
+        if (hipEventCreate(&ev) != hipSuccess) return EC_ERR_LAUNCH;
+    const unsigned long long ticks = (unsigned long long)spin_us * 100ull;
+    float best = 1e30f;
+    int rc = EC_OK;
+    for (int rep = 0; rep < 3 && rc == EC_OK; ++rep) {
+        float alone = 0.f, both = 0.f;
+        if (hipDeviceSynchronize() != hipSuccess) { rc = EC_ERR_LAUNCH; break; }
+        (void)hipEventRecord(e[0], sa);
+        hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, sa, ticks);
+        (void)hipEventRecord(e[1], sa);
+        if (hipDeviceSynchronize() != hipSuccess) { rc = EC_ERR_LAUNCH; break; }
+        (void)hipEventRecord(e[2], sa);                        // common start: b waits for it, a records it
+        (void)hipStreamWaitEvent(sb, e[2], 0);
+        hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, sa, ticks);
+        hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, sb, ticks);
+        (void)hipEventRecord(e[3], sb);
+        (void)hipStreamWaitEvent(sa, e[3], 0);                 // a's end event is behind both kernels
+        (void)hipEventRecord(e[1], sa);
+        if (hipDeviceSynchronize() != hipSuccess) { rc = EC_ERR_LAUNCH; break; }
+        if (hipEventElapsedTime(&both, e[2], e[1]) != hipSuccess) { rc = EC_ERR_LAUNCH; break; }
+        // (e[0] / e[1] were re-recorded: time the lone kernel again, behind everything, for the same clock state)
+        (void)hipEventRecord(e[0], sa);
+        hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, sa, ticks);
+        (void)hipEventRecord(e[3], sa);
+        if (hipDeviceSynchronize() != hipSuccess) { rc = EC_ERR_LAUNCH; break; }
+        if (hipEventElapsedTime(&alone, e[0], e[3]) != hipSuccess || alone <= 0.f) { rc = EC_ERR_LAUNCH; break; }
+        best = both / alone < best ? both / alone : best;
+    }
+    for (auto& ev : e) (void)hipEventDestroy(ev);
+    if (rc == EC_OK) *ratio = best;
+    return rc;
+}
+

@@ -200,10 +200,13 @@ class Worker:
         self.sums = torch.zeros(4, dtype=torch.float64, device=d)
         self.env = SyntheticEnv(N, T, d, seed=1000 + rank, frames_u8=frames_u8, host=frames_host)
         self.slices: List[_Slice] = []
+        # the slices' streams, verified to run CONCURRENTLY (a pair that landed on one hardware queue serialises the two
+        # encoder launches: _lib.concurrent_streams)
+        slice_streams = _lib.concurrent_streams(ns, d) if ns > 1 else [None]
         for i in range(ns):
             sl = _Slice()
             sl.o, sl.n, sl.enc, sl.pool = i * n, n, encs[i], pools[i]
-            sl.stream = torch.cuda.Stream(device=d) if ns > 1 else None
+            sl.stream = slice_streams[i]
             # zero-shot: the rollout buffer holds fp32 image embeddings [T+1, n, 1, 1024]; else bf16 feature maps
             sl.feat = torch.empty((T + 1, n, S2, self.C), dtype=torch.float32 if self.zeroshot else torch.bfloat16, device=d)
             sl.trunk_out = (torch.empty((n, self.trunk_S, self.trunk_S, self.trunk_C), dtype=torch.bfloat16, device=d)

@@ -49,6 +49,14 @@ enum { EC_ACT_NONE = 0, EC_ACT_RELU = 1, EC_ACT_QUICKGELU = 2 };
 int ec_version(void);
 const char* ec_strerror(int code);
 
+/* Stream plumbing for callers that keep several launches in flight (no reference counterpart: the reference runs on one
+ * stream).  The HIP runtime binds a stream to one of its few hardware queues at the stream's FIRST submission; two streams on
+ * the same queue run one after the other.  ec_bind_streams gives each of `n` freshly created streams its first work (a
+ * spin kernel of `spin_us`) while the others are busy, so that each gets a queue of its own; ec_stream_pair_overlap
+ * measures a pair: *ratio ~ 1 = concurrent, ~ 2 = serialised.  Both block (device synchronise): set-up time only. */
+int ec_bind_streams(ec_stream_t* streams, int n, int spin_us);
+int ec_stream_pair_overlap(ec_stream_t a, ec_stream_t b, int spin_us, float* ratio);
+
 /* ------------------------------------------------------------------------
  * Encoder building blocks (bf16 storage, fp32 accumulate on MFMA).
  * Replace the cuDNN/cuBLAS kernels the reference triggers through

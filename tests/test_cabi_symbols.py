@@ -45,7 +45,16 @@ def test_error_strings_and_version(repo_root):
     assert lib.ec_stem7_pool(None, 0, None, None, None, None, None, 1, 224, 224, None) == -1
     assert lib.ec_stem7_pool(1, 0, None, None, 1, 1, 1, 1, 222, 224, None) == -2             # H % 4
     assert lib.ec_stem7_pool(1, 1, None, None, 1, 1, 1, 1, 224, 224, None) == -1             # uint8 frames need mean / std
+    # output-row-stride variants and the stream plumbing: argument checks come first as well
+    assert lib.ec_conv_bf16_ld(None, None, None, None, None, 1, 1, 1, 8, 32, 1, 0, 0, 32, None) == -1
+    assert lib.ec_conv_bf16_ld(1, 1, None, None, 1, 1, 4, 4, 64, 64, 1, 0, 1, 60, None) == -2   # row stride below Cout
+    assert lib.ec_avgpool2_bf16_ld(None, None, 1, 2, 2, 8, 8, None) == -1
+    assert lib.ec_conv3x3_img_bf16_ld(None, None, None, None, 1, 14, 14, 256, 0, 256, None) == -1
+    assert lib.ec_bind_streams(None, 2, 100) == -1
+    assert lib.ec_stream_pair_overlap(None, None, 100, None) == -1
     import ctypes as C
+    r = C.c_float()
+    assert lib.ec_stream_pair_overlap(1, 1, 100, C.byref(r)) == -1                          # one stream is not a pair
     h = C.c_void_p()
     assert lib.ec_rn50tv_create(C.byref(h), None, 224, None, None, 0, None, 0) == -1
 
