@@ -95,12 +95,16 @@ class PluginPathRunner:
                 obs = {"rgb_clip_resnet": self.feat[t:t + 1], "goal": self.goals[t:t + 1]}
                 out, mem = self.model(obs, self._mem(t), None, self.masks[t:t + 1])
                 a = out.distributions.sample()
+                lp = out.distributions.log_prob(a)
+                # [U] OnPolicyRLEngine.collect_step_across_all_task_samplers: act -> vector_tasks.step(actions) (env.step happens
+                # here in the real system; its frames come back on the host) -> the preprocessor graph on the new observations ->
+                # ONE rollouts.insert(observations, memory, actions, action_log_probs, value_preds, rewards, masks)
+                nxt = self.pre.process({"rgb": self._observe()})
+                self.feat[t + 1] = nxt
                 self.actions[t] = a[0]
-                self.logp[t] = out.distributions.log_prob(a)[0].unsqueeze(-1)
+                self.logp[t] = lp[0].unsqueeze(-1)
                 self.values[t] = out.values[0]
                 self.memory[t + 1] = mem.tensor("rnn")
-                # env.step(a) happens here in the real system; its frames come back on the host
-                self.feat[t + 1] = self.pre.process({"rgb": self._observe()})
             out, _ = self.model({"rgb_clip_resnet": self.feat[T:T + 1], "goal": self.goals[T:T + 1]}, self._mem(T), None,
                                 self.masks[T:T + 1])
             self.values[T] = out.values[0]

@@ -19,13 +19,14 @@ def run(report):
             obs = {"rgb_clip_resnet": r.feat[t:t + 1], "goal": r.goals[t:t + 1]}
             out, mem = r.model(obs, r._mem(t), None, r.masks[t:t + 1])
             a = out.distributions.sample()
+            lp = out.distributions.log_prob(a)
+            h1 = time.perf_counter()
+            r.feat[t + 1] = r.pre.process({"rgb": r._observe()})      # (same order as PluginPathRunner.iteration: insert after the preprocessor)
+            h2 = time.perf_counter()
             r.actions[t] = a[0]
-            r.logp[t] = out.distributions.log_prob(a)[0].unsqueeze(-1)
+            r.logp[t] = lp[0].unsqueeze(-1)
             r.values[t] = out.values[0]
             r.memory[t + 1] = mem.tensor("rnn")
-            h1 = time.perf_counter()
-            r.feat[t + 1] = r.pre.process({"rgb": r._observe()})
-            h2 = time.perf_counter()
             host_act += h1 - h0; host_proc += h2 - h1
         t1 = now()
         out, _ = r.model({"rgb_clip_resnet": r.feat[T:T + 1], "goal": r.goals[T:T + 1]}, r._mem(T), None, r.masks[T:T + 1])

@@ -1,3 +1,14 @@
+"""What made bench.py's `sync_actions` leg read 0.77 x for three rounds: every SECOND two-slice worker of a process ran at
+48-51 k instead of 61-63 k env-frames/s, action-synchronous or not, with byte-identical buffer addresses -- its two slice
+streams had been bound to ONE hardware queue (the HIP runtime binds a stream at its first submission), so the two encoder
+launches of an env step ran one after the other.  Modes (python tools/sync_probe.py <mode>, one MI355X):
+  fresh / second / twice / long / second_keep / second_free / tiny_first / *_1stream   throughput of the n-th worker of a process
+  streamsN        N extra live streams in front of a fresh worker (no effect)
+  layout_*        buffer addresses of fast and slow workers (identical: not a layout effect)
+  concurrency     both-busy / alone time of a worker's slice streams, before and after its run
+  workers         six workers in a row through _lib.concurrent_streams (the fix): all at the first worker's rate
+(the modes from `second` to `layout_second` reproduce the slow worker only with Worker's streams created by plain
+torch.cuda.Stream(), i.e. before the fix.)"""
 import sys, time, gc, torch
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from embodied_clip_amd.engine import Worker
