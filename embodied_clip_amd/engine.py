@@ -202,7 +202,22 @@ class Worker:
         self.slices: List[_Slice] = []
         # the slices' streams, verified to run CONCURRENTLY (a pair that landed on one hardware queue serialises the two
         # encoder launches: _lib.concurrent_streams)
-        slice_streams = _lib.concurrent_streams(ns, d) if ns > 1 else [None]
+        # ... and with frames in host memory the slices' copy streams as well (two slices + two copy streams = the runtime's
+        # four hardware queues: a copy stream sharing a queue with the OTHER slice's compute stream cost 59 -> 42 k, tools/h2d_probe.py)
+        n_copy = ns if frames_host else 0
+        n_own = ns if ns > 1 else 0
+        try:
+            pool = _lib.concurrent_streams(n_own + n_copy, d) if n_own + n_copy > 1 else [torch.cuda.Stream(device=d) for _ in range(n_copy)]
+        except RuntimeError:
+            if not n_copy:
+                raise
+            # more streams than hardware queues (e.g. four slices with host frames): the compute streams must be
+            # concurrent, the copy streams then share queues with them
+            import warnings
+            warnings.warn(f"{n_own + n_copy} streams exceed the runtime's hardware queues: only the {n_own} slice streams are verified concurrent")
+            pool = (_lib.concurrent_streams(n_own, d) if n_own > 1 else []) + [torch.cuda.Stream(device=d) for _ in range(n_copy)]
+        slice_streams = pool[:n_own] if n_own else [None]
+        copy_streams = pool[n_own:]
         for i in range(ns):
             sl = _Slice()
             sl.o, sl.n, sl.enc, sl.pool = i * n, n, encs[i], pools[i]
@@ -225,7 +240,7 @@ class Worker:
             if frames_host:   # double-buffered device staging of the slice's frames + its own copy stream (SDMA)
                 fshape = (n,) + tuple(self.env.frames.shape[2:])
                 sl.stage = [torch.empty(fshape, dtype=self.env.frames.dtype, device=d) for _ in range(2)]
-                sl.copy_stream = torch.cuda.Stream(device=d)
+                sl.copy_stream = copy_streams[i]
                 sl.copied = [torch.cuda.Event() for _ in range(2)]
                 sl.consumed = [None, None]
                 sl.k = 0
