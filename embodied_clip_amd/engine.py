@@ -182,7 +182,6 @@ class Worker:
         self.params = self.policy.flatten(policy_sd if policy_sd is not None else syn.policy_state_dict(0, **pkw), d)
         self.grads = torch.zeros_like(self.params)
         self.rec = self.policy.recurrent_section()          # GRU + heads: the part of the bucket whose gradients are final first
-        self.comm_stream = torch.cuda.Stream(device=d)
         self.opt = FlatAdam(self.params, lr=lr, max_grad_norm=max_grad_norm)
         N, S2 = n_actors, self.S * self.S
         # [T, N] rollout scalars (global; tiny)
@@ -200,24 +199,35 @@ class Worker:
         self.sums = torch.zeros(4, dtype=torch.float64, device=d)
         self.env = SyntheticEnv(N, T, d, seed=1000 + rank, frames_u8=frames_u8, host=frames_host)
         self.slices: List[_Slice] = []
-        # the slices' streams, verified to run CONCURRENTLY (a pair that landed on one hardware queue serialises the two
-        # encoder launches: _lib.concurrent_streams)
-        # ... and with frames in host memory the slices' copy streams as well (two slices + two copy streams = the runtime's
-        # four hardware queues: a copy stream sharing a queue with the OTHER slice's compute stream cost 59 -> 42 k, tools/h2d_probe.py)
-        n_copy = ns if frames_host else 0
+        # Streams.  The HIP runtime has FOUR hardware queues and binds a stream to one of them at its first submission; two
+        # streams on one queue run one after the other (a slice pair that shared a queue serialised the two encoder launches:
+        # 48 instead of 63 k; a copy stream on the other slice's compute queue: 59 -> 42 k; tools/sync_probe.py, h2d_probe.py).
+        # So the slices' streams, the communication stream of the overlapped all-reduce (only where there is a collective) and
+        # the slices' copy streams (frames in host memory) come from ONE pool that _lib.concurrent_streams has verified pairwise
+        # concurrent; when that is more than the queues allow, the copy streams, then the communication stream, go unverified.
         n_own = ns if ns > 1 else 0
-        try:
-            pool = _lib.concurrent_streams(n_own + n_copy, d) if n_own + n_copy > 1 else [torch.cuda.Stream(device=d) for _ in range(n_copy)]
-        except RuntimeError:
-            if not n_copy:
-                raise
-            # more streams than hardware queues (e.g. four slices with host frames): the compute streams must be
-            # concurrent, the copy streams then share queues with them
-            import warnings
-            warnings.warn(f"{n_own + n_copy} streams exceed the runtime's hardware queues: only the {n_own} slice streams are verified concurrent")
-            pool = (_lib.concurrent_streams(n_own, d) if n_own > 1 else []) + [torch.cuda.Stream(device=d) for _ in range(n_copy)]
-        slice_streams = pool[:n_own] if n_own else [None]
-        copy_streams = pool[n_own:]
+        n_comm = 1 if (world > 1 or self.force_allreduce) else 0
+        n_copy = ns if frames_host else 0
+        plain = lambda k: [torch.cuda.Stream(device=d) for _ in range(k)]   # noqa: E731
+        pool = None
+        for take_comm, take_copy in ((n_comm, n_copy), (n_comm, 0), (0, 0)):
+            want = n_own + take_comm + take_copy
+            try:
+                pool = (_lib.concurrent_streams(want, d) if want > 1 else plain(want))
+            except RuntimeError:
+                if take_comm == 0 and take_copy == 0:
+                    raise
+                continue
+            if (take_comm, take_copy) != (n_comm, n_copy):
+                import warnings
+                warnings.warn(f"{n_own + n_comm + n_copy} streams exceed the runtime's hardware queues: only {want} are verified concurrent")
+            pool = pool + plain(n_comm - take_comm + n_copy - take_copy)
+            order = ["own"] * n_own + ["comm"] * take_comm + ["copy"] * take_copy + ["comm"] * (n_comm - take_comm) + ["copy"] * (n_copy - take_copy)
+            break
+        by = lambda kind: [s_ for s_, k_ in zip(pool, order) if k_ == kind]   # noqa: E731
+        slice_streams = by("own") if n_own else [None]
+        copy_streams = by("copy")
+        self.comm_stream = by("comm")[0] if n_comm else torch.cuda.Stream(device=d)
         for i in range(ns):
             sl = _Slice()
             sl.o, sl.n, sl.enc, sl.pool = i * n, n, encs[i], pools[i]
