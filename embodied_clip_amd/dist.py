@@ -29,6 +29,11 @@ def grad_scale(local_bsize: int, global_bsize: int) -> float:
     return float(local_bsize) / float(global_bsize)
 
 
+def collective_active(world: int, force: bool = False) -> bool:
+    """Will ``allreduce_flat`` issue a collective?  (a process group is up, and there is more than one rank or ``force``)"""
+    return (world > 1 or force) and dist.is_available() and dist.is_initialized()
+
+
 def allreduce_flat(flat_grads: torch.Tensor, group=None, force: bool = False) -> torch.Tensor:
     """In-place SUM over ranks of the flat gradient bucket (no-op when not initialised / world 1).
     ``force``: issue the collective also at world size 1 (an identity, but RCCL's communicator set-up and its kernel

@@ -31,7 +31,7 @@ import torch
 
 from . import _lib
 from . import synthetic as syn
-from .dist import allreduce_flat, check_job_seed
+from .dist import allreduce_flat, check_job_seed, collective_active
 from .encoder import AttentionPool, ClipTextEncoder, RN50Trunk, ViTEmbedder
 from .policy import PolicyHandle
 from .ppo import FlatAdam, linear_decay_lr, ppo_loss_raw
@@ -519,10 +519,7 @@ class Worker:
     @_lib.on_device
     def update(self):
         T = self.T
-        collective = self.world > 1 or self.force_allreduce
-        if collective:
-            import torch.distributed as tdist
-            collective = tdist.is_available() and tdist.is_initialized()
+        collective = collective_active(self.world, self.force_allreduce)
         self._gather_slice_batches()
         for _ in range(self.update_repeats):
             for (s0, s1) in self.minibatch_ranges():
