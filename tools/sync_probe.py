@@ -124,3 +124,9 @@ elif mode == "workers":
         lib.load().ec_stream_pair_overlap(w.slices[0].stream.cuda_stream, w.slices[1].stream.cuda_stream, 200, C.byref(ratio))
         print(f"worker {i + 1} ({'action-synchronous' if i % 2 else 'free-running'}): {round(r)} env-frames/s; slice streams both busy / alone = {ratio.value:.2f}")
         del w; gc.collect(); torch.cuda.empty_cache()
+elif mode == "sync_h2d":
+    # the plugin route's true peer: action-synchronous AND the frames crossing PCIe every step (raw uint8, pinned host memory)
+    for sync in (False, True):
+        w = Worker(256, sync_actions=sync, frames_host=True, frames_u8=True, **kw)
+        print(f"frames on the host (uint8), {'action-synchronous' if sync else 'free-running'}: {round(run(w))} env-frames/s")
+        del w; gc.collect(); torch.cuda.empty_cache()
