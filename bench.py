@@ -491,6 +491,14 @@ def run_rank(a, rank: int, local_rank: int, world: int, init_method=None):
                          "and issues its encode(t+1) + act(t+1) while the other slice's encoder is still running (same "
                          "per-actor arithmetic, same round trips per actor)"}
             del ws_
+            gc.collect(); torch.cuda.empty_cache()
+            # ... and with the frames crossing PCIe every step as well (raw uint8 in pinned host memory): the peer of the plugin
+            # route with uint8 sensor frames -- same order, same bytes over the bus, the engine's own storage and kernels
+            ws_ = Worker(per_gpu, frames_host=True, sync_actions=True, **{**wkw, "frames_u8": True})
+            dts = maxreduce(_time_iterations(ws_, a.sync_steps, 1, barrier))
+            r["host_frames_u8"] = {"value": round(a.rollout * per_gpu * world * a.sync_steps / dts, 1), "unit": "env-frames/s",
+                                   "order": "action-synchronous (one env for all actors), uint8 frames in pinned host memory copied every env step"}
+            del ws_
             return r
         dog.leg = "sync_actions"
         put("sync_actions", _soft("sync_actions", leg_sync, agree))
@@ -532,9 +540,13 @@ def run_rank(a, rank: int, local_rank: int, world: int, init_method=None):
             # the same route when the RGB sensor hands over raw uint8 frames (a quarter of the PCIe bytes)
             r8 = time_plugin_path(per_gpu, a.rollout, dev, steps=a.plugin_steps, warmup=1, update_repeats=a.update_repeats,
                                   frames_u8=True)
-            return {**r, "fraction_of_engine": round(r["value"] / value, 3),
-                    "u8_sensor_frames": {"value": r8["value"], "ms_per_step": r8["ms_per_step"],
-                                         "fraction_of_engine": round(r8["value"] / value, 3), "route": r8["route"]}}
+            res = {**r, "fraction_of_engine": round(r["value"] / value, 3),
+                   "u8_sensor_frames": {"value": r8["value"], "ms_per_step": r8["ms_per_step"],
+                                        "fraction_of_engine": round(r8["value"] / value, 3), "route": r8["route"]}}
+            peer = ((out or {}).get("sync_actions") or {}).get("host_frames_u8") if out is not None else None
+            if isinstance(peer, dict) and peer.get("value"):   # the engine in the same order with the same frames over PCIe
+                res["u8_sensor_frames"]["fraction_of_engine_same_order_host_frames"] = round(r8["value"] / peer["value"], 3)
+            return res
         dog.leg = "plugin_path"
         put("plugin_path", _soft("plugin_path", leg_plugin))
         gc.collect(); torch.cuda.empty_cache()
