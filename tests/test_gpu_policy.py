@@ -695,7 +695,7 @@ def test_infer_reuse_rebuilds_tables_when_geometry_or_dtype_changed(dev):
     assert torch.isfinite(d).all() and _rel(d, ref_b[:4]) < 1e-5
 
 
-@pytest.mark.parametrize("T,N,S,H", [(6, 4, 3, 32), (4, 37, 7, 32), (16, 64, 7, 512)])
+@pytest.mark.parametrize("T,N,S,H", [(1, 5, 3, 32), (6, 4, 3, 32), (4, 37, 7, 32), (16, 64, 7, 512)])
 def test_backward_event_marks_the_recurrent_section_final(dev, T, N, S, H):
     """``ec_policy_backward3``: the event is recorded where the gradients of GRU + heads (``recurrent_section()``: one
     contiguous run of the flat bucket, weight_ih_l0 ... critic.fc.bias) are FINAL -- a stream that waits for it reads exactly
