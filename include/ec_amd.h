@@ -259,8 +259,8 @@ int ec_rn50_forward(const ec_rn50_t* h, const float* rgb_nhwc, int batch, void* 
 int ec_rn50_forward_u8(const ec_rn50_t* h, const uint8_t* rgb_u8_nhwc, const float* h_mean3, const float* h_std3,
                        int batch, void* workspace, size_t ws_bytes, void* feat_bf16_nhwc, int chunk,
                        ec_stream_t stream);
-/* debugging / parity: copy of an intermediate stage of the LAST forward is not
- * kept; instead run only the first `n_ops` ops and return the op's output dims. */
+/* Number of ops in the handle's launch plan (from 128 frames on one kernel launch each: 38 for CLIP RN50 at 224 x 224;
+ * smaller launches run the five fused layer-3 blocks as three launches each).  Tests and tools/ key on it. */
 int ec_rn50_num_ops(const ec_rn50_t* h);
 /* 64-bit hash of the handle's launch plan (op kinds, shapes, buffer routing) and the library version: identifies
  * what a profiler summary under profiles/ was measured on (bench.py rejects a stale one). */
