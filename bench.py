@@ -231,6 +231,12 @@ def _claim_stdout():
 
 def _print_line(obj):
     out = _claim_stdout()
+    try:                      # whatever native libraries still hold in C stdio buffers (RCCL's banner) goes out BEFORE the line,
+        import ctypes         # so that the line is also the last thing written when a launcher merges the two streams
+        sys.stdout.flush(); sys.stderr.flush()
+        ctypes.CDLL(None).fflush(None)
+    except Exception:         # noqa: BLE001
+        pass
     out.write(json.dumps(obj) + "\n")
     out.flush()
 
