@@ -116,3 +116,42 @@ def test_dual_goal_encoder_is_two_single_towers_sharing_the_goal_embedding():
                 one[P + k + "." + wb] = sd[P + tag + k + "." + wb]
         parts.append(opol.goal_encoder(feat, goal, one).view(5, 32, S * S))
     assert torch.equal(x, torch.cat(parts, dim=1).reshape(5, -1))
+
+
+def test_categorical_head_matches_torch_distributions():
+    """[U] allenact ``CategoricalDistr`` subclasses ``torch.distributions.Categorical(logits=...)``: the oracle's written-out
+    ``log_prob`` / ``entropy`` against that class (an installed, independent implementation of row a14's arithmetic)."""
+    g = torch.Generator().manual_seed(5)
+    logits = torch.randn(7, 5, 6, generator=g) * 3.0
+    actions = torch.randint(0, 6, (7, 5), generator=g)
+    d = torch.distributions.Categorical(logits=logits)
+    assert torch.allclose(opol.categorical_log_prob(logits, actions), d.log_prob(actions), atol=1e-6)
+    assert torch.allclose(opol.categorical_entropy(logits), d.entropy(), atol=1e-6)
+    # saturated logits: p -> {0, 1}, entropy -> 0 without NaN (p log p at p = 0)
+    sat = torch.tensor([[60.0, -60.0, -60.0, -60.0, -60.0, -60.0]])
+    assert torch.isfinite(opol.categorical_entropy(sat)).all() and float(opol.categorical_entropy(sat)) < 1e-6
+
+
+def test_gae_reverse_scan_equals_its_definition_as_a_forward_sum():
+    """The oracle's GAE is the reverse scan of [U] ``RolloutStorage.compute_returns``.  Independent restatement: the DEFINITION
+    A[t] = sum_{k >= t} (gamma tau)^(k - t) * prod_{j = t+1 .. k} m[j] * delta[k],  delta[k] = r[k] + gamma V[k+1] m[k+1] - V[k],
+    R[t] = A[t] + V[t], evaluated as explicit O(T^2) sums in float64 with random episode resets."""
+    T, N, gamma, tau = 23, 4, 0.99, 0.95
+    g = torch.Generator().manual_seed(9)
+    r = torch.randn(T, N, 1, generator=g)
+    v = torch.randn(T + 1, N, 1, generator=g)
+    m = (torch.rand(T + 1, N, 1, generator=g) > 0.2).float()
+    R = oppo.compute_returns(r, v, m, gamma, tau)
+    r64, v64, m64 = r.double(), v.double(), m.double()
+    for t in range(T):
+        acc = torch.zeros(N, 1, dtype=torch.float64)
+        for k in range(t, T):
+            w = (gamma * tau) ** (k - t) * torch.ones(N, 1, dtype=torch.float64)
+            for j in range(t + 1, k + 1):
+                w = w * m64[j]
+            acc += w * (r64[k] + gamma * v64[k + 1] * m64[k + 1] - v64[k])
+        assert torch.allclose(R[t].double(), acc + v64[t], atol=1e-5), t
+    assert torch.equal(R[T], v[T])
+    adv, nadv = oppo.normalized_advantages(R, v)
+    assert torch.allclose(adv, R[:-1] - v[:-1]) and abs(float(nadv.mean())) < 1e-5
+    assert abs(float(nadv.std()) - 1.0) < 1e-3            # unbiased std (torch default), + eps in the denominator
