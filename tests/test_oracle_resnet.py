@@ -158,3 +158,27 @@ def test_bottleneck_matches_hf_resnet_bottleneck_layer():
         for fold in (True, False):
             out = R.bottleneck(x, sd, "blk", 1, emulate=False, fold=fold)
             assert (out - ref).abs().max() < 2e-5, (cin, cout, fold, float((out - ref).abs().max()))
+
+
+def test_stride2_bottleneck_equals_one_gemm_over_the_concatenated_k_axis():
+    """What the trunk plan does for layer3.0 / layer4.0 (EC_RN50_DSCAT): with the folded weights,
+    relu(bn3(conv3(avgpool(c2))) + bn_d(conv_d(avgpool(x)))) == relu([avgpool(c2) | avgpool(x)] . [W3 | Wd]^T + (b3 + bd)) -- the
+    oracle's Bottleneck (the restatement of [U] clip/model.py Bottleneck.forward) against that single GEMM, and against the
+    2 x 2 stride-2 convolution form of the anti-aliased stride (AvgPool2d(2) then a 1 x 1 conv == a 2 x 2 s2 conv with W / 4 taps)."""
+    import torch.nn.functional as F
+    sd = syn.rn50_visual_state_dict(4, width=16, layers=(1, 1, 1, 1), output_dim=32, heads=4, input_resolution=64)
+    p = "layer3.0"
+    g = torch.Generator().manual_seed(3)
+    cin = sd[p + ".conv1.weight"].shape[1]
+    x = torch.randn(2, cin, 8, 8, generator=g).relu()
+    ref = ocr.bottleneck(x, sd, p, stride=2)
+    w1, b1 = ocr.fold_bn(sd[p + ".conv1.weight"], sd, p + ".bn1")
+    w2, b2 = ocr.fold_bn(sd[p + ".conv2.weight"], sd, p + ".bn2")
+    w3, b3 = ocr.fold_bn(sd[p + ".conv3.weight"], sd, p + ".bn3")
+    wd, bd = ocr.fold_bn(sd[p + ".downsample.0.weight"], sd, p + ".downsample.1")
+    c2 = F.relu(F.conv2d(F.relu(F.conv2d(x, w1, b1)), w2, b2, padding=1))
+    cat = torch.cat([F.avg_pool2d(c2, 2), F.avg_pool2d(x, 2)], 1)
+    one = F.relu(F.conv2d(cat, torch.cat([w3, wd], 1), b3 + bd))
+    assert one.shape == ref.shape and torch.allclose(one, ref, rtol=1e-4, atol=1e-5)
+    two = F.relu(F.conv2d(c2, (w3 / 4).repeat(1, 1, 2, 2), b3, stride=2) + F.conv2d(x, (wd / 4).repeat(1, 1, 2, 2), bd, stride=2))
+    assert torch.allclose(two, ref, rtol=1e-4, atol=1e-5)
