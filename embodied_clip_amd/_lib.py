@@ -162,36 +162,40 @@ def stream_ptr(device=None) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
-def concurrent_streams(n: int, device, spin_us: int = 200, attempts: int = 4):
-    """``n`` new torch streams on ``device`` that really run concurrently.  The HIP runtime binds a stream to a hardware queue
-    at its FIRST submission, and two streams that land on one queue serialise (measured: every second two-slice worker of a
-    process ran its two encoder launches one after the other, 48 k instead of 63 k env-frames/s).  ``ec_bind_streams`` gives
-    every stream its first work while the others are busy; ``ec_stream_pair_overlap`` then checks every pair, and a set that
-    still shares a queue is replaced (the rejected streams stay alive until a good set exists, so the runtime cannot hand the
-    same queue out again).  Raises if no attempt yields a concurrent set: two launches in flight is what the engine's
-    numbers rest on, and a silent fall-back to serial streams would misreport them."""
+def concurrent_streams(n: int, device, spin_us: int = 200, max_candidates: int = 24):
+    """``n`` new torch streams on ``device`` that really run concurrently.  The HIP runtime binds a stream to one of its (four)
+    hardware queues at the stream's FIRST submission, and two streams that land on one queue serialise (measured: every second
+    two-slice worker of a process ran its two encoder launches one after the other, 48 k instead of 63 k env-frames/s).  The set
+    is built greedily: a candidate stream gets its first work while the accepted ones are busy (``ec_bind_streams``), is then
+    measured against every accepted stream (``ec_stream_pair_overlap``: both busy / one alone ~ 1 when concurrent, ~ 2 when
+    serialised) and joins the set only if it overlaps with all of them; rejected candidates stay alive until the set is complete,
+    so the runtime cannot hand their queue out again.  This finds ``n`` distinct queues whatever other live streams of the process
+    already sit on them.  Raises if ``max_candidates`` do not yield the set (``n`` above the number of hardware queues): two
+    launches in flight is what the engine's numbers rest on, and a silent fall-back to serial streams would misreport them."""
     import torch
     lib = load()
     dev = torch.device(device)
-    rejected, worst = [], 0.0
+    accepted, rejected, worst = [], [], 0.0
     with torch.cuda.device(dev):
-        for _ in range(attempts):
-            streams = [torch.cuda.Stream(device=dev) for _ in range(n)]
-            if n < 2:
-                return streams
-            arr = (C.c_void_p * n)(*[s.cuda_stream for s in streams])
-            check(lib.ec_bind_streams(arr, n, spin_us), "ec_bind_streams")
-            worst = 0.0
-            for i in range(n):
-                for j in range(i + 1, n):
-                    r = C.c_float()
-                    check(lib.ec_stream_pair_overlap(streams[i].cuda_stream, streams[j].cuda_stream, spin_us, C.byref(r)),
-                          "ec_stream_pair_overlap")
-                    worst = max(worst, r.value)
-            if worst < 1.5:
-                return streams
-            rejected.append(streams)
-    raise RuntimeError(f"could not obtain {n} concurrent HIP streams on {dev} (both-busy / alone = {worst:.2f} after {attempts} attempts)")
+        for _ in range(max_candidates):
+            if len(accepted) == n:
+                break
+            cand = torch.cuda.Stream(device=dev)
+            group = accepted + [cand]
+            arr = (C.c_void_p * len(group))(*[s.cuda_stream for s in group])
+            check(lib.ec_bind_streams(arr, len(group), spin_us), "ec_bind_streams")
+            ok = True
+            for s in accepted:
+                r = C.c_float()
+                check(lib.ec_stream_pair_overlap(s.cuda_stream, cand.cuda_stream, spin_us, C.byref(r)), "ec_stream_pair_overlap")
+                if r.value >= 1.5:
+                    ok, worst = False, max(worst, r.value)
+                    break
+            (accepted if ok else rejected).append(cand)
+    if len(accepted) < n:
+        raise RuntimeError(f"could not obtain {n} concurrent HIP streams on {dev}: {len(accepted)} found among {max_candidates} candidates "
+                           f"(both-busy / alone of a rejected pair = {worst:.2f})")
+    return accepted
 
 
 def on_device(fn):

@@ -210,3 +210,27 @@ def test_slice_streams_run_concurrently_in_every_worker_of_a_process():
     st = _lib.concurrent_streams(3, "cuda:0")
     assert len({s.cuda_stream for s in st}) == 3
 
+
+def test_copy_streams_of_a_host_frame_worker_run_beside_both_slice_streams():
+    """Frames in pinned host memory: two slice streams + two copy streams = the runtime's four hardware queues.  A copy stream on
+    the OTHER slice's compute queue made the third worker of a process run at 42 instead of 59 k env-frames/s
+    (tools/h2d_probe.py): all four come from one verified pool now."""
+    import ctypes as C
+    import gc
+    from embodied_clip_amd import _lib
+    from embodied_clip_amd.engine import Worker
+    lib = _lib.load()
+    for i in range(3):
+        w = Worker(64, T=4, device="cuda:0", seed=i, frames_host=True, frames_u8=True)
+        w.iteration()
+        torch.cuda.synchronize()
+        st = [sl.stream for sl in w.slices] + [sl.copy_stream for sl in w.slices]
+        assert len({s.cuda_stream for s in st}) == 4
+        for a in range(4):
+            for b in range(a + 1, 4):
+                r = C.c_float()
+                _lib.check(lib.ec_stream_pair_overlap(st[a].cuda_stream, st[b].cuda_stream, 300, C.byref(r)))
+                assert 0.5 < r.value < 1.5, (i, a, b, r.value)
+        del w, st
+        gc.collect()
+
