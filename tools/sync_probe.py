@@ -7,6 +7,8 @@ launches of an env step ran one after the other.  Modes (python tools/sync_probe
   layout_*        buffer addresses of fast and slow workers (identical: not a layout effect)
   concurrency     both-busy / alone time of a worker's slice streams, before and after its run
   workers         six workers in a row through _lib.concurrent_streams (the fix): all at the first worker's rate
+  artifact        the same six workers with plain torch.cuda.Stream() slice streams (the behaviour before the fix)
+  sync_h2d        the engine with uint8 frames crossing PCIe every step, free-running and action-synchronous (the plugin route's peer)
 (the modes from `second` to `layout_second` reproduce the slow worker only with Worker's streams created by plain
 torch.cuda.Stream(), i.e. before the fix.)"""
 import sys, time, gc, torch
@@ -130,3 +132,18 @@ elif mode == "sync_h2d":
         w = Worker(256, sync_actions=sync, frames_host=True, frames_u8=True, **kw)
         print(f"frames on the host (uint8), {'action-synchronous' if sync else 'free-running'}: {round(run(w))} env-frames/s")
         del w; gc.collect(); torch.cuda.empty_cache()
+elif mode == "artifact":
+    # the behaviour before the fix, reproduced: Worker's streams as plain torch.cuda.Stream() objects (first bound by the worker's
+    # own first submissions), six 256-actor workers in one process
+    import ctypes as C
+    from embodied_clip_amd import _lib as L
+    real = L.concurrent_streams
+    L.concurrent_streams = lambda n, device, **k: [torch.cuda.Stream(device=device) for _ in range(n)]
+    for i in range(6):
+        w = Worker(256, sync_actions=(i % 2 == 1), **kw)
+        r = run(w)
+        ratio = C.c_float()
+        L.load().ec_stream_pair_overlap(w.slices[0].stream.cuda_stream, w.slices[1].stream.cuda_stream, 200, C.byref(ratio))
+        print(f"plain streams, worker {i + 1} ({'action-synchronous' if i % 2 else 'free-running'}): {round(r)} env-frames/s; slice streams both busy / alone = {ratio.value:.2f}")
+        del w; gc.collect(); torch.cuda.empty_cache()
+    L.concurrent_streams = real
