@@ -205,6 +205,7 @@ def _time_iterations(w, steps, warmup, barrier):
         w.iteration()
     w.time_trunk = True
     w.trunk_events = []
+    w.update_events = []
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -272,12 +273,15 @@ def run_rank(a, rank: int, local_rank: int, world: int, init_method=None):
 
     from embodied_clip_amd.engine import Worker
     total = a.actors_total if a.actors_total else a.actors
-    if a.scaling == "strong":          # the same global actor list sharded over the ranks (N/G each)
-        if total % world != 0:
-            raise SystemExit(f"--scaling strong needs the actor total ({total}) divisible by the world size ({world})")
-        per_gpu = total // world
+    if a.scaling == "strong":          # the same global actor list sharded over the ranks (N/G each; shards
+        from embodied_clip_amd.dist import shard_actors   # may differ by one actor: engine.Worker scales by local / GLOBAL size)
+        if total < world:
+            raise SystemExit(f"--scaling strong needs at least one actor per rank ({total} actors, {world} ranks)")
+        per_gpu = shard_actors(total, rank, world)[1]
+        global_actors = total
     else:
         per_gpu = total
+        global_actors = total * world
     wkw = dict(T=a.rollout, device=dev, seed=0, rank=rank, world=world, update_repeats=a.update_repeats,
                encoder_chunk=a.encoder_chunk, encoder=a.encoder, encoder_streams=a.encoder_streams,
                frames_u8=a.frames_u8, num_mini_batch=a.num_mini_batch, force_allreduce=a.force_dist,
@@ -323,12 +327,14 @@ def run_rank(a, rank: int, local_rank: int, world: int, init_method=None):
         ref = w.trunk_events[0][0]
         busy = busy_union_ms([(ref.elapsed_time(e0), ref.elapsed_time(e1)) for e0, e1 in w.trunk_events])
         avg_union_ms = busy / max(1, len(w.trunk_events) // n_conc)        # per env step (n_conc launches each)
+    upd_ms = [e0.elapsed_time(e1) for e0, e1 in getattr(w, "update_events", [])]
+    update_ms = round(sum(upd_ms) / len(upd_ms), 2) if upd_ms else None
     info = w.loss_info()
     plan_hash = w.slices[0].enc.plan_hash() if hasattr(w.slices[0].enc, "plan_hash") else None
     enc_frames = w.encode_frames
     rccl_ranks = dist.get_world_size() if use_dist else 1
 
-    frames = a.rollout * per_gpu * world * a.steps
+    frames = a.rollout * global_actors * a.steps
     value = frames / dt
     enc_mac = {"rn50": TRUNK_MAC_PER_FRAME, "vit": VIT_MAC_PER_FRAME, "rn50x16": RN50X16_MAC_PER_FRAME,
                "zeroshot": TRUNK_MAC_PER_FRAME + ATTNPOOL_MAC_PER_FRAME}[a.encoder]
@@ -359,6 +365,21 @@ def run_rank(a, rank: int, local_rank: int, world: int, init_method=None):
             if trec.get("single_launch_256"):
                 frac_profiles_256 = round(2.0 * enc_mac * 256 / (trec["single_launch_256"]["kernel_time_us"] * 1e-6) / 1e12
                                           / MFMA_BF16_PEAK_TFLOPS, 4)
+        # ... and of the regime the headline runs in (two slice streams): the committed rocprofv3 kernel trace of the engine's
+        # steady state reduced to the per-env-step UNION of the encoder kernels' intervals (tools/engine_step_union.py)
+        frac_conc, conc_note = None, "no profiles/engine_step_union.json"
+        upath = os.path.join(ROOT, "profiles", "engine_step_union.json")
+        if a.encoder == "rn50" and os.path.exists(upath):
+            urec = json.load(open(upath))
+            if urec.get("plan_hash") in (None, "", plan_hash) and urec.get("frames_per_env_step") == per_gpu:
+                frac_conc = round(2.0 * enc_mac * urec["frames_per_env_step"] / (urec["union_ms_per_env_step"] * 1e-3) / 1e12
+                                  / MFMA_BF16_PEAK_TFLOPS, 4)
+                conc_note = (f"profiles/engine_step_union.json: encoder kernels of {urec.get('env_steps')} steady-state env steps, union "
+                             f"{urec['union_ms_per_env_step']} ms per env step (sum of kernel durations {urec.get('sum_kernel_ms_per_env_step')} ms, "
+                             f"overlap factor {urec.get('overlap_factor')})")
+            else:
+                conc_note = (f"profiles/engine_step_union.json was collected on plan {urec.get('plan_hash')} at "
+                             f"{urec.get('frames_per_env_step')} frames per env step; this run: plan {plan_hash}, {per_gpu} frames -- not quoted")
         # the second roof: L2-miss bytes of the concurrent launches of an env step over their union, against achievable HBM
         hbm_tbs = (traffic * n_conc / (avg_union_ms * 1e-3) / 1e12) if traffic else None
         workload = {"rn50": "RoboTHOR ObjectNav: frozen CLIP-RN50 encoder",
@@ -374,7 +395,7 @@ def run_rank(a, rank: int, local_rank: int, world: int, init_method=None):
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": workload + " (bf16 MFMA, fp32 accumulate) + 1-layer GRU actor-critic PPO (fp32), "
                                                "synthetic 224x224 RGB + random goal ids",
-                       "actors_per_gpu": per_gpu, "global_actors": per_gpu * world, "rollout": a.rollout,
+                       "actors_per_gpu": per_gpu, "global_actors": global_actors, "rollout": a.rollout,
                        "update_repeats": a.update_repeats, "num_mini_batch": a.num_mini_batch, "encoder_streams": a.encoder_streams,
                        "frames": ("pinned host -> H2D per step, " if a.frames_host else "resident in HBM, ") +
                                  ("uint8 HWC (normalisation fused)" if a.frames_u8 else "fp32 normalised HWC"),
@@ -388,12 +409,18 @@ def run_rank(a, rank: int, local_rank: int, world: int, init_method=None):
                        "policy_gemm_mode": ("fp32 x fp32 as bf16x3: six exact products forward, THREE leading products in the backward's "
                                             "large gradient GEMMs (EC_GEMM_BWD3=1)" if os.environ.get("EC_GEMM_BWD3", "0") not in ("", "0")
                                             else "fp32 x fp32 as bf16x3, six exact products forward and backward (fp32-exact; EC_GEMM_BWD3=0)")},
+            "update_ms": update_ms,      # the 4 PPO epochs (forward, loss, backward, all-reduce, clip + Adam) per iteration: HIP events, main stream
             "rccl_ranks": rccl_ranks, "allreduce_ms_per_rank": None,
-            "roofline": {"bound": "mfma",
-                         "kernel": ("ec_rn50_forward (conv_igemm / conv_pair / conv3x3_narrow MFMA kernels)"
-                                    if a.encoder != "vit" else "ec_vit_forward (conv_igemm GEMMs + mha/layernorm kernels)"),
+            "roofline": {"bound": "mfma", "co_bound": "mfma + hbm (co-bound: see hbm_frac)",
+                         # schema 2 (round 5 on): `frac` / `achieved` = the dominant kernel family over the busy union of its
+                         # launches (== `frac_union`); the whole-iteration figure of rounds 1-4 is `frac_iteration`
+                         "schema": 2,
+                         "kernel": ("ec_rn50_forward (conv_bneck whole-bottleneck / conv_igemm / conv_pair / conv3x3_narrow MFMA kernels)"
+                                    if a.encoder != "vit" else "ec_vit_forward (conv_igemm GEMMs with LayerNorm folded in + mha kernel)"),
                          "achieved": round(achieved_union, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved_union / MFMA_BF16_PEAK_TFLOPS, 4),
+                         "frac_union": round(achieved_union / MFMA_BF16_PEAK_TFLOPS, 4),
+                         "frac_profiles_concurrent": frac_conc, "frac_profiles_concurrent_note": conc_note,
                          "frac_iteration": round(achieved_iter / MFMA_BF16_PEAK_TFLOPS, 4), "achieved_iteration": round(achieved_iter, 1),
                          "frac_profiles": frac_profiles, "frac_profiles_single_256_launch": frac_profiles_256,
                          "hbm_frac": round(hbm_tbs / HBM_ACHIEVABLE_TBS, 4) if hbm_tbs else None,
@@ -466,10 +493,29 @@ def run_rank(a, rank: int, local_rank: int, world: int, init_method=None):
             for _ in range(20):
                 allreduce_flat(w.grads, force=True)
             e1.record(); torch.cuda.synchronize()
-            mine = torch.tensor([e0.elapsed_time(e1) / 20], dtype=torch.float64, device=dev)
+            whole = e0.elapsed_time(e1) / 20
+            # the two sections the overlapped worker sends: GRU + heads (under the goal encoder's backward) and the rest (exposed)
+            secs = []
+            for sec in [w.rec] + w._other_sections():
+                allreduce_flat(w.grads[sec], force=True)
+                e0.record()
+                for _ in range(20):
+                    allreduce_flat(w.grads[sec], force=True)
+                e1.record(); torch.cuda.synchronize()
+                secs.append(e0.elapsed_time(e1) / 20)
+            mine = torch.tensor([whole, secs[0], sum(secs[1:])], dtype=torch.float64, device=dev)
             allv = [torch.zeros_like(mine) for _ in range(world)]
             dist.all_gather(allv, mine)
-            return [round(float(v.item()), 4) for v in allv]
+            nopt = a.update_repeats * a.num_mini_batch
+            exposed = max(float(v[0 if a.no_overlap_allreduce else 2].item()) for v in allv)
+            put("allreduce_sections_ms_per_rank", {"recurrent_section": [round(float(v[1].item()), 4) for v in allv],
+                                                   "goal_encoder_section": [round(float(v[2].item()), 4) for v in allv]})
+            put("allreduce_exposed", {"ms_per_optimiser_step": round(exposed, 4), "optimiser_steps_per_iteration": nopt,
+                                      "share_of_iteration": round(nopt * exposed / (dt / a.steps * 1e3), 5),
+                                      "what": ("the whole 13.9-MB bucket after the backward (--no-overlap-allreduce)" if a.no_overlap_allreduce else
+                                               "the goal encoder's section, reduced after the backwards; the GRU + heads section (92 % of "
+                                               "the bytes) runs on the communication stream under the goal encoder's backward")})
+            return [round(float(v[0].item()), 4) for v in allv]
         dog.leg = "allreduce_ms_per_rank"
         put("allreduce_ms_per_rank", _soft("allreduce_ms_per_rank", leg_allreduce, agree))
 
@@ -483,7 +529,7 @@ def run_rank(a, rank: int, local_rank: int, world: int, init_method=None):
             free_worker()
             ws_ = Worker(per_gpu, frames_host=False, sync_actions=True, **wkw)
             dts = maxreduce(_time_iterations(ws_, a.sync_steps, 1, barrier))
-            r = {"value": round(a.rollout * per_gpu * world * a.sync_steps / dts, 1), "unit": "env-frames/s", "steps": a.sync_steps,
+            r = {"value": round(a.rollout * global_actors * a.sync_steps / dts, 1), "unit": "env-frames/s", "steps": a.sync_steps,
                  "order": "per env step: act(t) on every slice -> the sampled actions of all actors copied D2H and waited for "
                           "(what ONE VectorSampledTasks.step(actions) over all samplers forces) -> observe() -> encode(t+1); "
                           "the free-running headline lets the host issue arbitrarily far ahead"}
@@ -492,7 +538,7 @@ def run_rank(a, rank: int, local_rank: int, world: int, init_method=None):
             ws_ = Worker(per_gpu, frames_host=False, sync_actions="slice", **wkw)
             dts = maxreduce(_time_iterations(ws_, a.sync_steps, 1, barrier))
             r["per_slice_envs"] = {
-                "value": round(a.rollout * per_gpu * world * a.sync_steps / dts, 1), "unit": "env-frames/s",
+                "value": round(a.rollout * global_actors * a.sync_steps / dts, 1), "unit": "env-frames/s",
                 "order": "one vectorised env per actor slice: the host waits for slice s's actions only, steps that slice's env "
                          "and issues its encode(t+1) + act(t+1) while the other slice's encoder is still running (same "
                          "per-actor arithmetic, same round trips per actor)"}
@@ -502,7 +548,7 @@ def run_rank(a, rank: int, local_rank: int, world: int, init_method=None):
             # route with uint8 sensor frames -- same order, same bytes over the bus, the engine's own storage and kernels
             ws_ = Worker(per_gpu, frames_host=True, sync_actions=True, **{**wkw, "frames_u8": True})
             dts = maxreduce(_time_iterations(ws_, a.sync_steps, 1, barrier))
-            r["host_frames_u8"] = {"value": round(a.rollout * per_gpu * world * a.sync_steps / dts, 1), "unit": "env-frames/s",
+            r["host_frames_u8"] = {"value": round(a.rollout * global_actors * a.sync_steps / dts, 1), "unit": "env-frames/s",
                                    "order": "action-synchronous (one env for all actors), uint8 frames in pinned host memory copied every env step"}
             del ws_
             return r
@@ -515,7 +561,7 @@ def run_rank(a, rank: int, local_rank: int, world: int, init_method=None):
             u8 = a.encoder != "vit"          # (the ViT patch-embed kernel takes the sensor's fp32 frames only)
             wh = Worker(per_gpu, frames_host=True, **{**wkw, "frames_u8": u8})
             dth = maxreduce(_time_iterations(wh, a.h2d_steps, 1, barrier))
-            r = {"value": round(a.rollout * per_gpu * world * a.h2d_steps / dth, 1), "unit": "env-frames/s", "steps": a.h2d_steps,
+            r = {"value": round(a.rollout * global_actors * a.h2d_steps / dth, 1), "unit": "env-frames/s", "steps": a.h2d_steps,
                  "frames": ("uint8 HWC" if u8 else "fp32 normalised HWC") + " in PINNED HOST memory, copied per slice on its "
                            "own copy stream (double-buffered) while the other slice computes" +
                            ("; /255 + CLIP mean/std fused into the stem kernel" if u8 else ""),
@@ -605,7 +651,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-plugin", action="store_true",
                     help="skip the secondary `plugin_path` measurement: the same iteration driven through the drop-in plugin "
                          "classes with the reference's tensor contracts (embodied_clip_amd/plugin_path.py)")
-    ap.add_argument("--plugin-steps", type=int, default=1)
+    ap.add_argument("--plugin-steps", type=int, default=3, help="timed iterations of each plugin_path leg (>= 3: a 10 %% move is then not noise)")
     ap.add_argument("--h2d-steps", type=int, default=5, help="timed iterations of the h2d_inclusive measurement")
     ap.add_argument("--sync-actions", nargs="?", const=True, default=False, choices=[True, "slice"],
                     help="HEADLINE run in the action-synchronous order: every env step the sampled actions are copied D2H and "

@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libec_amd.so")
+# EC_AMD_LIB: another BUILD of this library (same C-ABI; same-box A/B of two builds, tools/ab.sh) -- still a HIP library, never a fallback
+LIB_PATH = os.environ.get("EC_AMD_LIB") or os.path.join(_HERE, "lib", "libec_amd.so")
 
 c_void_p, c_int, c_size_t, c_float = C.c_void_p, C.c_int, C.c_size_t, C.c_float
 

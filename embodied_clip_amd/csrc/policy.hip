@@ -1570,7 +1570,13 @@ extern "C" int ec_policy_forward2(const ec_policy_t* h, const float* params, con
             auto it = h->tables.find(workspace);
             if (reuse_tables && (it == h->tables.end() || it->second.T != T || it->second.N != N || it->second.bf16 != (feat_bf16 ? 1 : 0)))
                 reuse_tables = false;                            // nothing valid for THIS geometry / dtype in this workspace: build
-            if (!reuse_tables) h->tables[workspace] = ec_policy::Built{T, N, feat_bf16 ? 1 : 0};
+            if (!reuse_tables) {
+                // bounded: a caller that allocates a fresh act workspace per call would otherwise add an entry per allocator
+                // address for the life of the handle.  Dropping every record is always safe -- a REUSE call that
+                // finds none rebuilds its tables.
+                if (h->tables.size() >= 64 && h->tables.find(workspace) == h->tables.end()) h->tables.clear();
+                h->tables[workspace] = ec_policy::Built{T, N, feat_bf16 ? 1 : 0};
+            }
         }
     }
     // learn pass: the GRU's input projection reads the combiner output where it lies (pixel-major rows) against a re-ordered

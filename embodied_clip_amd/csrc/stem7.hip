@@ -131,7 +131,10 @@ __global__ __launch_bounds__(NT, 2) void stem7_pool_kernel(const void* __restric
                 }
                 uint16_t* dst = patch + r * PPITCH + 4 * q;      // element 4q of the row; the chunk starts one element earlier
                 if (q > 0) dst[-1] = ec_f2bf(v[0]);
-                *reinterpret_cast<uint32_t*>(dst) = ec_pack2(v[1], v[2]);
+                // (the last chunk of a row, 4 q == PPITCH, holds only element PPITCH - 1: its middle pair would land on elements
+                //  0..1 of patch row r + 1 -- real taps of conv column 0 -- in the same ds_write as that row's own chunk 0)
+                if (4 * q + 1 < PPITCH) *reinterpret_cast<uint32_t*>(dst) = ec_pack2(v[1], v[2]);
+                else if (4 * q < PPITCH) dst[0] = ec_f2bf(v[1]);
                 if (4 * q + 2 < PPITCH) dst[2] = ec_f2bf(v[3]);
             }
         }

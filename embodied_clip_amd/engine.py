@@ -31,7 +31,8 @@ import torch
 
 from . import _lib
 from . import synthetic as syn
-from .dist import allreduce_flat, check_job_seed, collective_active
+from .dist import (allreduce_flat, check_job_seed, collective_active, gather_actor_counts, global_minibatch_sizes,
+                   minibatch_bounds)
 from .encoder import AttentionPool, ClipTextEncoder, RN50Trunk, ViTEmbedder
 from .policy import PolicyHandle
 from .ppo import FlatAdam, linear_decay_lr, ppo_loss_raw
@@ -123,6 +124,11 @@ class Worker:
         if self.dev.index is None:
             self.dev = self.device = torch.device("cuda", torch.cuda.current_device())
         check_job_seed(seed, world, device=self.dev)        # ... which is ENFORCED when a process group is up (on THIS worker's GPU)
+        # every rank's actor count: the gradient scale is local / GLOBAL minibatch size ([U] backprop_step), and the global size
+        # is the sum over the ranks -- shards need not be equal (dist.shard_actors(10, r, 3) = 4, 3, 3)
+        self.shard_counts = gather_actor_counts(n_actors, world, device=self.dev)
+        assert all(num_mini_batch <= c for c in self.shard_counts), "num_mini_batch must not exceed the smallest shard"
+        self._mb_global = global_minibatch_sizes(self.shard_counts, num_mini_batch)
         self._init(n_actors, T, seed, rank, world, update_repeats, lr, max_grad_norm, gamma, tau, encoder_sd, policy_sd,
                    lr_total_steps, encoder_chunk, encoder, encoder_streams, frames_u8, frames_host)
 
@@ -267,6 +273,7 @@ class Worker:
         self.total_steps = 0
         self.iter = 0
         self.trunk_events: List = []             # (start, end) HIP event pairs around the encoder launches
+        self.update_events: List = []            # ... and around the update phase (GAE excluded), one pair per timed iteration
         self.time_trunk = False
         # first observation of the first rollout
         rgb = self.env.observe()
@@ -467,15 +474,14 @@ class Worker:
         """[U] allenact ``RolloutStorage.recurrent_generator``: the samplers (actors) are cut at
         ``round(linspace(0, N, num_mini_batch + 1))`` into contiguous ranges which are visited in a shuffled order;
         every range keeps its full T-step sequences (the GRU needs them)."""
-        N, M = self.N, self.num_mini_batch
-        inds = [int(round(i * N / M)) for i in range(M + 1)]      # == np.round(np.linspace(0, N, M + 1))
-        pairs = list(zip(inds[:-1], inds[1:]))
+        inds = minibatch_bounds(self.N, self.num_mini_batch)      # == np.round(np.linspace(0, N, M + 1))
+        # (s0, s1, samplers of this range over ALL ranks); the shuffle permutation depends on the list's length only
+        pairs = [(s0, s1, g) for s0, s1, g in zip(inds[:-1], inds[1:], self._mb_global)]
         self._mb_rng.shuffle(pairs)
         return pairs
 
     def _max_partial_range(self, sl) -> int:
-        N, M = self.N, self.num_mini_batch
-        inds = [int(round(i * N / M)) for i in range(M + 1)]
+        inds = minibatch_bounds(self.N, self.num_mini_batch)
         best = 1
         for s0, s1 in zip(inds[:-1], inds[1:]):
             a, b = max(s0, sl.o) - sl.o, min(s1, sl.o + sl.n) - sl.o
@@ -522,14 +528,13 @@ class Worker:
         collective = collective_active(self.world, self.force_allreduce)
         self._gather_slice_batches()
         for _ in range(self.update_repeats):
-            for (s0, s1) in self.minibatch_ranges():
+            for (s0, s1, nmb_global) in self.minibatch_ranges():
                 # the minibatch's actors, slice by slice (each part on its slice's stream)
                 parts = []
                 for sl in self.slices:
                     a, b = max(s0, sl.o) - sl.o, min(s1, sl.o + sl.n) - sl.o
                     if b > a:
                         parts.append((sl, a, b))
-                nmb = s1 - s0
                 early = collective and self.overlap_allreduce
                 if early:                      # (the previous optimiser step read self.grads on the main stream)
                     self.comm_stream.wait_stream(torch.cuda.current_stream())
@@ -540,8 +545,9 @@ class Worker:
                         feat, goal, masks, actions, logp, old_v, ret, nadv = self._gather_part(sl, a, b)
                         hv, dhv = sl.hv[:T * m], sl.dhv[:T * m]
                         # d(total)/d(hv) carries 1/B_part inside the loss kernel: rescale to the mean over the WHOLE
-                        # local minibatch, then local_bsize / global_bsize for the SUM all-reduce (global mean gradient)
-                        grad_scale = (m / nmb) * (1.0 / self.world)
+                        # local minibatch (m / nmb), then local_bsize / global_bsize (nmb / nmb_global: the sum of the
+                        # ranks' sizes of this range, equal shards or not) for the SUM all-reduce = the global mean gradient
+                        grad_scale = m / nmb_global
                         # (staggering the slices -- slice 1's forward starting when slice 0's is done, so that wide GEMMs
                         #  run beside the other slice's GRU recurrence -- was measured in round 3: 53 -> 58 ms per update;
                         #  the step kernels wait for CUs the GEMM workgroups hold)
@@ -579,13 +585,22 @@ class Worker:
     def after_update(self):
         for sl in self.slices:
             sl.feat[0].copy_(sl.feat[self.T])
-        self.total_steps += self.T * self.N * self.world
+        self.total_steps += self.T * sum(self.shard_counts)
         self.iter += 1
 
     def iteration(self):
         self.collect_rollout()
         self.compute_returns()
+        timed = self.time_trunk          # (bench.py: HIP events around the update phase on the main stream; no host sync)
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            with torch.cuda.device(self.dev):
+                e0.record(torch.cuda.current_stream())
         self.update()
+        if timed:
+            with torch.cuda.device(self.dev):
+                e1.record(torch.cuda.current_stream())
+            self.update_events.append((e0, e1))
         self.after_update()
 
     def loss_info(self) -> Dict[str, float]:

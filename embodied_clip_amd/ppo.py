@@ -164,16 +164,19 @@ class FusedClipAdam(torch.optim.Optimizer):
         self._buckets = {}
 
     @staticmethod
-    def _span(tensors):
+    def _span(tensors, max_gap: int = 3):
         """(storage offset of the first element, numel of the covering span) when ``tensors`` are non-overlapping contiguous
-        fp32 views of ONE storage in increasing order; else None."""
+        fp32 views of ONE storage that lie ADJACENT to one another (in any list order; gaps of at most ``max_gap`` elements,
+        the 16-byte alignment padding of the flat buckets); else None.  Adjacency matters: the kernel updates the whole
+        covering span, so a span with another group's tensors inside it would step those under this group's lr as well."""
         st = tensors[0].untyped_storage().data_ptr()
-        lo, end = None, None
         for t in tensors:
             if t.dtype != torch.float32 or not t.is_contiguous() or t.untyped_storage().data_ptr() != st:
                 return None
+        lo, end = None, None
+        for t in sorted(tensors, key=lambda x: x.storage_offset()):
             o = t.storage_offset()
-            if end is not None and o < end:
+            if end is not None and (o < end or o - end > max_gap):
                 return None
             lo = o if lo is None else lo
             end = o + t.numel()
@@ -187,9 +190,11 @@ class FusedClipAdam(torch.optim.Optimizer):
         b = self._buckets.get(gi)
         if b is not None and b["ptrs"] == tuple(p.data_ptr() for p in ps):
             return b
+        if any(p.dtype != torch.float32 for p in ps):
+            raise NotImplementedError("FusedClipAdam: non-fp32 parameters")
         span = self._span([p.data for p in ps])
         if span is None:        # flatten once: the parameters become views of one new buffer (values preserved)
-            flat = torch.cat([p.data.reshape(-1).float() for p in ps])
+            flat = torch.cat([p.data.reshape(-1) for p in ps])
             o = 0
             for p in ps:
                 p.data = flat[o:o + p.numel()].view(p.shape)

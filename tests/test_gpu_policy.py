@@ -664,6 +664,35 @@ def test_fused_clip_adam_is_a_torch_optimizer_drop_in(dev):
     for a, b in zip(pf, pt):
         assert (a - b).abs().max().item() < 2e-6
     assert float(of2.state[pf[0]]["step"]) == 4.0
+    # (c) two param_groups whose tensors INTERLEAVE in the module's flat bucket (separate lr for every second tensor): a group's
+    # covering span would contain the other group's tensors -- each group must step its own tensors only, once,
+    # under its own lr; and a list order that differs from the storage order stays on the in-place path
+    m_g, m_h = mk(), mk()
+    names = [n for n, _ in m_g.named_parameters()]
+    ga = [n for i, n in enumerate(names) if i % 2 == 0]
+    grp = lambda m: [dict(params=[p for n, p in m.named_parameters() if n in ga], lr=1e-3),       # noqa: E731
+                     dict(params=[p for n, p in m.named_parameters() if n not in ga], lr=5e-3)]
+    og, oh = FusedClipAdam(grp(m_g), max_grad_norm=None), torch.optim.Adam(grp(m_h))
+    for it in range(3):
+        gen = torch.Generator().manual_seed(300 + it)
+        grads = {n: torch.randn(p.shape, generator=gen) for n, p in m_g.named_parameters()}
+        for m, opt in ((m_g, og), (m_h, oh)):
+            opt.zero_grad()
+            m.ensure_flat()
+            for n, p in m.named_parameters():
+                p.grad.copy_(grads[n].to(dev))
+            opt.step()
+    for (n, a), (_, b) in zip(m_g.named_parameters(), m_h.named_parameters()):
+        assert (a - b).abs().max().item() < 2e-6, n
+    mm = mk()
+    mm.ensure_flat()
+    ps = [p.data for p in mm.parameters()]
+    assert FusedClipAdam._span(ps) is not None and FusedClipAdam._span(ps[::-1]) == FusedClipAdam._span(ps)
+    assert FusedClipAdam._span(ps[::2]) is None                  # gaps with foreign tensors inside: not one span
+    with pytest.raises(NotImplementedError):
+        oh16 = FusedClipAdam([torch.nn.Parameter(torch.zeros(4, dtype=torch.float16, device=dev))], lr=1e-3)
+        oh16.param_groups[0]["params"][0].grad = torch.zeros(4, dtype=torch.float16, device=dev)
+        oh16.step()
 
 
 def test_infer_reuse_rebuilds_tables_when_geometry_or_dtype_changed(dev):
