@@ -3,7 +3,7 @@
 
 #include "common.h"
 
-extern "C" int ec_version(void) { return 500; }   // 0.5.0 (bump whenever a kernel or a launch plan changes: keys profiles/*traffic*.json)
+extern "C" int ec_version(void) { return 600; }   // 0.6.0 (bump whenever a kernel or a launch plan changes: keys profiles/*traffic*.json)
 
 extern "C" const char* ec_strerror(int code) {
     switch (code) {

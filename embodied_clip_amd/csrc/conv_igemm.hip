@@ -83,6 +83,18 @@ struct ConvArgs {
     unsigned in_bytes, w_bytes;   // buffer-descriptor extents (out-of-range loads return 0)
     unsigned res_bytes;           // ... of the residual tensor (= output extent)
     int ablate;                   // profiling only (tools build, EC_CONV_ABLATE): 1 no global loads, 2 no MFMA, 8 no epilogue; 0 in the product library
+    // ---- LayerNorm folded into the GEMM (conv_igemm8, 1x1 only; ec_gemm_bf16_ln8) ----
+    // consumer: out = act(rstd[m] * (acc[m, n] - mean[m] * ln_s[n]) + bias[n]) with acc = x . (W diag(gamma))^T on the RAW rows x,
+    //           ln_s[n] = sum_k (W diag(gamma))[n, k], bias[n] = sum_k beta[k] W[n, k] + b[n]; (mean, rstd) of row m from the
+    //           ln_np partial records {sum, M2, count, -} the producer of x left in ln_stats[m][ln_np]
+    // producer: stats_out != nullptr: the epilogue also writes this tile's record of every output row (over its BN columns,
+    //           computed from the ROUNDED bf16 values it stores) to stats_out[m][ntn][4]
+    const float* ln_s = nullptr;
+    const float* ln_stats = nullptr;
+    int ln_np = 0;
+    float ln_eps = 1e-5f;
+    float* stats_out = nullptr;
+    int aux_off = 0;              // byte offset of the 4-KB auxiliary LDS area behind the stages / the epilogue image
 };
 
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
@@ -192,6 +204,48 @@ __device__ __forceinline__ void epi_stage_dispatch(const f32x16_t (&acc)[FM][FN]
         } else {
             if (has_res) epi_stage<EC_ACT_NONE, true, false, FM, FN, PITCH>(acc, smem, bias_n0, row0, col0, lane);
             else epi_stage<EC_ACT_NONE, false, false, FM, FN, PITCH>(acc, smem, bias_n0, row0, col0, lane);
+        }
+    }
+}
+
+// LayerNorm-folded epilogue (ConvArgs::ln_*): v = a_m * acc + (b_m * s[n] + c[n]) with (a_m, b_m) = (rstd, -mean * rstd) of the
+// lane's row out of the LDS table `rowab` (built at kernel entry from the producer's partial records), then the activation.
+template <int ACT, int FM, int FN, int PITCH>
+__device__ __forceinline__ void epi_stage_ln(const f32x16_t (&acc)[FM][FN], unsigned char* smem, const float* s_n0, const float* c_n0,
+                                             const float2* rowab, int row0, int col0, int lane) {
+    const int frow = lane & 31, fhalf = lane >> 5;
+    float2 ab[FM];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) ab[i] = rowab[row0 + i * 32 + frow];
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        float4 sv[4], cv[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            sv[g] = *reinterpret_cast<const float4*>(s_n0 + col0 + j * 32 + 8 * g + 4 * fhalf);
+            cv[g] = *reinterpret_cast<const float4*>(c_n0 + col0 + j * 32 + 8 * g + 4 * fhalf);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int lcol = col0 + j * 32 + 8 * g + 4 * fhalf;
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int lrow_px = row0 + i * 32 + frow;
+                float v0 = fmaf(ab[i].x, acc[i][j][4 * g + 0], fmaf(ab[i].y, sv[g].x, cv[g].x));
+                float v1 = fmaf(ab[i].x, acc[i][j][4 * g + 1], fmaf(ab[i].y, sv[g].y, cv[g].y));
+                float v2 = fmaf(ab[i].x, acc[i][j][4 * g + 2], fmaf(ab[i].y, sv[g].z, cv[g].z));
+                float v3 = fmaf(ab[i].x, acc[i][j][4 * g + 3], fmaf(ab[i].y, sv[g].w, cv[g].w));
+                if constexpr (ACT == EC_ACT_QUICKGELU) {
+                    v0 *= __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v0)); v1 *= __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v1));
+                    v2 *= __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v2)); v3 *= __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v3));
+                } else if constexpr (ACT == EC_ACT_RELU) {
+                    v0 = ec_relu(v0); v1 = ec_relu(v1); v2 = ec_relu(v2); v3 = ec_relu(v3);
+                }
+                uint2 o;
+                o.x = ec_pack2(v0, v1);
+                o.y = ec_pack2(v2, v3);
+                *reinterpret_cast<uint2*>(smem + lrow_px * PITCH + lcol * 2) = o;
+            }
         }
     }
 }
@@ -666,6 +720,33 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
     const int m0 = (tile / p.ntn) * BM;
     const int n0 = (tile % p.ntn) * BN;
 
+    // LayerNorm folded in (consumer side): (rstd, -mean * rstd) of the tile's 256 rows from the producer's partial records
+    // {sum, M2, count} (Chan's combination: no E[x^2] - mean^2 cancellation), into the auxiliary LDS area behind the stages.
+    // Read by the epilogue only, i.e. behind the __syncthreads() that ends the K walk.
+    constexpr bool LNOK = (KS == 1) && !POOL && !X3 && !S2;
+    if constexpr (LNOK) {
+        if (p.ln_stats && tid < BM) {
+            float2 ab = make_float2(0.f, 0.f);
+            const int row = m0 + tid;
+            if (row < p.M) {
+                const float4* rec = reinterpret_cast<const float4*>(p.ln_stats) + (size_t)row * p.ln_np;
+                float4 r[8];
+                float S = 0.f, Nn = 0.f;
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (q < p.ln_np) { r[q] = rec[q]; S += r[q].x; Nn += r[q].z; }
+                const float mean = S / Nn;
+                float M2 = 0.f;
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (q < p.ln_np) { const float d = r[q].x / r[q].z - mean; M2 += r[q].y + r[q].z * d * d; }
+                const float rstd = rsqrtf(M2 / Nn + p.ln_eps);
+                ab = make_float2(rstd, -mean * rstd);
+            }
+            reinterpret_cast<float2*>(smem + p.aux_off)[tid] = ab;
+        }
+    }
+
     // ---- loader geometry (K-invariant) ----
     const int chunk = (tid & 7) ^ ((tid >> 4) & 7);
     const int lrow = tid >> 3;
@@ -1082,14 +1163,42 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
         }
         __syncthreads();
     }
+    bool ln_done = false;
+    if constexpr (LNOK) {
+        if (p.ln_stats) {   // (wave-uniform; LayerNorm-folded launches carry no residual: ec_gemm_bf16_ln8)
+            const float2* rowab = reinterpret_cast<const float2*>(smem + p.aux_off);
+            if (p.act == EC_ACT_QUICKGELU) epi_stage_ln<EC_ACT_QUICKGELU, FM, FN, PITCH>(acc, smem, p.ln_s + n0, p.bias + n0, rowab, wm * TM, wn * TN, lane);
+            else epi_stage_ln<EC_ACT_NONE, FM, FN, PITCH>(acc, smem, p.ln_s + n0, p.bias + n0, rowab, wm * TM, wn * TN, lane);
+            ln_done = true;
+        }
+    }
+    if (!ln_done)
     epi_stage_dispatch<POOL, false, FM, FN, PITCH>(acc, smem, p.bias ? p.bias + n0 : nullptr, wm * TM, wn * TN, lane, p.act, has_res);
     __syncthreads();
 #pragma unroll
     for (int r0 = 0; r0 < OUT_ROWS; r0 += RPP) {
         const int row = r0 + srow;
+        const uint4 v = *reinterpret_cast<const uint4*>(smem + row * PITCH + schunk * 16);
         if (orow0 + row < Mout && !(ABL & 128))         // (ABL & 128, profiling only: LDS staging without the global stores)
-            *reinterpret_cast<uint4*>(p.out + (long)(orow0 + row) * p.ldo + n0 + schunk * 8) =
-                *reinterpret_cast<const uint4*>(smem + row * PITCH + schunk * 16);
+            *reinterpret_cast<uint4*>(p.out + (long)(orow0 + row) * p.ldo + n0 + schunk * 8) = v;
+        if constexpr (LNOK) {
+            if (p.stats_out) {
+                // this tile's LayerNorm record of the row: the CH lanes that hold its BN rounded values reduce {sum, then M2 about
+                // the tile mean} with a butterfly (CH = 16 / 32 consecutive lanes of a wave), fixed order -> deterministic
+                float x[8] = {ec_lo(v.x), ec_hi(v.x), ec_lo(v.y), ec_hi(v.y), ec_lo(v.z), ec_hi(v.z), ec_lo(v.w), ec_hi(v.w)};
+                float sm = ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+#pragma unroll
+                for (int o = CH / 2; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
+                const float mu = sm * (1.f / (float)BN);
+                float q = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = x[e] - mu; q = fmaf(d, d, q); }
+#pragma unroll
+                for (int o = CH / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+                if (schunk == 0 && orow0 + row < Mout)
+                    reinterpret_cast<float4*>(p.stats_out)[(size_t)(orow0 + row) * p.ntn + (tile % p.ntn)] = make_float4(sm, q, (float)BN, 0.f);
+            }
+        }
     }
     if constexpr ((ABL & 32) != 0) if (blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0) ec_dbg_stamps[grp * 1024 + 302] = __builtin_amdgcn_s_memtime();
 }
@@ -1106,7 +1215,8 @@ int launch8(const ConvArgs& a, hipStream_t s) {
     const size_t stages = ls ? (X3 ? (size_t)(2 * 256 + 3 * BN) * ROW_BYTES : 3 * (size_t)(256 + BN) * ROW_BYTES)
                              : 2 * (size_t)(256 + BN) * ROW_BYTES;
     const size_t epi = X3 ? (size_t)128 * (BN * 4 + 16) : (size_t)(POOL ? 64 : 256) * (BN * 2 + 16);
-    const size_t lds = (stages > epi ? stages : epi) + 4096;   // + stamp area (profiling)
+    const size_t lds = (stages > epi ? stages : epi) + 4096;   // + auxiliary area: LayerNorm row table (2 KB) / stamps (profiling)
+    p.aux_off = (int)(lds - 4096);
     auto go = [&](auto kern) {
         static std::atomic<uint64_t> attr_done{0};
         if (auto attr_g_ = ec_attr_needed(attr_done))
@@ -1414,6 +1524,52 @@ extern "C" int ec_gemm_bf16a_x3(const void* A, const void* Wplanes, const float*
         if (rc != EC_OK) return rc;
     }
     return EC_OK;
+}
+
+// GEMM on the 8-wave kernel with LayerNorm folded in (vit.hip run_blocks; not part of the C-ABI):
+//   consumer (ln_s != nullptr): out = act(LN(A) Wt^T + b) computed as rstd (A Wg^T - mean s) + c on the RAW rows A, with
+//     Wt = W diag(gamma) (bf16), ln_s[n] = sum_k Wt[n, k], bias = c[n] = sum_k beta[k] W[n, k] + b[n], and the rows' statistics from
+//     the ln_np partial records the producer of A left in ln_stats ([M][ln_np][4] floats: sum, M2, count, -);
+//   producer (stats_out != nullptr): out = act(A Wt^T + bias (+ res)) and the tile's record of every output row into
+//     stats_out[M][N / tile width][4]; *np_out = records per row.
+// Replaces `x + attn(ln_1(x))` / `x + mlp(ln_2(x))`'s nn.LayerNorm launches ([U] clip/model.py ResidualAttentionBlock.forward).
+int ec_gemm_bf16_ln8(const void* A, const void* Wt, const float* bias, const void* res, void* out, int M, int N, int K, int act,
+                     const float* ln_s, const float* ln_stats, int ln_np, float* stats_out, int* np_out, ec_stream_t stream) {
+    if (!A || !Wt || !out || !bias) return EC_ERR_ARG;
+    if (M <= 0 || N % 128 != 0 || K % 64 != 0 || K < 64) return EC_ERR_SHAPE;
+    if (res && act == EC_ACT_QUICKGELU) return EC_ERR_UNSUPPORTED;
+    if (ln_s && (res || !ln_stats || ln_np < 1 || ln_np > 8)) return EC_ERR_ARG;
+    ConvArgs a;
+    a.in = (const uint16_t*)A;
+    a.w = (const uint16_t*)Wt;
+    a.bias = bias;
+    a.res = (const uint16_t*)res;
+    a.out = (uint16_t*)out;
+    a.H = 1; a.W = M; a.Cin = K; a.Cout = N; a.ldo = N;
+    a.K = K; a.M = M;
+    a.cin_log2 = 0;
+    a.act = act;
+    a.ntn = 0;
+    if ((long)M * K * 2 >= (1L << 31) || (long)N * K * 2 >= (1L << 31)) return EC_ERR_SHAPE;
+    a.in_bytes = (unsigned)((long)M * K * 2);
+    a.w_bytes = (unsigned)((long)N * K * 2);
+    if (res && (long)M * N * 2 >= (1L << 32) - 16) return EC_ERR_SHAPE;
+    a.res_bytes = res ? (unsigned)((long)M * N * 2) : 0u;
+    a.ln_s = ln_s; a.ln_stats = ln_s ? ln_stats : nullptr; a.ln_np = ln_np; a.stats_out = stats_out;
+    // tile width: 256 where it divides N and leaves enough tiles (QKV / c_fc at >= 3,200 rows); 128-wide long-segment tiles
+    // otherwise (out_proj / c_proj: N = D; every N of a narrow tower).  A producer's records must fit the consumer's 8 slots.
+    // One 8-wave workgroup per CU: a launch costs ceil(tiles / 256) rounds of its tile.  256-wide tiles when they need no more
+    // rounds-worth of work than 128-wide ones (a 256-wide tile = two 128-wide ones): QKV at 6,400 rows is 225 wide tiles (one
+    // round) against 450 narrow ones (two half rounds) -- wide; c_fc is 300 wide tiles (two rounds, the second 17 % full) against
+    // 600 narrow ones (three half rounds) -- narrow: 50 -> 38 us alone.  EC_VIT_WIDE: 0 = always 128-wide, 1 = this rule, 2 = 256-wide wherever N allows.
+    const long rt = (M + 255) / 256;
+    static const int wide_mode = [] { const char* e = getenv("EC_VIT_WIDE"); return e ? atoi(e) : 1; }();
+    const long r256 = (rt * (N / 256) + 255) / 256 * 2, r128 = (rt * (N / 128) + 255) / 256;
+    bool wide = (N % 256 == 0) && ((wide_mode == 1 && rt * (N / 256) >= 100 && r256 <= r128) || wide_mode == 2);
+    if (stats_out && N / 128 > 8 && N % 256 == 0) wide = true;
+    if (stats_out && N / (wide ? 256 : 128) > 8) return EC_ERR_SHAPE;
+    if (np_out) *np_out = N / (wide ? 256 : 128);
+    return wide ? launch8<256, 1, false>(a, (hipStream_t)stream) : launch8<128, 1, false>(a, (hipStream_t)stream);
 }
 
 extern "C" int ec_gemm_bf16(const void* A, const void* Wt, const float* bias, const void* res, void* out, int M, int N,

@@ -23,6 +23,10 @@ extern "C" int ec_gemm_bf16(const void* A, const void* Wt, const float* bias, co
 
 extern "C" int ec_bf16_to_f32(const void* in, float* out, long rows, long row_len, long in_stride, ec_stream_t stream);
 
+// conv_igemm.hip: the 8-wave GEMM with LayerNorm folded in (consumer) / emitting the rows' LayerNorm records (producer)
+int ec_gemm_bf16_ln8(const void* A, const void* Wt, const float* bias, const void* res, void* out, int M, int N, int K, int act,
+                     const float* ln_s, const float* ln_stats, int ln_np, float* stats_out, int* np_out, ec_stream_t stream);
+
 namespace {
 
 __device__ __forceinline__ float wave_sum_f(float v) {
@@ -64,7 +68,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void layernorm_kernel(const uint16_t* __restrict__ in, const float* __restrict__ cls,
                                                        const float* __restrict__ pos, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, uint16_t* __restrict__ out,
-                                                       long rows, int D, int L, float eps) {
+                                                       long rows, int D, int L, float eps, float4* __restrict__ stats_out = nullptr) {
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
@@ -131,12 +135,74 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const uint16_t* __restri
         if (i < per) { const float d0 = v[i] - mean; q += d0 * d0; }
     const float rstd = rsqrtf(wave_sum_f(q) / (float)D + eps);
     uint16_t* o = out + row * D;
+    float so = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i)
         if (i < per) {
             const int d = i * 64 + lane;
-            o[d] = (uint16_t)(ec_pack2((v[i] - mean) * rstd * gamma[d] + beta[d], 0.f) & 0xffffu);
+            const uint16_t ob = (uint16_t)(ec_pack2((v[i] - mean) * rstd * gamma[d] + beta[d], 0.f) & 0xffffu);
+            o[d] = ob;
+            v[i] = ec_bf2f(ob);                                  // the ROUNDED value: what the next block's folded LayerNorm sees
+            so += v[i];
         }
+    if (stats_out) {   // the output row's LayerNorm record {sum, M2, count} for the first block's folded ln_1 (one record per row)
+        so = wave_sum_f(so);
+        const float mo = so / (float)D;
+        float qo = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i)
+            if (i < per) { const float d0 = v[i] - mo; qo += d0 * d0; }
+        qo = wave_sum_f(qo);
+        if (lane == 0) stats_out[row] = make_float4(so, qo, (float)D, 0.f);
+    }
+}
+
+// LayerNorm record {sum, M2, count} of every bf16 row of x [rows, D] (one wave per row): the input of a tower whose first block
+// is not preceded by a LayerNorm launch (the text tower's token + positional embedding)
+__global__ __launch_bounds__(256) void row_stats_kernel(const uint16_t* __restrict__ x, float4* __restrict__ stats, long rows, int D) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float v[16];
+    const int per = D / 64;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if (i < per) { v[i] = ec_bf2f(x[row * D + i * 64 + lane]); s += v[i]; }
+    s = wave_sum_f(s);
+    const float m = s / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if (i < per) { const float d0 = v[i] - m; q += d0 * d0; }
+    q = wave_sum_f(q);
+    if (lane == 0) stats[row] = make_float4(s, q, (float)D, 0.f);
+}
+
+// Folds a LayerNorm into the Linear that consumes it ([U] clip/model.py ResidualAttentionBlock: attn(ln_1(x)), mlp(ln_2(x))):
+//   LN(x) W^T + b = rstd (x (W diag(gamma))^T - mean s) + c,   s[n] = sum_k Wg[n, k],   c[n] = sum_k beta[k] W[n, k] + b[n]
+// Wg is rounded to bf16 and s sums the ROUNDED values (what the MFMA multiplies), so the mean term cancels exactly.  One
+// workgroup per output row n; once per set of weights.
+__global__ __launch_bounds__(256) void ln_fold_kernel(const uint16_t* __restrict__ W, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, const float* __restrict__ b,
+                                                     uint16_t* __restrict__ Wg, float* __restrict__ s_out, float* __restrict__ c_out, int K) {
+    const int n = blockIdx.x;
+    float s = 0.f, c = 0.f;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const float w = ec_bf2f(W[(long)n * K + k]);
+        const uint16_t g = (uint16_t)(ec_pack2(w * gamma[k], 0.f) & 0xffffu);
+        Wg[(long)n * K + k] = g;
+        s += ec_bf2f(g);
+        c = fmaf(beta[k], w, c);
+    }
+    __shared__ float rs[4], rc[4];
+    s = wave_sum_f(s); c = wave_sum_f(c);
+    if ((threadIdx.x & 63) == 0) { rs[threadIdx.x >> 6] = s; rc[threadIdx.x >> 6] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s_out[n] = (rs[0] + rs[1]) + (rs[2] + rs[3]);
+        c_out[n] = ((rc[0] + rc[1]) + (rc[2] + rc[3])) + b[n];
+    }
 }
 
 // Multi-head self-attention core for L <= 64 tokens and head dim 64: one wave per (frame, head).
@@ -459,12 +525,25 @@ inline size_t al256(size_t v) { return (v + 255) / 256 * 256; }
 
 }  // namespace
 
+// LayerNorm-folded copies of a tower's blocks (handle-owned, built once at create time by ln_fold_kernel): per block
+// Wg_qkv [3D][D] and Wg_fc [4D][D] (bf16, = W diag(gamma)) and the fp32 vectors s_qkv, c_qkv (3D each), s_fc, c_fc (4D each).
+struct ec_lnfold {
+    uint16_t* w = nullptr;
+    float* f = nullptr;
+    bool ok = false;
+    ~ec_lnfold() {
+        if (w) (void)hipFree(w);
+        if (f) (void)hipFree(f);
+    }
+};
+
 struct ec_vit {
     int width, layers, heads, patch, res, grid, L;
     const uint16_t* w;
     const float* f;
     size_t n_w, n_f;
     int conv8_min_tiles = 0;      // 0 = library default (ec_vit_set_conv8_min_tiles)
+    ec_lnfold fold;
 };
 
 #define RC(x) do { int rc__ = (x); if (rc__ != EC_OK) return rc__; } while (0)
@@ -475,12 +554,43 @@ size_t mha_general_lds(int L) { return (size_t)L * 72 * 2 * 2 + 4 * 64 * 4 + 4 *
 
 // `layers` ResidualAttentionBlocks ([U] clip/model.py) on the bf16 residual stream x [B*L, D]; w / f point at the
 // first block's weights (wqkv, wo, wfc, wpr) / params (ln1 w,b, bqkv, bo, ln2 w,b, bfc, bpr) and are advanced.
+// Builds the folded copies for `layers` blocks whose weights / params start at (w, f): EC_OK, or leaves fold.ok = false when the
+// geometry does not suit the folded GEMMs (D % 128 != 0, more than 8 records per row) -- run_blocks then keeps the LayerNorm launches.
+int build_lnfold(ec_lnfold& fold, const uint16_t* w, const float* f, int layers, int D) {
+    if (layers <= 0 || D % 128 != 0 || D / 128 > 8) return EC_OK;
+    const size_t Dz = (size_t)D, wl = 7 * Dz * Dz, fl = 14 * Dz;
+    if (hipMalloc(&fold.w, layers * wl * sizeof(uint16_t)) != hipSuccess) { fold.w = nullptr; return EC_ERR_ALLOC; }
+    if (hipMalloc(&fold.f, layers * fl * sizeof(float)) != hipSuccess) { fold.f = nullptr; return EC_ERR_ALLOC; }
+    for (int l = 0; l < layers; ++l) {
+        const float *ln1w = f, *ln1b = f + D, *bqkv = f + 2 * D, *bo = bqkv + 3 * D, *ln2w = bo + D, *ln2b = ln2w + D, *bfc = ln2b + D;
+        const uint16_t *wqkv = w, *wfc = w + (size_t)4 * D * D;
+        uint16_t* wg = fold.w + l * wl;
+        float* fg = fold.f + l * fl;
+        hipLaunchKernelGGL(ln_fold_kernel, dim3((unsigned)(3 * D)), dim3(256), 0, nullptr, wqkv, ln1w, ln1b, bqkv, wg, fg, fg + 3 * Dz, D);
+        hipLaunchKernelGGL(ln_fold_kernel, dim3((unsigned)(4 * D)), dim3(256), 0, nullptr, wfc, ln2w, ln2b, bfc, wg + 3 * Dz * Dz,
+                           fg + 6 * Dz, fg + 10 * Dz, D);
+        f += 13 * Dz;
+        w += 12 * Dz * Dz;
+    }
+    if (hipStreamSynchronize(nullptr) != hipSuccess || hipGetLastError() != hipSuccess) return EC_ERR_LAUNCH;
+    fold.ok = true;
+    return EC_OK;
+}
+
+// `layers` ResidualAttentionBlocks ([U] clip/model.py) on the bf16 residual stream x [B*L, D]; w / f point at the
+// first block's weights (wqkv, wo, wfc, wpr) / params (ln1 w,b, bqkv, bo, ln2 w,b, bfc, bpr) and are advanced.
+// fold != nullptr (built by build_lnfold): ln_1 / ln_2 are folded into the QKV / c_fc GEMMs -- no LayerNorm launch, no
+// normalised copy of x: the GEMMs multiply the RAW rows against W diag(gamma) and apply (mean, rstd) in their epilogue; the rows'
+// statistics come as partial records out of the epilogue of the GEMM that produced x (out_proj / c_proj + residual), `stats`
+// holding `np` records per row on entry (the caller's: ln_pre's output rows, or row_stats_kernel).
 int run_blocks(const uint16_t*& w, const float*& f, int layers, int heads, uint16_t* x, uint16_t* hbuf, uint16_t* qkv,
-               uint16_t* att, uint16_t* mlp, int B, int L, int D, bool causal, ec_stream_t stream) {
+               uint16_t* att, uint16_t* mlp, int B, int L, int D, bool causal, const ec_lnfold* fold, float* stats, int np,
+               ec_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     const long rows = (long)B * L;
     const unsigned lnb = (unsigned)((rows + 3) / 4);
     const bool general = causal || L > 64;
+    const bool folded = fold && fold->ok && stats;
     if (general) {
         if (L > MHA_GENERAL_MAX_TOKENS) return EC_ERR_SHAPE;
         static std::atomic<uint64_t> attr_done{0};
@@ -496,9 +606,16 @@ int run_blocks(const uint16_t*& w, const float*& f, int layers, int heads, uint1
         f = bpr + D;
         const uint16_t *wqkv = w, *wo = w + (size_t)3 * D * D, *wfc = wo + (size_t)D * D, *wpr = wfc + (size_t)4 * D * D;
         w = wpr + (size_t)4 * D * D;
+        const size_t Dz = (size_t)D;
+        const uint16_t* wg = folded ? fold->w + (size_t)l * 7 * Dz * Dz : nullptr;
+        const float* fg = folded ? fold->f + (size_t)l * 14 * Dz : nullptr;
+        if (folded)
+            RC(ec_gemm_bf16_ln8(x, wg, fg + 3 * Dz, nullptr, qkv, (int)rows, 3 * D, D, EC_ACT_NONE, fg, stats, np, nullptr, nullptr, stream));
+        else {
         hipLaunchKernelGGL(layernorm_kernel<0>, dim3(lnb), dim3(256), 0, s, x, nullptr, nullptr, ln1w, ln1b, hbuf, rows, D,
-                           L, 1e-5f);
+                           L, 1e-5f, nullptr);
         RC(ec_gemm_bf16(hbuf, wqkv, bqkv, nullptr, qkv, (int)rows, 3 * D, D, EC_ACT_NONE, stream));
+        }
         if (!general)
             hipLaunchKernelGGL(mha_kernel, dim3((unsigned)(B * heads)), dim3(64), 0, s, qkv, att, L, D, heads, 0.125f);
         else if (causal)
@@ -507,9 +624,16 @@ int run_blocks(const uint16_t*& w, const float*& f, int layers, int heads, uint1
         else
             hipLaunchKernelGGL(mha_general_kernel<false>, dim3((unsigned)(B * heads)), dim3(256), mha_general_lds(L), s, qkv, att,
                                L, D, heads, 0.125f);
+        if (folded) {
+            RC(ec_gemm_bf16_ln8(att, wo, bo, x, x, (int)rows, D, D, EC_ACT_NONE, nullptr, nullptr, 0, stats, &np, stream));   // x += out_proj(...); + ln_2's records
+            RC(ec_gemm_bf16_ln8(x, wg + 3 * Dz * Dz, fg + 10 * Dz, nullptr, mlp, (int)rows, 4 * D, D, EC_ACT_QUICKGELU, fg + 6 * Dz, stats, np,
+                                nullptr, nullptr, stream));
+            RC(ec_gemm_bf16_ln8(mlp, wpr, bpr, x, x, (int)rows, D, 4 * D, EC_ACT_NONE, nullptr, nullptr, 0, stats, &np, stream));   // x += c_proj(...); + the next ln_1's records
+            continue;
+        }
         RC(ec_gemm_bf16(att, wo, bo, x, x, (int)rows, D, D, EC_ACT_NONE, stream));          // x += out_proj(...)
         hipLaunchKernelGGL(layernorm_kernel<0>, dim3(lnb), dim3(256), 0, s, x, nullptr, nullptr, ln2w, ln2b, hbuf, rows, D,
-                           L, 1e-5f);
+                           L, 1e-5f, nullptr);
         RC(ec_gemm_bf16(hbuf, wfc, bfc, nullptr, mlp, (int)rows, 4 * D, D, EC_ACT_QUICKGELU, stream));
         RC(ec_gemm_bf16(mlp, wpr, bpr, x, x, (int)rows, D, 4 * D, EC_ACT_NONE, stream));     // x += c_proj(...)
     }
@@ -532,6 +656,10 @@ extern "C" int ec_vit_create(ec_vit_t** out, int width, int layers_run, int head
     if (!h) return EC_ERR_ALLOC;
     h->width = width; h->layers = layers_run; h->heads = heads; h->patch = patch; h->res = input_resolution;
     h->grid = G; h->L = L; h->w = (const uint16_t*)w_bf16; h->f = params_f32; h->n_w = n_w; h->n_f = n_f;
+    {   // LayerNorm-folded copies of the blocks' QKV / c_fc weights (the weights must be on the device by now: they are read here)
+        const int rc = build_lnfold(h->fold, h->w + D * Kp, h->f + D + L * D + 2 * D, layers_run, width);
+        if (rc != EC_OK) { delete h; return rc; }
+    }
     *out = h;
     return EC_OK;
 }
@@ -559,7 +687,7 @@ extern "C" size_t ec_vit_workspace_bytes(const ec_vit_t* h, int batch) {
     if (!h || batch <= 0) return 0;
     const size_t D = h->width, Kp = (size_t)h->patch * h->patch * 3, G2 = (size_t)h->grid * h->grid, L = h->L, B = batch;
     return al256(B * G2 * Kp * 2) + al256(B * G2 * D * 2) + al256(B * L * D * 2) + al256(B * L * 3 * D * 2) +
-           al256(B * L * D * 2) + al256(B * L * 4 * D * 2);
+           al256(B * L * D * 2) + al256(B * L * 4 * D * 2) + al256(B * L * 8 * 16);   // (+ the rows' LayerNorm records: 8 x {sum, M2, count, -})
 }
 
 extern "C" int ec_vit_forward(const ec_vit_t* h, const float* rgb, int batch, void* workspace, size_t ws_bytes,
@@ -578,7 +706,8 @@ extern "C" int ec_vit_forward(const ec_vit_t* h, const float* rgb, int batch, vo
     uint16_t* hbuf = (uint16_t*)p;    p += al256((size_t)B * L * D * 2);
     uint16_t* qkv = (uint16_t*)p;     p += al256((size_t)B * L * 3 * D * 2);
     uint16_t* att = (uint16_t*)p;     p += al256((size_t)B * L * D * 2);
-    uint16_t* mlp = (uint16_t*)p;
+    uint16_t* mlp = (uint16_t*)p;     p += al256((size_t)B * L * 4 * D * 2);
+    float* stats = (float*)p;
     uint16_t* x = (uint16_t*)tokens_bf16;   // residual stream lives in the output buffer
     const uint16_t* w = h->w;
     const float* f = h->f;
@@ -595,8 +724,8 @@ extern "C" int ec_vit_forward(const ec_vit_t* h, const float* rgb, int batch, vo
     const long rows = (long)B * L;
     const unsigned lnb = (unsigned)((rows + 3) / 4);
     hipLaunchKernelGGL(layernorm_kernel<1>, dim3(lnb), dim3(256), 0, s, pemb, cls, pos, lnpre_w, lnpre_b, x, rows, D, L,
-                       1e-5f);
-    RC(run_blocks(w, f, h->layers, h->heads, x, hbuf, qkv, att, mlp, B, L, D, false, stream));
+                       1e-5f, h->fold.ok ? (float4*)stats : nullptr);   // (+ the record of every output row: block 0's folded ln_1)
+    RC(run_blocks(w, f, h->layers, h->heads, x, hbuf, qkv, att, mlp, B, L, D, false, &h->fold, stats, 1, stream));
     EC_CHECK_LAUNCH();
     return EC_OK;
 }
@@ -610,6 +739,7 @@ struct ec_text {
     int width, layers, heads, ctx, vocab, embed;
     const uint16_t* w;
     const float* f;
+    ec_lnfold fold;
 };
 
 extern "C" int ec_text_create(ec_text_t** out, int width, int layers, int heads, int context_length, int vocab_size,
@@ -626,6 +756,10 @@ extern "C" int ec_text_create(ec_text_t** out, int width, int layers, int heads,
     if (!h) return EC_ERR_ALLOC;
     h->width = width; h->layers = layers; h->heads = heads; h->ctx = context_length; h->vocab = vocab_size;
     h->embed = embed_dim; h->w = (const uint16_t*)w_bf16; h->f = params_f32;
+    {
+        const int rc = build_lnfold(h->fold, h->w, h->f + (size_t)vocab_size * D + (size_t)context_length * D, layers, width);
+        if (rc != EC_OK) { delete h; return rc; }
+    }
     *out = h;
     return EC_OK;
 }
@@ -635,7 +769,7 @@ extern "C" size_t ec_text_workspace_bytes(const ec_text_t* h, int batch) {
     if (!h || batch <= 0) return 0;
     const size_t D = h->width, L = h->ctx, B = batch;
     return al256(B * L * D * 2) * 3 + al256(B * L * 3 * D * 2) + al256(B * L * 4 * D * 2) + al256(B * D * 2) +
-           al256(B * (size_t)h->embed * 2);
+           al256(B * (size_t)h->embed * 2) + al256(B * L * 8 * 16);
 }
 
 extern "C" int ec_text_forward(const ec_text_t* h, const int32_t* tokens, int batch, void* workspace, size_t ws_bytes,
@@ -653,7 +787,8 @@ extern "C" int ec_text_forward(const ec_text_t* h, const int32_t* tokens, int ba
     uint16_t* qkv = (uint16_t*)p;  p += al256((size_t)B * L * 3 * D * 2);
     uint16_t* mlp = (uint16_t*)p;  p += al256((size_t)B * L * 4 * D * 2);
     uint16_t* eot = (uint16_t*)p;  p += al256((size_t)B * D * 2);
-    uint16_t* emb = (uint16_t*)p;
+    uint16_t* emb = (uint16_t*)p;  p += al256((size_t)B * E * 2);
+    float* stats = (float*)p;
     const float* f = h->f;
     const float *tok_emb = f, *pos = f + (size_t)h->vocab * D;
     f = pos + (size_t)L * D;
@@ -662,7 +797,9 @@ extern "C" int ec_text_forward(const ec_text_t* h, const int32_t* tokens, int ba
     const long n2 = rows * (D / 2);
     hipLaunchKernelGGL(embed_tokens_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, s, tokens, tok_emb, pos, x, rows, L,
                        D, h->vocab);
-    RC(run_blocks(w, f, h->layers, h->heads, x, hbuf, qkv, att, mlp, B, L, D, true, stream));
+    if (h->fold.ok)   // the embedding rows' LayerNorm records for block 0's folded ln_1
+        hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, (float4*)stats, rows, D);
+    RC(run_blocks(w, f, h->layers, h->heads, x, hbuf, qkv, att, mlp, B, L, D, true, &h->fold, stats, 1, stream));
     hipLaunchKernelGGL(eot_layernorm_kernel, dim3((unsigned)B), dim3(64), 0, s, tokens, x, f, f + D, eot, L, D, 1e-5f);
     RC(ec_gemm_bf16(eot, w, nullptr, nullptr, emb, B, E, D, EC_ACT_NONE, stream));          // @ text_projection
     RC(ec_bf16_to_f32(emb, out, B, E, E, stream));
