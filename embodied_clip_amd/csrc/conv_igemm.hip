@@ -687,11 +687,14 @@ __device__ unsigned long long ec_dbg_stamps[2 * 1024];   // profiling only (tool
 // ([Cout][3][K], lowest plane first in the K walk); a K-tile of A is walked three times, once against each plane, into
 // the same accumulators, and the epilogue writes fp32 (bias / ReLU) -- the bf16x3 "exact fp32" product of gemm_f32.hip on
 // this kernel's schedule.
-template <int BN, int KS, bool POOL, int ABL, bool X3 = false, bool S2 = false>
+// BM (round 6): 192-row tiles for GEMMs whose 256-row tiling leaves CUs idle -- ViT-B/32's N = 768 GEMMs at 6,400 tokens are
+// 25 x 6 = 150 tiles on 256 CUs; 34 x 6 = 204 tiles of 192 x 128 take 0.75 of a 256 x 128 tile's time each (ec_gemm_bf16_ln8).
+template <int BN, int KS, bool POOL, int ABL, bool X3 = false, bool S2 = false, int BM = 256>
 __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
     // wave grid: 2 (M) x 4 (N) for 256-wide tiles (wave tile 128 x 64); 4 x 2 for 128-wide tiles (wave tile 64 x 64:
-    // 4 fragment reads per 4 MFMAs instead of the 5 a 128 x 32 wave tile needs)
-    constexpr int BM = 256, WN = (BN >= 256) ? 4 : 2, WMW = 8 / WN;
+    // 4 fragment reads per 4 MFMAs instead of the 5 a 128 x 32 wave tile needs); 192-row tiles: 2 x 4, wave tile 96 x 32
+    static_assert(BM == 256 || (BM == 192 && BN == 128 && !POOL && !X3), "tile heights: 256; 192 for 128-wide 1x1 / 3x3 tiles");
+    constexpr int WN = (BN >= 256 || BM == 192) ? 4 : 2, WMW = 8 / WN;
     constexpr int TM = BM / WMW, TN = BN / WN;
     constexpr int FM = TM / 32, FN = TN / 32;
     constexpr int NT = 512, LR = NT / 8;
@@ -1203,18 +1206,18 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
     if constexpr ((ABL & 32) != 0) if (blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0) ec_dbg_stamps[grp * 1024 + 302] = __builtin_amdgcn_s_memtime();
 }
 
-template <int BN, int KS, bool POOL, bool X3 = false, bool S2 = false>
+template <int BN, int KS, bool POOL, bool X3 = false, bool S2 = false, int BM = 256>
 int launch8(const ConvArgs& a, hipStream_t s) {
     ConvArgs p = a;
     p.ntn = a.Cout / BN;
-    p.ntiles = ((a.M + 255) / 256) * p.ntn;
+    p.ntiles = ((a.M + BM - 1) / BM) * p.ntn;
     const int ablate = ec_tools_ablate();
     p.ablate = ablate;
     const bool ls = BN == 128 && ec_config().conv8_longseg;
     // (long segments: three stages; X3: two A chunks + three plane tiles)
-    const size_t stages = ls ? (X3 ? (size_t)(2 * 256 + 3 * BN) * ROW_BYTES : 3 * (size_t)(256 + BN) * ROW_BYTES)
-                             : 2 * (size_t)(256 + BN) * ROW_BYTES;
-    const size_t epi = X3 ? (size_t)128 * (BN * 4 + 16) : (size_t)(POOL ? 64 : 256) * (BN * 2 + 16);
+    const size_t stages = ls ? (X3 ? (size_t)(2 * 256 + 3 * BN) * ROW_BYTES : 3 * (size_t)(BM + BN) * ROW_BYTES)
+                             : 2 * (size_t)(BM + BN) * ROW_BYTES;
+    const size_t epi = X3 ? (size_t)128 * (BN * 4 + 16) : (size_t)(POOL ? 64 : BM) * (BN * 2 + 16);
     const size_t lds = (stages > epi ? stages : epi) + 4096;   // + auxiliary area: LayerNorm row table (2 KB) / stamps (profiling)
     p.aux_off = (int)(lds - 4096);
     auto go = [&](auto kern) {
@@ -1250,12 +1253,12 @@ int launch8(const ConvArgs& a, hipStream_t s) {
 #endif
     if constexpr (BN == 128) {
         if (ls) {
-            go(conv_igemm8_kernel<BN, KS, POOL, 512, X3, S2>);
+            go(conv_igemm8_kernel<BN, KS, POOL, 512, X3, S2, BM>);
             EC_CHECK_LAUNCH();
             return EC_OK;
         }
     }
-    go(conv_igemm8_kernel<BN, KS, POOL, 0, X3, S2>);
+    go(conv_igemm8_kernel<BN, KS, POOL, 0, X3, S2, BM>);
     EC_CHECK_LAUNCH();
     return EC_OK;
 }
@@ -1556,20 +1559,27 @@ int ec_gemm_bf16_ln8(const void* A, const void* Wt, const float* bias, const voi
     if (res && (long)M * N * 2 >= (1L << 32) - 16) return EC_ERR_SHAPE;
     a.res_bytes = res ? (unsigned)((long)M * N * 2) : 0u;
     a.ln_s = ln_s; a.ln_stats = ln_s ? ln_stats : nullptr; a.ln_np = ln_np; a.stats_out = stats_out;
-    // tile width: 256 where it divides N and leaves enough tiles (QKV / c_fc at >= 3,200 rows); 128-wide long-segment tiles
-    // otherwise (out_proj / c_proj: N = D; every N of a narrow tower).  A producer's records must fit the consumer's 8 slots.
-    // One 8-wave workgroup per CU: a launch costs ceil(tiles / 256) rounds of its tile.  256-wide tiles when they need no more
-    // rounds-worth of work than 128-wide ones (a 256-wide tile = two 128-wide ones): QKV at 6,400 rows is 225 wide tiles (one
-    // round) against 450 narrow ones (two half rounds) -- wide; c_fc is 300 wide tiles (two rounds, the second 17 % full) against
-    // 600 narrow ones (three half rounds) -- narrow: 50 -> 38 us alone.  EC_VIT_WIDE: 0 = always 128-wide, 1 = this rule, 2 = 256-wide wherever N allows.
+    // Tile width: 256 where it divides N and leaves at least 100 tiles (QKV / c_fc at 6,400 rows: 225 / 300), 128-wide
+    // long-segment tiles otherwise (out_proj / c_proj: N = D).  Measured and rejected (same box, round 6): choosing the width by
+    // rounds of workgroups -- c_fc as 600 narrow tiles (three half rounds) instead of 300 wide ones (two rounds, the second
+    // 17 % full) -- loses alone (1.905 -> 1.969 ms per 128 frames) and with two launches in flight (81.1 -> 79.2 k
+    // env-frames/s): the 256-wide tile is the cheaper one per flop.  EC_VIT_WIDE: 0 = always 128-wide, 2 = 256-wide wherever N allows.
     const long rt = (M + 255) / 256;
     static const int wide_mode = [] { const char* e = getenv("EC_VIT_WIDE"); return e ? atoi(e) : 1; }();
-    const long r256 = (rt * (N / 256) + 255) / 256 * 2, r128 = (rt * (N / 128) + 255) / 256;
-    bool wide = (N % 256 == 0) && ((wide_mode == 1 && rt * (N / 256) >= 100 && r256 <= r128) || wide_mode == 2);
-    if (stats_out && N / 128 > 8 && N % 256 == 0) wide = true;
+    bool wide = (N % 256 == 0) && ((wide_mode == 1 && rt * (N / 256) >= 100) || wide_mode == 2);
+    if (stats_out && N / 128 > 8 && N % 256 == 0) wide = true;        // (a producer's records must fit the consumer's 8 slots)
     if (stats_out && N / (wide ? 256 : 128) > 8) return EC_ERR_SHAPE;
     if (np_out) *np_out = N / (wide ? 256 : 128);
-    return wide ? launch8<256, 1, false>(a, (hipStream_t)stream) : launch8<128, 1, false>(a, (hipStream_t)stream);
+    if (wide) return launch8<256, 1, false>(a, (hipStream_t)stream);
+    // 128-wide tiles: 192 rows instead of 256 when that costs fewer rounds-worth of work (a 192-row tile = 0.75 of a 256-row one):
+    // N = 768 at 6,400 rows is 150 tiles (one round on 59 % of the CUs) against 204 (one round at 0.75).  Same box, round 6: the
+    // forward alone 1.905 -> 1.80 ms per 128 frames; with two launches in flight (whose idle CUs the other launch fills) neutral
+    // (81.1 / 80.6 -> 81.1 / 80.7 k env-frames/s).  EC_VIT_BM192 = 0: off
+    static const int bm192 = [] { const char* e = getenv("EC_VIT_BM192"); return e ? atoi(e) : 1; }();
+    const long t256 = rt * (N / 128), t192 = ((M + 191) / 192) * (long)(N / 128);
+    if (bm192 && ((t192 + 255) / 256) * 3 < ((t256 + 255) / 256) * 4)
+        return launch8<128, 1, false, false, false, 192>(a, (hipStream_t)stream);
+    return launch8<128, 1, false>(a, (hipStream_t)stream);
 }
 
 extern "C" int ec_gemm_bf16(const void* A, const void* Wt, const float* bias, const void* res, void* out, int M, int N,
