@@ -406,9 +406,12 @@ def run_rank(a, rank: int, local_rank: int, world: int, init_method=None):
                                       (": one call after the backward)" if a.no_overlap_allreduce else
                                        ": GRU + heads section (12.8 MB) under the goal encoder's backward, the remaining 1.1 MB after it)"),
                        "flop_per_frame": flop_per_frame,
-                       "policy_gemm_mode": ("fp32 x fp32 as bf16x3: six exact products forward, THREE leading products in the backward's "
-                                            "large gradient GEMMs (EC_GEMM_BWD3=1)" if os.environ.get("EC_GEMM_BWD3", "0") not in ("", "0")
-                                            else "fp32 x fp32 as bf16x3, six exact products forward and backward (fp32-exact; EC_GEMM_BWD3=0)")},
+                       "policy_gemm_mode": (
+                           "EC_POLICY_FAST=0: every policy GEMM fp32-exact (fp32 x fp32 as six bf16 products, bf16 x fp32 as three planes)"
+                           if os.environ.get("EC_POLICY_FAST", "1") in ("", "0") and os.environ.get("EC_GEMM_BWD3", "0") in ("", "0") else
+                           "forward fp32-exact except the compressor conv over the stored features (two leading planes of W1: 16 mantissa "
+                           "bits); backward: the large gradient GEMMs on the three leading bf16x3 products, dW1 on two planes of dc1 "
+                           "(products accurate to 2^-16 .. 2^-17; parity tests at unchanged tolerances; EC_POLICY_FAST=0 = fp32-exact)")},
             "update_ms": update_ms,      # the 4 PPO epochs (forward, loss, backward, all-reduce, clip + Adam) per iteration: HIP events, main stream
             "rccl_ranks": rccl_ranks, "allreduce_ms_per_rank": None,
             "roofline": {"bound": "mfma", "co_bound": "mfma + hbm (co-bound: see hbm_frac)",

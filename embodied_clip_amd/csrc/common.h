@@ -137,7 +137,11 @@ struct EcConfig {
     int rn50_dscat;       // EC_RN50_DSCAT    (1)   stride-2 Bottlenecks of layers 3-4: conv3 and the downsample conv as ONE GEMM over the concatenated K axis (pooled conv2 output | pooled block input)
     // --- policy / update ---
     int gemm_no_x3;       // EC_GEMM_NO_X3    (0)   policy GEMMs on the fp32 MFMA instead of bf16x3
-    int gemm_bwd3;        // EC_GEMM_BWD3     (0)   ec_policy_backward's large gradient GEMMs on three of the six bf16x3 products
+    int gemm_bwd3;        // EC_GEMM_BWD3     (0)   ec_policy_backward's large gradient GEMMs on three of the six bf16x3 products (also on under EC_POLICY_FAST)
+    int policy_fast;      // EC_POLICY_FAST   (1)   learn pass: the backward's large gradient GEMMs on the three leading bf16x3 products, the compressor conv over the
+                          //                        stored features and its weight gradient on the two leading planes of the fp32 operand (16 mantissa bits; products
+                          //                        accurate to 2^-16 .. 2^-17 -- finer than the TF32 the reference's torch 1.7 uses for fp32 matmuls on Ampere);
+                          //                        0: every policy GEMM fp32-exact (six products / three planes)
     int act_split;        // EC_ACT_SPLIT     (1)   act step: K-split kernels for its two long-K GEMMs
     int tail_fused;       // EC_TAIL_FUSED    (1)   compressor tail / combiner fused kernels
     int gru_fused;        // EC_GRU_FUSED     (2)   0 GEMM + gate kernels, 1 fused 32x32-tile step kernels, 2 + 16x16-tile kernels in the update

@@ -689,7 +689,9 @@ __device__ unsigned long long ec_dbg_stamps[2 * 1024];   // profiling only (tool
 // this kernel's schedule.
 // BM (round 6): 192-row tiles for GEMMs whose 256-row tiling leaves CUs idle -- ViT-B/32's N = 768 GEMMs at 6,400 tokens are
 // 25 x 6 = 150 tiles on 256 CUs; 34 x 6 = 204 tiles of 192 x 128 take 0.75 of a 256 x 128 tile's time each (ec_gemm_bf16_ln8).
-template <int BN, int KS, bool POOL, int ABL, bool X3 = false, bool S2 = false, int BM = 256>
+// XP (X3 only): planes of the weight operand that are walked -- 3 = the exact-fp32 product; 2 = the two leading planes (16
+// mantissa bits of W, relative product error 2^-17: ec_gemm_bf16a_xp, the learn pass's compressor conv under EC_POLICY_FAST).
+template <int BN, int KS, bool POOL, int ABL, bool X3 = false, bool S2 = false, int BM = 256, int XP = 3>
 __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
     // wave grid: 2 (M) x 4 (N) for 256-wide tiles (wave tile 128 x 64); 4 x 2 for 128-wide tiles (wave tile 64 x 64:
     // 4 fragment reads per 4 MFMAs instead of the 5 a 128 x 32 wave tile needs); 192-row tiles: 2 x 4, wave tile 96 x 32
@@ -801,7 +803,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
 #endif
     const int wave_lds = wave * 1024;
-    const int nk = (X3 ? 3 : 1) * (p.K / BK);           // Cin % 64 == 0: whole K-tiles, one tap per K-tile
+    const int nk = (X3 ? XP : 1) * (p.K / BK);          // Cin % 64 == 0: whole K-tiles, one tap per K-tile
 
     // piece q of K-tile kt into stage buf: q < A_IT -> 8 pixel rows per wave, else 8 weight rows
     int g_toff = 0; unsigned g_tapbit = 1u; int g_kb = 0;
@@ -816,12 +818,12 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
         if (X3) {                                       // K-tile kt = (A chunk kt / 3) x (weight plane 2 - kt % 3)
             // LDS: [A chunk 0][A chunk 1][B 0][B 1] -- the A chunk is fetched ONCE (with the K-tile of its first plane)
             // and read by the three K-tiles of the chunk; only the 16-KB plane tiles alternate per K-tile
-            const int ch = kt / 3, pl = 2 - (kt - 3 * ch);
+            const int ch = kt / XP, pl = (XP - 1) - (kt - XP * ch);          // (lowest walked plane first)
             g_toff = ch * (BK * 2);
             g_kb = (pl * p.K + ch * BK) * 2;
             g_sa = smem + (ch & 1) * A_BYTES + wave_lds;
             g_sb = smem + 2 * A_BYTES + (LS ? buf : (kt & 1)) * B_BYTES + wave_lds;
-            g_issue_a = (kt == 3 * ch);
+            g_issue_a = (kt == XP * ch);
         }
         if (KS == 3) {
             const int k = kt * BK;
@@ -898,7 +900,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
         const unsigned char* sta = smem + stg * STAGE;
         const unsigned char* stb = sta;
         if (X3) {                                       // (fb_base carries + A_BYTES: see the LDS map in glds_begin)
-            sta = smem + ((kt / 3) & 1) * A_BYTES;
+            sta = smem + ((kt / XP) & 1) * A_BYTES;
             stb = smem + A_BYTES + stg * B_BYTES;
         }
 #pragma unroll
@@ -1206,7 +1208,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs p) {
     if constexpr ((ABL & 32) != 0) if (blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0) ec_dbg_stamps[grp * 1024 + 302] = __builtin_amdgcn_s_memtime();
 }
 
-template <int BN, int KS, bool POOL, bool X3 = false, bool S2 = false, int BM = 256>
+template <int BN, int KS, bool POOL, bool X3 = false, bool S2 = false, int BM = 256, int XP = 3>
 int launch8(const ConvArgs& a, hipStream_t s) {
     ConvArgs p = a;
     p.ntn = a.Cout / BN;
@@ -1253,12 +1255,12 @@ int launch8(const ConvArgs& a, hipStream_t s) {
 #endif
     if constexpr (BN == 128) {
         if (ls) {
-            go(conv_igemm8_kernel<BN, KS, POOL, 512, X3, S2, BM>);
+            go(conv_igemm8_kernel<BN, KS, POOL, 512, X3, S2, BM, XP>);
             EC_CHECK_LAUNCH();
             return EC_OK;
         }
     }
-    go(conv_igemm8_kernel<BN, KS, POOL, 0, X3, S2, BM>);
+    go(conv_igemm8_kernel<BN, KS, POOL, 0, X3, S2, BM, XP>);
     EC_CHECK_LAUNCH();
     return EC_OK;
 }
@@ -1500,9 +1502,16 @@ extern "C" int ec_conv_bf16_s2(const void* in, const void* w, const float* bias,
 // the exact-fp32 product of a bf16 activation matrix with an fp32 weight matrix, on the 8-wave ping-pong kernel.
 // Replaces the resnet_compressor's first 1x1 conv over the stored features
 // (allenact_plugins/.../resnet_tensor... ResnetTensorGoalEncoder.resnet_compressor[0], SURVEY.md section 8 row a).
+int ec_gemm_bf16a_xp(const void* A, const void* Wplanes, const float* bias, float* out, long M, int N, int K, int act, int planes,
+                     ec_stream_t stream);
 extern "C" int ec_gemm_bf16a_x3(const void* A, const void* Wplanes, const float* bias, float* out, long M, int N, int K,
                                 int act, ec_stream_t stream) {
-    if (!A || !Wplanes || !out) return EC_ERR_ARG;
+    return ec_gemm_bf16a_xp(A, Wplanes, bias, out, M, N, K, act, 3, stream);
+}
+// ... walking only the `planes` (2 or 3) leading planes of W (not part of the C-ABI; policy.hip's learn pass)
+int ec_gemm_bf16a_xp(const void* A, const void* Wplanes, const float* bias, float* out, long M, int N, int K, int act, int planes,
+                     ec_stream_t stream) {
+    if (!A || !Wplanes || !out || (planes != 2 && planes != 3)) return EC_ERR_ARG;
     if (M <= 0 || N % 128 != 0 || K % 64 != 0 || K < 64) return EC_ERR_SHAPE;
     if ((long)N * 3 * K * 2 >= (1L << 31)) return EC_ERR_SHAPE;
     // 32-bit byte offsets inside a launch: rows are processed in slabs of < 4 GiB of A
@@ -1523,7 +1532,8 @@ extern "C" int ec_gemm_bf16a_x3(const void* A, const void* Wplanes, const float*
         a.in_bytes = (unsigned)(rows * K * 2);
         a.w_bytes = (unsigned)((long)N * 3 * K * 2);
         a.res_bytes = 0u;
-        int rc = launch8<128, 1, false, true>(a, (hipStream_t)stream);
+        int rc = planes == 3 ? launch8<128, 1, false, true>(a, (hipStream_t)stream)
+                             : launch8<128, 1, false, true, false, 256, 2>(a, (hipStream_t)stream);
         if (rc != EC_OK) return rc;
     }
     return EC_OK;

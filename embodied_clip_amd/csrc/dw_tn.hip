@@ -47,6 +47,9 @@ struct DwArgs {
     int ntile, nsplit;    // column tiles (NX / 256), token splits
 };
 
+// NPL: planes of dY that are multiplied -- 3 = the exact-fp32 product, 2 = the two leading planes (EC_POLICY_FAST; all three
+// are still copied to LDS: the copy geometry is the plane layout's)
+template <int NPL>
 __global__ __launch_bounds__(512) void dw_tn_x3_kernel(DwArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -158,6 +161,7 @@ __global__ __launch_bounds__(512) void dw_tn_x3_kernel(DwArgs p) {
         const unsigned ax0 = sb + xb[0], ax1 = sb + xb[1], ay0 = sb + yb[0], ay1 = sb + yb[1];
         s16x4_t xa0, xa1, xa2, xa3, xc0, xc1, xc2, xc3;    // X fragments of k-step 0 / 1
         s16x4_t p0, p1, p2, p3, q0, q1, q2, q3;            // Y plane fragments, two sets in rotation
+        if constexpr (NPL == 3) {
         READ_X(0, xa0, xa1, xa2, xa3);
         READ_Y(0, 2, p0, p1, p2, p3);
         WAIT4(xa0, xa1, xa2, xa3);
@@ -180,6 +184,24 @@ __global__ __launch_bounds__(512) void dw_tn_x3_kernel(DwArgs p) {
         MFMA4(p0, p1, p2, p3, xc0, xc1, xc2, xc3);
         WAIT0(q0, q1, q2, q3);
         MFMA4(q0, q1, q2, q3, xc0, xc1, xc2, xc3);
+        } else {   // planes 1 and 0 only, lower one first (same read-ahead pattern: one group of four reads in flight)
+        READ_X(0, xa0, xa1, xa2, xa3);
+        READ_Y(0, 1, p0, p1, p2, p3);
+        WAIT4(xa0, xa1, xa2, xa3);
+        READ_Y(0, 0, q0, q1, q2, q3);
+        WAIT4(p0, p1, p2, p3);
+        MFMA4(p0, p1, p2, p3, xa0, xa1, xa2, xa3);
+        READ_X(1, xc0, xc1, xc2, xc3);
+        WAIT4(q0, q1, q2, q3);
+        MFMA4(q0, q1, q2, q3, xa0, xa1, xa2, xa3);
+        READ_Y(1, 1, p0, p1, p2, p3);
+        WAIT4(xc0, xc1, xc2, xc3);
+        READ_Y(1, 0, q0, q1, q2, q3);
+        WAIT4(p0, p1, p2, p3);
+        MFMA4(p0, p1, p2, p3, xc0, xc1, xc2, xc3);
+        WAIT0(q0, q1, q2, q3);
+        MFMA4(q0, q1, q2, q3, xc0, xc1, xc2, xc3);
+        }
     }
 #undef TR_READ
 #undef READ_X
@@ -227,8 +249,13 @@ extern "C" int ec_dw_tn_x3_splits(long M, int NX) {
 }
 
 // dW[128][NX] += dY^T X with dY given as bf16 planes [M][3][128] (ec_split3_bf16 layout) and X bf16 [M][NX]
+int ec_dw_tn_xp(const void* dYplanes, const void* X, float* part, float* dW, long M, int NX, int planes, ec_stream_t stream);
 extern "C" int ec_dw_tn_x3(const void* dYplanes, const void* X, float* part, float* dW, long M, int NX, ec_stream_t stream) {
-    if (!dYplanes || !X || !part || !dW) return EC_ERR_ARG;
+    return ec_dw_tn_xp(dYplanes, X, part, dW, M, NX, 3, stream);
+}
+// ... multiplying only the `planes` (2 or 3) leading planes of dY (not part of the C-ABI; policy.hip under EC_POLICY_FAST)
+int ec_dw_tn_xp(const void* dYplanes, const void* X, float* part, float* dW, long M, int NX, int planes, ec_stream_t stream) {
+    if (!dYplanes || !X || !part || !dW || (planes != 2 && planes != 3)) return EC_ERR_ARG;
     const int ns = ec_dw_tn_x3_splits(M, NX);
     if (ns <= 0) return EC_ERR_SHAPE;
     DwArgs a;
@@ -241,11 +268,15 @@ extern "C" int ec_dw_tn_x3(const void* dYplanes, const void* X, float* part, flo
     if (a.tok_per_split * (long)NX * 2 >= (1L << 32) - (1L << 20)) return EC_ERR_SHAPE;   // 32-bit offsets inside a split
     const size_t lds = (size_t)NSTG * STG;
     static std::atomic<uint64_t> attr_done{0};
-    if (auto attr_g_ = ec_attr_needed(attr_done))
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dw_tn_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (auto attr_g_ = ec_attr_needed(attr_done)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dw_tn_x3_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dw_tn_x3_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
     a.ntile = NX / NXT;
     a.nsplit = ns;
-    hipLaunchKernelGGL(dw_tn_x3_kernel, dim3((unsigned)(8 * a.ntile * ((ns + 7) / 8))), dim3(512), lds, (hipStream_t)stream, a);
+    const dim3 grid((unsigned)(8 * a.ntile * ((ns + 7) / 8)));
+    if (planes == 3) hipLaunchKernelGGL(dw_tn_x3_kernel<3>, grid, dim3(512), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(dw_tn_x3_kernel<2>, grid, dim3(512), lds, (hipStream_t)stream, a);
     const long n4 = (long)NYT * NX / 4;
     hipLaunchKernelGGL(dw_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, part, ns, n4, dW);
     EC_CHECK_LAUNCH();

@@ -24,6 +24,9 @@
 
 extern "C" int ec_dw_tn_x3_splits(long M, int NX);
 extern "C" int ec_dw_tn_x3(const void* dYplanes, const void* X, float* part, float* dW, long M, int NX, ec_stream_t stream);
+int ec_dw_tn_xp(const void* dYplanes, const void* X, float* part, float* dW, long M, int NX, int planes, ec_stream_t stream);   // dw_tn.hip
+int ec_gemm_bf16a_xp(const void* A, const void* Wplanes, const float* bias, float* out, long M, int N, int K, int act, int planes,
+                     ec_stream_t stream);                                                                                        // conv_igemm.hip
 extern "C" int ec_split3_bf16(const float* W, void* planes, long rows, int K, ec_stream_t stream);
 extern "C" int ec_gemm_bf16a_x3(const void* A, const void* Wplanes, const float* bias, float* out, long M, int N, int K,
                                 int act, ec_stream_t stream);
@@ -1627,7 +1630,10 @@ extern "C" int ec_policy_forward2(const ec_policy_t* h, const float* params, con
     bool c1_final = false;                                       // c1 already carries bias + ReLU (no partial matrices to fold)
     if (c1_pp && feat_bf16 && c.compress_hid % 128 == 0 && C % 64 == 0 && M49 >= 256 * 128) {
         RC(ec_split3_bf16(WS(P_W1), ws + w.w1p, c.compress_hid, C, stream));
-        RC(ec_gemm_bf16a_x3(featS, ws + w.w1p, WS(P_B1), ws + o_c1, M49, c.compress_hid, C, 1 /* EC_ACT_RELU */, stream));
+        // (EC_POLICY_FAST: the two leading planes of W1 -- 16 mantissa bits -- instead of all three: a third fewer MFMAs in a
+        //  launch that is MFMA-bound at three products per feature byte; learn pass only, the act step stays exact)
+        RC(ec_gemm_bf16a_xp(featS, ws + w.w1p, WS(P_B1), ws + o_c1, M49, c.compress_hid, C, 1 /* EC_ACT_RELU */,
+                            (ec_config().policy_fast && !infer_only) ? 2 : 3, stream));
     } else if (act_split && feat_bf16 && !c.dual && (C % 128) == 0 && (c.compress_hid % 32) == 0) {
         // act step: one launch, K split over the waves of a workgroup, W1's three bf16 planes cached in the workspace with E1
         if (!reuse_tables) {
@@ -1888,7 +1894,7 @@ extern "C" int ec_policy_backward3(const ec_policy_t* h, const float* params, co
     // EC_GEMM_BWD3: the large gradient GEMMs (weight gradients over all T*N rows, dx = dgi @ W_ih) on the three leading bf16
     // products of the bf16x3 split (relative product error 2^-16; the parameters' gradients then agree with the fp32 oracle to
     // ~1e-5 instead of ~1e-6)
-    const int bwd3 = ec_config().gemm_bwd3 ? EC_GEMM_3PRODUCTS : 0;
+    const int bwd3 = (ec_config().gemm_bwd3 || ec_config().policy_fast) ? EC_GEMM_3PRODUCTS : 0;
     // weight grads of the recurrence / input projection (TN over all T*N rows)
     auto tn = [&](const float* dY, int ldy, const void* X, int ldx, int x_bf16, float* dW, int Mo, int No, long K,
                   int ldc) {
@@ -2008,7 +2014,7 @@ extern "C" int ec_policy_backward3(const ec_policy_t* h, const float* params, co
           c.num_goals, cat));
     RC(ec_gemm_f32(ws + w.dE1, WS(P_W3) + c.compress_out, GS(P_EMB), c.num_goals, c.goal_dims, c.comb_hid, c.comb_hid, 1,
                    cat, 1, c.goal_dims, EC_GEMM_ACCUMULATE, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 1, stream));
-    if (dw1_planes) RC(ec_dw_tn_x3(ws + w.dc1, featS, ws + w.tpart, GS(P_W1), M49, C, stream));   // (tpart: free again after the reducer)
+    if (dw1_planes) RC(ec_dw_tn_xp(ws + w.dc1, featS, ws + w.tpart, GS(P_W1), M49, C, ec_config().policy_fast ? 2 : 3, stream));   // (tpart: free again after the reducer)
     else RC(tn(ws + w.dc1, c.compress_hid, featS, C, feat_bf16, GS(P_W1), c.compress_hid, C, M49, C));
     }   // streams
     EC_CHECK_LAUNCH();
