@@ -210,6 +210,9 @@ __global__ __launch_bounds__(256) void ln_fold_kernel(const uint16_t* __restrict
 //   S^T[key][query] = K Q^T   (swapped operands: a lane owns ONE query column and 32 of the 64 keys,
 //                              so the softmax is in-lane + one exchange with the other half-wave)
 //   O[query][d]     = P V     (P stays in registers; V is read from LDS through ds_read_b64_tr_b16 with the matching k-permutation)
+// (component-wise: `ok ? v : zero` on the uint4 STRUCT is a pointer select and pins both operands in scratch memory)
+__device__ __forceinline__ uint4 ec_sel4(bool ok, const uint4& v) { return make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u); }
+
 __global__ __launch_bounds__(64) void mha_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int L,
                                                  int D, int heads, float scale) {
     __shared__ __attribute__((aligned(16))) uint16_t sv[64 * 72];    // V: [token][d], row pitch 72 (144 B)
@@ -221,24 +224,30 @@ __global__ __launch_bounds__(64) void mha_kernel(const uint16_t* __restrict__ qk
     // channels per k-step: one 16-byte load each, all 16 issued before the first use); only V goes through LDS, because
     // the PV step needs it transposed.  9 KB of LDS per workgroup instead of 27: every (frame, head) wave of a CU is
     // resident at once.  Tokens >= L are zero.
-    uint4 qg[4][2], kg[4][2];
+    // Every global load of the wave is issued BEFORE the first use (24 x 16 B per lane in flight): rows past L are read from a
+    // clamped address and zeroed with a select -- behind an exec-masked `if (t < L)` the compiler waits for each load before it
+    // issues the next (a serial chain of L2 round trips: this kernel was 14 us for 38 MB; round 6).
+    uint4 qg[4][2], kg[4][2], vv[8];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
-            const int t = a * 32 + fr;
-            qg[ks][a] = kg[ks][a] = make_uint4(0, 0, 0, 0);
-            if (t < L) {
-                const uint16_t* r = base + (long)t * 3 * D + ks * 16 + fh * 8;
-                qg[ks][a] = *reinterpret_cast<const uint4*>(r);
-                kg[ks][a] = *reinterpret_cast<const uint4*>(r + D);
-            }
+            const int t = a * 32 + fr, tc = t < L ? t : L - 1;
+            const uint16_t* r = base + (long)tc * 3 * D + ks * 16 + fh * 8;
+            qg[ks][a] = *reinterpret_cast<const uint4*>(r);
+            kg[ks][a] = *reinterpret_cast<const uint4*>(r + D);
         }
-    for (int e = lane; e < 64 * 8; e += 64) {
-        const int t = e >> 3, c = e & 7;
-        uint4 v4 = make_uint4(0, 0, 0, 0);
-        if (t < L) v4 = *reinterpret_cast<const uint4*>(base + (long)t * 3 * D + 2 * D + c * 8);
-        *reinterpret_cast<uint4*>(sv + t * 72 + c * 8) = v4;     // row-major: the PV step turns it with ds_read_b64_tr_b16
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int e = i * 64 + lane, t = e >> 3, c = e & 7, tc = t < L ? t : L - 1;
+        vv[i] = *reinterpret_cast<const uint4*>(base + (long)tc * 3 * D + 2 * D + c * 8);
+    }
+    __builtin_amdgcn_sched_barrier(0);     // (keeps the 24 loads together: the scheduler otherwise interleaves load / wait / use)
+    const bool okt[2] = {fr < L, 32 + fr < L};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int e = i * 64 + lane, t = e >> 3, c = e & 7;
+        *reinterpret_cast<uint4*>(sv + t * 72 + c * 8) = ec_sel4(t < L, vv[i]);     // row-major: the PV step turns it with ds_read_b64_tr_b16
     }
     __syncthreads();
     // ---- S^T = K Q^T : acc[kf][qf], rows = keys, cols = queries ----
@@ -255,8 +264,8 @@ __global__ __launch_bounds__(64) void mha_kernel(const uint16_t* __restrict__ qk
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int c = 0; c < 2; ++c)
-                st[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, kg[ks][a]),
-                                                                  __builtin_bit_cast(bf16x8_t, qg[ks][c]), st[a][c], 0, 0, 0);
+                st[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ec_sel4(okt[a], kg[ks][a])),
+                                                                  __builtin_bit_cast(bf16x8_t, ec_sel4(okt[c], qg[ks][c])), st[a][c], 0, 0, 0);
     }
     // ---- softmax over keys, per query column (query = qf*32 + fr) ----
     // this lane's keys: kf*32 + (r&3) + 8*(r>>2) + 4*fh
