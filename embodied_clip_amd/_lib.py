@@ -111,6 +111,7 @@ SIGNATURES = {
     "ec_attnpool_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "ec_attnpool_forward": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int] + [c_void_p] * 8 + [c_size_t, c_void_p,
                                     c_void_p]),
+    "ec_clip_adam_scratch_doubles": (c_int, []),
     "ec_clip_adam_step": (c_int, [c_void_p] * 5 + [C.c_long, c_float, c_float, c_float, c_float, c_float, c_int,
                                   c_void_p]),
 }

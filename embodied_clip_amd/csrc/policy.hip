@@ -601,7 +601,7 @@ __global__ __launch_bounds__(256) void gru_step_bwd512_kernel(const float* __res
     carry[o] = m * dh * z;
 }
 
-// out[n] += sum_m Y[m*ld + n]
+// part[blockIdx.y][n] = sum over the block's rows of Y[m*ld + n]   (no atomics: colsum_fold_kernel adds the row blocks in order)
 __global__ void colsum_kernel(const float* __restrict__ Y, float* __restrict__ out, long M, int N, int ld,
                               int rows_per_block) {
     const int n = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -614,7 +614,7 @@ __global__ void colsum_kernel(const float* __restrict__ Y, float* __restrict__ o
     __shared__ float red[4][64];
     red[sub][threadIdx.x & 63] = s;
     __syncthreads();
-    if (sub == 0 && n < N) atomicAdd(out + n, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (sub == 0 && n < N) out[(long)blockIdx.y * N + n] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 // The same for wide matrices (N % 4 == 0, ld % 4 == 0: the GRU's [T*N x 3H] gate gradients, 100 MB each per optimiser step):
@@ -642,7 +642,7 @@ __global__ __launch_bounds__(256) void colsum4_kernel(const float* __restrict__ 
     __shared__ f32x4_t red[4][64];
     red[sub][lane] = s;
     __syncthreads();
-    if (c < N) atomicAdd(out + c + sub, ((red[0][lane][sub] + red[1][lane][sub]) + red[2][lane][sub]) + red[3][lane][sub]);
+    if (c < N) out[(long)blockIdx.y * N + c + sub] = ((red[0][lane][sub] + red[1][lane][sub]) + red[2][lane][sub]) + red[3][lane][sub];
 }
 
 // dE1[goal[b], n] += sum_p dm1[(b*S + p)*N + n]
@@ -1032,6 +1032,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // accumulators for all of its tiles and leave as one partial set per wave; tail_bwd_reduce_kernel folds the sets into the
 // gradient tensors.  dE1 is accumulated in an LDS table per workgroup (a 32-row tile touches at most two row groups: S >= 32).
 constexpr int TB_MAX_WG = 256;
+constexpr int TB_MAXG = 16;                       // goal rows of the per-wave dE1 register tables (num_goals <= 16 on the fused path)
 constexpr int TB_W = 3 * 4096;                    // dW4 [32][128], dW3a [128][32], dW2 [32][128]
 constexpr int TB_PART = TB_W + 64 + 64 + 256;     // + db4, db2 (two lane halves each), db1 (two halves)
 
@@ -1045,7 +1046,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     float* sW3T = sW4T + 128 * TL_P32;            // [32 n][132]:  sW3T[n][k] = W3[k][n], n < 32
     float* sW2T = sW3T + 32 * TL_P128;            // [128 n][36]:  sW2T[n][k] = W2[k][n]
     float* sE = sW2T + 128 * TL_P32;              // [num_goals][128]
-    float* wave_base = sE + num_goals * 128;
+    float* wave_base = sE + (num_goals * 128 > 1024 ? num_goals * 128 : 1024);   // (== the host's tb_lds formula)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float* Tm = wave_base + wave * (32 * TL_P128 + 32 * TL_P32);   // m1 tile -> dm1 -> c1 tile -> dc1
     float* Tx = Tm + 32 * TL_P128;                                 // dx4 tile -> c2 tile -> dc2
@@ -1056,8 +1057,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int k3 = idx >> 5, n3 = idx & 31;
         sW3T[n3 * TL_P128 + k3] = W3[(long)k3 * w3_ld + n3];
     }
-    for (int idx = tid; idx < num_goals * 128; idx += 256) sE[idx] = 0.f;
     __syncthreads();
+    // dE1 (round 6: no float atomics): the tile's two row-group sums go through a wave-private 256-float line of the sE area
+    // into PER-WAVE register tables regE[goal][2] (lane owns columns lane, lane + 64; the goal ids are wave-uniform, the
+    // table update is 16 predicated adds) -- a wave folds its tiles in a fixed order, one table per wave leaves the kernel.
+    float* sEw = sE + wave * 256;
+    float regE[TB_MAXG][2];
+#pragma unroll
+    for (int g = 0; g < TB_MAXG; ++g) { regE[g][0] = 0.f; regE[g][1] = 0.f; }
 
     const int i = lane & 31, hh = lane >> 5;
     const long ntiles = (M + 31) / 32;
@@ -1146,9 +1153,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     *pm = v;
                     if (row < nb) e0 += v; else e1 += v;
                 }
-                atomicAdd(sE + g0 * 128 + jt * 32 + i, e0);
-                if (nb < 32) atomicAdd(sE + g1 * 128 + jt * 32 + i, e1);
+                e0 += __shfl_xor(e0, 32, 64);                        // the two lane halves hold the column's rows 4 hh .. : add them
+                e1 += __shfl_xor(e1, 32, 64);
+                if (hh == 0) { sEw[jt * 32 + i] = e0; sEw[128 + jt * 32 + i] = e1; }
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            const float c0a = sEw[lane], c0b = sEw[64 + lane], c1a = sEw[128 + lane], c1b = sEw[192 + lane];
+            const bool two = nb < 32;
+#pragma unroll
+            for (int g = 0; g < TB_MAXG; ++g) {
+                regE[g][0] += (g == g0 ? c0a : 0.f) + ((two && g == g1) ? c1a : 0.f);
+                regE[g][1] += (g == g0 ? c0b : 0.f) + ((two && g == g1) ? c1b : 0.f);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (the line is rewritten by the next tile)
+            __builtin_amdgcn_wave_barrier();
         }
         // ---- stage c2 (dx4 is dead); fetch the next tile's dx4 ----
 #pragma unroll
@@ -1277,17 +1296,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     pp[TB_W + 64 + hh * 32 + i] = db2p;
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) pp[TB_W + 128 + hh * 128 + jt * 32 + i] = db1p[jt];
-    __syncthreads();
-    for (int idx = tid; idx < num_goals * 128; idx += 256) partE[(long)blockIdx.x * num_goals * 128 + idx] = sE[idx];
+    float* pe = partE + ((long)blockIdx.x * 4 + wave) * num_goals * 128;
+#pragma unroll
+    for (int g = 0; g < TB_MAXG; ++g)
+        if (g < num_goals) { pe[g * 128 + lane] = regE[g][0]; pe[g * 128 + 64 + lane] = regE[g][1]; }
 }
 
-// folds the per-wave partial sets of tail_bwd_kernel into the gradient tensors (grads +=, dE1 +=)
+// folds the per-wave partial sets of tail_bwd_kernel into the gradient tensors (grads +=, dE1 +=).  Two stages, no atomics:
+// y-slice blockIdx.y adds the sets p = y, y + ny, ... in increasing order into red[y][e]; tail_bwd_fold_kernel adds the ny
+// slices in slice order onto the gradient.
+__device__ __forceinline__ float* tail_dst(int e, float* gW4, float* gW3, int w3_ld, float* gW2, float* gb4, float* gb2, float* gb1,
+                                           float* dE1) {
+    if (e < 4096) return gW4 + e;
+    if (e < 8192) { const int q = e - 4096; return gW3 + (long)(q >> 5) * w3_ld + (q & 31); }
+    if (e < TB_W) return gW2 + (e - 8192);
+    if (e < TB_W + 64) return gb4 + ((e - TB_W) & 31);
+    if (e < TB_W + 128) return gb2 + ((e - TB_W - 64) & 31);
+    if (e < TB_PART) return gb1 + ((e - TB_W - 128) & 127);
+    return dE1 + (e - TB_PART);
+}
 __global__ __launch_bounds__(256) void tail_bwd_reduce_kernel(const float* __restrict__ part, int nsets,
-                                                               const float* __restrict__ partE, int nwg, int num_goals,
-                                                               float* __restrict__ gW4, float* __restrict__ gW3, int w3_ld,
-                                                               float* __restrict__ gW2, float* __restrict__ gb4,
-                                                               float* __restrict__ gb2, float* __restrict__ gb1,
-                                                               float* __restrict__ dE1) {
+                                                               const float* __restrict__ partE, int num_goals,
+                                                               float* __restrict__ red) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     const int ne = TB_PART + num_goals * 128;
     if (e >= ne) return;
@@ -1296,17 +1326,47 @@ __global__ __launch_bounds__(256) void tail_bwd_reduce_kernel(const float* __res
         for (int p = blockIdx.y; p < nsets; p += gridDim.y) s += part[(long)p * TB_PART + e];
     } else {
         const int q = e - TB_PART;
-        for (int p = blockIdx.y; p < nwg; p += gridDim.y) s += partE[(long)p * num_goals * 128 + q];
+        for (int p = blockIdx.y; p < nsets; p += gridDim.y) s += partE[(long)p * num_goals * 128 + q];
     }
-    float* dst;
-    if (e < 4096) dst = gW4 + e;
-    else if (e < 8192) { const int q = e - 4096; dst = gW3 + (long)(q >> 5) * w3_ld + (q & 31); }
-    else if (e < TB_W) dst = gW2 + (e - 8192);
-    else if (e < TB_W + 64) dst = gb4 + ((e - TB_W) & 31);
-    else if (e < TB_W + 128) dst = gb2 + ((e - TB_W - 64) & 31);
-    else if (e < TB_PART) dst = gb1 + ((e - TB_W - 128) & 127);
-    else dst = dE1 + (e - TB_PART);
-    atomicAdd(dst, s);
+    red[(long)blockIdx.y * ne + e] = s;
+}
+// red[ny][ne] -> gradient; a bias element, whose two lane halves sit in 2 slots of a set, is summed by ONE thread
+__global__ __launch_bounds__(256) void tail_bwd_fold_kernel(const float* __restrict__ red, int ny, int num_goals,
+                                                             float* __restrict__ gW4, float* __restrict__ gW3, int w3_ld,
+                                                             float* __restrict__ gW2, float* __restrict__ gb4, float* __restrict__ gb2,
+                                                             float* __restrict__ gb1, float* __restrict__ dE1) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    const int ne = TB_PART + num_goals * 128;
+    if (e >= ne) return;
+    auto slot = [&](int q) { float t = 0.f; for (int y = 0; y < ny; ++y) t += red[(long)y * ne + q]; return t; };
+    if (e >= TB_W && e < TB_PART) {                        // bias slots: [db4 h0 | db4 h1 | db2 h0 | db2 h1 | db1 h0 (128) | db1 h1 (128)]
+        const int q = e - TB_W;
+        if (q < 32) gb4[q] += slot(e) + slot(e + 32);
+        else if (q >= 64 && q < 96) gb2[q - 64] += slot(e) + slot(e + 32);
+        else if (q >= 128 && q < 256) gb1[q - 128] += slot(e) + slot(e + 128);
+        return;
+    }
+    *tail_dst(e, gW4, gW3, w3_ld, gW2, gb4, gb2, gb1, dE1) += slot(e);
+}
+
+// out[n] += sum_m Y[m*ld + n] WITHOUT atomics: row block blockIdx.y leaves its column sums in part[y][n] (colsum_part* below),
+// colsum_fold_kernel adds the row blocks in order
+__global__ __launch_bounds__(256) void colsum_fold_kernel(const float* __restrict__ part, int nby, int N, float* __restrict__ out) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int y = 0; y < nby; ++y) s += part[(long)y * N + n];
+    out[n] += s;
+}
+// dW[m*ldc + n] += sum_k parts[k][m][n]: the ordered fold of a split-K weight-gradient GEMM's partial matrices (EC_GEMM_SPLIT_PARTS)
+__global__ __launch_bounds__(256) void splitk_fold_kernel(const float* __restrict__ parts, int sk, int Mo, int No, int ldc,
+                                                         float* __restrict__ dW) {
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= (long)Mo * No) return;
+    float s = 0.f;
+    for (int k = 0; k < sk; ++k) s += parts[(long)k * Mo * No + q];
+    const long m = q / No, n = q - m * No;
+    dW[m * ldc + n] += s;
 }
 
 inline size_t al(size_t v) { return (v + 255) / 256 * 256; }
@@ -1388,7 +1448,7 @@ Ws layout(const ec_policy* h, int T, int N, bool bwd) {
         w.dc1 = take(M49 * c.compress_hid * 3 / 2 + 4);   // fp32 [M49][hid], or its three bf16 planes [M49][3][hid]
         w.dE1 = take((size_t)c.num_goals * c.comb_hid);
         w.tpart = take(c.fusion ? 0 : (size_t)TB_MAX_WG * 4 * TB_PART);              // tail_bwd_kernel's partial sets
-        w.tpartE = take(c.fusion ? 0 : (size_t)TB_MAX_WG * c.num_goals * 128);
+        w.tpartE = take(c.fusion ? 0 : (size_t)TB_MAX_WG * 4 * c.num_goals * 128);   // ... and its per-wave dE1 tables
         w.whhT = take(H * 3 * H);                                                       // W_hh^T (fused backward step)
         w.wihP = take(c.fusion ? 0 : 3 * H * flat);                                     // weight_ih in pixel-major column order (EC_WIH_PERM)
         w.gwihP = take(c.fusion ? 0 : 3 * H * flat);                                    // ... and its gradient
@@ -1822,26 +1882,48 @@ extern "C" int ec_policy_backward3(const ec_policy_t* h, const float* params, co
     auto W = [&](int i) { return params + h->off[i]; };
     auto G = [&](int i) { return grads + h->off[i]; };
     const int* goal32 = (const int*)(ws + w.goal32);
+    // column sums (bias gradients) without atomics: row block y leaves its sums in cpart[y][Ncol] (the forward's per-step `gh`
+    // scratch: N x 3H floats, idle in the backward), colsum_fold_kernel adds the row blocks in order onto the gradient
+    float* cpart = ws + w.gh;
+    const size_t cpart_cap = (size_t)N * 3 * H;
     auto colsum = [&](const float* Y, float* out, long M, int Ncol, int ld) {
-        if ((Ncol & 3) == 0 && (ld & 3) == 0 && Ncol >= 256 && M >= 1024) {
-            const int rpb4 = 256;
-            dim3 grid4((unsigned)((Ncol + 255) / 256), (unsigned)((M + rpb4 - 1) / rpb4));
-            hipLaunchKernelGGL(colsum4_kernel, grid4, dim3(256), 0, s, Y, out, M, Ncol, ld, rpb4);
-            return;
-        }
-        const int rpb = 2048;
-        dim3 grid((unsigned)((Ncol + 63) / 64), (unsigned)((M + rpb - 1) / rpb));
-        hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, s, Y, out, M, Ncol, ld, rpb);
+        const bool wide = (Ncol & 3) == 0 && (ld & 3) == 0 && Ncol >= 256 && M >= 1024;
+        long nby = (M + (wide ? 255 : 2047)) / (wide ? 256 : 2048);
+        const long fit = (long)(cpart_cap / (size_t)Ncol);
+        if (nby > fit) nby = fit;
+        if (nby < 1) nby = 1;                                   // (Ncol <= 3H always: at least one row block fits)
+        const int rpb = (int)(((M + nby - 1) / nby + 3) / 4 * 4);
+        nby = (M + rpb - 1) / rpb;
+        if (wide) hipLaunchKernelGGL(colsum4_kernel, dim3((unsigned)((Ncol + 255) / 256), (unsigned)nby), dim3(256), 0, s, Y, cpart, M, Ncol, ld, rpb);
+        else hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((Ncol + 63) / 64), (unsigned)nby), dim3(256), 0, s, Y, cpart, M, Ncol, ld, rpb);
+        hipLaunchKernelGGL(colsum_fold_kernel, dim3((unsigned)((Ncol + 255) / 256)), dim3(256), 0, s, cpart, (int)nby, Ncol, out);
+    };
+    // weight-gradient GEMMs that split K: every K slice writes its own partial matrix (EC_GEMM_SPLIT_PARTS) into `sparts` and
+    // splitk_fold_kernel adds the slices in order onto the gradient -- the fp32 atomics this replaces made two runs from one
+    // seed differ in the last bits.  sparts: the dx area (free until dx / dx4 is computed, behind the weight gradients; with
+    // the re-ordered weight_ih and in fusion mode it is never used at all).
+    float* sparts = ws + w.dx;
+    const size_t sparts_cap = (size_t)B * flat;
+    auto gemm_acc_split = [&](const void* A_, const void* B_, float* dW, int Mo, int No, long K, long sam, long sak, long sbk, long sbn,
+                              int ldc, int flags, int sk) {
+        while (sk > 1 && (size_t)sk * Mo * No > sparts_cap) --sk;
+        if (sk <= 1)
+            return ec_gemm_f32(A_, B_, dW, Mo, No, (int)K, sam, sak, sbk, sbn, ldc, EC_GEMM_ACCUMULATE | flags, nullptr, nullptr, nullptr, 0,
+                               nullptr, nullptr, 1, stream);
+        const int rc = ec_gemm_f32(A_, B_, sparts, Mo, No, (int)K, sam, sak, sbk, sbn, No, EC_GEMM_SPLIT_PARTS | flags, nullptr, nullptr,
+                                   nullptr, 0, nullptr, nullptr, sk, stream);
+        if (rc != EC_OK) return rc;
+        const long nq = (long)Mo * No;
+        hipLaunchKernelGGL(splitk_fold_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, sparts, sk, Mo, No, ldc, dW);
+        return (int)EC_OK;
     };
     // ---- heads ----
     RC(ec_gemm_f32(dhv, W(P_WA), ws + w.dhs, B, H, A, A1, 1, H, 1, H, 0, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
                    1, stream));
     RC(ec_gemm_f32(dhv + A, W(P_WC), ws + w.dhs, B, H, 1, A1, 1, H, 1, H, EC_GEMM_ACCUMULATE, nullptr, nullptr, nullptr,
                    0, nullptr, nullptr, 1, stream));
-    RC(ec_gemm_f32(dhv, ws + w.hs, G(P_WA), A, H, B, 1, A1, H, 1, H, EC_GEMM_ACCUMULATE, nullptr, nullptr, nullptr, 0,
-                   nullptr, nullptr, pick_splitk(A, H, B), stream));
-    RC(ec_gemm_f32(dhv + A, ws + w.hs, G(P_WC), 1, H, B, 1, A1, H, 1, H, EC_GEMM_ACCUMULATE, nullptr, nullptr, nullptr,
-                   0, nullptr, nullptr, pick_splitk(1, H, B), stream));
+    RC(gemm_acc_split(dhv, ws + w.hs, G(P_WA), A, H, B, 1, A1, H, 1, H, 0, pick_splitk(A, H, B)));
+    RC(gemm_acc_split(dhv + A, ws + w.hs, G(P_WC), 1, H, B, 1, A1, H, 1, H, 0, pick_splitk(1, H, B)));
     colsum(dhv, G(P_BA), B, A, A1);
     colsum(dhv + A, G(P_BC), B, 1, A1);
     // ---- GRU, reverse time ----
@@ -1896,9 +1978,13 @@ extern "C" int ec_policy_backward3(const ec_policy_t* h, const float* params, co
     // ~1e-5 instead of ~1e-6)
     const int bwd3 = (ec_config().gemm_bwd3 || ec_config().policy_fast) ? EC_GEMM_3PRODUCTS : 0;
     // weight grads of the recurrence / input projection (TN over all T*N rows)
+    bool parts_ok = true;       // (cleared once dx / dx4 occupies the partial-matrix area)
     auto tn = [&](const float* dY, int ldy, const void* X, int ldx, int x_bf16, float* dW, int Mo, int No, long K,
                   int ldc) {
-        const int sk = pick_splitk(Mo, No, K);   // grads += ... (atomics when split, += otherwise)
+        // grads += ...: K slices into partial matrices folded in order while the dx area is free (`parts_ok`); the tail's
+        // unfused fallback GEMMs (EC_TAIL_FUSED=0, the dual encoder) run after dx exists and keep the atomic split
+        const int sk = pick_splitk(Mo, No, K);
+        if (parts_ok) return gemm_acc_split(dY, X, dW, Mo, No, K, 1, ldy, ldx, 1, ldc, (x_bf16 ? EC_GEMM_B_BF16 : 0) | bwd3, sk);
         return ec_gemm_f32(dY, X, dW, Mo, No, (int)K, 1, ldy, ldx, 1, ldc,
                            EC_GEMM_ACCUMULATE | (x_bf16 ? EC_GEMM_B_BF16 : 0) | bwd3, nullptr, nullptr, nullptr, 0, nullptr,
                            nullptr, sk, stream);
@@ -1912,8 +1998,7 @@ extern "C" int ec_policy_backward3(const ec_policy_t* h, const float* params, co
                            ws + w.tA, (int)K, Mo);
         hipLaunchKernelGGL(transpose_f32_kernel, dim3((unsigned)((No + 31) / 32), (unsigned)((K + 31) / 32)), dim3(256), 0, s, X,
                            ws + w.tB, (int)K, No);
-        return ec_gemm_f32(ws + w.tA, ws + w.tB, dW, Mo, No, (int)K, K, 1, 1, K, ldc, EC_GEMM_ACCUMULATE | bwd3, nullptr, nullptr, nullptr,
-                           0, nullptr, nullptr, pick_splitk(Mo, No, K), stream);
+        return gemm_acc_split(ws + w.tA, ws + w.tB, dW, Mo, No, K, K, 1, 1, K, ldc, bwd3, pick_splitk(Mo, No, K));
     };
     if (dw_t) RC(tn_t(ws + w.dghb, ws + w.hp, G(P_WHH), 3 * H, H, B, H));
     else
@@ -1940,6 +2025,7 @@ extern "C" int ec_policy_backward3(const ec_policy_t* h, const float* params, co
         EC_CHECK_LAUNCH();
         return EC_OK;
     }
+    parts_ok = wih_perm;        // (the plain path writes dx into the partial-matrix area now; with the re-ordered weight_ih it stays free)
     // dx = dgi @ W_ih
     if (wih_perm) { // dx4 = dgi @ (re-ordered weight_ih): already pixel-major.  The weight is transposed first (9.6 MB, into
                     // the gradient staging buffer, free again by now) so that BOTH operands are K-contiguous: the GEMM's
@@ -1963,10 +2049,10 @@ extern "C" int ec_policy_backward3(const ec_policy_t* h, const float* params, co
                            ws + w.dx4, S, c.comb_out, total, flat, sidx * flat1);
     }
     const int tail_fused = ec_config().tail_fused;
-    const size_t tb_lds = ((size_t)2 * 128 * TL_P32 + 32 * TL_P128 + (size_t)c.num_goals * 128 +
-                           4 * (size_t)(32 * TL_P128 + 32 * TL_P32)) * sizeof(float);
+    const size_t tb_lds = ((size_t)2 * 128 * TL_P32 + 32 * TL_P128 + std::max<size_t>((size_t)c.num_goals * 128, 4 * 256) +
+                           4 * (size_t)(32 * TL_P128 + 32 * TL_P32)) * sizeof(float);   // (the sE area: four wave-private 256-float lines)
     const bool fused_bwd = tail_fused && c.compress_hid == 128 && c.compress_out == 32 && c.comb_hid == 128 &&
-                           c.comb_out == 32 && S >= 32 && tb_lds <= 160 * 1024;
+                           c.comb_out == 32 && S >= 32 && tb_lds <= 160 * 1024 && c.num_goals <= TB_MAXG;
     // EC_DW1_TR (default 1): dW1 through the transpose-read kernel (dw_tn.hip); dc1 then only exists as bf16 planes
     const int dw1_tr = ec_config().dw1_tr;
     const bool dw1_planes = fused_bwd && dw1_tr && feat_bf16 && C % 256 == 0 && M49 >= 2048 &&
@@ -1986,9 +2072,16 @@ extern "C" int ec_policy_backward3(const ec_policy_t* h, const float* params, co
                            dw1_planes ? (uint16_t*)(ws + w.dc1) : nullptr, ws + w.tpart, ws + w.tpartE,
                            (long)M49);
         const int ne = TB_PART + c.num_goals * 128;
-        hipLaunchKernelGGL(tail_bwd_reduce_kernel, dim3((unsigned)((ne + 255) / 256), 8), dim3(256), 0, s, ws + w.tpart,
-                           (int)nwg * 4, ws + w.tpartE, (int)nwg, c.num_goals, GS(P_W4), GS(P_W3), cat, GS(P_W2), GS(P_B4), GS(P_B2),
-                           GS(P_B1), ws + w.dE1);
+        // the y-slices' sums: behind the used partial sets when there is room (nwg < TB_MAX_WG), else in the dm1 area, which
+        // the fused path never materialises (nwg == TB_MAX_WG means M49 >= 32,768 rows: 4 M floats)
+        float* red = (nwg < TB_MAX_WG) ? ws + w.tpart + (size_t)nwg * 4 * TB_PART : ws + w.dm1;
+        const size_t red_cap = (nwg < TB_MAX_WG) ? (size_t)(TB_MAX_WG - nwg) * 4 * TB_PART : (size_t)M49 * c.comb_hid;
+        int ny = (int)std::min<size_t>(8, red_cap / (size_t)ne);
+        if (ny < 1) return EC_ERR_WORKSPACE;
+        hipLaunchKernelGGL(tail_bwd_reduce_kernel, dim3((unsigned)((ne + 255) / 256), (unsigned)ny), dim3(256), 0, s, ws + w.tpart,
+                           (int)nwg * 4, ws + w.tpartE, c.num_goals, red);
+        hipLaunchKernelGGL(tail_bwd_fold_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, red, ny, c.num_goals, GS(P_W4),
+                           GS(P_W3), cat, GS(P_W2), GS(P_B4), GS(P_B2), GS(P_B1), ws + w.dE1);
     } else {
     // ---- target_obs_combiner ----
     RC(tn(ws + w.dx4, c.comb_out, ws + o_m1, c.comb_hid, 0, GS(P_W4), c.comb_out, c.comb_hid, M49, c.comb_hid));

@@ -19,10 +19,12 @@ __device__ __forceinline__ double wave_sum(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
     return v;
 }
-// block (256 threads) reduction of up to NV doubles, then one atomicAdd per value
-template <int NV>
-__device__ __forceinline__ void block_atomic_sum(double (&v)[NV], double* out) {
-    __shared__ double red[4][NV];
+// Block reduction of up to NV doubles in a FIXED order (wave butterflies, then the waves' sums in wave order): thread 0 returns
+// the totals.  No atomics anywhere in this file's reductions (round 6): a floating-point atomicAdd per block made the advantage
+// statistics, the loss sums and the gradient norm depend on the order the blocks happened to retire in -- two runs from one
+// seed differed in the last bits, and Adam's sign-like steps amplify that.
+template <int NV, int NWAVES>
+__device__ __forceinline__ void block_sum(double (&v)[NV], double (*red)[NV]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -30,18 +32,25 @@ __device__ __forceinline__ void block_atomic_sum(double (&v)[NV], double* out) {
         if (lane == 0) red[wave][i] = s;
     }
     __syncthreads();
-    if (threadIdx.x < NV) atomicAdd(out + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            double t = 0.0;
+            for (int w = 0; w < NWAVES; ++w) t += red[w][i];
+            v[i] = t;
+        }
+    }
 }
 
 // One lane per sampler: reverse scan over T.
 //   delta = r[t] + g*V[t+1]*m[t+1] - V[t];  gae = delta + g*tau*m[t+1]*gae;  R[t] = gae + V[t]
 // adv[t] = R[t] - V[t]; also accumulates sum(adv), sum(adv^2) for the normalisation.
-__global__ void gae_kernel(const float* __restrict__ rew, const float* __restrict__ val, const float* __restrict__ msk,
-                           float* __restrict__ ret, float* __restrict__ adv, double* __restrict__ stats, int T, int N,
-                           float gamma, float tau) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(1024) void gae_kernel(const float* __restrict__ rew, const float* __restrict__ val, const float* __restrict__ msk,
+                                                  float* __restrict__ ret, float* __restrict__ adv, double* __restrict__ stats, int T, int N,
+                                                  float gamma, float tau) {
+    // ONE workgroup: every sampler's scan is a serial chain over T anyway, and the statistics then need no cross-block sum
     double acc[2] = {0.0, 0.0};
-    if (n < N) {
+    for (int n = threadIdx.x; n < N; n += 1024) {
         float gae = 0.f;
         ret[(long)T * N + n] = val[(long)T * N + n];
         for (int t = T - 1; t >= 0; --t) {
@@ -55,7 +64,9 @@ __global__ void gae_kernel(const float* __restrict__ rew, const float* __restric
             acc[1] += (double)gae * (double)gae;
         }
     }
-    block_atomic_sum<2>(acc, stats);
+    __shared__ double red[16][2];
+    block_sum<2, 16>(acc, red);
+    if (threadIdx.x == 0) { stats[0] = acc[0]; stats[1] = acc[1]; }
 }
 
 // norm_adv = (adv - mean) / (std_unbiased + eps)
@@ -73,14 +84,15 @@ __global__ void adv_norm_kernel(const float* __restrict__ adv, const double* __r
 // hv[b, 0:A] = logits, hv[b, A] = value.  sums[0..3] += {action, value, entropy(-H), ratio}
 // dhv = d(total)/d(hv) * grad_scale with total = mean(La) + vc*mean(Lv) + ec*mean(Le).
 template <int MAXA>
-__global__ void ppo_loss_kernel(const float* __restrict__ hv, const long long* __restrict__ actions,
+__global__ __launch_bounds__(1024) void ppo_loss_kernel(const float* __restrict__ hv, const long long* __restrict__ actions,
                                 const float* __restrict__ old_logp, const float* __restrict__ old_val,
                                 const float* __restrict__ returns, const float* __restrict__ nadv,
                                 float* __restrict__ dhv, double* __restrict__ sums, long B, int A, float clip,
                                 float vclip, float vcoef, float ecoef, float grad_scale) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    // ONE workgroup of 1024 threads walks the B steps (a few thousand per actor slice: ~10 us): the four loss sums are then
+    // folded in a fixed order inside it -- no cross-block atomics, bit-identical run to run
     double acc[4] = {0, 0, 0, 0};
-    if (i < B) {
+    for (long i = threadIdx.x; i < B; i += 1024) {
         const float* row = hv + i * (A + 1);
         float lg[MAXA];
         float mx = -INFINITY;
@@ -134,10 +146,12 @@ __global__ void ppo_loss_kernel(const float* __restrict__ hv, const long long* _
                 drow[k] = invB * (dla_dlp * dlp + ecoef * dent);
             }
         drow[A] = invB * vcoef * dlv_dv;
-        acc[0] = la; acc[1] = lv; acc[2] = -ent; acc[3] = ratio;
+        acc[0] += la; acc[1] += lv; acc[2] += -ent; acc[3] += ratio;
         if (a < 0 || a >= A) acc[0] = (double)NAN;   // an out-of-range action id poisons the loss instead of passing silently
     }
-    block_atomic_sum<4>(acc, sums);
+    __shared__ double red[16][4];
+    block_sum<4, 16>(acc, red);
+    if (threadIdx.x == 0) { sums[0] = acc[0]; sums[1] = acc[1]; sums[2] = acc[2]; sums[3] = acc[3]; }
 }
 
 __device__ __forceinline__ uint64_t mix64(uint64_t z) {
@@ -172,10 +186,31 @@ __global__ void sample_kernel(const float* __restrict__ hv, long long* __restric
     if (values) values[n] = row[A];
 }
 
-__global__ void sumsq_kernel(const float* __restrict__ g, double* __restrict__ out, long n) {
+// sum of squares of the flat gradient bucket: every block folds its stride of the bucket in a fixed order and stores its partial
+// in scratch[1 + block]; the block that draws the last ticket (an INTEGER atomic: order-free) adds the partials in block order
+// into scratch[0].  scratch = EC_CLIP_ADAM_SCRATCH_DOUBLES doubles: [0] total, [1 .. 1024] partials, [1025] the ticket counter.
+constexpr int SUMSQ_MAX_BLOCKS = 1024;
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, double* __restrict__ scratch, long n) {
     double acc[1] = {0.0};
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) acc[0] += (double)g[i] * (double)g[i];
-    block_atomic_sum<1>(acc, out);
+    __shared__ double red[4][1];
+    __shared__ unsigned last;
+    block_sum<1, 4>(acc, red);
+    if (threadIdx.x == 0) {
+        scratch[1 + blockIdx.x] = acc[0];
+        __threadfence();                                             // the partial is visible device-wide before the ticket is
+        unsigned* ticket = reinterpret_cast<unsigned*>(scratch + 1 + SUMSQ_MAX_BLOCKS);
+        last = (atomicAdd(ticket, 1u) == gridDim.x - 1) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();                                                 // acquire: the other blocks' partials
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (unsigned b = 0; b < gridDim.x; ++b) t += __hip_atomic_load(scratch + 1 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        scratch[0] = t;
+        *reinterpret_cast<unsigned*>(scratch + 1 + SUMSQ_MAX_BLOCKS) = 0u;
+    }
 }
 
 // clip_grad_norm_ (coef = min(1, max_norm/(norm+1e-6))) fused into torch.optim.Adam's update
@@ -205,9 +240,7 @@ extern "C" int ec_gae(const float* rewards, const float* values, const float* ma
     if (!rewards || !values || !masks || !returns || !adv || !stats2) return EC_ERR_ARG;
     if (T <= 0 || N <= 0) return EC_ERR_SHAPE;
     hipStream_t s = (hipStream_t)stream;
-    (void)hipMemsetAsync(stats2, 0, 2 * sizeof(double), s);
-    hipLaunchKernelGGL(gae_kernel, dim3((N + 255) / 256), dim3(256), 0, s, rewards, values, masks, returns, adv, stats2, T,
-                       N, gamma, tau);
+    hipLaunchKernelGGL(gae_kernel, dim3(1), dim3(1024), 0, s, rewards, values, masks, returns, adv, stats2, T, N, gamma, tau);
     if (norm_adv) {
         const long n = (long)T * N;
         hipLaunchKernelGGL(adv_norm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, adv, stats2, norm_adv, n,
@@ -231,13 +264,11 @@ extern "C" int ec_ppo_loss_ex(const float* hv, const int64_t* actions, const flo
     if (!hv || !actions || !old_logp || !old_values || !returns || !norm_adv || !dhv || !sums4) return EC_ERR_ARG;
     if (B <= 0 || A <= 0 || A > 16) return EC_ERR_SHAPE;
     hipStream_t s = (hipStream_t)stream;
-    (void)hipMemsetAsync(sums4, 0, 4 * sizeof(double), s);
-    dim3 grid((unsigned)((B + 255) / 256));
     if (A <= 8)
-        hipLaunchKernelGGL(ppo_loss_kernel<8>, grid, dim3(256), 0, s, hv, (const long long*)actions, old_logp, old_values,
+        hipLaunchKernelGGL(ppo_loss_kernel<8>, dim3(1), dim3(1024), 0, s, hv, (const long long*)actions, old_logp, old_values,
                            returns, norm_adv, dhv, sums4, B, A, clip, value_clip, vcoef, ecoef, grad_scale);
     else
-        hipLaunchKernelGGL(ppo_loss_kernel<16>, grid, dim3(256), 0, s, hv, (const long long*)actions, old_logp, old_values,
+        hipLaunchKernelGGL(ppo_loss_kernel<16>, dim3(1), dim3(1024), 0, s, hv, (const long long*)actions, old_logp, old_values,
                            returns, norm_adv, dhv, sums4, B, A, clip, value_clip, vcoef, ecoef, grad_scale);
     EC_CHECK_LAUNCH();
     return EC_OK;
@@ -253,15 +284,17 @@ extern "C" int ec_sample_actions(const float* hv, int64_t* actions, float* logp,
     return EC_OK;
 }
 
+extern "C" int ec_clip_adam_scratch_doubles(void) { return 1 + SUMSQ_MAX_BLOCKS + 1; }
+
 extern "C" int ec_clip_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, double* sumsq1,
                                  long n, float max_grad_norm, float lr, float beta1, float beta2, float eps, int step,
                                  ec_stream_t stream) {
     if (!params || !grads || !exp_avg || !exp_avg_sq || !sumsq1) return EC_ERR_ARG;
     if (n <= 0 || step <= 0) return EC_ERR_SHAPE;
     hipStream_t s = (hipStream_t)stream;
-    (void)hipMemsetAsync(sumsq1, 0, sizeof(double), s);
+    (void)hipMemsetAsync(sumsq1 + 1 + SUMSQ_MAX_BLOCKS, 0, sizeof(double), s);      // the ticket counter
     long blocks = (n + 255) / 256;
-    hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, s, grads, sumsq1, n);
+    hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)(blocks > SUMSQ_MAX_BLOCKS ? SUMSQ_MAX_BLOCKS : blocks)), dim3(256), 0, s, grads, sumsq1, n);
     const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
     const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
     hipLaunchKernelGGL(clip_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, params, grads, exp_avg, exp_avg_sq,

@@ -117,10 +117,11 @@ class FlatAdam:
         self.p = flat_params
         self.m = torch.zeros_like(flat_params)
         self.v = torch.zeros_like(flat_params)
-        self.sumsq = torch.zeros(1, dtype=torch.float64, device=flat_params.device)
+        self.lib = _lib.load()
+        # scratch of the norm reduction ([0] = ||g||^2 after a step; block partials and a ticket counter behind it)
+        self.sumsq = torch.zeros(self.lib.ec_clip_adam_scratch_doubles(), dtype=torch.float64, device=flat_params.device)
         self.lr, self.betas, self.eps, self.max_grad_norm = lr, betas, eps, max_grad_norm
         self.step_count = 0
-        self.lib = _lib.load()
 
     def step(self, flat_grads: torch.Tensor, lr: Optional[float] = None):
         self.step_count += 1
@@ -132,7 +133,7 @@ class FlatAdam:
                        "ec_clip_adam_step")
 
     def grad_norm(self) -> float:
-        return float(self.sumsq.sqrt().item())
+        return float(self.sumsq[0].sqrt().item())
 
 
 class FusedClipAdam(torch.optim.Optimizer):
@@ -212,7 +213,8 @@ class FusedClipAdam(torch.optim.Optimizer):
             stt["exp_avg"], stt["exp_avg_sq"] = m[r:r + p.numel()].view(p.shape), v[r:r + p.numel()].view(p.shape)
             stt.setdefault("step", torch.tensor(0.0))
         b = self._buckets[gi] = dict(ptrs=tuple(p.data_ptr() for p in ps), off=off, n=n, flat=flat, m=m, v=v, rel=rel,
-                                     sumsq=torch.zeros(1, dtype=torch.float64, device=flat.device), gscratch=None)
+                                     sumsq=torch.zeros(self.lib.ec_clip_adam_scratch_doubles(), dtype=torch.float64, device=flat.device),
+                                     gscratch=None)
         return b
 
     @torch.no_grad()
@@ -255,7 +257,7 @@ class FusedClipAdam(torch.optim.Optimizer):
 
     def grad_norm(self, group: int = 0) -> float:
         """Global gradient norm the last ``step()`` of ``group`` saw (one host sync; for logging)."""
-        return float(self._buckets[group]["sumsq"].sqrt().item())
+        return float(self._buckets[group]["sumsq"][0].sqrt().item())
 
 
 def linear_decay_lr(base_lr: float, step: int, total_steps: int) -> float:

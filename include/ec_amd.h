@@ -401,7 +401,9 @@ int ec_ppo_loss_ex(const float* hv, const int64_t* actions, const float* old_log
 int ec_sample_actions(const float* hv, int64_t* actions, float* logp, float* values, int N, int A,
                       uint64_t seed, uint64_t step, int first_actor, ec_stream_t stream);
 /* clip_grad_norm_(max_grad_norm) (<=0 disables) then Adam (1-based `step`) over n floats;
- * sumsq1: 1 double scratch that receives ||grads||^2. */
+ * sumsq1: device scratch of ec_clip_adam_scratch_doubles() doubles; sumsq1[0] receives ||grads||^2 (the blocks' partial sums
+ * and a ticket counter live behind it: the norm is folded in a fixed order, bit-identical run to run). */
+int ec_clip_adam_scratch_doubles(void);
 int ec_clip_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, double* sumsq1,
                       long n, float max_grad_norm, float lr, float beta1, float beta2, float eps, int step,
                       ec_stream_t stream);

@@ -234,3 +234,32 @@ def test_copy_streams_of_a_host_frame_worker_run_beside_both_slice_streams():
         del w, st
         gc.collect()
 
+
+
+@pytest.mark.parametrize("n_actors,slices", [(6, 1), (64, 2)])
+def test_two_runs_from_one_seed_end_bit_identical(n_actors, slices):
+    """Reproducibility (the reference's only hook is ``pl.seed_everything(1)``, primitive_probing/train.py:117): two workers built
+    from one seed run ``iteration()`` twice each and must end with IDENTICAL parameters, Adam moments, rollout scalars and loss
+    sums -- no floating-point atomics are left on the default path (advantage statistics, loss sums and the gradient norm fold in
+    fixed orders; bias gradients, the tail's dE1 tables and the split-K weight-gradient GEMMs go through ordered partial sums).
+    64 actors = two actor slices on two streams (T = 8: every learn pass has 25,088 feature rows per slice, i.e. split-K
+    weight gradients, several row blocks per column sum and many partial sets in the tail's fold)."""
+    from embodied_clip_amd.engine import Worker
+    enc_sd, pol_sd = syn.rn50_visual_state_dict(0), syn.policy_state_dict(0)
+    outs = []
+    for _ in range(2):
+        w = Worker(n_actors, T=8, device="cuda:0", seed=11, update_repeats=2, encoder_sd=enc_sd, policy_sd=pol_sd,
+                   encoder_streams=slices)
+        assert w.ns == slices
+        for _it in range(2):
+            w.iteration()
+        torch.cuda.synchronize()
+        outs.append(dict(params=w.params.clone(), m=w.opt.m.clone(), v=w.opt.v.clone(), actions=w.actions.clone(),
+                         logp=w.logp.clone(), returns=w.returns.clone(), nadv=w.nadv.clone(),
+                         sums=torch.stack([sl.sums for sl in w.slices]).clone(), gn=w.opt.sumsq[0].clone()))
+        del w
+        torch.cuda.empty_cache()
+    a, b = outs
+    assert (a["params"] - torch.zeros_like(a["params"])).abs().max() > 0
+    for k in a:
+        assert torch.equal(a[k], b[k]), (k, (a[k].double() - b[k].double()).abs().max().item())
