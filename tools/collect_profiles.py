@@ -8,7 +8,7 @@ for f in ("bench_line.json", "bench_vit_line.json", "bench_zeroshot_line.json", 
           "strong_scaling_projection.json", "trunk_b128_per_kernel.txt", "trunk_b256_per_kernel.txt",
           "update_kernel_stats.txt", "update_pmc_by_kernel.txt", "update_ms.txt", "vit_b128_per_kernel.txt",
           "trunk_b32_per_kernel.txt", "bneck_stamps.txt", "img3x3_vs_conv_igemm.txt", "act_step_us.txt", "env_step_32actors.txt",
-          "winograd_feed_emulation.txt", "bench_32actors_forcedist_line.json", "plugin_iteration_phases.txt", "tvresnet_b128.txt"):
+          "winograd_feed_emulation.txt", "bench_32actors_forcedist_line.json", "plugin_iteration_phases.txt", "tvresnet_b128.txt", "engine_step_union.txt"):
     if os.path.exists(f"{O}/{f}"):
         shutil.copy(f"{O}/{f}", f"profiles/{R}_{f}")
     else:
@@ -17,4 +17,6 @@ t, t256 = json.load(open(f"{O}/trunk_b128_hbm_traffic.json")), json.load(open(f"
 t["single_launch_256"] = {k: t256[k] for k in ("plan_hash", "kernel_time_us", "hbm_bytes_per_launch", "mfma_busy_frac_of_busy_cus")}
 json.dump(t, open("profiles/trunk_hbm_traffic.json", "w"), indent=1)
 json.dump(json.load(open(f"{O}/vit_b128_hbm_traffic.json")), open("profiles/vit_hbm_traffic.json", "w"), indent=1)
+if os.path.exists(f"{O}/engine_step_union.json"):
+    shutil.copy(f"{O}/engine_step_union.json", "profiles/engine_step_union.json")
 print(json.dumps(t)[:600])

@@ -75,11 +75,7 @@ cd $GRAFT_REPO_ROOT
 (echo "# rocprofv3 --kernel-trace --stats of tools/bench_update.py --iters 3 (4 updates of 4 epochs incl. warm-up + one 128-step rollout): non-encoder kernels, total ms / calls / avg us / min us"; python tools/stats_noconv.py $(find $O/prof_upd -name "*kernel_stats.csv" | head -1) 0.5; grep "conv_igemm8.*true>" $(find $O/prof_upd -name "*kernel_stats.csv" | head -1) | cut -c1-160; tail -1 $O/update_under_rocprof.log) > $O/update_kernel_stats.txt
 rm -rf $O/prof_upd
 python tools/bench_update.py --iters 3 | tail -1 > $O/update_ms.txt
-# fused bottleneck launch: phase stamps of workgroup 0 (shader clocks, wall time, implied clock) alone / 128 / 256 workgroups
-(for B in 1 128 256; do python tools/bench_bneck.py --B $B --iters 20 --stamps 2>&1 | grep -v "amdgpu.ids\|unfused (3x3"; done) > $O/bneck_stamps.txt
 python tools/bench_img3x3.py 2>&1 | grep -v amdgpu.ids > $O/img3x3_vs_conv_igemm.txt
-# Winograd feed emulation of the whole-block launch (tools build) next to the real launch
-(for B in 128 256; do python tools/bench_bneck.py --B $B --iters 20 --wino-emu --stamps 2>&1 | grep -v "amdgpu.ids"; done) > $O/winograd_feed_emulation.txt
 # the exchange step at world size 1 through RCCL (communicator + kernel really run): per-call time of the 13.9 MB bucket all-reduce
 python bench.py --gpus 1 --force-dist --actors 32 --steps 2 --warmup 1 --no-cpu-baseline --no-h2d --no-plugin --no-sync-actions --no-traffic > $O/bench_32actors_forcedist_line.json 2> $O/bench32fd.err
 # the plugin route's phases (one full iteration, fp32 and uint8 sensor frames)
@@ -94,4 +90,11 @@ cd /tmp
 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$O/tr32 -o t -- python $GRAFT_REPO_ROOT/bench.py --actors 32 --steps 1 --warmup 1 --no-cpu-baseline --no-h2d --no-plugin --no-sync-actions --no-traffic > /dev/null 2>&1
 cd $GRAFT_REPO_ROOT
 python tools/trace_step.py $(find $O/tr32 -name "*kernel_trace.csv" | head -1) 40 > $O/env_step_32actors.txt; rm -rf $O/tr32
+# the regime the headline runs in: rocprofv3 kernel trace of bench.py itself (two slice streams) -> per-env-step UNION of the
+# encoder kernels' intervals (profiles/engine_step_union.json: what bench.py's frac_profiles_concurrent is computed from)
+cd /tmp
+rocprofv3 --kernel-trace --output-format csv -d /tmp/esu -o t -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-h2d --no-plugin --no-sync-actions --no-traffic > $GRAFT_REPO_ROOT/$O/esu_line.json 2> /dev/null
+cd $GRAFT_REPO_ROOT
+python tools/engine_step_union.py $(find /tmp/esu -name "*kernel_trace.csv" | head -1) $O/esu_line.json $O/engine_step_union.json > $O/engine_step_union.txt 2>&1
+rm -rf /tmp/esu
 tail -c 600 $O/bench_line.json; echo; tail -3 $O/trunk_summary_tail.txt; tail -2 $O/vit_summary_tail.txt
