@@ -1906,6 +1906,10 @@ extern "C" int ec_policy_backward3(const ec_policy_t* h, const float* params, co
     const size_t sparts_cap = (size_t)B * flat;
     auto gemm_acc_split = [&](const void* A_, const void* B_, float* dW, int Mo, int No, long K, long sam, long sak, long sbk, long sbn,
                               int ldc, int flags, int sk) {
+        // every K slice costs a partial matrix written and read back: no more slices than fill the chip twice with 128 x 128 tiles
+        const long tiles_ = (long)((Mo + 127) / 128) * ((No + 127) / 128);
+        const int sk_cap = (int)std::max<long>(2, 512 / (tiles_ > 0 ? tiles_ : 1));
+        if (sk > sk_cap) sk = sk_cap;
         while (sk > 1 && (size_t)sk * Mo * No > sparts_cap) --sk;
         if (sk <= 1)
             return ec_gemm_f32(A_, B_, dW, Mo, No, (int)K, sam, sak, sbk, sbn, ldc, EC_GEMM_ACCUMULATE | flags, nullptr, nullptr, nullptr, 0,

@@ -92,7 +92,8 @@ __global__ __launch_bounds__(1024) void ppo_loss_kernel(const float* __restrict_
     // ONE workgroup of 1024 threads walks the B steps (a few thousand per actor slice: ~10 us): the four loss sums are then
     // folded in a fixed order inside it -- no cross-block atomics, bit-identical run to run
     double acc[4] = {0, 0, 0, 0};
-    for (long i = threadIdx.x; i < B; i += 1024) {
+#pragma unroll 4
+    for (long i = threadIdx.x; i < B; i += 1024) {                   // (unrolled: four elements' loads and exp / log chains in flight per thread)
         const float* row = hv + i * (A + 1);
         float lg[MAXA];
         float mx = -INFINITY;
@@ -205,10 +206,14 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
     __syncthreads();
     if (!last) return;
     __threadfence();                                                 // acquire: the other blocks' partials
+    // thread t adds partials t, t + 256, ... (independent loads in flight), then the same fixed-order block fold: the order
+    // depends on the grid size only
+    double f[1] = {0.0};
+    for (unsigned b = threadIdx.x; b < gridDim.x; b += 256) f[0] += __hip_atomic_load(scratch + 1 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();                                                 // (red is reused)
+    block_sum<1, 4>(f, red);
     if (threadIdx.x == 0) {
-        double t = 0.0;
-        for (unsigned b = 0; b < gridDim.x; ++b) t += __hip_atomic_load(scratch + 1 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        scratch[0] = t;
+        scratch[0] = f[0];
         *reinterpret_cast<unsigned*>(scratch + 1 + SUMSQ_MAX_BLOCKS) = 0u;
     }
 }

@@ -20,9 +20,10 @@ bash tools/pmc_collect.sh vit_$R tools/bench_vit.py --batch 128 --min-tiles 50 -
 NV=$(python - <<PY
 import csv,glob
 f=glob.glob("gpurun_out/pmc_vit_$R/kt/*kernel_trace.csv")[0]
-rows=[r for r in csv.DictReader(open(f))]
-# launches of the last forward = total / number of forwards (warm-up + 1 timed)
-print(len(rows)//2)
+rows=sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
+# launches of the last forward = everything from its patchify launch on (ec_vit_create's weight-folding launches precede the forwards)
+last=max(i for i,r in enumerate(rows) if "patchify_kernel" in r["Kernel_Name"])
+print(len(rows)-last)
 PY
 )
 HV=$(grep -h plan_hash gpurun_out/pmc_vit_$R.kt.log | tail -1 | cut -d" " -f2)
