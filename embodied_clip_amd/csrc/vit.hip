@@ -567,6 +567,8 @@ size_t mha_general_lds(int L) { return (size_t)L * 72 * 2 * 2 + 4 * 64 * 4 + 4 *
 // geometry does not suit the folded GEMMs (D % 128 != 0, more than 8 records per row) -- run_blocks then keeps the LayerNorm launches.
 int build_lnfold(ec_lnfold& fold, const uint16_t* w, const float* f, int layers, int D) {
     if (layers <= 0 || D % 128 != 0 || D / 128 > 8) return EC_OK;
+    // (the weights may have been uploaded on a non-blocking stream of the caller's: the fold below reads them on the null stream)
+    if (hipDeviceSynchronize() != hipSuccess) return EC_ERR_LAUNCH;
     const size_t Dz = (size_t)D, wl = 7 * Dz * Dz, fl = 14 * Dz;
     if (hipMalloc(&fold.w, layers * wl * sizeof(uint16_t)) != hipSuccess) { fold.w = nullptr; return EC_ERR_ALLOC; }
     if (hipMalloc(&fold.f, layers * fl * sizeof(float)) != hipSuccess) { fold.f = nullptr; return EC_ERR_ALLOC; }

@@ -776,3 +776,25 @@ def test_recurrent_section_of_the_dual_encoder_stops_before_the_depth_stream(dev
     assert len(names) == 25
     first_depth = names[17]
     assert rec.start == h.offsets["state_encoder.rnn.weight_ih_l0"][0] and rec.stop == h.offsets[first_depth][0] < h.flat_size
+
+
+@pytest.mark.parametrize("fast", ["1", "0"])
+def test_learn_pass_policy_gemm_modes_match_oracle_at_pingpong_size(fast):
+    """EC_POLICY_FAST (default 1: the learn pass's compressor conv over the stored features on the two leading bf16 planes of W1,
+    dW1 on two planes of dc1, the backward's large gradient GEMMs on three bf16x3 products) and the fp32-exact mode (0), each in
+    its own process, at T*N*49 = 37,632 rows -- where c1 really takes the 8-wave ping-pong kernel -- against the oracle's forward
+    and autograd gradients at the UNCHANGED tolerances: forward 2e-5, gradients 2e-4 rel-L2 per tensor."""
+    import json
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "_policy_mode_check.py")], env={**os.environ, "EC_POLICY_FAST": fast},
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["mode"] == fast and out["rows"] >= 256 * 128
+    assert out["logits"] < 2e-5 and out["values"] < 2e-5, out
+    for name, e in out["grads"].items():
+        assert e < 2e-4, (name, e, out)
+    print(out)
