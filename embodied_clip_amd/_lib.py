@@ -88,6 +88,8 @@ SIGNATURES = {
                                   c_void_p, c_size_t, c_int, c_void_p, c_void_p, c_void_p]),
     "ec_policy_forward2": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                    c_void_p, c_size_t, c_int, c_void_p, c_void_p, c_void_p]),
+    "ec_policy_act": (c_int, [c_void_p] * 4 + [c_int] + [c_void_p] * 3 + [c_int, c_void_p, c_size_t, c_int] + [c_void_p] * 5
+                      + [C.c_uint64, C.c_uint64, c_int, c_void_p]),
     "ec_policy_backward2": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_size_t,
                                     c_void_p, c_void_p, c_void_p, c_void_p]),
     "ec_policy_backward3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_size_t,

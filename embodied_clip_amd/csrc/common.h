@@ -40,6 +40,35 @@ __device__ __forceinline__ void ec_split3x4(const float (&x)[4], uint2& p0, uint
     p2.x = ec_pack2(r0 - ec_lo(p1.x), r1 - ec_hi(p1.x)); p2.y = ec_pack2(r2 - ec_lo(p1.y), r3 - ec_hi(p1.y));
 }
 
+// CategoricalDistr.sample() + log_prob() of one row of logits ([U] allenact base_abstractions/distributions.py): inverse CDF on a
+// counter-based uniform keyed by (seed, step, GLOBAL actor id).  Shared by sample_kernel (ppo.hip) and the act step's heads
+// launch (policy.hip: ec_policy_act) -- the same arithmetic, so the two routes sample identical actions.
+__device__ __forceinline__ uint64_t ec_mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+template <class RowFn>
+__device__ __forceinline__ void ec_sample_row(RowFn row, int A, uint64_t seed, uint64_t step, uint64_t global_actor, int& a_out,
+                                              float& logp_out) {
+    float mx = -INFINITY;
+    for (int k = 0; k < A; ++k) mx = fmaxf(mx, row(k));
+    float se = 0.f;
+    for (int k = 0; k < A; ++k) se += expf(row(k) - mx);
+    const float lse = mx + logf(se);
+    const uint64_t h = ec_mix64(ec_mix64(seed) ^ (step * 0x100000001B3ull + global_actor));
+    const float u = (float)((h >> 40) * (1.0 / 16777216.0));   // [0,1) with 24 bits
+    float cdf = 0.f;
+    int a = A - 1;
+    for (int k = 0; k < A; ++k) {
+        cdf += expf(row(k) - lse);
+        if (u < cdf) { a = k; break; }
+    }
+    a_out = a;
+    logp_out = row(a) - lse;
+}
+
 // Bijective XCD-aware remap of a linear block id (cdna guide T1): the
 // dispatcher places block b on XCD b % 8; give each XCD a contiguous chunk of
 // the logical tile space so neighbouring tiles share an L2.

@@ -1472,11 +1472,20 @@ int pick_splitk(long M, long N, long K) {
 // LinearActorHead + LinearCriticHead ([U] allenact basic_models.py): hv[b, :A] = hs[b] . Wa^T + ba, hv[b, A] = hs[b] . wc + bc.
 // A+1 <= 8 outputs of a 512-long dot product per row: one wave per row (the tiled GEMM would run this as ONE
 // workgroup -- 44 us for 128 rows).  Lane l owns elements l, l+64, ... of the row; fixed-order wave reduction.
+// smp.actions != nullptr (ec_policy_act): the wave that owns a row also samples its action from the logits it has just reduced
+// (CategoricalDistr.sample + log_prob, ec_sample_row: the arithmetic of sample_kernel) -- the act step's sixth launch folded into its fifth.
+struct SampleArgs {
+    long long* actions = nullptr;
+    float* logp = nullptr;
+    float* values = nullptr;
+    uint64_t seed = 0, step = 0;
+    int first_actor = 0;
+};
 template <int MAXO>
 __global__ __launch_bounds__(256) void heads_fwd_kernel(const float* __restrict__ hs, const float* __restrict__ Wa,
                                                        const float* __restrict__ ba, const float* __restrict__ Wc,
                                                        const float* __restrict__ bc, float* __restrict__ hv, long B,
-                                                       int H, int A) {
+                                                       int H, int A, SampleArgs smp) {
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= B) return;
@@ -1517,6 +1526,26 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(const float* __restrict_
         for (int o = 0; o < MAXO; ++o)
             if (o == lane) r = acc[o];
         hv[row * (A + 1) + lane] = r + (lane < A ? ba[lane] : bc[0]);
+    }
+    if (smp.actions) {   // (wave-uniform) every lane holds every reduced output: lane 0 samples from the final logits
+        float lg[MAXO];
+#pragma unroll
+        for (int o = 0; o < MAXO; ++o) lg[o] = acc[o] + (o < A ? ba[o] : (o == A ? bc[0] : 0.f));
+        if (lane == 0) {
+            int a;
+            float lp;
+            ec_sample_row([&](int k) { float v = 0.f;
+#pragma unroll
+                              for (int o = 0; o < MAXO; ++o) if (o == k) v = lg[o];
+                              return v; },
+                          A, smp.seed, smp.step, (uint64_t)(row + smp.first_actor), a, lp);
+            smp.actions[row] = a;
+            smp.logp[row] = lp;
+            float vv = 0.f;
+#pragma unroll
+            for (int o = 0; o < MAXO; ++o) if (o == A) vv = lg[o];
+            if (smp.values) smp.values[row] = vv;
+        }
     }
 }
 
@@ -1598,10 +1627,40 @@ extern "C" int ec_policy_forward(const ec_policy_t* h, const float* params, cons
                               h_final, stream);
 }
 
+namespace {
+int policy_forward_impl(const ec_policy_t* h, const float* params, const void* feat, const void* feat2, int feat_bf16,
+                        const int64_t* goal, const float* h0, const float* masks, int T, int N,
+                        void* workspace, size_t ws_bytes, int for_backward, float* hv, float* h_final, const SampleArgs& smp,
+                        ec_stream_t stream);
+}
 extern "C" int ec_policy_forward2(const ec_policy_t* h, const float* params, const void* feat, const void* feat2, int feat_bf16,
                                   const int64_t* goal, const float* h0, const float* masks, int T, int N,
                                   void* workspace, size_t ws_bytes, int for_backward, float* hv, float* h_final,
                                   ec_stream_t stream) {
+    return policy_forward_impl(h, params, feat, feat2, feat_bf16, goal, h0, masks, T, N, workspace, ws_bytes, for_backward, hv, h_final,
+                               SampleArgs{}, stream);
+}
+
+// The act step in ONE call ([U] allenact OnPolicyRLEngine.act: actor_critic(...) then distributions.sample() / log_probs()):
+// ec_policy_forward2(T = 1, EC_POLICY_INFER | EC_POLICY_INFER_REUSE) whose heads launch also samples -- exactly the results of
+// ec_policy_forward2 followed by ec_sample_actions, one launch less on the act step's serial chain.
+extern "C" int ec_policy_act(const ec_policy_t* h, const float* params, const void* feat, const void* feat2, int feat_bf16,
+                             const int64_t* goal, const float* h0, const float* masks, int N, void* workspace, size_t ws_bytes,
+                             int reuse_tables, float* hv, float* h_final, int64_t* actions, float* logp, float* values,
+                             uint64_t seed, uint64_t step, int first_actor, ec_stream_t stream) {
+    if (!actions || !logp) return EC_ERR_ARG;
+    if (!h || h->c.num_actions + 1 > 8) return EC_ERR_UNSUPPORTED;       // (the one-wave-per-row heads launch)
+    SampleArgs smp;
+    smp.actions = (long long*)actions; smp.logp = logp; smp.values = values; smp.seed = seed; smp.step = step; smp.first_actor = first_actor;
+    return policy_forward_impl(h, params, feat, feat2, feat_bf16, goal, h0, masks, 1, N, workspace, ws_bytes,
+                               reuse_tables ? EC_POLICY_INFER_REUSE : EC_POLICY_INFER, hv, h_final, smp, stream);
+}
+
+namespace {
+int policy_forward_impl(const ec_policy_t* h, const float* params, const void* feat, const void* feat2, int feat_bf16,
+                        const int64_t* goal, const float* h0, const float* masks, int T, int N,
+                        void* workspace, size_t ws_bytes, int for_backward, float* hv, float* h_final, const SampleArgs& smp,
+                        ec_stream_t stream) {
     if (!h || !params || !feat || !goal || !h0 || !masks || !workspace || !hv) return EC_ERR_ARG;
     if (h->c.dual && !feat2) return EC_ERR_ARG;
     if (T <= 0 || N <= 0) return EC_ERR_SHAPE;
@@ -1838,7 +1897,7 @@ extern "C" int ec_policy_forward2(const ec_policy_t* h, const float* params, con
     // heads: hv[:, :A] = actor logits, hv[:, A] = critic value
     if (A1 <= 8) {
         hipLaunchKernelGGL(heads_fwd_kernel<8>, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s, hs_base, W(P_WA), W(P_BA),
-                           W(P_WC), W(P_BC), hv, (long)B, H, c.num_actions);
+                           W(P_WC), W(P_BC), hv, (long)B, H, c.num_actions, smp);
     } else {
         RC(ec_gemm_f32(hs_base, W(P_WA), hv, B, c.num_actions, H, H, 1, 1, H, A1, 0, W(P_BA), nullptr, nullptr, 0,
                        nullptr, nullptr, 1, stream));
@@ -1850,6 +1909,7 @@ extern "C" int ec_policy_forward2(const ec_policy_t* h, const float* params, con
     EC_CHECK_LAUNCH();
     return EC_OK;
 }
+}  // namespace
 
 extern "C" int ec_policy_backward(const ec_policy_t* h, const float* params, const void* feat, int feat_bf16,
                                   const float* masks, int T, int N, void* workspace, size_t ws_bytes, const float* dhv,

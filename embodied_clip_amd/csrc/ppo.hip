@@ -155,35 +155,18 @@ __global__ __launch_bounds__(1024) void ppo_loss_kernel(const float* __restrict_
     if (threadIdx.x == 0) { sums[0] = acc[0]; sums[1] = acc[1]; sums[2] = acc[2]; sums[3] = acc[3]; }
 }
 
-__device__ __forceinline__ uint64_t mix64(uint64_t z) {
-    z += 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
-
-// CategoricalDistr.sample() + log_prob(): inverse-CDF on a counter-based uniform.
+// CategoricalDistr.sample() + log_prob(): inverse-CDF on a counter-based uniform (ec_sample_row, common.h).
 template <int MAXA>
 __global__ void sample_kernel(const float* __restrict__ hv, long long* __restrict__ actions, float* __restrict__ logp,
                               float* __restrict__ values, int N, int A, uint64_t seed, uint64_t step, int first_actor) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= N) return;
     const float* row = hv + (long)n * (A + 1);
-    float mx = -INFINITY;
-    for (int k = 0; k < A; ++k) mx = fmaxf(mx, row[k]);
-    float se = 0.f;
-    for (int k = 0; k < A; ++k) se += expf(row[k] - mx);
-    const float lse = mx + logf(se);
-    const uint64_t h = mix64(mix64(seed) ^ (step * 0x100000001B3ull + (uint64_t)(n + first_actor)));   // keyed by GLOBAL actor id
-    const float u = (float)((h >> 40) * (1.0 / 16777216.0));   // [0,1) with 24 bits
-    float cdf = 0.f;
-    int a = A - 1;
-    for (int k = 0; k < A; ++k) {
-        cdf += expf(row[k] - lse);
-        if (u < cdf) { a = k; break; }
-    }
+    int a;
+    float lp;
+    ec_sample_row([&](int k) { return row[k]; }, A, seed, step, (uint64_t)(n + first_actor), a, lp);   // keyed by GLOBAL actor id
     actions[n] = a;
-    logp[n] = row[a] - lse;
+    logp[n] = lp;
     if (values) values[n] = row[A];
 }
 

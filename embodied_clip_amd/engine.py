@@ -269,6 +269,7 @@ class Worker:
         self._conv8_min_tiles = (50 if n >= 128 else (75 if n >= 64 else 0)) if ns == 2 else 0
         for e in encs:
             e.set_conv8_min_tiles(self._conv8_min_tiles)
+        self._act_fused = os.environ.get("EC_ACT_FUSED_SAMPLE", "1") != "0" and self.A + 1 <= 8   # (A/B switch; > 7 actions: two calls)
         self.seed = seed + 7919 * rank
         self.total_steps = 0
         self.iter = 0
@@ -348,6 +349,13 @@ class Worker:
         o, n, sp = sl.o, sl.n, _lib.stream_ptr()
         rs = slice(o, o + n)
         h_in, h_out = (self.h, self.h_next) if (t & 1) == 0 else (self.h_next, self.h)   # ping-pong by step parity
+        if sample and self._act_fused:
+            # forward + CategoricalDistr.sample / log_prob in one call: the heads launch samples (ec_policy_act, one launch less)
+            self.policy.act(self.params, sl.feat[t], self.env.goals[t][rs], h_in[rs], self.env.masks[t][rs], n, sl.ws_act,
+                            self.hv_act[rs], h_out[rs], self.actions[t][rs], self.logp[t][rs], self.values[t][rs], self.seed,
+                            self.iter * (self.T + 1) + t, o, reuse_tables=sl.act_tables_valid)
+            sl.act_tables_valid = True
+            return
         self.policy.forward(self.params, sl.feat[t], self.env.goals[t][rs], h_in[rs], self.env.masks[t][rs], 1, n,
                             sl.ws_act, hv=self.hv_act[rs], h_final=h_out[rs], for_backward=False,
                             reuse_tables=sl.act_tables_valid)      # (E1 depends on the parameters only)

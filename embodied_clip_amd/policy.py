@@ -111,6 +111,19 @@ class PolicyHandle:
             mode = 1 if for_backward else (2 if reuse_tables else 0)
             return self._forward(flat_params, feat, goal, h0, masks, T, N, ws, hv, h_final, dev, mode, feat2)
 
+    def act(self, flat_params, feat, goal, h0, masks, N, ws, hv, h_final, actions, logp, values, seed: int, step: int,
+            first_actor: int, reuse_tables: bool = False, feat2=None):
+        """The act step in one call (``ec_policy_act``): the T = 1 inference forward whose heads launch also samples
+        ``actions`` / ``logp`` (and copies ``values``) -- the results of ``forward(for_backward=False)`` + ``ec_sample_actions``."""
+        assert feat.is_contiguous() and feat.dtype in (torch.bfloat16, torch.float32)
+        with _lib.tensor_guard(flat_params):
+            _lib.check(self.lib.ec_policy_act(
+                self.h, flat_params.data_ptr(), feat.data_ptr(), _lib.ptr(feat2), int(feat.dtype == torch.bfloat16), goal.data_ptr(),
+                h0.data_ptr(), masks.data_ptr(), N, ws.data_ptr(), ws.numel() * ws.element_size(), int(reuse_tables),
+                hv.data_ptr(), h_final.data_ptr(), actions.data_ptr(), logp.data_ptr(), _lib.ptr(values), seed, step, first_actor,
+                _lib.stream_ptr()), "ec_policy_act")
+        return hv, h_final
+
     def _forward(self, flat_params, feat, goal, h0, masks, T, N, ws, hv, h_final, dev, for_backward=True, feat2=None):
         if hv is None:
             hv = torch.empty((T * N, self.A + 1), dtype=torch.float32, device=dev)

@@ -356,6 +356,15 @@ int ec_policy_forward(const ec_policy_t* h, const float* params, const void* fea
 int ec_policy_forward2(const ec_policy_t* h, const float* params, const void* feat, const void* feat2, int feat_bf16,
                        const int64_t* goal, const float* h0, const float* masks, int T, int N,
                        void* workspace, size_t ws_bytes, int for_backward, float* hv, float* h_final, ec_stream_t stream);
+/* The act step in ONE call ([U] allenact OnPolicyRLEngine.act: `actor_critic(...)`, then `distributions.sample()` and
+ * `log_probs(actions)`): ec_policy_forward2 with T = 1 and EC_POLICY_INFER (reuse_tables = 0) / EC_POLICY_INFER_REUSE (1), whose
+ * heads launch also samples -- actions int64 [N], logp f32 [N], values f32 [N] or NULL, keyed as in ec_sample_actions.  Bit-for-bit
+ * the results of ec_policy_forward2 followed by ec_sample_actions; one launch less on the act step's serial chain.
+ * EC_ERR_UNSUPPORTED for more than 7 actions (use the two calls). */
+int ec_policy_act(const ec_policy_t* h, const float* params, const void* feat, const void* feat2, int feat_bf16,
+                  const int64_t* goal, const float* h0, const float* masks, int N, void* workspace, size_t ws_bytes,
+                  int reuse_tables, float* hv, float* h_final, int64_t* actions, float* logp, float* values,
+                  uint64_t seed, uint64_t step, int first_actor, ec_stream_t stream);
 /* dhv f32 [T*N, A+1] = dLoss/dhv; dh_final [N,H] or NULL; grads += dLoss/dparams.
  * `workspace` must be the one the matching ec_policy_forward filled (for_backward size). */
 int ec_policy_backward(const ec_policy_t* h, const float* params, const void* feat, int feat_bf16,

@@ -798,3 +798,33 @@ def test_learn_pass_policy_gemm_modes_match_oracle_at_pingpong_size(fast):
     for name, e in out["grads"].items():
         assert e < 2e-4, (name, e, out)
     print(out)
+
+
+def test_policy_act_is_forward_plus_sample(dev):
+    """``ec_policy_act`` (the act step's heads launch also samples) == ``ec_policy_forward2(T = 1, inference)`` followed by
+    ``ec_sample_actions``: hv, the new memory, the actions, their log-probabilities and the values bit for bit -- first call
+    (tables built) and a reuse call, actor offsets keyed globally."""
+    from embodied_clip_amd import _lib
+    from embodied_clip_amd.policy import PolicyHandle
+    lib = _lib.load()
+    h = PolicyHandle()
+    flat = h.flatten(syn.policy_state_dict(5), dev)
+    N = 37
+    g = torch.Generator().manual_seed(9)
+    feat = (torch.randn(N, 49, 2048, generator=g).abs() * 0.5).to(torch.bfloat16).to(dev)
+    goal = syn.synthetic_goals(6, (N,)).to(dev)
+    h0 = (torch.randn(N, 512, generator=g) * 0.3).to(dev)
+    m = (torch.rand(N, generator=g) > 0.2).float().to(dev)
+    ws_a = torch.empty(h.workspace_bytes(1, N, False), dtype=torch.uint8, device=dev)
+    ws_b = torch.empty_like(ws_a)
+    for call, reuse in enumerate((False, True)):
+        hv_a, hf_a = h.forward(flat, feat, goal, h0, m, 1, N, ws_a, for_backward=False, reuse_tables=reuse)
+        act_a = torch.zeros(N, dtype=torch.int64, device=dev); lp_a = torch.zeros(N, device=dev); v_a = torch.zeros(N, device=dev)
+        _lib.check(lib.ec_sample_actions(hv_a.data_ptr(), act_a.data_ptr(), lp_a.data_ptr(), v_a.data_ptr(), N, 6, 123, 40 + call, 1000, 0))
+        hv_b = torch.empty_like(hv_a); hf_b = torch.empty_like(hf_a)
+        act_b = torch.zeros(N, dtype=torch.int64, device=dev); lp_b = torch.zeros(N, device=dev); v_b = torch.zeros(N, device=dev)
+        h.act(flat, feat, goal, h0, m, N, ws_b, hv_b, hf_b, act_b, lp_b, v_b, 123, 40 + call, 1000, reuse_tables=reuse)
+        torch.cuda.synchronize()
+        assert torch.equal(hv_a, hv_b) and torch.equal(hf_a, hf_b)
+        assert torch.equal(act_a, act_b) and torch.equal(lp_a, lp_b) and torch.equal(v_a, v_b)
+        assert len(set(act_a.tolist())) > 1 and (lp_a < 0).all()
