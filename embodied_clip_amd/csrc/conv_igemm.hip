@@ -1548,10 +1548,10 @@ int ec_gemm_bf16a_xp(const void* A, const void* Wplanes, const float* bias, floa
 // Replaces `x + attn(ln_1(x))` / `x + mlp(ln_2(x))`'s nn.LayerNorm launches ([U] clip/model.py ResidualAttentionBlock.forward).
 int ec_gemm_bf16_ln8(const void* A, const void* Wt, const float* bias, const void* res, void* out, int M, int N, int K, int act,
                      const float* ln_s, const float* ln_stats, int ln_np, float* stats_out, int* np_out, ec_stream_t stream) {
-    if (!A || !Wt || !out || !bias) return EC_ERR_ARG;
+    if (!A || !Wt || !out) return EC_ERR_ARG;
     if (M <= 0 || N % 128 != 0 || K % 64 != 0 || K < 64) return EC_ERR_SHAPE;
     if (res && act == EC_ACT_QUICKGELU) return EC_ERR_UNSUPPORTED;
-    if (ln_s && (res || !ln_stats || ln_np < 1 || ln_np > 8)) return EC_ERR_ARG;
+    if (ln_s && (res || !bias || !ln_stats || ln_np < 1 || ln_np > 8)) return EC_ERR_ARG;   // (plain calls -- the patch embedding -- may come without a bias)
     ConvArgs a;
     a.in = (const uint16_t*)A;
     a.w = (const uint16_t*)Wt;

@@ -730,6 +730,10 @@ extern "C" int ec_vit_forward(const ec_vit_t* h, const float* rgb, int batch, vo
         if (blocks > 8192) blocks = 8192;
         hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)blocks), dim3(256), 0, s, rgb, patches, h->res, P, G, total4);
     }
+    // (through the folded GEMMs' tile chooser when the geometry suits the 8-wave kernel: 192-row tiles for N = D, §4.9)
+    if (h->fold.ok && Kp % 64 == 0)
+        RC(ec_gemm_bf16_ln8(patches, w, nullptr, nullptr, pemb, B * G2, D, Kp, EC_ACT_NONE, nullptr, nullptr, 0, nullptr, nullptr, stream));
+    else
     RC(ec_gemm_bf16(patches, w, nullptr, nullptr, pemb, B * G2, D, Kp, EC_ACT_NONE, stream));
     w += (size_t)D * Kp;
     const long rows = (long)B * L;
