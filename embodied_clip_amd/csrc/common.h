@@ -2,9 +2,7 @@
 // embodied-clip hot path.  HIP only -- no CUDA compatibility layer.
 #pragma once
 #include <hip/hip_runtime.h>
-#include <hip/hip_ext.h>
 #include <stdint.h>
-#include <stdlib.h>
 
 #include <atomic>
 
@@ -122,70 +120,6 @@ struct ec_min_tiles_scope {
     ~ec_min_tiles_scope() { ec_tls_conv8_min_tiles = prev; }
 };
 
-// ---- any-order launch chain (round 6; rn50.hip, small launches of layers 3-4) ------------------------------------------------
-// A run of DEPENDENT launches on one stream whose members after the first are dispatched without the stream's barrier bit
-// (hipExtAnyOrderLaunch) and carry their dependency themselves: every workgroup of launch k bumps launch k's done counter
-// after its (write-through) stores have been acknowledged; every workgroup of launch k + 1 runs its producer-independent
-// prologue, polls that counter against the expected total, acquires, and only then touches launch k's output -- so the next
-// launch's dispatch and prologue run under the tail of the previous one (tools/ubench/anyorder.hip: 25.1 -> 23.9 us per
-// launch of 256 workgroups, correct across XCDs).  The counters are monotonic (the host keeps the expected totals), so
-// nothing is reset between forwards.  A launch function that supports the protocol calls ec_chain_take(); the executor
-// breaks the chain behind any call that did not (that launch then runs in order, which is always correct).
-struct EcChain {
-    unsigned* flags = nullptr;        // device: one done counter per slot
-    unsigned* expect = nullptr;       // host shadow: the total each slot will have reached when its current launch is done
-    int nslots = 0, pos = 0;
-    const unsigned* wait_ptr = nullptr;   // the previous chained launch's counter / total (nullptr: launch in order)
-    unsigned wait_target = 0;
-    bool taken = false;               // set by ec_chain_take: the call just issued was a chain member
-};
-extern thread_local EcChain* ec_tls_chain;       // rn50.hip: non-null while the executor issues a chainable launch
-struct EcChainLink { const unsigned* wait; unsigned target; unsigned* done; bool anyorder; };
-inline bool ec_chain_wt() { static const bool v = [] { const char* e = getenv("EC_CHAIN_WT"); return e ? atoi(e) != 0 : true; }(); return v; }
-inline EcChainLink ec_chain_take(unsigned nwg) {
-    EcChain* c = ec_tls_chain;
-    if (!c) return EcChainLink{nullptr, 0u, nullptr, false};
-    EcChainLink l{c->wait_ptr, c->wait_target, c->flags + c->pos, c->wait_ptr != nullptr};
-    c->expect[c->pos] += nwg;
-    c->wait_ptr = l.done;
-    c->wait_target = c->expect[c->pos];
-    c->pos = c->pos + 1 == c->nslots ? 0 : c->pos + 1;
-    c->taken = true;
-    return l;
-}
-// consumer side: lane 0 polls (bounded: a lost producer must not hang the box), one agent-scope acquire, then the workgroup
-__device__ __forceinline__ void ec_chain_wait(const unsigned* wait, unsigned target) {
-    if (!wait) return;
-    if (threadIdx.x == 0) {
-        int it = 0;
-        while ((int)(__hip_atomic_load(wait, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-            __builtin_amdgcn_s_sleep(2);
-            if (++it > (1 << 22)) break;
-        }
-    }
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // (buffer_inv sc1: this CU's L1; the producer stored write-through)
-}
-// producer side: every wave's stores acknowledged, then one relaxed agent-scope bump (the stores were sc1 = write-through)
-__device__ __forceinline__ void ec_chain_done(unsigned* done, bool wt = true) {
-    if (!done) return;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        if (!wt) {   // plain stores: write the XCD L2's dirty lines back (they stay resident for same-XCD readers)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-// 16-byte global store, write-through (sc1) when the launch is a chain member
-typedef unsigned int ec_u32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void ec_store16(void* ptr, ec_u32x4_t v, bool wt) {
-    if (wt) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(ptr), "v"(v) : "memory");
-    else *reinterpret_cast<ec_u32x4_t*>(ptr) = v;
-}
-
 // Once-per-workgroup staging loops (weights -> LDS).  Written as `for (idx = tid; ...) lds[f(idx)] = global[g(idx)]` hipcc
 // emits load -> s_waitcnt vmcnt(0) -> ds_write per iteration: TOTAL / NT serial L2 round trips at the head of EVERY
 // launch (18 of them, ~15 us, in the narrow 3x3 kernels -- round-3 EC_ROWS_DBG ablation).  Here all of a thread's loads
@@ -229,7 +163,6 @@ struct EcConfig {
     int rn50_bneck;       // EC_RN50_BNECK    (128) launches of at least this many frames run layer3.1-5 as fused bottleneck launches (conv_bneck.hip); 0: never
     int rn50_bneck3;      // EC_RN50_BNECK3   (1)   the fused bottleneck launches include conv1 (the whole block in one launch)
     int rn50_img3;        // EC_RN50_IMG3     (1)   small launches run the 14x14x256 (<= 32 frames) / 7x7x512 (<= 64 frames) 3x3 convs on the image-resident K-split kernel
-    int rn50_anyorder;    // EC_RN50_ANYORDER (0)   launches of at most this many frames run layers 3-4 as any-order launch chains (device-side done counters instead of the stream's barrier bit); 0: never
     int rn50_dscat;       // EC_RN50_DSCAT    (1)   stride-2 Bottlenecks of layers 3-4: conv3 and the downsample conv as ONE GEMM over the concatenated K axis (pooled conv2 output | pooled block input)
     // --- policy / update ---
     int gemm_no_x3;       // EC_GEMM_NO_X3    (0)   policy GEMMs on the fp32 MFMA instead of bf16x3

@@ -524,10 +524,6 @@ struct ImgArgs {
     int B;
     unsigned w_bytes;
     int ldo;               // POOL variant: row stride of `out` in elements (C = dense)
-    const unsigned* ch_wait = nullptr;   // any-order launch chain (common.h EcChain)
-    unsigned ch_target = 0;
-    unsigned* ch_done = nullptr;
-    int ch_wt = 1;
 };
 
 // NCH > 1: the input map does not fit the LDS (14 x 14 x 512 = 200 KB): it is made resident in NCH channel chunks, one after
@@ -594,7 +590,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_img_kernel(ImgArgs p) {
     };
     issue_w(0, 0);
     issue_w(1, 1);
-    ec_chain_wait(p.ch_wait, p.ch_target);                        // chain member: the first weight tiles are on their way; the map comes from the producer
     load_T(0);
     __syncthreads();
 
@@ -746,7 +741,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_img_kernel(ImgArgs p) {
             w.x = ec_pack2(o[0], o[1]); w.y = ec_pack2(o[2], o[3]);
             *reinterpret_cast<uint2*>(p.out + ((size_t)img * PP + q) * p.ldo + n0 + c4 * 4) = w;
         }
-        return;                                                  // (the pooled variant is never a chain member: launch code below)
+        return;
     }
     if (wave < NT) {
         const int ti = wave, i = ti / FN, f = ti - i * FN;
@@ -769,10 +764,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_img_kernel(ImgArgs p) {
         for (int h2 = 0; h2 < 2; ++h2) {
             const int er = (lane >> 2) + 16 * h2, px = i * 32 + er;
             const u32x4_t v = *reinterpret_cast<const u32x4_t*>(E + er * 64 + ((ec ^ ((er >> 2) & 3)) << 4));
-            if (px < PIX) ec_store16(yo + (size_t)px * C + ec * 8, v, p.ch_done != nullptr && p.ch_wt);
+            if (px < PIX) *reinterpret_cast<u32x4_t*>(yo + (size_t)px * C + ec * 8) = v;
         }
     }
-    ec_chain_done(p.ch_done, p.ch_wt != 0);
 }
 
 // Streaming order of a [N][K] bf16 weight matrix for bneck23_kernel: 16-byte unit ((s * K/32 + kt) * 32 + r) * 4 + pc holds
@@ -820,13 +814,6 @@ extern "C" int ec_conv3x3_img_bf16_ld(const void* in, const void* packed, const 
     auto go = [&](auto kern, int nslice, size_t lds, std::atomic<uint64_t>& done) {
         if (auto attr_g_ = ec_attr_needed(done))
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (ec_tls_chain && !pool) {   // any-order launch chain (common.h)
-            const EcChainLink l = ec_chain_take((unsigned)(B * nslice));
-            a.ch_wait = l.wait; a.ch_target = l.target; a.ch_done = l.done; a.ch_wt = ec_chain_wt() ? 1 : 0;
-            hipExtLaunchKernelGGL(kern, dim3((unsigned)(B * nslice)), dim3(512), lds, (hipStream_t)stream, nullptr, nullptr,
-                                  l.anyorder ? hipExtAnyOrderLaunch : 0, a);
-            return;
-        }
         hipLaunchKernelGGL(kern, dim3((unsigned)(B * nslice)), dim3(512), lds, (hipStream_t)stream, a);
     };
     if (H == 14 && C == 256 && !pool) {

@@ -51,7 +51,6 @@
 #include "common.h"
 
 thread_local int ec_tls_conv8_min_tiles = EC_CONV8_MIN_TILES_DEFAULT;   // common.h: set per call from the encoder handle
-thread_local EcChain* ec_tls_chain = nullptr;                           // common.h: any-order launch chain of the trunk executor
 
 namespace {
 
@@ -96,11 +95,6 @@ struct ConvArgs {
     float ln_eps = 1e-5f;
     float* stats_out = nullptr;
     int aux_off = 0;              // byte offset of the 4-KB auxiliary LDS area behind the stages / the epilogue image
-    // ---- any-order launch chain (common.h EcChain; conv_igemm_kernel only) ----
-    const unsigned* ch_wait = nullptr;   // the producer launch's done counter, reached ch_target when all of its workgroups are done
-    unsigned ch_target = 0;
-    unsigned* ch_done = nullptr;         // this launch's done counter (stores go write-through when set)
-    int ch_wt = 1;
 };
 
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
@@ -395,8 +389,6 @@ __global__ __launch_bounds__(WM * WN * 64, (BM > 192) ? 2 : ((WM * WN == 8) ? 4 
     const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, p.res ? p.res_bytes : 0u, 0x00020000);
 #endif
     const int wave_lds = wave * 1024;                       // 64 lanes x 16 B
-    // chain member: everything above (tile decode, descriptors) ran under the producer's tail; its output is touched from here on
-    ec_chain_wait(p.ch_wait, p.ch_target);
     // per-K-tile addressing state shared by the pieces of one tile
     const int nk = (p.K + BK - 1) / BK;
     const int kt0 = 0, kt1 = nk, k_lim = p.K;   // the K-tile range; k >= k_lim reads as zeros
@@ -625,14 +617,13 @@ __global__ __launch_bounds__(WM * WN * 64, (BM > 192) ? 2 : ((WM * WN == 8) ? 4 
     for (int r0 = 0; r0 < OUT_ROWS; r0 += RPP) {
         const int row = r0 + srow;
         if (orow0 + row < Mout && (MV == BM || row < MV))
-            ec_store16(p.out + (long)(orow0 + row) * p.ldo + e_n0 + schunk * 8,
-                       *reinterpret_cast<const ec_u32x4_t*>(smem + row * PITCH + schunk * 16), p.ch_done != nullptr && p.ch_wt);
+            *reinterpret_cast<uint4*>(p.out + (long)(orow0 + row) * p.ldo + e_n0 + schunk * 8) =
+                *reinterpret_cast<const uint4*>(smem + row * PITCH + schunk * 16);
     }
         }   // !(ablate & 8)
         if (!has_next) break;
         __syncthreads();                                     // epilogue's LDS reads are done before the next store_tile
     }
-    ec_chain_done(p.ch_done, p.ch_wt != 0);
 }
 
 template <int BM, int BN, int WM, int WN, int KS, bool POOL, bool PF = false, int MV = BM, int NS = 0, bool ILV = false, bool S2 = false>
@@ -659,13 +650,6 @@ int launch(const ConvArgs& a, hipStream_t s) {
     const int ring_per_cu = NS >= 3 ? (int)std::min<size_t>(2, (160 * 1024) / lds) : 0;
     const int cap = NS >= 3 ? 256 * ring_per_cu : ((BM * BN >= 256 * 256) ? 256 : wg_cap);      // 8-wave 256x256 tiles: one workgroup per CU
     const int nwg = p.ntiles < cap ? p.ntiles : cap;
-    if (ec_tls_chain) {   // any-order launch chain (common.h): members after the first go out without the stream's barrier bit
-        const EcChainLink l = ec_chain_take((unsigned)nwg);
-        p.ch_wait = l.wait; p.ch_target = l.target; p.ch_done = l.done; p.ch_wt = ec_chain_wt() ? 1 : 0;
-        hipExtLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(WM * WN * 64), lds, s, nullptr, nullptr, l.anyorder ? hipExtAnyOrderLaunch : 0, p);
-        EC_CHECK_LAUNCH();
-        return EC_OK;
-    }
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(WM * WN * 64), lds, s, p);
     EC_CHECK_LAUNCH();
     return EC_OK;

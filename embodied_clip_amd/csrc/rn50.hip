@@ -56,17 +56,9 @@ struct ec_rn50 {
     int conv8_min_tiles = 0;      // 0 = library default (ec_rn50_set_conv8_min_tiles)
     uint16_t* wbneck = nullptr;   // streaming-order weights of the fused bottleneck launches (ec_bneck_pack_weights), one block per OP_BNECK
     float* bias_cat = nullptr;    // summed biases of the K-concatenated convs (Op::bcat_off)
-    // any-order launch chains (common.h EcChain): 64 monotonic done counters on the device and the totals the host expects of
-    // them.  A forward that uses them is NOT re-entrant on this handle (one handle per stream, as the engine's slices have).
-    static constexpr int CHAIN_SLOTS = 64;
-    unsigned* chain_flags = nullptr;
-    mutable unsigned chain_expect[CHAIN_SLOTS] = {};
-    mutable int chain_pos = 0;
-    int chain_from = -1;          // first op of the chained region (the first layer-3 bottleneck), -1: none
     ~ec_rn50() {
         if (wbneck) (void)hipFree(wbneck);
         if (bias_cat) (void)hipFree(bias_cat);
-        if (chain_flags) (void)hipFree(chain_flags);
     }
 };
 
@@ -339,12 +331,6 @@ int rn50_build(ec_rn50_t** out, bool tv, int width, const int* layers4, int inpu
             (void)hipStreamSynchronize(nullptr);
         }
     }
-    for (size_t i = 0; i < h->ops.size(); ++i)
-        if (h->ops[i].kind == OP_BNECK) { h->chain_from = (int)i; break; }
-    if (h->chain_from >= 0) {
-        if (hipMalloc(&h->chain_flags, ec_rn50::CHAIN_SLOTS * sizeof(unsigned)) != hipSuccess) { h->chain_flags = nullptr; delete h; return EC_ERR_LAUNCH; }
-        if (hipMemset(h->chain_flags, 0, ec_rn50::CHAIN_SLOTS * sizeof(unsigned)) != hipSuccess) { delete h; return EC_ERR_LAUNCH; }
-    }
     *out = h;
     return EC_OK;
 }
@@ -425,22 +411,8 @@ int rn50_run(const ec_rn50_t* h, const void* rgb, bool u8, const float* mean3, c
             if (id == -3) return (uint16_t*)feat + (size_t)b0 * out_stride;
             return base + (size_t)id * bufsz;
         };
-        // Small launches: layers 3-4 (from the first layer-3 bottleneck on) as any-order launch chains -- every conv launch there
-        // is 10-15 us, most of it fixed cost; a chain member's dispatch and prologue run under its producer's tail.  A launch that
-        // does not speak the protocol (pools, 8-wave tiles) runs in order and the chain restarts behind it.
-        EcChain chain;
-        const bool chain_on = h->chain_flags && ec_config().rn50_anyorder > 0 && nb <= ec_config().rn50_anyorder;
-        if (chain_on) { chain.flags = h->chain_flags; chain.expect = h->chain_expect; chain.nslots = ec_rn50::CHAIN_SLOTS; chain.pos = h->chain_pos; }
-        struct ChainScope {     // arms the thread's chain pointer for ONE call and breaks the chain if that call did not join it
-            EcChain* c;
-            explicit ChainScope(EcChain* c_) : c(c_) { if (c) { c->taken = false; ec_tls_chain = c; } }
-            ~ChainScope() { if (c) { ec_tls_chain = nullptr; if (!c->taken) c->wait_ptr = nullptr; } }
-        };
-        int op_index = -1;
         for (const Op& o : h->ops) {
             int rc;
-            ++op_index;
-            EcChain* const ch = (chain_on && op_index >= h->chain_from) ? &chain : nullptr;
             const hipStream_t stream = (hipStream_t)stream_main;
             switch (o.kind) {
                 case OP_STEM1:
@@ -491,29 +463,22 @@ int rn50_run(const ec_rn50_t* h, const void* rgb, bool u8, const float* mean3, c
                                                   buf(o.res), buf(o.dst), nb, o.H, o.W, o.Cin, stream);
                     else {   // small launches: the convs separately (buffer 1 = conv1's, buffer 2 = conv2's output, as in the unfused plan)
                         if (o.wc1_off >= 0) {
-                            ChainScope cs(ch);
                             rc = ec_conv_bf16(buf(o.res), h->w + o.wc1_off, h->bias + o.bc1_off, nullptr, buf(o.src), nb, o.H, o.W,
                                                  o.Cout, o.Cin, 1, 0, EC_ACT_RELU, stream);
                             if (rc != EC_OK) return rc;
                         }
                         // ... conv2 on the image-resident K-split kernel while its (image, slice) workgroups fit one round
-                        {
-                        ChainScope cs(ch);
                         if (ec_config().rn50_img3 && nb * 8 <= 256)
                             rc = ec_conv3x3_img_bf16(buf(o.src), h->wbneck + o.wimg_off, h->bias + o.b_off, buf(2), nb, o.H, o.W, o.Cin, 0, stream);
                         else
                         rc = ec_conv_bf16(buf(o.src), h->w + o.w_off, h->bias + o.b_off, nullptr, buf(2), nb, o.H, o.W,
                                              o.Cin, o.Cin, 3, 0, EC_ACT_RELU, stream);
-                        }
-                        if (rc == EC_OK) {
-                            ChainScope cs(ch);
+                        if (rc == EC_OK)
                             rc = ec_conv_bf16(buf(2), h->w + o.w1_off, h->bias + o.b1_off, buf(o.res), buf(o.dst), nb, o.H,
                                                  o.W, o.Cin, o.Cout, 1, 0, EC_ACT_RELU, stream);
-                        }
                     }
                     break;
-                default: {
-                    ChainScope cs(ch);        // (OP_CONV in the chained region: conv_igemm_kernel / conv3x3_img_kernel launches join, others break the chain)
+                default:
                     if (o.stride == 2) {
                         rc = ec_conv_bf16_s2(buf(o.src), h->w + o.w_off, h->bias + o.b_off, o.res >= 0 ? buf(o.res) : nullptr, buf(o.dst),
                                              nb, o.H, o.W, o.Cin, o.Cout, o.ks, o.act, stream);
@@ -533,12 +498,9 @@ int rn50_run(const ec_rn50_t* h, const void* rgb, bool u8, const float* mean3, c
                     rc = ec_conv_bf16_ld(buf(o.src), h->w + o.w_off, h->bias + o.b_off, o.res >= 0 ? buf(o.res) : nullptr,
                                          (uint16_t*)buf(o.dst) + o.ocol, nb, o.H, o.W, o.Cin, o.Cout, o.ks, o.pool, o.act,
                                          o.ldo ? o.ldo : o.Cout, stream);
-                }
             }
-            if (ch && (o.kind == OP_POOL || o.kind == OP_PAIR || o.kind == OP_STEM1 || o.kind == OP_STEM7)) chain.wait_ptr = nullptr;   // in-order launches: the chain restarts behind them
             if (rc != EC_OK) return rc;
         }
-        if (chain_on) h->chain_pos = chain.pos;
     }
     return EC_OK;
 }
