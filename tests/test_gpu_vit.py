@@ -140,3 +140,30 @@ def test_text_tower_matches_oracle_and_is_causal(dev):
         assert torch.equal(enc.encode_text(t2).cpu(), got)
         tab = enc.goal_table(tokens).cpu()
         assert torch.allclose(tab.norm(dim=-1), torch.ones(n), atol=1e-5)
+
+
+def test_folded_layernorm_with_a_large_row_mean(dev):
+    """The LayerNorm folded into the QKV / c_fc GEMMs (round 6) computes rstd * (x Wg^T - mean * s) + c on the RAW residual rows:
+    the mean term must cancel against the GEMM's own sum.  Stress: a residual stream whose rows have |mean| = 3-4 x their standard
+    deviation (ln_pre's bias shifted by +6, block LayerNorm gains spread over 0.25 .. 4) -- same tolerances as the plain tower."""
+    from embodied_clip_amd.encoder import ViTEmbedder
+    sd = syn.vit_visual_state_dict(11, width=128, layers=3, heads=2, patch_size=32, input_resolution=224, output_dim=64)
+    sd = {k: v.clone() for k, v in sd.items()}
+    sd["ln_pre.bias"] += 6.0
+    g = torch.Generator().manual_seed(3)
+    for k in list(sd):
+        if k.endswith("ln_1.weight") or k.endswith("ln_2.weight"):
+            sd[k] = sd[k] * torch.exp2(torch.rand(sd[k].shape, generator=g) * 4 - 2)
+        if k.endswith("ln_1.bias") or k.endswith("ln_2.bias"):
+            sd[k] = sd[k] + torch.randn(sd[k].shape, generator=g)
+    rgb = syn.synthetic_rgb(78, 3)
+    vit = ViTEmbedder(sd, device=dev, heads=2)
+    tok = vit.to_f32(vit.forward(rgb.to(dev))).cpu()
+    x = rgb.permute(0, 3, 1, 2)
+    ref = ovit.vit_embedder(x, sd, heads=2, drop_last=1)
+    m, s_ = ref.mean(-1).abs().mean().item(), ref.std(-1).mean().item()
+    assert m > 2.0 * s_, (m, s_)                        # the rows really are mean-dominated
+    # (centred comparison as well: the mean itself is several times the signal, it would mask an error in the part LayerNorm keeps)
+    cen = lambda t: t - t.mean(-1, keepdim=True)
+    assert _rel(tok, ref) < 3e-2, _rel(tok, ref)
+    assert _rel(cen(tok), cen(ref)) < 3e-2, _rel(cen(tok), cen(ref))
