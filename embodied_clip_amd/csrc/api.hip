@@ -40,6 +40,7 @@ EcConfig read_config() {
     c.rn50_bneck3 = env_int("EC_RN50_BNECK3", 1);
     c.rn50_img3 = env_int("EC_RN50_IMG3", 1);
     c.rn50_dscat = env_int("EC_RN50_DSCAT", 1);
+    c.rn50_poolout = env_int("EC_RN50_POOLOUT", 1);
     c.gemm_no_x3 = env_int("EC_GEMM_NO_X3", 0);
     c.gemm_bwd3 = env_int("EC_GEMM_BWD3", 0);
     c.policy_fast = env_int("EC_POLICY_FAST", 1);
@@ -69,7 +70,7 @@ uint64_t ec_config_hash() {
     // EVERY field selects kernels: all of them key the profiles under profiles/ (ec_rn50_plan_hash / ec_vit_plan_hash)
     mix(c.conv_narrow); mix(c.conv_rowsn); mix(c.conv_big); mix(c.conv8_min_tiles); mix(c.conv8_bn128); mix(c.conv8_longseg);
     mix(c.conv_t224); mix(c.conv_t64); mix(c.conv_ring); mix(c.conv_regw); mix(c.rn50_fuse); mix(c.rn50_bneck); mix(c.rn50_bneck3);
-    mix(c.rn50_img3); mix(c.rn50_dscat); mix(c.gemm_no_x3); mix(c.gemm_bwd3); mix(c.policy_fast); mix(c.act_split); mix(c.tail_fused); mix(c.gru_fused); mix(c.c1_pingpong);
+    mix(c.rn50_img3); mix(c.rn50_dscat); mix(c.rn50_poolout); mix(c.gemm_no_x3); mix(c.gemm_bwd3); mix(c.policy_fast); mix(c.act_split); mix(c.tail_fused); mix(c.gru_fused); mix(c.c1_pingpong);
     mix(c.dw1_tr); mix(c.wih_perm); mix(c.dw_transposed);
     return x;
 }

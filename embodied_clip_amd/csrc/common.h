@@ -164,6 +164,7 @@ struct EcConfig {
     int rn50_bneck3;      // EC_RN50_BNECK3   (1)   the fused bottleneck launches include conv1 (the whole block in one launch)
     int rn50_img3;        // EC_RN50_IMG3     (1)   small launches run the 14x14x256 (<= 32 frames) / 7x7x512 (<= 64 frames) 3x3 convs on the image-resident K-split kernel
     int rn50_dscat;       // EC_RN50_DSCAT    (1)   stride-2 Bottlenecks of layers 3-4: conv3 and the downsample conv as ONE GEMM over the concatenated K axis (pooled conv2 output | pooled block input)
+    int rn50_poolout;     // EC_RN50_POOLOUT  (1)   layer 2's last conv3 also emits AvgPool2d(2) of its output (the pooled block input of layer3.0's K-concatenated GEMM): no pooling pass
     // --- policy / update ---
     int gemm_no_x3;       // EC_GEMM_NO_X3    (0)   policy GEMMs on the fp32 MFMA instead of bf16x3
     int gemm_bwd3;        // EC_GEMM_BWD3     (0)   ec_policy_backward's large gradient GEMMs on three of the six bf16x3 products (also on under EC_POLICY_FAST)

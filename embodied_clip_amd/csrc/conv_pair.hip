@@ -544,10 +544,21 @@ struct RegwArgs {
     uint16_t* y;
     int ntiles;
     int ldy;      // row stride of y / res in elements: N * (number of channel groups); blockIdx.y = channel group
+    uint16_t* yp; // PL: AvgPool2d(2)(y), pooled pixel q at yp + q * ldp (a column block of a wider tensor)
+    int ldp;
+    int H, W;     // PL: frame geometry
 };
 
-template <int K, int N, bool RES, bool RELU>
+// PL (round 6): the tile's 32 rows are EIGHT 2 x 2 POOLING WINDOWS in quad order -- tile row r = window 8 t + (r >> 2) of the
+// launch (windows numbered frame-major, then row-major over the H/2 x W/2 pooled map), corner r & 3 -- so that the kernel also
+// emits AvgPool2d(2)(y), the pooled block input of the next layer's downsample path ([U] clip/model.py Bottleneck.downsample:
+// AvgPool2d(stride) in front of the 1x1 conv), as 8 contiguous pooled rows per tile instead of a separate pass over y
+// (avgpool2_kernel: 98 MB read per 128 frames).  A 1x1 conv is per pixel: the order of the rows changes no value; the pooled
+// values are the mean of the ROUNDED bf16 outputs, summed ((c0 + c1) + c2) + c3 as avgpool2_kernel does.  A window index is
+// wave-uniform per load / store instruction, so it is decoded on the scalar unit.
+template <int K, int N, bool RES, bool RELU, bool PL = false>
 __global__ __launch_bounds__(256, 1) void conv1x1_regw_kernel(RegwArgs p) {
+    static_assert(!PL || (K == 128 && N == 512 && RES), "pooled variant: layer 2's last conv3");
     constexpr int NPW = N / 4, FJ = NPW / 32, KS = K / 16;
     constexpr int AP = K * 2 + 16;            // operand-tile row pitch (K*2 B is a multiple of 256 B: +16 staggers banks)
     constexpr int OPW = NPW * 2 + 16;         // staging pitch of the wave's output slice
@@ -579,8 +590,29 @@ __global__ __launch_bounds__(256, 1) void conv1x1_regw_kernel(RegwArgs p) {
     if (t >= p.ntiles) return;
     const int G = gridDim.x;
     u32x4 an[AL], rn[RES ? OL : 1];
+    // PL: first pixel (corner 0) of pooling window q, on the scalar unit; a lane's corner is lane >> 4 in every row-chunk
+    // enumeration below (16 chunks per row: row = 4 I + (lane >> 4), i.e. window I of the tile / of the wave's 8 operand rows)
+    const int Wq = PL ? p.W / 2 : 1, QPF = PL ? (p.H / 2) * Wq : 1;
+    const int coff = PL ? ((lane >> 5) & 1) * p.W + ((lane >> 4) & 1) : 0;
+    auto qpix = [&](int q_) -> long {
+        const int q = __builtin_amdgcn_readfirstlane(q_);
+        const int f = q / QPF, rem = q - f * QPF, qr = rem / Wq, qc = rem - qr * Wq;
+        return ((long)f * p.H + 2 * qr) * p.W + 2 * qc;
+    };
+    long opix[PL ? OL : 1];   // PL: this lane's pixel per output / residual row-chunk of the tile in the prefetch registers
     auto prefetch = [&](int tile) {
         const long m0 = (long)tile * PX;
+        if constexpr (PL) {
+            static_assert(!PL || (CPR == 16 && OC == 16 && AL == 2 && OL == 8), "row = 4 I + (lane >> 4)");
+            [&]<int... I>(std::integer_sequence<int, I...>) {
+                ((an[I] = *reinterpret_cast<const u32x4*>(p.a + (qpix(8 * tile + 2 * wave + I) + coff) * K + (lane & 15) * 8)), ...);
+            }(std::make_integer_sequence<int, AL>{});
+            [&]<int... I>(std::integer_sequence<int, I...>) {
+                ((opix[I] = qpix(8 * tile + I) + coff,
+                  rn[I] = *reinterpret_cast<const u32x4*>(resg + opix[I] * ld + NPW * wave + (lane & 15) * 8)), ...);
+            }(std::make_integer_sequence<int, OL>{});
+            return;
+        }
         [&]<int... I>(std::integer_sequence<int, I...>) {
             ((an[I] = *reinterpret_cast<const u32x4*>(p.a + (m0 + 8 * wave + (I * 64 + lane) / CPR) * K + ((I * 64 + lane) % CPR) * 8)), ...);
         }(std::make_integer_sequence<int, AL>{});
@@ -603,8 +635,12 @@ __global__ __launch_bounds__(256, 1) void conv1x1_regw_kernel(RegwArgs p) {
         const long m0 = (long)t * PX;
         const unsigned char* at = atile + (it & 1) * (PX * AP);
         u32x4 rc[RES ? OL : 1];
+        long opc[PL ? OL : 1];
         if constexpr (RES) {
             [&]<int... I>(std::integer_sequence<int, I...>) { ((rc[I] = rn[I]), ...); }(std::make_integer_sequence<int, OL>{});
+        }
+        if constexpr (PL) {
+            [&]<int... I>(std::integer_sequence<int, I...>) { ((opc[I] = opix[I]), ...); }(std::make_integer_sequence<int, OL>{});
         }
         const int tn = t + G;
         const bool more = tn < p.ntiles;
@@ -657,7 +693,28 @@ __global__ __launch_bounds__(256, 1) void conv1x1_regw_kernel(RegwArgs p) {
         for (int i = 0; i < OL; ++i) {
             const int idx = i * 64 + lane;
             const u32x4 v = *reinterpret_cast<const u32x4*>(stg + (idx / OC) * OPW + (idx % OC) * 16);
+            if constexpr (PL) *reinterpret_cast<u32x4*>(yg + opc[i] * ld + NPW * wave + (idx % OC) * 8) = v;
+            else
             *reinterpret_cast<u32x4*>(yg + (m0 + idx / OC) * ld + NPW * wave + (idx % OC) * 8) = v;
+        }
+        if constexpr (PL) {   // window w = tile rows 4 w .. 4 w + 3; a lane takes two (window, 8-channel chunk) items of the wave's slice
+#pragma unroll
+            for (int it2 = 0; it2 < 2; ++it2) {
+                const int item = it2 * 64 + lane, w = item >> 4, c = item & 15;
+                const uint4 r0 = *reinterpret_cast<const uint4*>(stg + (4 * w + 0) * OPW + c * 16);
+                const uint4 r1 = *reinterpret_cast<const uint4*>(stg + (4 * w + 1) * OPW + c * 16);
+                const uint4 r2 = *reinterpret_cast<const uint4*>(stg + (4 * w + 2) * OPW + c * 16);
+                const uint4 r3 = *reinterpret_cast<const uint4*>(stg + (4 * w + 3) * OPW + c * 16);
+                auto avg2 = [](unsigned a, unsigned b, unsigned cc, unsigned d) {
+                    const float lo = 0.25f * (ec_lo(a) + ec_lo(b) + ec_lo(cc) + ec_lo(d));
+                    const float hi = 0.25f * (ec_hi(a) + ec_hi(b) + ec_hi(cc) + ec_hi(d));
+                    return ec_pack2(lo, hi);
+                };
+                u32x4 po;
+                po[0] = avg2(r0.x, r1.x, r2.x, r3.x); po[1] = avg2(r0.y, r1.y, r2.y, r3.y);
+                po[2] = avg2(r0.z, r1.z, r2.z, r3.z); po[3] = avg2(r0.w, r1.w, r2.w, r3.w);
+                *reinterpret_cast<u32x4*>(p.yp + ((long)t * 8 + w) * p.ldp + c0 + NPW * wave + c * 8) = po;
+            }
         }
         if (!more) break;
         publish_a((it + 1) & 1);     // last readers of that buffer: the GEMM of tile it-1, before the previous barrier
@@ -666,11 +723,11 @@ __global__ __launch_bounds__(256, 1) void conv1x1_regw_kernel(RegwArgs p) {
     }
 }
 
-template <int K, int N, bool RES, bool RELU>
+template <int K, int N, bool RES, bool RELU, bool PL = false>
 int launch_regw(const RegwArgs& p, hipStream_t s, int groups = 1) {
     constexpr size_t lds = 2 * (size_t)PX * (K * 2 + 16) + N * 4 + 4 * (size_t)PX * (N / 4 * 2 + 16);
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kern = conv1x1_regw_kernel<K, N, RES, RELU>;
+    auto kern = conv1x1_regw_kernel<K, N, RES, RELU, PL>;
     static std::atomic<uint64_t> attr_done{0};
     if (auto attr_g_ = ec_attr_needed(attr_done)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -731,11 +788,28 @@ int ec_conv1x1_regw(const void* a, const void* w, const float* bias, const void*
     const bool on = ec_config().conv_regw != 0;
     if (!on || (M % PX) != 0 || M / PX > 0x7fffffffL) return EC_ERR_SHAPE;
     const long tiles = M / PX;
-    RegwArgs p{(const uint16_t*)a, (const uint16_t*)w, (const uint16_t*)res, bias, (uint16_t*)y, (int)tiles, N};
+    RegwArgs p{(const uint16_t*)a, (const uint16_t*)w, (const uint16_t*)res, bias, (uint16_t*)y, (int)tiles, N, nullptr, 0, 0, 0};
     if (tiles >= 1024) {
         if (K == 256 && N == 512 && !res && act == EC_ACT_NONE) return launch_regw<256, 512, false, false>(p, s);
         if (K == 512 && N == 256 && !res && act == EC_ACT_RELU) return launch_regw<512, 256, false, true>(p, s);
         if (K == 128 && N == 512 && res && act == EC_ACT_RELU) return launch_regw<128, 512, true, true>(p, s);
     }
     return EC_ERR_SHAPE;
+}
+
+// ... and layer 2's last conv3 (128 -> 512 + identity + ReLU @28x28) emitting AvgPool2d(2) of its output as well (PL above):
+// y_pooled + q * ld_pooled = pooled pixel q.  EC_ERR_SHAPE = not this shape / too few tiles / windows not a multiple of 8:
+// the caller runs the conv and the pooling pass separately.
+int ec_conv1x1_regw_pool(const void* a, const void* w, const float* bias, const void* res, void* y, void* y_pooled, int B, int H,
+                         int W, int K, int N, int act, int ld_pooled, hipStream_t s) {
+    if (!a || !w || !bias || !res || !y || !y_pooled) return EC_ERR_ARG;
+    if (!ec_config().conv_regw || !ec_config().rn50_poolout) return EC_ERR_SHAPE;
+    if (K != 128 || N != 512 || act != EC_ACT_RELU || B <= 0 || (H & 1) || (W & 1) || ld_pooled < N || (ld_pooled & 7) ||
+        ((size_t)y_pooled & 15))
+        return EC_ERR_SHAPE;
+    const long windows = (long)B * (H / 2) * (W / 2);
+    if ((windows % 8) != 0 || windows / 8 < 1024 || windows / 8 > 0x7fffffffL) return EC_ERR_SHAPE;
+    RegwArgs p{(const uint16_t*)a, (const uint16_t*)w, (const uint16_t*)res, bias, (uint16_t*)y, (int)(windows / 8), N,
+               (uint16_t*)y_pooled, ld_pooled, H, W};
+    return launch_regw<128, 512, true, true, true>(p, s);
 }

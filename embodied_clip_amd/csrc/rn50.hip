@@ -39,7 +39,11 @@ struct Op {
     long wimg_off = -1;      // offset (elements, into wbneck) of this 3x3 conv's streaming-order weights for the small-launch kernel
     int ldo = 0, ocol = 0;   // OP_CONV / OP_POOL writing a column block of a wider tensor: row stride (0 = dense) and first column (elements)
     long wcat_off = -1;      // OP_CONV over a concatenated K axis (conv3 | downsample conv of a stride-2 block): its [Cout][K1 + K2] weights in wbneck,
-    long bcat_off = -1;      // ... its summed bias in bias_cat; w_off / b_off = conv3's, w1_off / b1_off = the downsample conv's, Cin = K1 + K2, N2 = K1
+    long bcat_off = -1;      // ... its summed bias in bias_cat; w_off / b_off = conv3's, w1_off / b1_off = the downsample conv's, Cin = K1 + K2, N2 = K1    // OP_CONV (a block's conv3) that may also emit AvgPool2d(2) of its output for the NEXT block's K-concatenated GEMM (buffer pdst, row stride
+    // pld, first column pcol): taken when the launch runs on conv1x1_regw_kernel<.., PL>; the OP_POOL that follows the next block's conv2 carries
+    // pool_of = 1 and is skipped then
+    int pdst = -1, pld = 0, pcol = 0;
+    int pool_of = 0;
 };
 
 }  // namespace
@@ -199,13 +203,27 @@ int rn50_build(ec_rn50_t** out, bool tv, int width, const int* layers4, int inpu
             // input from the layer-1 boundary launch and chains conv3 into the next conv1: left as is.)
             if (ds && !tv && stride > 1 && li >= 2 && pooled_in < 0 && ec_config().rn50_dscat && (planes % 8) == 0) {
                 const int Kc = planes + inplanes;
-                Op& c2op = h->ops.back();                       // conv2 (+ pool) -> buffer 2, columns [0, planes)
+                // The concatenated operand lives in buffer 3 (free in layers 3-4), not in buffer 2: the conv3 that PRODUCES this block's
+                // input reads its own conv2 output from buffer 2 and may write the pooled columns in the same launch (below).
+                const int cat = 3;
+                Op& c2op = h->ops.back();                       // conv2 (+ pool) -> buffer `cat`, columns [0, planes)
                 c2op.ldo = Kc;
-                Op pl{OP_POOL, x, 2, -1, R, R, inplanes, inplanes, 0, 0, 0, 0, 0};
-                pl.ldo = Kc; pl.ocol = planes;                 // pooled block input -> buffer 2, columns [planes, Kc)
+                c2op.dst = cat;
+                Op pl{OP_POOL, x, cat, -1, R, R, inplanes, inplanes, 0, 0, 0, 0, 0};
+                pl.ldo = Kc; pl.ocol = planes;                 // pooled block input -> buffer `cat`, columns [planes, Kc)
+                // layer 2's last conv3 (128 -> 512 + identity @28x28; three ops back: behind it came this block's conv1 and conv2) can emit
+                // the pooled copy itself (conv1x1_regw_kernel<.., PL>); whether it did is known per launch (rn50_run)
+                if (ec_config().rn50_poolout && h->ops.size() >= 3) {
+                    Op& pr = h->ops[h->ops.size() - 3];
+                    if (pr.kind == OP_CONV && pr.ks == 1 && pr.dst == x && pr.res >= 0 && pr.Cin == 128 && pr.Cout == inplanes && inplanes == 512 &&
+                        pr.H == R && pr.W == R && pr.act == EC_ACT_RELU && !pr.pool && !pr.ldo && pr.wcat_off < 0) {
+                        pr.pdst = cat; pr.pld = Kc; pr.pcol = planes;
+                        pl.pool_of = 1;
+                    }
+                }
                 h->ops.push_back(pl);
                 track(Ro, Ro, Kc);
-                Op o{OP_CONV, 2, y, -1, Ro, Ro, Kc, planes * 4, 1, 0, EC_ACT_RELU, w_c3, b_c3};
+                Op o{OP_CONV, cat, y, -1, Ro, Ro, Kc, planes * 4, 1, 0, EC_ACT_RELU, w_c3, b_c3};
                 o.w1_off = wo; o.b1_off = bo;                   // the downsample conv's slot
                 o.N2 = planes;
                 o.wcat_off = 0;                                 // (assigned below, with the other packed weights)
@@ -353,7 +371,7 @@ extern "C" uint64_t ec_rn50_plan_hash(const ec_rn50_t* h) {
     mix(h->width); mix(h->res); mix(h->conv8_min_tiles); mix(h->tv);
     for (const Op& o : h->ops) {
         mix(o.kind); mix(o.src); mix(o.dst); mix(o.res); mix(o.H); mix(o.W); mix(o.Cin); mix(o.Cout); mix(o.ks);
-        mix(o.pool); mix(o.act); mix(o.stride); mix(o.src1); mix(o.dst2); mix(o.N2); mix(o.dst3); mix(o.wc1_off >= 0); mix(o.ldo); mix(o.ocol); mix(o.wcat_off >= 0);
+        mix(o.pool); mix(o.act); mix(o.stride); mix(o.src1); mix(o.dst2); mix(o.N2); mix(o.dst3); mix(o.wc1_off >= 0); mix(o.ldo); mix(o.ocol); mix(o.wcat_off >= 0); mix(o.pdst); mix(o.pld); mix(o.pcol); mix(o.pool_of);
     }
     return x;
 }
@@ -369,6 +387,8 @@ extern "C" size_t ec_rn50_workspace_bytes(const ec_rn50_t* h, int batch) {
     return NBUF * align_up(h->max_elems_per_frame * 2 * (size_t)batch, 256);
 }
 
+int ec_conv1x1_regw_pool(const void* a, const void* w, const float* bias, const void* res, void* y, void* y_pooled, int B, int H,
+                         int W, int K, int N, int act, int ld_pooled, hipStream_t s);   // conv_pair.hip
 extern "C" int ec_stem_conv1_u8(const uint8_t* rgb_u8, const float* mean3, const float* std3, const float* w,
                                 const float* bias, void* out, int B, int H, int W, int Cout, ec_stream_t stream);
 
@@ -411,6 +431,7 @@ int rn50_run(const ec_rn50_t* h, const void* rgb, bool u8, const float* mean3, c
             if (id == -3) return (uint16_t*)feat + (size_t)b0 * out_stride;
             return base + (size_t)id * bufsz;
         };
+        bool pooled_emitted = false;   // the last conv3 wrote the pooled copy of its output: the OP_POOL marked pool_of is skipped
         for (const Op& o : h->ops) {
             int rc;
             const hipStream_t stream = (hipStream_t)stream_main;
@@ -429,6 +450,7 @@ int rn50_run(const ec_rn50_t* h, const void* rgb, bool u8, const float* mean3, c
                                        u8 ? 1 : 0, mean3, std3, h->stem_w, h->bias + o.b_off, buf(o.dst), nb, o.H, o.W, stream);
                     break;
                 case OP_POOL:
+                    if (o.pool_of && pooled_emitted) { pooled_emitted = false; rc = EC_OK; break; }
                     if (o.ldo) rc = ec_avgpool2_bf16_ld(buf(o.src), (uint16_t*)buf(o.dst) + o.ocol, nb, o.H, o.W, o.Cin, o.ldo, stream);
                     else
                     rc = ec_avgpool2_bf16(buf(o.src), buf(o.dst), nb, o.H, o.W, o.Cin, stream);
@@ -494,6 +516,12 @@ int rn50_run(const ec_rn50_t* h, const void* rgb, bool u8, const float* mean3, c
                         rc = ec_conv_bf16(buf(o.src), h->wbneck + o.wcat_off, h->bias_cat + o.bcat_off, nullptr, buf(o.dst), nb, o.H, o.W,
                                           o.Cin, o.Cout, 1, 0, o.act, stream);
                         break;
+                    }
+                    if (o.pdst >= 0) {
+                        rc = ec_conv1x1_regw_pool(buf(o.src), h->w + o.w_off, h->bias + o.b_off, buf(o.res), buf(o.dst),
+                                                  (uint16_t*)buf(o.pdst) + o.pcol, nb, o.H, o.W, o.Cin, o.Cout, o.act, o.pld, stream);
+                        if (rc == EC_OK) { pooled_emitted = true; break; }
+                        if (rc != EC_ERR_SHAPE) return rc;
                     }
                     rc = ec_conv_bf16_ld(buf(o.src), h->w + o.w_off, h->bias + o.b_off, o.res >= 0 ? buf(o.res) : nullptr,
                                          (uint16_t*)buf(o.dst) + o.ocol, nb, o.H, o.W, o.Cin, o.Cout, o.ks, o.pool, o.act,

@@ -742,3 +742,38 @@ def test_trunk_with_folded_downsample_convs_matches_the_chained_plan(dev, tmp_pa
     ra, rb = _rel(a, ref), _rel(chained["nchw"], ref)
     assert ra < 2e-2 and rb < 2e-2 and ra <= rb + 5e-4, (ra, rb)
     assert _rel(a, chained["nchw"]) < 7e-3
+
+
+def test_pooled_copy_from_layer2s_last_conv3_is_bit_identical_to_the_pooling_pass(dev, tmp_path):
+    """EC_RN50_POOLOUT (default 1): layer 2's last conv3 (conv1x1_regw_kernel<.., PL>: tiles of eight 2 x 2 windows in quad
+    order) also writes AvgPool2d(2) of its output -- the pooled block input of layer3.0's K-concatenated GEMM ([U] clip/model.py
+    Bottleneck.downsample) -- and the avgpool2_kernel launch is skipped.  Same features, bit for bit, as the plan that pools in
+    its own pass (child process, EC_RN50_POOLOUT=0) at 128 and 44 frames (the smallest even count with >= 1024 tiles); 43 frames
+    (odd: windows not a multiple of 8) and 5 frames run the pooling pass inside the same plan."""
+    import os
+    import subprocess
+    import sys
+    from embodied_clip_amd.encoder import RN50Trunk
+    sd = syn.rn50_visual_state_dict(0)
+    x = syn.synthetic_rgb(33, 8).repeat(16, 1, 1, 1)
+    x = torch.stack([x[i].roll(shifts=5 * (i // 8), dims=0) for i in range(128)]).contiguous().to(dev)
+    base = RN50Trunk(sd, device=dev)
+    mine = {n: base.forward(x[:n].contiguous()).float().cpu() for n in (128, 44, 43, 5)}
+    out = str(tmp_path / "nopoolout.pt")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, torch; sys.path.insert(0, %r)\n"
+            "from embodied_clip_amd import synthetic as syn\n"
+            "from embodied_clip_amd.encoder import RN50Trunk\n"
+            "t = RN50Trunk(syn.rn50_visual_state_dict(0), device='cuda:0')\n"
+            "x = syn.synthetic_rgb(33, 8).repeat(16, 1, 1, 1)\n"
+            "x = torch.stack([x[i].roll(shifts=5 * (i // 8), dims=0) for i in range(128)]).contiguous().to('cuda:0')\n"
+            "torch.save({'f': {n: t.forward(x[:n].contiguous()).float().cpu() for n in (128, 44, 43, 5)},\n"
+            "            'hash': t.plan_hash(), 'ops': t.lib.ec_rn50_num_ops(t.h)}, %r)\n") % (root, out)
+    r = subprocess.run([sys.executable, "-c", code], env={**os.environ, "EC_RN50_POOLOUT": "0"}, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = torch.load(out)
+    assert got["hash"] != base.plan_hash() and got["ops"] == base.lib.ec_rn50_num_ops(base.h)   # (the pooling op stays in the plan: skipped per launch)
+    for n in (128, 44, 43, 5):
+        assert torch.equal(got["f"][n], mine[n]), n
+    assert not torch.equal(mine[128][:44], mine[128][44:88])                                     # distinct frames
