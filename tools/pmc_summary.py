@@ -44,6 +44,18 @@ def find_csv(d, suffix):
     return None
 
 
+FIRST = ('stem_conv1', 'stem7_pool', 'patchify_kernel')   # the first launch of a forward
+
+
+def last_forward(items, name_of):
+    """The launches of the LAST forward: the last n_last matching launches, or (n_last == 0) everything from the last first-of-a-forward
+    launch on -- the launch count of a plan depends on the batch (ops that emit a second output skip the launch that would have made it)."""
+    if n_last > 0:
+        return items[-n_last:]
+    starts = [i for i, it in enumerate(items) if any(k in name_of(it) for k in FIRST)]
+    return items[starts[-1]:] if starts else items
+
+
 per = collections.OrderedDict()
 for p in sorted(os.listdir(root)):
     f = find_csv(os.path.join(root, p), 'counter_collection.csv')
@@ -54,13 +66,13 @@ for p in sorted(os.listdir(root)):
         d = int(r['Dispatch_Id'])
         disp.setdefault(d, {'name': r['Kernel_Name'], 'grid': int(r['Grid_Size']) // max(1, int(r['Workgroup_Size']))})
         disp[d][r['Counter_Name']] = disp[d].get(r['Counter_Name'], 0.0) + float(r['Counter_Value'])
-    ids = [d for d in disp if any(k in disp[d]['name'] for k in KEYS)][-n_last:]
+    ids = last_forward([d for d in disp if any(k in disp[d]['name'] for k in KEYS)], lambda d: disp[d]['name'])
     for i, d in enumerate(ids):
         per.setdefault(i, {}).update(disp[d])
 # durations from the plain kernel trace
 kt = find_csv(os.path.join(root, 'kt'), 'kernel_trace.csv')
 if kt:
-    rows = [r for r in csv.DictReader(open(kt)) if any(k in r['Kernel_Name'] for k in KEYS)][-n_last:]
+    rows = last_forward([r for r in csv.DictReader(open(kt)) if any(k in r['Kernel_Name'] for k in KEYS)], lambda r: r['Kernel_Name'])
     for i, r in enumerate(rows):
         per.setdefault(i, {})['dur_us'] = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
         per[i].setdefault('name', r['Kernel_Name'])

@@ -7,15 +7,15 @@ O=gpurun_out/$R; mkdir -p $O
 bash tools/pmc_collect.sh trunk_$R tools/bench_trunk.py --batch 128 --min-tiles 50 --iters 1 > $O/pmc_trunk.log 2>&1
 H=$(grep -h plan_hash gpurun_out/pmc_trunk_$R.kt.log | tail -1 | cut -d" " -f2)
 NL=$(grep -h num_ops gpurun_out/pmc_trunk_$R.kt.log | tail -1 | cut -d" " -f2)      # launches per forward (>= 128 frames: one per op)
-python tools/pmc_summary.py gpurun_out/pmc_trunk_$R $NL 128 $O/trunk_b128 $H 45.7 > $O/trunk_summary_tail.txt 2>&1
+python tools/pmc_summary.py gpurun_out/pmc_trunk_$R 0 128 $O/trunk_b128 $H 45.7 > $O/trunk_summary_tail.txt 2>&1
 # ... and the single 256-frame launch (default threshold), the shape rounds 1-2 profiled: per-kernel table for continuity
 bash tools/pmc_collect.sh trunk256_$R tools/bench_trunk.py --batch 256 --iters 1 > $O/pmc_trunk256.log 2>&1
 H2=$(grep -h plan_hash gpurun_out/pmc_trunk256_$R.kt.log | tail -1 | cut -d" " -f2)
-python tools/pmc_summary.py gpurun_out/pmc_trunk256_$R $NL 256 $O/trunk_b256 $H2 45.7 > $O/trunk256_summary_tail.txt 2>&1
+python tools/pmc_summary.py gpurun_out/pmc_trunk256_$R 0 256 $O/trunk_b256 $H2 45.7 > $O/trunk256_summary_tail.txt 2>&1
 # the strong-scaling operating point: one 32-frame launch (the fused layer-3 ops fall back to three launches each: + 10)
 bash tools/pmc_collect.sh trunk32_$R tools/bench_trunk.py --batch 32 --iters 1 > $O/pmc_trunk32.log 2>&1
 H3=$(grep -h plan_hash gpurun_out/pmc_trunk32_$R.kt.log | tail -1 | cut -d" " -f2)
-python tools/pmc_summary.py gpurun_out/pmc_trunk32_$R $((NL + 10)) 32 $O/trunk_b32 $H3 45.7 > $O/trunk32_summary_tail.txt 2>&1
+python tools/pmc_summary.py gpurun_out/pmc_trunk32_$R 0 32 $O/trunk_b32 $H3 45.7 > $O/trunk32_summary_tail.txt 2>&1
 bash tools/pmc_collect.sh vit_$R tools/bench_vit.py --batch 128 --min-tiles 50 --iters 1 > $O/pmc_vit.log 2>&1
 NV=$(python - <<PY
 import csv,glob
