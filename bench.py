@@ -682,6 +682,8 @@ def parse_args(argv=None):
 
 def main(argv=None):
     a = parse_args(argv)
+    if os.environ.get("EC_STREAMS_UNVERIFIED") == "1":   # (the profiler-only waiver of the stream-concurrency check: tools/pmc_collect.sh)
+        raise SystemExit("bench.py does not run with EC_STREAMS_UNVERIFIED=1: its numbers rest on two launches really in flight")
     env_world = int(os.environ.get("WORLD_SIZE", "0") or 0)
     if env_world >= 1 and "RANK" in os.environ:       # launched one process per GPU by torch.distributed.run
         world, rank = env_world, int(os.environ["RANK"])

@@ -196,6 +196,13 @@ def concurrent_streams(n: int, device, spin_us: int = 200, max_candidates: int =
                     ok, worst = False, max(worst, r.value)
                     break
             (accepted if ok else rejected).append(cand)
+    if len(accepted) < n and os.environ.get("EC_STREAMS_UNVERIFIED") == "1":
+        # counter-collecting profiler runs only (tools/pmc_collect.sh: rocprofv3 --pmc serialises every dispatch, so no pair of streams can pass the
+        # check there, and per-kernel counters do not depend on it); bench.py refuses to run with this set
+        import sys
+        print(f"embodied_clip_amd: EC_STREAMS_UNVERIFIED=1 -- using {n - len(accepted)} stream(s) that FAILED the concurrency check "
+              f"(both-busy / alone = {worst:.2f}); timings of this process say nothing about the two-stream engine", file=sys.stderr)
+        return accepted + rejected[:n - len(accepted)]
     if len(accepted) < n:
         raise RuntimeError(f"could not obtain {n} concurrent HIP streams on {dev}: {len(accepted)} found among {max_candidates} candidates "
                            f"(both-busy / alone of a rejected pair = {worst:.2f})")
