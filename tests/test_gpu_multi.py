@@ -3,7 +3,9 @@
 the driver's 1-GPU test box skips it (the N > 1 path is covered on CPU by tests/test_dist_gloo.py and
 tests/test_bench_launch.py).  Also here, behind device-count guards: BASELINE config 4 (512 actors sharded 8-way),
 config 5's 2-GPU leg (zero-shot worker) and the a18 check proper -- HIP shard gradients summed THROUGH RCCL compared
-with the oracle's unsharded gradient (the 1-GPU form of it runs in tests/test_gpu_configs.py)."""
+with the oracle's unsharded gradient (the 1-GPU form of it runs in tests/test_gpu_configs.py).
+At the end of the file (round 6): the a18 check and the replicas-stay-identical check with the two ranks SHARING cuda:0 and
+exchanging over gloo -- the N > 1 engine path on real HIP kernels on the driver's 1-GPU box, even and uneven (3 + 2) shards."""
 import json
 import os
 import subprocess
@@ -93,17 +95,20 @@ def test_config5_zeroshot_two_ranks_over_rccl():
     assert "Zero-shot" in line["config"]["workload"] and line["value"] > 0
 
 
-def _rank_grads(rank, world, store, q):
-    """One rank of the a18 check: HIP gradients of this rank's actor shard -> flat bucket -> RCCL SUM."""
+def _rank_grads(rank, world, store, q, backend="nccl", gpu=None):
+    """One rank of the a18 check: HIP gradients of this rank's actor shard -> flat bucket -> SUM over the ranks (RCCL with one
+    GPU per rank; gloo when the ranks share GPU `gpu`: the 1-GPU box's form of the check)."""
     os.environ.update(MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    torch.cuda.set_device(rank)
-    torch.distributed.init_process_group("nccl", init_method=f"file://{store}", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    gid = rank if gpu is None else gpu
+    torch.cuda.set_device(gid)
+    torch.distributed.init_process_group(backend, init_method=f"file://{store}", rank=rank, world_size=world)
     from embodied_clip_amd import synthetic as syn
     from embodied_clip_amd.dist import allreduce_flat, grad_scale, shard_actors
     from embodied_clip_amd.policy import PolicyHandle
     from embodied_clip_amd.ppo import ppo_loss_raw
     import _a18_case
-    dev = torch.device(f"cuda:{rank}")
+    dev = torch.device(f"cuda:{gid}")
     T, N, case = _a18_case.make()
     h = PolicyHandle()
     flat = h.flatten(syn.policy_state_dict(0), dev)
@@ -150,15 +155,16 @@ def test_rccl_summed_hip_gradients_equal_the_oracles_unsharded_gradient(tmp_path
         assert rel < 2e-4, (name, rel)
 
 
-def _rank(rank, world, store, q):
+def _rank(rank, world, store, q, backend="nccl", gpu=None, actors=(4, 4)):
     os.environ.update(MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    torch.cuda.set_device(rank)
-    torch.distributed.init_process_group("nccl", init_method=f"file://{store}", rank=rank, world_size=world)
+    gid = rank if gpu is None else gpu
+    torch.cuda.set_device(gid)
+    torch.distributed.init_process_group(backend, init_method=f"file://{store}", rank=rank, world_size=world)
     from embodied_clip_amd.engine import Worker
-    w = Worker(4, T=4, device=f"cuda:{rank}", seed=0, rank=rank, world=world, update_repeats=2)
+    w = Worker(actors[rank], T=4, device=f"cuda:{gid}", seed=0, rank=rank, world=world, update_repeats=2)
     w.iteration()
     torch.cuda.synchronize()
-    q.put((rank, w.params.cpu()))
+    q.put((rank, w.params.cpu(), list(w.shard_counts)))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
@@ -172,8 +178,55 @@ def test_replicas_stay_identical_after_allreduced_updates(tmp_path):
     ps = [ctx.Process(target=_rank, args=(r, 2, store, q)) for r in range(2)]
     for p in ps:
         p.start()
-    got = dict(q.get() for _ in range(2))
+    got = dict((r[0], r[1]) for r in (q.get() for _ in range(2)))
     for p in ps:
         p.join(120)
         assert p.exitcode == 0
     assert torch.equal(got[0], got[1])            # same summed gradient bucket, same Adam step on every rank
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The same two checks on the driver's 1-GPU box: two ranks (two processes) SHARE cuda:0 and exchange over gloo.  RCCL refuses two
+# ranks on one device; gloo does not care where the tensors live, and everything else of the N > 1 path is the product code:
+# the HIP kernels of both ranks, the per-rank shard and gradient scale, `gather_actor_counts` / `check_job_seed`, the sectioned
+# bucket summed on the communication stream under the goal encoder's backward, the fused clip + Adam step on the summed bucket.
+# ---------------------------------------------------------------------------------------------------------------------------
+def _spawn2(target, tmp_path, name, **kw):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    store = str(tmp_path / name)
+    ps = [ctx.Process(target=target, args=(r, 2, store, q), kwargs=kw) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = [q.get() for _ in range(2)]
+    for p in ps:
+        p.join(180)
+        assert p.exitcode == 0
+    return sorted(got, key=lambda g: g[0])
+
+
+def test_two_ranks_sharing_one_gpu_hip_gradients_summed_over_gloo_equal_the_oracles_unsharded_gradient(tmp_path):
+    """Row a18 with BOTH ranks' gradients computed by the HIP path on this GPU and summed through `allreduce_flat` (gloo):
+    equal on the two ranks, and the ORACLE's gradient of the unsharded batch to 2e-4 per tensor."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import _a18_case
+    from embodied_clip_amd import synthetic as syn
+    got = _spawn2(_rank_grads, tmp_path, "store_a18_gloo", backend="gloo", gpu=0)
+    ref = _a18_case.oracle_gradient(syn.policy_state_dict(0))
+    assert torch.equal(got[0][1], got[1][1])
+    for name, (o, k) in got[0][2].items():
+        a, b = got[0][1][o:o + k], ref[name].reshape(-1)
+        rel = ((a - b).norm() / b.norm().clamp_min(1e-20)).item()
+        assert rel < 2e-4, (name, rel)
+
+
+@pytest.mark.parametrize("actors", [(4, 4), (3, 2)])
+def test_two_ranks_sharing_one_gpu_stay_identical_after_allreduced_updates(tmp_path, actors):
+    """Two `engine.Worker`s (even and UNEVEN shards: 3 + 2 actors) run one full iteration each -- rollout, GAE, 4 epochs x 2 repeats
+    of the sectioned, overlapped bucket exchange + fused clip + Adam -- and end with `torch.equal` parameters; both saw the same
+    gathered actor counts."""
+    got = _spawn2(_rank, tmp_path, "store_gloo_%d_%d" % actors, backend="gloo", gpu=0, actors=actors)
+    assert got[0][2] == list(actors) and got[1][2] == list(actors)
+    assert torch.equal(got[0][1], got[1][1])
+    assert torch.isfinite(got[0][1]).all()
