@@ -262,14 +262,18 @@ def run_rank(a, rank: int, local_rank: int, world: int, init_method=None):
         return 0 if ok else 1
 
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback for the product path)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device(f"cuda:{local_rank}")
+    gpu = 0 if a.share_gpu else local_rank      # --share-gpu (tests only): every rank on cuda:0, exchange over gloo
+    torch.cuda.set_device(gpu)
+    dev = torch.device(f"cuda:{gpu}")
     use_dist = world > 1 or a.force_dist        # --force-dist: RCCL initialised and used also at world size 1
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", init_method=init_method, rank=rank, world_size=world,
-                                device_id=dev)   # RCCL over xGMI
+        if a.share_gpu:
+            dist.init_process_group("gloo", init_method=init_method, rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", init_method=init_method, rank=rank, world_size=world,
+                                    device_id=dev)   # RCCL over xGMI
 
     from embodied_clip_amd.engine import Worker
     total = a.actors_total if a.actors_total else a.actors
@@ -392,7 +396,8 @@ def run_rank(a, rank: int, local_rank: int, world: int, init_method=None):
             "metric": "env-frames/sec (CLIP encode + policy fwd/bwd + PPO update)",
             "value": round(value, 1), "unit": "env-frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": a.scaling,
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic" if not a.share_gpu else "synthetic; --share-gpu TEST MODE: all ranks on ONE GPU over gloo, not a throughput",
             "config": {"workload": workload + " (bf16 MFMA, fp32 accumulate) + 1-layer GRU actor-critic PPO (fp32), "
                                                "synthetic 224x224 RGB + random goal ids",
                        "actors_per_gpu": per_gpu, "global_actors": global_actors, "rollout": a.rollout,
@@ -665,6 +670,10 @@ def parse_args(argv=None):
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL (backend nccl) and run the flat-bucket all-reduce also at world size 1 -- the "
                          "first-contact check of the N > 1 path on a 1-GPU box (tests/test_gpu_multi.py)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="TESTS ONLY: every rank runs on cuda:0 and the ranks exchange over gloo (RCCL refuses two ranks on one "
+                         "device) -- the N > 1 code path of this file on a 1-GPU box; the line says so in `data` and its value is "
+                         "not a throughput of anything (tests/test_gpu_multi.py)")
     ap.add_argument("--no-overlap-allreduce", action="store_true",
                     help="one 13.9-MB all-reduce AFTER the backward instead of the GRU + heads section reduced under the goal "
                          "encoder's backward (engine.Worker(overlap_allreduce=False)); only matters with a collective")

@@ -230,3 +230,27 @@ def test_two_ranks_sharing_one_gpu_stay_identical_after_allreduced_updates(tmp_p
     assert got[0][2] == list(actors) and got[1][2] == list(actors)
     assert torch.equal(got[0][1], got[1][1])
     assert torch.isfinite(got[0][1]).all()
+
+
+def test_bench_py_launched_as_the_driver_launches_it_with_two_ranks_sharing_one_gpu():
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P bench.py --gpus 2 ...` --
+    the driver's launch line for N = 2 -- with `--share-gpu` (both ranks on cuda:0, gloo): the N > 1 branch of bench.py on real HIP
+    kernels on the 1-GPU box: RANK / LOCAL_RANK / WORLD_SIZE from the environment, strong-scaling shards of an ODD actor total (33 =
+    17 + 16), barrier + synchronize bracketing, MAX over ranks, rank 0 alone printing ONE JSON line, per-rank all-reduce timing."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--actors", "33", "--rollout", "8",
+           "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-h2d", "--no-traffic", "--no-plugin", "--no-sync-actions"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT,
+                       env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines                              # rank 0 alone prints
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and "TEST MODE" in line["data"]
+    assert line["scaling"] == "strong" and line["config"]["global_actors"] == 33
+    assert isinstance(line["allreduce_ms_per_rank"], list) and len(line["allreduce_ms_per_rank"]) == 2
+    assert line["value"] > 0 and all(v == v and abs(v) < 1e6 for v in line["loss"].values())   # finite
