@@ -120,6 +120,16 @@ def measured_traffic(encoder: str, plan_hash, frames_per_launch: int):
     if not os.path.exists(path):
         return None, f"no PMC summary at {os.path.relpath(path, ROOT)} (run tools/pmc_collect.sh + tools/pmc_summary.py)", None
     rec = json.load(open(path))
+    alt = rec.get("single_launch_256") or {}
+    if plan_hash is not None and rec.get("plan_hash") not in (None, "", plan_hash) and alt.get("plan_hash") == plan_hash:
+        # a one-slice worker (fewer than EC_TWO_SLICE_MIN actors per GPU: the strong-scaling operating points) runs the plan with the
+        # library's default dispatch threshold, which the summary holds as its 256-frame single-launch record
+        per_frame = alt["hbm_bytes_per_launch"] / 256.0
+        return per_frame * frames_per_launch, (
+            f"bytes per launch = PMC-measured {alt['hbm_bytes_per_launch'] / 1e9:.2f} GB per 256-frame launch of THIS plan "
+            f"({os.path.relpath(path, ROOT)}: single_launch_256; same counters and corrections as the engine plan's record) scaled per frame to "
+            f"{frames_per_launch} frames -- an approximation below 128 frames per launch, where layer 3 runs as separate conv launches "
+            "and the per-launch weight reads weigh more"), rec
     if plan_hash is not None and rec.get("plan_hash") not in (None, "", plan_hash):
         # stale evidence is never quoted: the line carries traffic = null and says why (and how to refresh it)
         msg = (f"{os.path.relpath(path, ROOT)} is STALE: measured on launch plan {rec.get('plan_hash')}, the library now runs "
